@@ -1,0 +1,659 @@
+// ics_api.hip -- the C ABI of libics_hip.so (include/ics_hip.h): contexts, the device-resident
+// Richardson-Lucy job, the outer/inner iteration schedule of lib/deconvolution.pyx:460-659, and the
+// standalone operators.  Host side only; kernels live in ics_conv.hip / ics_kernels.hip /
+// ics_stats.hip / ics_filters.hip.
+//
+// Schedule of one inner iteration (all on one HIP stream, no host round trip):
+//   k_conv<mode 0>  A1+A2   error = conv(u, psf) - image
+//   k_conv<mode 1>  A3+A7   gradu = corr(error, psf); max|g_k|, max u_k  -> device keys
+//   k_update        A5-A10  dt on device from the keys; u update + DoF blend
+//   blind only: k_conv<mode 0> (A11), k_gradk + k_gradk_reduce (A13, MFMA), k_psf (A14-A17)
+// Once per outer iteration: ut = u (D2D), window statistics + FFT whiteness metric (A18/A19), one
+// 64-byte D2H of the scalars, and the stop decision on the host (pyx:643-654).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/ics_hip.h"
+#include "ics_kernels.h"
+
+// -------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPCHK(x)                                                                                \
+  do {                                                                                           \
+    hipError_t e_ = (x);                                                                         \
+    if (e_ != hipSuccess)                                                                        \
+      return fail(e_ == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "%s failed: %s (%s:%d)", #x, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                    \
+  } while (0)
+
+struct ics_ctx {
+  int device;
+  hipStream_t stream;
+  int cus;
+  char name[256];
+  uint64_t hbm;
+};
+
+struct ics_rl {
+  ics_ctx* ctx;
+  IcsGeom g;
+  size_t frame_floats, origin;
+  float *u, *ut, *gr, *f, *e;          // frame bases (origin = base + origin)
+  float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
+  int gradk_blocks;
+  uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
+  uint32_t* dofkeys;                    // 4 words
+  float* scal;                          // ICS_SC_COUNT
+  float* wsc;                           // 8
+  int* flags;                           // [0] frozen, [1] hasnan
+  // stop-test scratch (allocated for the window of the last run)
+  float2* z; float2* tw; float* weights;
+  int P, logP, wt, wb, wl, wr;
+  float* h_scal;                        // pinned host mirror of scal (+ flags)
+  bool uploaded;
+  // profiling
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_class;
+  size_t ev_used;
+  hipEvent_t ev_begin, ev_end;
+};
+
+static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
+
+// -------------------------------------------------------------------------------------------------
+extern "C" int ics_abi_version(void) { return ICS_ABI_VERSION; }
+extern "C" const char* ics_last_error(void) { return g_err; }
+
+extern "C" int ics_device_count(int* count) {
+  if (!count) return fail(ICS_EINVAL, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(ICS_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return ICS_OK;
+}
+
+extern "C" int ics_ctx_create(int device, ics_ctx** out) {
+  if (!out) return fail(ICS_EINVAL, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(ICS_ENODEV, "no HIP device available (%s); libics_hip has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return fail(ICS_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(ICS_ENODEV, "device %d is %s; this library only contains gfx950 (MI355X) code", device, prop.gcnArchName);
+  ics_ctx* c = new ics_ctx();
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  c->hbm = prop.totalGlobalMem;
+  snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+  hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { delete c; return fail(ICS_EHIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+  *out = c;
+  return ICS_OK;
+}
+
+extern "C" void ics_ctx_destroy(ics_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int ics_ctx_synchronize(ics_ctx* c) {
+  if (!c) return fail(ICS_EINVAL, "ctx is NULL");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return ICS_OK;
+}
+
+extern "C" int ics_ctx_info(ics_ctx* c, char* name, size_t name_len, int* cus, uint64_t* hbm) {
+  if (!c) return fail(ICS_EINVAL, "ctx is NULL");
+  if (name && name_len) { strncpy(name, c->name, name_len - 1); name[name_len - 1] = 0; }
+  if (cus) *cus = c->cus;
+  if (hbm) *hbm = c->hbm;
+  return ICS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+static int dalloc(T** p, size_t count, bool zero = true) {
+  *p = nullptr;
+  HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
+  if (zero) HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+  return ICS_OK;
+}
+
+extern "C" void ics_rl_destroy(ics_rl* j) {
+  if (!j) return;
+  hipSetDevice(j->ctx->device);
+  hipStreamSynchronize(j->ctx->stream);
+  void* ptrs[] = {j->u, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
+                  j->red, j->dofkeys, j->scal, j->wsc, j->flags, j->z, j->tw, j->weights};
+  for (void* p : ptrs) if (p) hipFree(p);
+  if (j->h_scal) hipHostFree(j->h_scal);
+  for (hipEvent_t e : j->ev) hipEventDestroy(e);
+  if (j->ev_begin) hipEventDestroy(j->ev_begin);
+  if (j->ev_end) hipEventDestroy(j->ev_end);
+  delete j;
+}
+
+extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
+  if (!c || !out) return fail(ICS_EINVAL, "NULL argument");
+  *out = nullptr;
+  if (M < 1 || N < 1) return fail(ICS_EINVAL, "image size %dx%d", M, N);
+  if (MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "MK must be odd and >= 3 (got %d)", MK);
+  if (!ics_conv_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..31)", MK);
+  HIPCHK(hipSetDevice(c->device));
+  ics_rl* j = new ics_rl();  // value-initialised: every pointer/flag starts at 0
+  j->ctx = c;
+  j->g = ics_make_geom(M, N, MK);
+  j->frame_floats = ics_frame_floats(j->g);
+  j->origin = ics_origin_offset(j->g);
+  const size_t n = (size_t)3 * MK * MK;
+  const int nt = 16 * ((MK + 15) / 16);
+  j->gradk_blocks = ics_gradk_blocks(j->g, c->cus);
+  int rc;
+#define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
+  TRY(dalloc(&j->u, j->frame_floats)); TRY(dalloc(&j->ut, j->frame_floats)); TRY(dalloc(&j->gr, j->frame_floats));
+  TRY(dalloc(&j->f, j->frame_floats)); TRY(dalloc(&j->e, j->frame_floats));
+  TRY(dalloc(&j->psf, n)); TRY(dalloc(&j->gradk, n)); TRY(dalloc(&j->psf_caller, n));
+  TRY(dalloc(&j->wconv, (size_t)MK * j->g.wrow)); TRY(dalloc(&j->wcorr, (size_t)MK * j->g.wrow));
+  TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt));
+  TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE)); TRY(dalloc(&j->dofkeys, (size_t)4));
+  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT)); TRY(dalloc(&j->wsc, (size_t)8)); TRY(dalloc(&j->flags, (size_t)4));
+#undef TRY
+  hipError_t e = hipHostMalloc((void**)&j->h_scal, (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);
+  if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
+  hipEventCreate(&j->ev_begin); hipEventCreate(&j->ev_end);
+  *out = j;
+  return ICS_OK;
+}
+
+static int copy_in(ics_rl* j, float* frame, const float* host, int rows, int cols_px, int oy, int ox) {
+  float* dst = org(j, frame) + (ptrdiff_t)oy * j->g.pitch + 3 * ox;
+  HIPCHK(hipMemcpy2DAsync(dst, (size_t)j->g.pitch * 4, host, (size_t)cols_px * 12, (size_t)cols_px * 12, rows,
+                          hipMemcpyHostToDevice, j->ctx->stream));
+  return ICS_OK;
+}
+static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px, int oy, int ox) {
+  const float* src = org(j, frame) + (ptrdiff_t)oy * j->g.pitch + 3 * ox;
+  HIPCHK(hipMemcpy2DAsync(host, (size_t)cols_px * 12, src, (size_t)j->g.pitch * 4, (size_t)cols_px * 12, rows,
+                          hipMemcpyDeviceToHost, j->ctx->stream));
+  return ICS_OK;
+}
+
+static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hipStream_t s) {
+  IcsPsfArgs a;
+  a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.psf_caller = j->psf_caller;
+  a.scal = j->scal; a.frozen = j->flags; a.step = step; a.K = j->g.K; a.wrow = j->g.wrow;
+  a.correlation = correlation; a.do_step = do_step;
+  HIPCHK(ics_launch_psf(a, s));
+  return ICS_OK;
+}
+
+extern "C" int ics_rl_upload(ics_rl* j, const float* image, const float* u, const float* psf) {
+  if (!j) return fail(ICS_EINVAL, "job is NULL");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  const IcsGeom& g = j->g;
+  int rc;
+  if (image && (rc = copy_in(j, j->f, image, g.M, g.N, g.pad, g.pad)) != ICS_OK) return rc;
+  if (u && (rc = copy_in(j, j->u, u, g.uM, g.uN, 0, 0)) != ICS_OK) return rc;
+  if (psf) {
+    const size_t n = (size_t)3 * g.K * g.K * 4;
+    HIPCHK(hipMemcpyAsync(j->psf, psf, n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(j->psf_caller, psf, n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(j->flags, 0, 4 * sizeof(int), s));
+    if ((rc = pack_weights(j, 0, 0.f, 0, s)) != ICS_OK) return rc;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (image && u && psf) j->uploaded = true;
+  return ICS_OK;
+}
+
+extern "C" int ics_rl_download(ics_rl* j, float* u, float* psf_local, float* psf_caller) {
+  if (!j) return fail(ICS_EINVAL, "job is NULL");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  const IcsGeom& g = j->g;
+  int rc;
+  if (u && (rc = copy_out(j, j->u, u, g.uM, g.uN, 0, 0)) != ICS_OK) return rc;
+  const size_t n = (size_t)3 * g.K * g.K * 4;
+  if (psf_local) HIPCHK(hipMemcpyAsync(psf_local, j->psf, n, hipMemcpyDeviceToHost, s));
+  if (psf_caller) HIPCHK(hipMemcpyAsync(psf_caller, j->psf_caller, n, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ICS_OK;
+}
+
+static int frame_of(ics_rl* j, int which, float** frame, int* rows, int* cols, int* oy, int* ox) {
+  const IcsGeom& g = j->g;
+  switch (which) {
+    case ICS_BUF_U: *frame = j->u; break;
+    case ICS_BUF_UT: *frame = j->ut; break;
+    case ICS_BUF_GRADU: *frame = j->gr; break;
+    case ICS_BUF_IMAGE: *frame = j->f; break;
+    case ICS_BUF_ERROR: *frame = j->e; break;
+    default: return -1;
+  }
+  if (which == ICS_BUF_IMAGE || which == ICS_BUF_ERROR) { *rows = g.M; *cols = g.N; *oy = g.pad; *ox = g.pad; }
+  else { *rows = g.uM; *cols = g.uN; *oy = 0; *ox = 0; }
+  return 0;
+}
+
+extern "C" int ics_rl_read(ics_rl* j, int which, float* host, size_t count) {
+  if (!j || !host) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  const size_t n = (size_t)3 * j->g.K * j->g.K;
+  float* frame; int rows, cols, oy, ox;
+  if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) == 0) {
+    if (count != (size_t)rows * cols * 3) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, (size_t)rows * cols * 3, count);
+    int rc = copy_out(j, frame, host, rows, cols, oy, ox);
+    if (rc != ICS_OK) return rc;
+  } else if (which == ICS_BUF_PSF || which == ICS_BUF_GRADK) {
+    if (count != n) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, n, count);
+    HIPCHK(hipMemcpyAsync(host, which == ICS_BUF_PSF ? j->psf : j->gradk, n * 4, hipMemcpyDeviceToHost, s));
+  } else if (which == ICS_BUF_SCALARS) {
+    if (count != ICS_SC_COUNT) return fail(ICS_EINVAL, "scalars hold %d floats", ICS_SC_COUNT);
+    HIPCHK(hipMemcpyAsync(host, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+  } else {
+    return fail(ICS_EINVAL, "unknown buffer %d", which);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return ICS_OK;
+}
+
+extern "C" int ics_rl_write(ics_rl* j, int which, const float* host, size_t count) {
+  if (!j || !host) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  const size_t n = (size_t)3 * j->g.K * j->g.K;
+  float* frame; int rows, cols, oy, ox;
+  if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) == 0) {
+    if (count != (size_t)rows * cols * 3) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, (size_t)rows * cols * 3, count);
+    int rc = copy_in(j, frame, host, rows, cols, oy, ox);
+    if (rc != ICS_OK) return rc;
+  } else if (which == ICS_BUF_PSF || which == ICS_BUF_GRADK) {
+    if (count != n) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, n, count);
+    HIPCHK(hipMemcpyAsync(which == ICS_BUF_PSF ? j->psf : j->gradk, host, n * 4, hipMemcpyHostToDevice, s));
+    if (which == ICS_BUF_PSF) { int rc = pack_weights(j, 0, 0.f, 0, s); if (rc != ICS_OK) return rc; }
+  } else {
+    return fail(ICS_EINVAL, "buffer %d is not writable", which);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return ICS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// stop-test scratch: Gaussian window weights (pyx:393-404), twiddles, P x P x 3 complex buffer
+static int ensure_window(ics_rl* j, const ics_rl_params* p) {
+  if (j->z && j->wt == p->top && j->wb == p->bottom && j->wl == p->left && j->wr == p->right) return ICS_OK;
+  const int H = p->bottom - p->top, W = p->right - p->left;
+  if (H < 1 || W < 1) return fail(ICS_EINVAL, "empty stats window [%d:%d, %d:%d]", p->top, p->bottom, p->left, p->right);
+  if (p->top < 0 || p->left < 0 || p->bottom > j->g.M || p->right > j->g.N)
+    return fail(ICS_EINVAL, "stats window [%d:%d, %d:%d] outside the %dx%d image", p->top, p->bottom, p->left, p->right, j->g.M, j->g.N);
+  const int need = 2 * (H > W ? H : W) - 1;
+  int P = 2, logP = 1;
+  while (P < need) { P <<= 1; ++logP; }
+  if (P > 2048) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 2048)", H, W, P);
+  if (j->z) { hipFree(j->z); j->z = nullptr; }
+  if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
+  if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
+  int rc;
+  if ((rc = dalloc(&j->z, (size_t)3 * P * P, false)) != ICS_OK) return rc;
+  if ((rc = dalloc(&j->tw, (size_t)P / 2 + 1, false)) != ICS_OK) return rc;
+  if ((rc = dalloc(&j->weights, (size_t)H * W, false)) != ICS_OK) return rc;
+  std::vector<float2> tw(P / 2 + 1);
+  for (int k = 0; k < P / 2; ++k) {
+    const double ang = -2.0 * M_PI * (double)k / (double)P;
+    tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+  }
+  tw[P / 2] = make_float2(0.f, 0.f);
+  // np.linspace(-1., 1., num, dtype=float32) then gaussian_weight(x, 0, 1) in float (pyx:35-36,397-401)
+  auto serie = [](int num, std::vector<float>& out) {
+    out.resize(num);
+    const double step = num > 1 ? 2.0 / (double)(num - 1) : 0.0;
+    const float PI = 3.141592653589793f;
+    for (int i = 0; i < num; ++i) {
+      double y = (double)i * step + (-1.0);
+      if (num > 1 && i == num - 1) y = 1.0;
+      const float x = (float)y;
+      out[i] = expf(-powf(x - 0.f, 2.f) / (2 * powf(1.f, 2.f))) / (1.f * powf(2 * PI, 0.5f));
+    }
+  };
+  std::vector<float> wi, he, w((size_t)H * W);
+  serie(H, wi); serie(W, he);
+  double sum = 0.0;
+  for (int r = 0; r < H; ++r)
+    for (int c = 0; c < W; ++c) { w[(size_t)r * W + c] = sqrtf(wi[r] * he[c]); sum += w[(size_t)r * W + c]; }
+  const float fs = (float)sum;
+  for (auto& v : w) v = v / fs;
+  HIPCHK(hipMemcpy(j->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(j->weights, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  j->P = P; j->logP = logP; j->wt = p->top; j->wb = p->bottom; j->wl = p->left; j->wr = p->right;
+  return ICS_OK;
+}
+
+// ---- launch helpers with optional event bracketing -----------------------------------------------
+struct Prof {
+  ics_rl* j; bool on;
+  int begin(int cls) {
+    if (!on) return ICS_OK;
+    if (j->ev_used + 2 > j->ev.size()) {
+      for (int i = 0; i < 64; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); j->ev.push_back(e); }
+    }
+    j->ev_class.resize(j->ev.size());
+    j->ev_class[j->ev_used] = cls;
+    HIPCHK(hipEventRecord(j->ev[j->ev_used], j->ctx->stream));
+    return ICS_OK;
+  }
+  int end() {
+    if (!on) return ICS_OK;
+    HIPCHK(hipEventRecord(j->ev[j->ev_used + 1], j->ctx->stream));
+    j->ev_used += 2;
+    return ICS_OK;
+  }
+  // call after a stream synchronisation
+  int collect(double* ms, int* launches) {
+    if (!on) return ICS_OK;
+    for (size_t i = 0; i + 1 < j->ev_used; i += 2) {
+      float t = 0.f;
+      HIPCHK(hipEventElapsedTime(&t, j->ev[i], j->ev[i + 1]));
+      ms[j->ev_class[i]] += t; launches[j->ev_class[i]] += 1;
+    }
+    j->ev_used = 0;
+    return ICS_OK;
+  }
+};
+
+#define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
+
+static int do_conv(ics_rl* j, int mode, float lambd, int slot, Prof& pr) {
+  IcsConvArgs a;
+  a.g = j->g; a.lambd = lambd;
+  if (mode == 0) { a.in = org(j, j->u); a.w = j->wconv; a.out = org(j, j->e); }
+  else { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
+  a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, j->ut);
+  a.red = j->red + slot * ICS_RED_STRIDE;
+  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
+  HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
+  IcsUpdateArgs a;
+  a.u = org(j, j->u); a.ut = org(j, j->ut); a.g = org(j, j->gr); a.f = org(j, j->f);
+  a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
+  RC(pr.begin(ICS_K_UPDATE));
+  HIPCHK(ics_launch_update(a, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int do_gradk(ics_rl* j, Prof& pr) {
+  IcsGradkArgs a;
+  a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
+  RC(pr.begin(ICS_K_PSF_GRADIENT));
+  HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
+  HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int do_psf(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  RC(pr.begin(ICS_K_PSF_UPDATE));
+  RC(pack_weights(j, 1, p->step_factor, p->correlation, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int do_majorize(ics_rl* j, Prof& pr) {
+  RC(pr.begin(ICS_K_MAJORIZE));
+  HIPCHK(hipMemcpyAsync(j->ut, j->u, j->frame_floats * 4, hipMemcpyDeviceToDevice, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  IcsStatsArgs a;
+  a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.wsc = j->wsc;
+  a.z = j->z; a.tw = j->tw; a.weights = j->weights;
+  a.top = p->top; a.bottom = p->bottom; a.left = p->left; a.right = p->right;
+  a.P = j->P; a.logP = j->logP; a.do_mr = p->stop_test; a.geo = j->g;
+  RC(pr.begin(ICS_K_STATS));
+  HIPCHK(ics_launch_stats(a, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int reset_dofkeys(ics_rl* j) {
+  static const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+  HIPCHK(hipMemcpyAsync(j->dofkeys, init, sizeof init, hipMemcpyHostToDevice, j->ctx->stream));
+  return ICS_OK;
+}
+
+static int check_params(ics_rl* j, const ics_rl_params* p) {
+  if (!j || !p) return fail(ICS_EINVAL, "NULL argument");
+  if (p->tv_mode != ICS_TV_SHIPPED) return fail(ICS_ENOSUP, "tv_mode %d not implemented (only ICS_TV_SHIPPED)", p->tv_mode);
+  if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
+  return ICS_OK;
+}
+
+extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
+  RC(check_params(j, p));
+  if (!st) return fail(ICS_EINVAL, "stats is NULL");
+  if (!j->uploaded) return fail(ICS_ESTATE, "ics_rl_run before ics_rl_upload");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  RC(ensure_window(j, p));
+  memset(st, 0, sizeof *st);
+  Prof pr{j, p->profile != 0};
+  j->ev_used = 0;
+  double ms[ICS_KERNEL_COUNT] = {0};
+  int launches[ICS_KERNEL_COUNT] = {0};
+  const int INNER = 5;  // pyx:375
+  int it = 0, stop = 0, inner_done = 0;
+  float M_r = 0.f, M_r_prev = 0.f, Hu = 0.f, varu = 0.f, dmin = 0.f, dmax = 0.f;
+  HIPCHK(hipMemsetAsync(j->flags, 0, 4 * sizeof(int), s));
+  // the caller's psf array is the local psf when the call starts (pyx:341)
+  HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf, (size_t)3 * j->g.K * j->g.K * 4, hipMemcpyDeviceToDevice, s));
+  RC(pack_weights(j, 0, 0.f, 0, s));
+  HIPCHK(hipEventRecord(j->ev_begin, s));
+  while (it < p->iterations && !stop) {                       // pyx:460
+    RC(do_majorize(j, pr));                                   // pyx:462
+    HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+    RC(reset_dofkeys(j));
+    for (int itt = 0; itt < INNER; ++itt) {                   // pyx:473
+      RC(do_conv(j, 0, p->lambd, itt, pr));                   // A1+A2
+      RC(do_conv(j, 1, p->lambd, itt, pr));                   // A3 (+A7)
+      RC(do_update(j, p, itt, itt == INNER - 1, pr));         // A5,A6,A8,A10
+      if (p->blind) {                                         // pyx:555
+        RC(do_conv(j, 0, p->lambd, itt, pr));                 // A11
+        RC(do_gradk(j, pr));                                  // A12+A13
+        RC(do_psf(j, p, pr));                                 // A14-A17
+      }
+      ++inner_done;
+    }
+    RC(do_stats(j, p, pr));                                   // A18 + A19
+    HIPCHK(hipMemcpyAsync(j->h_scal, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    RC(pr.collect(ms, launches));
+    if (it > 0) M_r_prev = M_r;                               // pyx:623-624
+    M_r = p->stop_test ? j->h_scal[ICS_SC_MR] : nanf("");
+    Hu = j->h_scal[ICS_SC_HU]; varu = j->h_scal[ICS_SC_VARU];
+    dmin = j->h_scal[ICS_SC_DOFMIN]; dmax = j->h_scal[ICS_SC_DOFMAX];
+    const int slot = it < ICS_MAX_TRACE ? it : ICS_MAX_TRACE - 1;
+    st->trace_M_r[slot] = M_r; st->trace_Hu[slot] = Hu; st->trace_varu[slot] = varu;
+    st->trace_dof_min[slot] = dmin; st->trace_dof_max[slot] = dmax;
+    st->trace_len = slot + 1;
+    if (it > 1 && p->stop_test) {                             // pyx:643-654
+      if (p->blind) { if (M_r > M_r_prev) stop = 1; }
+      else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
+    }
+    ++it;
+  }
+  HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
+  HIPCHK(hipEventRecord(j->ev_end, s));
+  int hflags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(hflags, j->flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  float total = 0.f;
+  HIPCHK(hipEventElapsedTime(&total, j->ev_begin, j->ev_end));
+  st->iterations_done = it; st->stopped = stop; st->has_nan = hflags[1];
+  st->M_r = M_r; st->Hu = Hu; st->varu = varu; st->dof_min = dmin; st->dof_max = dmax;
+  st->ms_total = total; st->inner_iterations = inner_done;
+  for (int k = 0; k < ICS_KERNEL_COUNT; ++k) {
+    st->launches[k] = launches[k];
+    st->ms_kernel[k] = launches[k] ? (float)(ms[k] / launches[k]) : 0.f;
+  }
+  return ICS_OK;
+}
+
+extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
+  RC(check_params(j, p));
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  Prof pr{j, false};
+  switch (stage) {
+    case ICS_STAGE_SYNTH_RESIDUAL:
+      RC(pack_weights(j, 0, 0.f, 0, s));
+      RC(do_conv(j, 0, p->lambd, 0, pr));
+      break;
+    case ICS_STAGE_BACKPROJECT:
+      RC(pack_weights(j, 0, 0.f, 0, s));
+      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      RC(do_conv(j, 1, p->lambd, 0, pr));
+      break;
+    case ICS_STAGE_UPDATE:
+      RC(reset_dofkeys(j));
+      RC(do_update(j, p, 0, 1, pr));
+      break;
+    case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, pr)); break;
+    case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
+    case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;
+    case ICS_STAGE_STATS:
+      RC(ensure_window(j, p));
+      RC(do_stats(j, p, pr));
+      break;
+    default: return fail(ICS_EINVAL, "unknown stage %d", stage);
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return ICS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// standalone operators
+namespace {
+// lib/deconvolution.pyx:47-70: clamp negatives, divide each channel by its sequential float32 sum
+__global__ __launch_bounds__(256) void k_normalize(float* kern, int K) {
+  __shared__ float ssum[4];
+  const int n = 3 * K * K, tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) if (kern[i] < 0.f) kern[i] = 0.f;
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.f;
+    for (int i = 0; i < K * K; ++i) s = __fadd_rn(s, kern[3 * i + tid]);
+    ssum[tid] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += 256) kern[i] = __fdiv_rn(kern[i], ssum[i % 3]);
+}
+}  // namespace
+
+extern "C" int ics_normalize_kernel(ics_ctx* c, float* kern, int MK) {
+  if (!c || !kern) return fail(ICS_EINVAL, "NULL argument");
+  if (MK < 1) return fail(ICS_EINVAL, "MK = %d", MK);
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)3 * MK * MK;
+  float* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * 4));
+  hipError_t e = hipMemcpyAsync(d, kern, n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) { hipLaunchKernelGGL(k_normalize, dim3(1), dim3(256), 0, c->stream, d, MK); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipMemcpyAsync(kern, d, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d);
+  if (e != hipSuccess) return fail(ICS_EHIP, "normalize_kernel: %s", hipGetErrorString(e));
+  return ICS_OK;
+}
+
+extern "C" int ics_tv(ics_ctx* c, const float* u, int M, int N, float eps, int order, int norm, float* out, float* div) {
+  if (!c || !u || !out || !div) return fail(ICS_EINVAL, "NULL argument");
+  if ((order != 1 && order != 2) || (norm != 1 && norm != 2)) return fail(ICS_EINVAL, "order/norm must be 1 or 2");
+  if (M < 1 || N < 1) return fail(ICS_EINVAL, "size %dx%d", M, N);
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)M * N * 3;
+  float *du = nullptr, *dout = nullptr, *ddiv = nullptr;
+  hipError_t e = hipMalloc((void**)&du, n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&ddiv, n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(du, u, n * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(dout, 0, n * 4, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ddiv, 0, n * 4, c->stream);
+  if (e == hipSuccess) e = ics_launch_tv(du, M, N, eps, order, norm, dout, ddiv, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(div, ddiv, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(du); hipFree(dout); hipFree(ddiv);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "tv: %s", hipGetErrorString(e));
+  return ICS_OK;
+}
+
+static int conv2d_common(ics_ctx* c, const double* src, int H, int W, const double* kern, int KH, int KW, int usm, double amount, double* out) {
+  if (!c || !src || !kern || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (H < 1 || W < 1 || KH < 1 || KW < 1) return fail(ICS_EINVAL, "bad sizes");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)H * W, nk = (size_t)KH * KW;
+  double *ds = nullptr, *dk = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dk, nk * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dk, kern, nk * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = ics_launch_conv2d_symm(ds, H, W, dk, KH, KW, dout, usm, amount, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(ds); hipFree(dk); hipFree(dout);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "conv2d_symm: %s", hipGetErrorString(e));
+  return ICS_OK;
+}
+
+extern "C" int ics_conv2d_symm(ics_ctx* c, const double* src, int H, int W, const double* kern, int KH, int KW, double* out) {
+  return conv2d_common(c, src, H, W, kern, KH, KW, 0, 0.0, out);
+}
+extern "C" int ics_usm(ics_ctx* c, const double* src, int H, int W, const double* kern, int KH, int KW, double amount, double* out) {
+  return conv2d_common(c, src, H, W, kern, KH, KW, 1, amount, out);
+}
+
+extern "C" int ics_bilateral(ics_ctx* c, const double* src, int H, int W, int radius, double std_i, double std_s, double* out) {
+  if (!c || !src || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (H < 1 || W < 1 || radius < 0) return fail(ICS_EINVAL, "bad sizes");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)H * W;
+  double *ds = nullptr, *dout = nullptr;
+  hipError_t e = hipMalloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = ics_launch_bilateral(ds, H, W, radius, std_i, std_s, dout, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(ds); hipFree(dout);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "bilateral: %s", hipGetErrorString(e));
+  return ICS_OK;
+}

@@ -1,0 +1,100 @@
+// ics_common.h -- shared definitions for the gfx950 kernels of libics_hip.so.
+//
+// Device data layout ("frames").  Every full-size array of the reference loop
+// (lib/deconvolution.pyx:378-390: u, ut, gradu, image, error) lives in one common geometry,
+// expressed in the coordinates of `u` (the "u-frame", (M+2pad) x (N+2pad) x 3, HWC fp32):
+//
+//        <- ax px -><------------ uN px (tiles of 64) ------------->< slack ><- ax ->
+//   ay rows of zeros (ay >= pad)
+//   +----------------+--------------------------------------------------------------+
+//   | apron (zeros)  |  u-frame rows 0..uM-1; the image/error live at (+pad,+pad)   |
+//   ...
+//   slack rows up to a multiple of 64, then ay rows of zeros
+//
+//   * pitch (floats per row) is a multiple of 64 floats (256 B) and ax is a multiple of 4 px, so
+//     every 64-px tile row starts 16-B aligned for dwordx4 traffic although a pixel is 12 B.
+//   * the apron is >= pad on every side and is never written, so convolution tiles load their
+//     halo without bounds checks and the `full` back-projection (pyx:491) sees its zero
+//     extension for free.
+//   * `image`, `error` use the same geometry shifted by (+pad,+pad) and are zero outside M x N.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ICS_TILE 64 /* tile edge in pixels; frames are padded to a multiple of it */
+
+struct IcsGeom {
+  int M, N;      // image size
+  int K, pad;    // PSF size and K/2
+  int uM, uN;    // u-frame size = M+2pad, N+2pad
+  int ax, ay;    // apron: ax px left/right (multiple of 4, >= pad), ay rows top/bottom (>= pad)
+  int pitch;     // floats per row
+  int rows;      // allocated rows
+  int tiles_x, tiles_y;
+  int wrow;      // floats per packed PSF row = round_up(3*K, 4)
+};
+
+static inline IcsGeom ics_make_geom(int M, int N, int K) {
+  IcsGeom g;
+  g.M = M; g.N = N; g.K = K; g.pad = K / 2;
+  g.uM = M + 2 * g.pad; g.uN = N + 2 * g.pad;
+  // 16*nb: the PSF-gradient kernel (ics_kernels.hip, k_gradk) evaluates 16x16 blocks of taps with
+  // MFMA and therefore touches up to 16*nb rows/pixels around a tile
+  const int nb = (K + 15) / 16;
+  g.ax = (g.pad + 3) & ~3; if (g.ax < 16 * nb) g.ax = 16 * nb;
+  g.ay = 16 * nb;
+  g.tiles_x = (g.uN + ICS_TILE - 1) / ICS_TILE;
+  g.tiles_y = (g.uM + ICS_TILE - 1) / ICS_TILE;
+  int px = g.ax + g.tiles_x * ICS_TILE + g.ax;
+  g.pitch = ((3 * px + 63) / 64) * 64;
+  g.rows = g.ay + g.tiles_y * ICS_TILE + g.ay + 1;  // +1: slack row for tiles that over-read
+  g.wrow = (3 * K + 3) & ~3;
+  return g;
+}
+static inline size_t ics_frame_floats(const IcsGeom& g) { return (size_t)g.rows * g.pitch; }
+static inline size_t ics_origin_offset(const IcsGeom& g) { return (size_t)g.ay * g.pitch + 3 * (size_t)g.ax; }
+
+// Order-preserving float <-> uint32 key so that atomicMax/atomicMin on the key is a float max/min.
+// Key 0 is below every float (used as the "empty" value for max), 0xFFFFFFFF above (for min).
+__host__ __device__ static inline uint32_t ics_f2key(float f) {
+  union { float f; uint32_t u; } v; v.f = f;
+  return (v.u & 0x80000000u) ? ~v.u : (v.u | 0x80000000u);
+}
+__host__ __device__ static inline float ics_key2f(uint32_t k) {
+  union { float f; uint32_t u; } v;
+  v.u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return v.f;
+}
+
+// Reduction slots written by the back-projection kernel (one set per inner iteration).
+#define ICS_RED_MAXG 0 /* 3 keys: max |gradu_k| after A6 (pyx:524)  */
+#define ICS_RED_MAXU 3 /* 3 keys: max u_k                (pyx:524)  */
+#define ICS_RED_STRIDE 8
+
+// Device scalar block (floats), mirrored by ICS_BUF_SCALARS in include/ics_hip.h.
+#define ICS_SC_DT 0
+#define ICS_SC_MAXU 3
+#define ICS_SC_MAXG 6
+#define ICS_SC_DTPSF 9
+#define ICS_SC_MR 10
+#define ICS_SC_HU 11
+#define ICS_SC_VARU 12
+#define ICS_SC_DOFMIN 13
+#define ICS_SC_DOFMAX 14
+#define ICS_SC_COUNT 16
+
+// ---- launchers implemented in the .hip translation units ------------------------------------
+struct IcsConvArgs {
+  const float* in;   // frame origin of the convolved array (u for A1, error for A3)
+  const float* w;    // packed PSF, correlation orientation, [K][wrow]
+  float* out;        // frame origin of the output (error for A1, gradu for A3)
+  const float* f;    // A1: image frame origin
+  const float* u;    // A3: u frame origin   (for the fused A6/A7 reductions)
+  const float* ut;   // A3: ut frame origin
+  uint32_t* red;     // A3: reduction keys (ICS_RED_*)
+  float lambd;
+  IcsGeom g;
+};
+// mode 0 = A1+A2 (valid convolution + residual), mode 1 = A3 (+A6/A7 reductions)
+hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s);
+bool ics_conv_supported(int K);

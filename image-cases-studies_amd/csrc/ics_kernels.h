@@ -1,0 +1,71 @@
+// ics_kernels.h -- launchers of the non-convolution kernels (ics_kernels.hip, ics_stats.hip, ics_filters.hip).
+#pragma once
+#include "ics_common.h"
+
+// ---- A5/A6/A8/A10 (lib/deconvolution.pyx:499-552): image update + DoF blend -------------------
+struct IcsUpdateArgs {
+  float* u;            // frame origin, updated in place
+  const float* ut;     // majoriser (pyx:462)
+  const float* g;      // raw back-projection (A3)
+  const float* f;      // image
+  const uint32_t* red; // reduction keys of this inner iteration (ICS_RED_*)
+  float* scal;         // device scalar block (ICS_SC_*): dt, maxu, maxg are recorded
+  uint32_t* dofkeys;   // [0] = min key, [1] = max key, [2] = NaN flag (only when want_dof)
+  float step, lambd;
+  int blind;
+  int want_dof;
+  IcsGeom geo;
+};
+hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s);
+
+// ---- A13 (pyx:567-571): PSF gradient, fp32 MFMA ------------------------------------------------
+struct IcsGradkArgs {
+  const float* e;   // residual frame origin (zero outside the M x N interior)
+  const float* u;   // u frame origin
+  float* partial;   // [nblocks][3][16nb][16nb] per-workgroup partial sums
+  IcsGeom geo;
+};
+int ics_gradk_blocks(const IcsGeom& g, int cus);  // grid size (persistent workgroups)
+hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s);
+// gradk[a][b][c] = sum over workgroups (double accumulation, fixed order)
+hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s);
+
+// ---- A14-A17 (pyx:574-589) + weight packing ---------------------------------------------------
+struct IcsPsfArgs {
+  float* psf;          // [K][K][3] local psf (pyx: the name `psf` inside the function)
+  const float* gradk;  // [K][K][3]
+  float* wconv;        // [K][wrow] rot180(psf): weights of A1 in correlation orientation
+  float* wcorr;        // [K][wrow] psf:         weights of A3 in correlation orientation
+  float* psf_caller;   // what the caller's array holds (correlation quirk, pyx:585)
+  float* scal;         // ICS_SC_DTPSF recorded
+  int* frozen;         // device flag: caller array detached (pyx:585 rebinding)
+  float step;
+  int K, wrow;
+  int correlation;
+  int do_step;         // 0: only (re)pack the weights from psf
+};
+hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s);
+
+// ---- A18/A19 (pyx:593-638): window statistics and residual-whiteness metric -------------------
+struct IcsStatsArgs {
+  const float* e;      // residual frame origin
+  const float* u;      // u frame origin
+  float* scal;         // ICS_SC_MR / HU / VARU written
+  const uint32_t* dofkeys;
+  float* wsc;          // work scalars (8 floats)
+  float2* z;           // [3][P][P] complex scratch
+  const float2* tw;    // [P/2] twiddles exp(-2 pi i k / P)
+  const float* weights;// [H][W] Gaussian window (pyx:393-404)
+  int top, bottom, left, right;
+  int P, logP;
+  int do_mr;
+  IcsGeom geo;
+};
+hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s);
+hipError_t ics_launch_hasnan(const float* u, const IcsGeom& g, int* flag, hipStream_t s);
+
+// ---- standalone operators ----------------------------------------------------------------------
+hipError_t ics_launch_tv(const float* u, int M, int N, float eps, int order, int norm, float* out, float* div, hipStream_t s);
+hipError_t ics_launch_conv2d_symm(const double* src, int H, int W, const double* kern, int KH, int KW, double* out,
+                                  int usm, double amount, hipStream_t s);
+hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, double std_s, double* out, hipStream_t s);

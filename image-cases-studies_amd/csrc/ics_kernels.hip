@@ -1,0 +1,361 @@
+// ics_kernels.hip -- image update, PSF gradient (MFMA) and PSF step of the RL/MM loop, gfx950.
+#include "ics_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t key_of(float f) {
+  if (f != f) return 0xFFC00000u;  // canonical +NaN: propagates through an integer max like np.amax
+  return ics_f2key(f);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = v > o ? v : o; }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64); v = v < o ? v : o; }
+  return v;
+}
+
+// =================================================================================================
+// A5 + A6 + A8 + A10 (lib/deconvolution.pyx:499-552), one pass over the u-frame.
+//   DoF   = ((gradu - image)/(gradu + image))^2 [ / lambd when non-blind ]      (:499-502, interior)
+//   g     = lambd*gradu + (u - ut)/2.                                           (:519, else-branch)
+//   dt_k  = step*(max u_k + 0)/(max|g_k| + 1e-15)                               (:524, 1/(M*N) == 0)
+//   u    -= dt_k * g                                                            (:531)
+//   u     = (1 - DoF)*u + DoF*image   on the interior                           (:552)
+// A9 (:534-549) subtracts exactly zero from `image` and is therefore omitted.
+// Every operation is rounded separately (__f*_rn) like the reference's C / numpy float32 code.
+// Memory-bound: 4 frame reads + 1 write (60 B/px), dwordx4 on the flattened x*3+c axis.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
+  const IcsGeom& G = a.geo;
+  const int ngx = G.tiles_x * 16;  // groups of 4 px per row
+  const long total = (long)G.uM * ngx;
+  float dt[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float maxu = ics_key2f(a.red[ICS_RED_MAXU + c]);
+    const float maxg = ics_key2f(a.red[ICS_RED_MAXG + c]);
+    dt[c] = __fdiv_rn(__fmul_rn(a.step, maxu), __fadd_rn(maxg, 1e-15f));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.scal[ICS_SC_DT + c] = dt[c]; a.scal[ICS_SC_MAXU + c] = maxu; a.scal[ICS_SC_MAXG + c] = maxg;
+    }
+  }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, knan = 0u;
+  const float lambd = a.lambd;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int y = (int)(gid / ngx);
+    const int xp = 4 * (int)(gid - (long)y * ngx);
+    if (xp >= G.uN) continue;
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
+    float uv[12], tv[12], gv[12], fv[12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 p = reinterpret_cast<const float4*>(a.u + o)[j];
+      const float4 q = reinterpret_cast<const float4*>(a.ut + o)[j];
+      const float4 r = reinterpret_cast<const float4*>(a.g + o)[j];
+      const float4 s = reinterpret_cast<const float4*>(a.f + o)[j];
+      uv[4*j] = p.x; uv[4*j+1] = p.y; uv[4*j+2] = p.z; uv[4*j+3] = p.w;
+      tv[4*j] = q.x; tv[4*j+1] = q.y; tv[4*j+2] = q.z; tv[4*j+3] = q.w;
+      gv[4*j] = r.x; gv[4*j+1] = r.y; gv[4*j+2] = r.z; gv[4*j+3] = r.w;
+      fv[4*j] = s.x; fv[4*j+1] = s.y; fv[4*j+2] = s.z; fv[4*j+3] = s.w;
+    }
+    const bool yin = (y >= G.pad) && (y < G.pad + G.M);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int x = xp + p;
+      const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int i = 3 * p + c;
+        const float g = __fadd_rn(__fmul_rn(lambd, gv[i]), __fmul_rn(__fsub_rn(uv[i], tv[i]), 0.5f));
+        float un = __fsub_rn(uv[i], __fmul_rn(dt[c], g));
+        if (inside) {
+          const float d = __fdiv_rn(__fsub_rn(gv[i], fv[i]), __fadd_rn(gv[i], fv[i]));
+          float D = __fmul_rn(d, d);
+          if (!a.blind) D = __fdiv_rn(D, lambd);
+          un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fv[i]));
+          if (a.want_dof) {
+            if (D != D) knan = 1u;
+            else { const uint32_t k = ics_f2key(D); kmin = kmin < k ? kmin : k; kmax = kmax > k ? kmax : k; }
+          }
+        }
+        uv[i] = un;
+      }
+    }
+    if (xp + 3 < G.uN) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        reinterpret_cast<float4*>(a.u + o)[j] = make_float4(uv[4*j], uv[4*j+1], uv[4*j+2], uv[4*j+3]);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (xp + p < G.uN) { a.u[o + 3*p] = uv[3*p]; a.u[o + 3*p + 1] = uv[3*p+1]; a.u[o + 3*p + 2] = uv[3*p+2]; }
+    }
+  }
+  if (a.want_dof) {  // wave shuffle -> one atomic per wave (grid is capped, so a few thousand atomics)
+    kmin = wave_min_u32(kmin); kmax = wave_max_u32(kmax); knan = wave_max_u32(knan);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(a.dofkeys + 0, kmin); atomicMax(a.dofkeys + 1, kmax);
+      if (knan) atomicOr(a.dofkeys + 2, 1u);
+    }
+  }
+}
+
+// =================================================================================================
+// A13 (lib/deconvolution.pyx:567-571): gradk = convolve(rot180(u), error, "valid"), i.e.
+//     gradk[a, b, c] = sum_{y,x} E[y, x, c] * U[y + pad - a, x + pad - b, c]      (u-frame coords)
+// 3*K*K outputs, each an M*N-term dot product.  Unlike the image convolutions this IS a dense
+// contraction: for one image row y and channel c,
+//     D[a][b] += sum_k A[a][k] * B[k][b],   A[a][k] = U[y+pad-a][xk],  B[k][b] = E[y][xk - pad + b]
+// with the long pixel axis as K, so it runs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact
+// fp32 == an fmaf chain) at (K/16)^2 = 88 % useful work for a 15x15 PSF.  rot180(u) (A12, pyx:567)
+// is never materialised: the flip is the minus sign in the indices.
+// Workgroups are persistent (grid-stride over 64x32-px tiles) and keep their 16x16 accumulators in
+// registers across tiles; one partial block per workgroup is written at the end and reduced in
+// double, in a fixed order, by k_gradk_reduce (deterministic, no float atomics).
+// =================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+struct GradkCfg {
+  static constexpr int TW = 64, TH = 32, NT = 16 * NB;
+  static constexpr int UROWS = TH + NT - 1;
+  static constexpr int LWU = 3 * TW + 2;          // == 2 (mod 32): the 16 rows x 2 k of an A read hit 32 banks
+  static constexpr int EPX = TW + 24 * NB;        // E pixels staged per row: [x0 - 8NB, x0 + 64 + 16NB)
+  static constexpr int LWE = 3 * EPX;
+  static constexpr size_t LDS_FLOATS = (size_t)UROWS * LWU + (size_t)TH * LWE;
+  static constexpr size_t RED_FLOATS = 4 * 3 * NB * NB * 256;
+  static constexpr size_t LDS_BYTES = 4 * (LDS_FLOATS > RED_FLOATS ? LDS_FLOATS : RED_FLOATS);
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
+  using C = GradkCfg<NB>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* ul = lds;
+  float* el = lds + C::UROWS * C::LWU;
+  const IcsGeom& G = a.geo;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int ntx = G.tiles_x, nty = G.tiles_y * (ICS_TILE / C::TH);
+  const int pad = G.pad, pitch = G.pitch;
+
+  f32x4 acc[3][NB][NB];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[c][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+    const int x0 = (t % ntx) * C::TW, y0 = (t / ntx) * C::TH;
+    __syncthreads();  // previous tile fully consumed
+    {  // U rows [y0 + pad - NT + 1, y0 + pad + TH), px [x0, x0 + 64)
+      const float* src = a.u + (ptrdiff_t)(y0 + pad - C::NT + 1) * pitch + 3 * x0;
+      constexpr int W4 = 3 * C::TW / 4;
+      for (int v = tid; v < C::UROWS * W4; v += 256) {
+        const int row = v / W4, c4 = v - row * W4;
+        const float4 val = *reinterpret_cast<const float4*>(src + (ptrdiff_t)row * pitch + 4 * c4);
+        float2* d = reinterpret_cast<float2*>(ul + row * C::LWU + 4 * c4);  // LWU rows are only 8-B aligned
+        d[0] = make_float2(val.x, val.y); d[1] = make_float2(val.z, val.w);
+      }
+      // E rows [y0, y0 + TH), px [x0 - 8NB, x0 + 64 + 16NB)
+      const float* srce = a.e + (ptrdiff_t)y0 * pitch + 3 * (x0 - 8 * NB);
+      constexpr int E4 = C::LWE / 4;
+      for (int v = tid; v < C::TH * E4; v += 256) {
+        const int row = v / E4, c4 = v - row * E4;
+        *reinterpret_cast<float4*>(el + row * C::LWE + 4 * c4) =
+            *reinterpret_cast<const float4*>(srce + (ptrdiff_t)row * pitch + 4 * c4);
+      }
+    }
+    __syncthreads();
+    // wave w owns tile rows [8w, 8w+8)
+    for (int yy = wave * (C::TH / 4); yy < (wave + 1) * (C::TH / 4); ++yy) {
+      const float* arow = ul + (yy + C::NT - 1 - m) * C::LWU + 3 * q;           // + 12*xk + c, - 16*ab rows
+      const float* brow = el + yy * C::LWE + 3 * (q + m + 8 * NB - pad);       // + 12*xk + c, + 48*bb
+#pragma unroll 4
+      for (int xk = 0; xk < C::TW / 4; ++xk) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float av[NB], bv[NB];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) av[i] = arow[12 * xk + c - 16 * i * C::LWU];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) bv[j] = brow[12 * xk + c + 48 * j];
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[c][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[c][i][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- cross-wave reduction (fixed order) and partial write -----------------------------------
+  __syncthreads();
+  float* red = lds;  // [wave][c][ab][bb][256]: element (row = 4*q + j, col = m) at [j*64 + lane]
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          red[(((wave * 3 + c) * NB + i) * NB + j) * 256 + r * 64 + lane] = acc[c][i][j][r];
+  __syncthreads();
+  constexpr int PER = 3 * NB * NB * 256;
+  float* dst = a.partial + (size_t)blockIdx.x * (3 * C::NT * C::NT);
+  for (int v = tid; v < PER; v += 256) {
+    const float s = ((red[v] + red[PER + v]) + red[2 * PER + v]) + red[3 * PER + v];
+    // v = ((c*NB + i)*NB + j)*256 + r*64 + l  ->  a = 16 i + 4 (l>>4) + r, b = 16 j + (l & 15)
+    const int l = v & 63, r = (v >> 6) & 3, blk = v >> 8;
+    const int j = blk % NB, i = (blk / NB) % NB, c = blk / (NB * NB);
+    const int ta = 16 * i + 4 * (l >> 4) + r, tb = 16 * j + (l & 15);
+    dst[(c * C::NT + ta) * C::NT + tb] = s;
+  }
+}
+
+// gradk[a][b][c] = float( sum_blocks double(partial) ): 32 lanes per output, fixed order.
+__global__ __launch_bounds__(256) void k_gradk_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ gradk, int K, int NT) {
+  const int o = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
+  const int n = 3 * K * K;
+  double s = 0.0;
+  int c = 0, ta = 0, tb = 0;
+  if (o < n) {
+    tb = o % K; ta = (o / K) % K; c = o / (K * K);
+    const size_t stride = (size_t)3 * NT * NT;
+    const float* p = partial + (size_t)(c * NT + ta) * NT + tb;
+    for (int b = sub; b < nblocks; b += 32) s += (double)p[b * stride];
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 32);
+  if (o < n && sub == 0) gradk[(ta * K + tb) * 3 + c] = (float)s;
+}
+
+// =================================================================================================
+// A14-A17 (lib/deconvolution.pyx:574-589) + packing of the convolution weights.  One workgroup.
+//   dtpsf = step/MK * (max psf + 0) / (max|gradk| + 1e-15)       (:574, global over 3 channels)
+//   psf  -= dtpsf * gradk                                         (:577-581)
+//   correlation: psf = dstack(mean_c psf x3)                      (:584-585; rebinding: the caller's
+//                array keeps the state after the first gradient step, `psf_caller`/`frozen`)
+//   clamp < 0 -> 0, divide each channel by its sequential float32 sum   (:587 -> :47-70)
+//   psf_rotated = rot180(psf)                                     (:589) -> wconv
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* p = lds;                       // 3*K*K
+  __shared__ uint32_t sred[8];
+  __shared__ float ssum[4];
+  const int K = a.K, n = 3 * K * K, tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) p[i] = a.psf[i];
+  if (tid < 8) sred[tid] = 0u;
+  __syncthreads();
+  if (a.do_step) {
+    uint32_t kp = 0u, kg = 0u;
+    for (int i = tid; i < n; i += 256) {
+      const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(a.gradk[i]));
+      kp = kp > k1 ? kp : k1; kg = kg > k2 ? kg : k2;
+    }
+    kp = wave_max_u32(kp); kg = wave_max_u32(kg);
+    if ((tid & 63) == 0) { atomicMax(&sred[0], kp); atomicMax(&sred[1], kg); }
+    __syncthreads();
+    const float maxp = ics_key2f(sred[0]), maxg = ics_key2f(sred[1]);
+    const float dtpsf = __fdiv_rn(__fmul_rn(__fdiv_rn(a.step, (float)K), maxp), __fadd_rn(maxg, 1e-15f));
+    if (tid == 0) a.scal[ICS_SC_DTPSF] = dtpsf;
+    const int frozen = *a.frozen;
+    for (int i = tid; i < n; i += 256) {
+      p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, a.gradk[i]));
+      if (!frozen) a.psf_caller[i] = p[i];
+    }
+    __syncthreads();
+    if (a.correlation) {
+      for (int i = tid; i < K * K; i += 256) {
+        const float mval = __fdiv_rn(__fadd_rn(__fadd_rn(p[3*i], p[3*i+1]), p[3*i+2]), 3.0f);
+        p[3*i] = mval; p[3*i+1] = mval; p[3*i+2] = mval;
+      }
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) if (p[i] < 0.f) p[i] = 0.f;
+    __syncthreads();
+    if (tid < 3) {  // sequential float32 sum in the reference's order (i, j) -- pyx:58-64
+      float s = 0.f;
+      for (int i = 0; i < K * K; ++i) s = __fadd_rn(s, p[3 * i + tid]);
+      ssum[tid] = s;
+    }
+    __syncthreads();
+    const bool detach = a.correlation != 0;
+    for (int i = tid; i < n; i += 256) {
+      p[i] = __fdiv_rn(p[i], ssum[i % 3]);
+      a.psf[i] = p[i];
+      if (!frozen && !detach) a.psf_caller[i] = p[i];
+    }
+    if (tid == 0 && detach) *a.frozen = 1;
+    __syncthreads();
+  }
+  // pack: wcorr[a][3b+c] = psf[a][b][c];  wconv[a][3b+c] = psf[K-1-a][K-1-b][c]; row padding zeroed
+  for (int i = tid; i < K * a.wrow; i += 256) {
+    const int ra = i / a.wrow, rc = i - ra * a.wrow;
+    float v1 = 0.f, v2 = 0.f;
+    if (rc < 3 * K) {
+      const int b = rc / 3, c = rc - 3 * b;
+      v1 = p[(ra * K + b) * 3 + c];
+      v2 = p[((K - 1 - ra) * K + (K - 1 - b)) * 3 + c];
+    }
+    a.wcorr[i] = v1; a.wconv[i] = v2;
+  }
+}
+
+}  // namespace
+
+hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
+  const long total = (long)a.geo.uM * a.geo.tiles_x * 16;
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(k_update, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+int ics_gradk_blocks(const IcsGeom& g, int cus) {
+  const int nb = (g.K + 15) / 16;
+  const int tiles = g.tiles_x * g.tiles_y * 2;
+  int blocks = cus * (nb == 1 ? 2 : 1);
+  return blocks < tiles ? blocks : tiles;
+}
+
+template <int NB>
+static hipError_t launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+  using C = GradkCfg<NB>;
+  static bool configured = false;
+  auto kern = k_gradk<NB>;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    configured = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), C::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+  const int nb = (a.geo.K + 15) / 16;
+  if (nb == 1) return launch_gradk<1>(a, nblocks, s);
+  if (nb == 2) return launch_gradk<2>(a, nblocks, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s) {
+  const int n = 3 * g.K * g.K;
+  const int nt = 16 * ((g.K + 15) / 16);
+  hipLaunchKernelGGL(k_gradk_reduce, dim3((n * 32 + 255) / 256), dim3(256), 0, s, partial, nblocks, gradk, g.K, nt);
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_psf, dim3(1), dim3(256), (size_t)3 * a.K * a.K * sizeof(float), s, a);
+  return hipGetLastError();
+}

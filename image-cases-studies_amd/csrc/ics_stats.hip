@@ -1,0 +1,210 @@
+// ics_stats.hip -- per-outer-iteration statistics and the residual-whiteness stop metric, on device.
+//
+//   A18 (lib/deconvolution.pyx:600-601): varu = std(u[window])^2,  Hu = ||error[window]||^2 / (n*3)
+//   A19 (lib/deconvolution.pyx:627-638): t = (e - mean e)/std e;  t /= max|t|;
+//        per channel  ac = convolve(t, rot180 t, "same");  M_r = mean(ac^2 * w)
+// The reference evaluates the autocorrelation with scipy's FFT convolution (pyx:632).  Here the
+// window (<= 1024 px) is zero-padded to a power of two P >= 2*max(H,W)-1 and autocorrelated by
+// Wiener-Khinchin with a radix-2 Stockham FFT that runs entirely in LDS (one line per workgroup):
+// rows, columns, |Z|^2, inverse columns, inverse rows.  3*P*P complex64 = 6 MB for a 255^2 window,
+// a few tens of microseconds per outer iteration, so the stop test never leaves the GPU.
+#include "ics_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) s += sh[i];
+  return s;
+}
+__device__ __forceinline__ float block_maxf(float v, float* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) { const float o = __shfl_xor(v, off, 64); v = (v > o || v != v) ? v : o; }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = sh[0];
+  const int nw = blockDim.x >> 6;
+  for (int i = 1; i < nw; ++i) { const float o = sh[i]; s = (s > o || s != s) ? s : o; }
+  return s;
+}
+
+// wsc: [0]=mean_e [1]=std_e [2]=max|t| [3]=Hu [4]=varu
+__global__ __launch_bounds__(1024) void k_win_moments(IcsStatsArgs a) {
+  __shared__ double shd[16];
+  __shared__ float shf[16];
+  const IcsGeom& G = a.geo;
+  const int H = a.bottom - a.top, W = a.right - a.left, pad = G.pad;
+  const int ne = H * W * 3;
+  // error window [top:bottom, left:right] (image coords -> u-frame +pad)
+  double s = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+    const int r = i / (3 * W), c = i - r * 3 * W;
+    const float v = a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c];
+    s += v; s2 += (double)v * v;
+  }
+  s = block_sum(s, shd); s2 = block_sum(s2, shd);
+  const float mean_e = (float)(s / ne);
+  const float Hu = (float)(s2 / ((double)H * W * 3));
+  double d2 = 0.0;
+  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+    const int r = i / (3 * W), c = i - r * 3 * W;
+    const float v = __fsub_rn(a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_e);
+    d2 += (double)v * v;
+  }
+  d2 = block_sum(d2, shd);
+  const float std_e = sqrtf((float)(d2 / ne));
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
+    const int r = i / (3 * W), c = i - r * 3 * W;
+    const float v = __fdiv_rn(__fsub_rn(a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_e), std_e);
+    const float av = __builtin_fabsf(v);
+    mx = (mx > av || mx != mx) ? mx : av;
+  }
+  mx = block_maxf(mx, shf);
+  // u window [top+pad : bottom-pad, left+pad : right-pad] in u coordinates (pyx:600)
+  const int Hu_r = (a.bottom - pad) - (a.top + pad), Wu = (a.right - pad) - (a.left + pad);
+  float varu = __builtin_nanf("");
+  if (Hu_r > 0 && Wu > 0) {
+    const int nu = Hu_r * Wu * 3;
+    double su = 0.0;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
+      const int r = i / (3 * Wu), c = i - r * 3 * Wu;
+      su += a.u[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c];
+    }
+    su = block_sum(su, shd);
+    const float mean_u = (float)(su / nu);
+    double du = 0.0;
+    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
+      const int r = i / (3 * Wu), c = i - r * 3 * Wu;
+      const float v = __fsub_rn(a.u[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_u);
+      du += (double)v * v;
+    }
+    du = block_sum(du, shd);
+    const float sd = sqrtf((float)(du / nu));
+    varu = __fmul_rn(sd, sd);
+  }
+  if (threadIdx.x == 0) {
+    a.wsc[0] = mean_e; a.wsc[1] = std_e; a.wsc[2] = mx; a.wsc[3] = Hu; a.wsc[4] = varu;
+    a.scal[ICS_SC_HU] = Hu; a.scal[ICS_SC_VARU] = varu;
+    a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[0]);
+    a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[1]);
+  }
+}
+
+// z[c][i][j] = ((e - mean)/std)/max|t| inside the window, 0 elsewhere (zero padding to P x P)
+__global__ __launch_bounds__(256) void k_win_fill(IcsStatsArgs a) {
+  const IcsGeom& G = a.geo;
+  const int H = a.bottom - a.top, W = a.right - a.left, P = a.P, pad = G.pad;
+  const float mean_e = a.wsc[0], std_e = a.wsc[1], mx = a.wsc[2];
+  const long total = 3L * P * P;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int j = (int)(i % P), r = (int)((i / P) % P), c = (int)(i / ((long)P * P));
+    float v = 0.f;
+    if (r < H && j < W) {
+      const float e = a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad + j) + c];
+      v = __fdiv_rn(__fdiv_rn(__fsub_rn(e, mean_e), std_e), mx);
+    }
+    a.z[i] = make_float2(v, 0.f);
+  }
+}
+
+// One P-point complex FFT per workgroup (P/2 threads), radix-2 Stockham autosort in LDS.
+// element j of line `b` lives at data[b_off + j*stride]; forward: exp(-i...), inverse: conjugate, unscaled.
+__global__ void k_fft(float2* data, int P, int logP, long stride_elem, long line_stride, int lines_per_plane,
+                      long plane_stride, int inverse, const float2* __restrict__ tw) {
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  float2* x = sm;
+  float2* y = sm + P;
+  const int t = P >> 1, tid = threadIdx.x;
+  const int line = blockIdx.x;
+  float2* base = data + (long)(line / lines_per_plane) * plane_stride + (long)(line % lines_per_plane) * line_stride;
+  x[tid] = base[(long)tid * stride_elem];
+  x[tid + t] = base[(long)(tid + t) * stride_elem];
+  __syncthreads();
+  for (int s = 0, p = 1; s < logP; ++s, p <<= 1) {
+    const int k = tid & (p - 1);
+    const int j = ((tid - k) << 1) + k;
+    float2 w = tw[k * (t / p)];
+    if (inverse) w.y = -w.y;
+    const float2 u0 = x[tid], v = x[tid + t];
+    const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+    y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+    y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    __syncthreads();
+    float2* tmp = x; x = y; y = tmp;
+  }
+  base[(long)tid * stride_elem] = x[tid];
+  base[(long)(tid + t) * stride_elem] = x[tid + t];
+}
+
+__global__ __launch_bounds__(256) void k_abs2(float2* z, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float2 v = z[i];
+    z[i] = make_float2(v.x * v.x + v.y * v.y, 0.f);
+  }
+}
+
+// M_r = mean over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
+__global__ __launch_bounds__(1024) void k_mr(IcsStatsArgs a) {
+  __shared__ double shd[16];
+  const int H = a.bottom - a.top, W = a.right - a.left, P = a.P;
+  const float inv = 1.0f / ((float)P * (float)P);
+  double s = 0.0;
+  const int n = H * W * 3;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int b = i % W, r = (i / W) % H, c = i / (W * H);
+    const int zr = (r - H / 2 + P) & (P - 1), zc = (b - W / 2 + P) & (P - 1);
+    const float ac = a.z[((long)c * P + zr) * P + zc].x * inv;
+    s += (double)__fmul_rn(__fmul_rn(ac, ac), a.weights[r * W + b]);
+  }
+  s = block_sum(s, shd);
+  if (threadIdx.x == 0) a.scal[ICS_SC_MR] = (float)(s / n);
+}
+
+__global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* flag) {
+  const int ngx = G.tiles_x * 16;
+  const long total = (long)G.uM * ngx;
+  int bad = 0;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int y = (int)(gid / ngx), xp = 4 * (int)(gid - (long)y * ngx);
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
+    for (int p = 0; p < 4; ++p)
+      if (xp + p < G.uN)
+        for (int c = 0; c < 3; ++c) { const float v = u[o + 3 * p + c]; bad |= (v != v); }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+}  // namespace
+
+hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_win_moments, dim3(1), dim3(1024), 0, s, a);
+  if (a.do_mr) {
+    const int P = a.P;
+    const long total = 3L * P * P;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_win_fill, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    const size_t lds = 2 * (size_t)P * sizeof(float2);
+    const long plane = (long)P * P;
+    // rows: line = row, elements contiguous; columns: line = column, element stride P
+    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, 1L, (long)P, P, plane, 0, a.tw);
+    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, (long)P, 1L, P, plane, 0, a.tw);
+    hipLaunchKernelGGL(k_abs2, dim3((unsigned)blocks), dim3(256), 0, s, a.z, total);
+    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, (long)P, 1L, P, plane, 1, a.tw);
+    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, 1L, (long)P, P, plane, 1, a.tw);
+    hipLaunchKernelGGL(k_mr, dim3(1), dim3(1024), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_hasnan(const float* u, const IcsGeom& g, int* flag, hipStream_t s) {
+  hipLaunchKernelGGL(k_hasnan, dim3(2048), dim3(256), 0, s, u, g, flag);
+  return hipGetLastError();
+}

@@ -1,0 +1,255 @@
+"""ctypes binding of libics_hip.so (C ABI declared in include/ics_hip.h).
+
+This is the only place the product touches native code.  There is deliberately no CPU fallback:
+if the shared library is missing, or no gfx950 device is usable, importing succeeds (so that the
+symbol-level tests can run on a GPU-less machine) but every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libics_hip.so"))
+
+ICS_MAX_TRACE = 1024
+ICS_KERNEL_COUNT = 8
+KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "-")
+
+# error codes (include/ics_hip.h)
+ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
+
+# stages / buffers
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS = range(1, 8)
+BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS = range(8)
+SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
+                "dof_min", "dof_max", "_")
+
+
+class RLParams(C.Structure):
+    _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
+                ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
+                ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
+                ("stop_test", C.c_int), ("profile", C.c_int), ("reserved", C.c_int * 3)]
+
+
+class RLStats(C.Structure):
+    _fields_ = [("iterations_done", C.c_int), ("stopped", C.c_int), ("has_nan", C.c_int),
+                ("M_r", C.c_float), ("Hu", C.c_float), ("varu", C.c_float),
+                ("dof_min", C.c_float), ("dof_max", C.c_float), ("trace_len", C.c_int),
+                ("trace_M_r", C.c_float * ICS_MAX_TRACE), ("trace_Hu", C.c_float * ICS_MAX_TRACE),
+                ("trace_varu", C.c_float * ICS_MAX_TRACE), ("trace_dof_min", C.c_float * ICS_MAX_TRACE),
+                ("trace_dof_max", C.c_float * ICS_MAX_TRACE),
+                ("ms_total", C.c_float), ("inner_iterations", C.c_int),
+                ("ms_kernel", C.c_float * ICS_KERNEL_COUNT), ("launches", C.c_int * ICS_KERNEL_COUNT)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libics_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def _fp(dtype):
+    return np.ctypeslib.ndpointer(dtype=dtype, flags="C_CONTIGUOUS")
+
+
+def load():
+    """dlopen libics_hip.so and declare the prototypes.  Raises ImportError loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError("libics_hip.so not found at %s -- build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                          "(or `make -C image-cases-studies_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cf, cd = C.c_void_p, C.c_int, C.c_float, C.c_double
+    lib.ics_abi_version.restype = ci
+    lib.ics_last_error.restype = C.c_char_p
+    lib.ics_device_count.argtypes = [C.POINTER(ci)]
+    lib.ics_ctx_create.argtypes = [ci, C.POINTER(vp)]
+    lib.ics_ctx_destroy.argtypes = [vp]; lib.ics_ctx_destroy.restype = None
+    lib.ics_ctx_synchronize.argtypes = [vp]
+    lib.ics_ctx_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(ci), C.POINTER(C.c_uint64)]
+    lib.ics_rl_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
+    lib.ics_rl_destroy.argtypes = [vp]; lib.ics_rl_destroy.restype = None
+    lib.ics_rl_upload.argtypes = [vp, vp, vp, vp]
+    lib.ics_rl_download.argtypes = [vp, vp, vp, vp]
+    lib.ics_rl_run.argtypes = [vp, C.POINTER(RLParams), C.POINTER(RLStats)]
+    lib.ics_rl_stage.argtypes = [vp, ci, C.POINTER(RLParams)]
+    lib.ics_rl_read.argtypes = [vp, ci, vp, C.c_size_t]
+    lib.ics_rl_write.argtypes = [vp, ci, vp, C.c_size_t]
+    lib.ics_normalize_kernel.argtypes = [vp, vp, ci]
+    lib.ics_tv.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp]
+    lib.ics_conv2d_symm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
+    lib.ics_usm.argtypes = [vp, vp, ci, ci, vp, ci, ci, cd, vp]
+    lib.ics_bilateral.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp]
+    for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
+                 "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_normalize_kernel",
+                 "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral"):
+        getattr(lib, name).restype = ci
+    if lib.ics_abi_version() != 1:
+        raise ImportError("libics_hip.so ABI version %d, expected 1" % lib.ics_abi_version())
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != ICS_OK:
+        raise NativeError(rc, load().ics_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().ics_device_count(C.byref(n))
+    return n.value if rc == ICS_OK else 0
+
+
+def default_device():
+    """One process per GPU: LOCAL_RANK picks the device (torchrun / bench.py), ICS_DEVICE overrides."""
+    return int(os.environ.get("ICS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+class Context:
+    """ics_ctx: one HIP stream on one gfx950 device."""
+    _cache = {}
+
+    def __init__(self, device=None):
+        lib = load()
+        self.device = default_device() if device is None else int(device)
+        h = C.c_void_p()
+        _check(lib.ics_ctx_create(self.device, C.byref(h)))
+        self._h = h
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        hbm = C.c_uint64(0)
+        _check(lib.ics_ctx_info(h, name, 256, C.byref(cus), C.byref(hbm)))
+        self.name, self.compute_units, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
+
+    @classmethod
+    def get(cls, device=None):
+        device = default_device() if device is None else int(device)
+        if device not in cls._cache:
+            cls._cache[device] = cls(device)
+        return cls._cache[device]
+
+    def synchronize(self):
+        _check(load().ics_ctx_synchronize(self._h))
+
+    # ---- standalone operators ---------------------------------------------------------------
+    def normalize_kernel(self, kern, MK):
+        _check(load().ics_normalize_kernel(self._h, _ptr(kern), int(MK)))
+
+    def tv(self, u, epsilon, order, norm):
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        out, div = np.empty_like(u), np.empty_like(u)
+        _check(load().ics_tv(self._h, _ptr(u), u.shape[0], u.shape[1], float(epsilon), int(order), int(norm), _ptr(out), _ptr(div)))
+        return out, div
+
+    def conv2d_symm(self, src, kern):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        kern = np.ascontiguousarray(kern, dtype=np.float64)
+        out = np.empty_like(src)
+        _check(load().ics_conv2d_symm(self._h, _ptr(src), src.shape[0], src.shape[1], _ptr(kern), kern.shape[0], kern.shape[1], _ptr(out)))
+        return out
+
+    def usm(self, src, kern, amount):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        kern = np.ascontiguousarray(kern, dtype=np.float64)
+        out = np.empty_like(src)
+        _check(load().ics_usm(self._h, _ptr(src), src.shape[0], src.shape[1], _ptr(kern), kern.shape[0], kern.shape[1], float(amount), _ptr(out)))
+        return out
+
+    def bilateral(self, src, radius, std_i, std_s):
+        src = np.ascontiguousarray(src, dtype=np.float64)
+        out = np.empty_like(src)
+        _check(load().ics_bilateral(self._h, _ptr(src), src.shape[0], src.shape[1], int(radius), float(std_i), float(std_s), _ptr(out)))
+        return out
+
+
+class RLJob:
+    """ics_rl: device-resident frames of one richardson_lucy_MM problem (M x N x 3, MK x MK x 3)."""
+
+    def __init__(self, M, N, MK, ctx=None):
+        self.ctx = ctx or Context.get()
+        self.M, self.N, self.MK = int(M), int(N), int(MK)
+        self.pad = self.MK // 2
+        self.uM, self.uN = self.M + 2 * self.pad, self.N + 2 * self.pad
+        h = C.c_void_p()
+        _check(load().ics_rl_create(self.ctx._h, self.M, self.N, self.MK, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ics_rl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _shape(self, which):
+        if which in (BUF_U, BUF_UT, BUF_GRADU):
+            return (self.uM, self.uN, 3)
+        if which in (BUF_IMAGE, BUF_ERROR):
+            return (self.M, self.N, 3)
+        if which in (BUF_PSF, BUF_GRADK):
+            return (self.MK, self.MK, 3)
+        return (16,)
+
+    def upload(self, image, u, psf):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        psf = np.ascontiguousarray(psf, dtype=np.float32)
+        assert image.shape == (self.M, self.N, 3) and u.shape == (self.uM, self.uN, 3) and psf.shape == (self.MK, self.MK, 3), \
+            (image.shape, u.shape, psf.shape)
+        _check(load().ics_rl_upload(self._h, _ptr(image), _ptr(u), _ptr(psf)))
+
+    def download(self):
+        u = np.empty((self.uM, self.uN, 3), np.float32)
+        psf_local = np.empty((self.MK, self.MK, 3), np.float32)
+        psf_caller = np.empty((self.MK, self.MK, 3), np.float32)
+        _check(load().ics_rl_download(self._h, _ptr(u), _ptr(psf_local), _ptr(psf_caller)))
+        return u, psf_local, psf_caller
+
+    def read(self, which):
+        out = np.empty(self._shape(which), np.float32)
+        _check(load().ics_rl_read(self._h, which, _ptr(out), out.size))
+        return out
+
+    def write(self, which, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        assert arr.shape == self._shape(which), (arr.shape, self._shape(which))
+        _check(load().ics_rl_write(self._h, which, _ptr(arr), arr.size))
+
+    def scalars(self):
+        return dict(zip(SCALAR_NAMES, self.read(BUF_SCALARS).tolist()))
+
+    @staticmethod
+    def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
+               stop_test=1, profile=0):
+        p = RLParams()
+        p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
+        p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
+        p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), 0
+        p.stop_test, p.profile = int(stop_test), int(profile)
+        return p
+
+    def run(self, params):
+        st = RLStats()
+        _check(load().ics_rl_run(self._h, C.byref(params), C.byref(st)))
+        return st
+
+    def stage(self, stage, params):
+        _check(load().ics_rl_stage(self._h, int(stage), C.byref(params)))

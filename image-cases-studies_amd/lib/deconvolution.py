@@ -1,0 +1,110 @@
+"""Drop-in for the reference's compiled module `lib.deconvolution` (lib/deconvolution.pyx).
+
+Same public names, argument order and side effects as the reference:
+
+    richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations,
+                       step_factor, lambd, blind=True, correlation=False, p=1., norm=1, order=2,
+                       priority=0, refocus=0)            -> lib/deconvolution.pyx:341-342
+    normalize_kernel(kern, MK)                          -> lib/deconvolution.pyx:73-75
+    DTYPE = numpy.float32                                -> lib/deconvolution.pyx:31
+
+but the loop runs on an MI355X through libics_hip.so (hand-written gfx950 kernels, C ABI in
+include/ics_hip.h, bound with ctypes in lib/_native.py).  There is no CPU path in this module.
+
+Behaviour kept from the reference:
+  * `image`, `u`, `psf` must be float32 ndarrays with ndim 3 (any strides); wrong dtype/ndim raise the
+    same ValueError texts Cython's buffer check produces.
+  * `u` is updated IN PLACE and the return value is a VIEW of the caller's `u` (pyx:675).
+  * `psf` is updated in place when `blind`; under `correlation=True` the caller's array only
+    receives the first gradient step because pyx:585 rebinds the local name.
+  * `p, norm, order, priority, refocus` are accepted and ignored; `iterations` counts OUTER
+    iterations of 5 inner ones (pyx:375).
+  * The reference's progress lines are printed (after the device run, from the returned trace).
+Extras: `richardson_lucy_MM.last` holds the `RLStats` of the most recent call.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+
+DTYPE = np.float32
+
+_job_cache = {}
+
+
+def _check_buffer(name, arr):
+    if not isinstance(arr, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)" % (name, type(arr).__name__))
+    if arr.ndim != 3:
+        raise ValueError("Buffer has wrong number of dimensions (expected 3, got %d)" % arr.ndim)
+    if arr.dtype != np.float32:
+        cname = {"float64": "double", "int64": "long", "int32": "int", "uint8": "unsigned char",
+                 "float16": "short"}.get(arr.dtype.name, arr.dtype.name)
+        raise ValueError("Buffer dtype mismatch, expected 'DTYPE_t' but got '%s'" % cname)
+
+
+def _get_job(M, N, MK):
+    """Keep the frames of the last problem size alive: deblur_module calls the solver repeatedly."""
+    key = (int(M), int(N), int(MK), _native.default_device())
+    job = _job_cache.get(key)
+    if job is None:
+        for old in list(_job_cache.values()):
+            old.close()
+        _job_cache.clear()
+        job = _native.RLJob(M, N, MK)
+        _job_cache[key] = job
+    return job
+
+
+def normalize_kernel(kern, MK):
+    """lib/deconvolution.pyx:73-75 -- clamp negatives to 0 and normalise every channel to sum 1, in place."""
+    _check_buffer("kern", kern)
+    MK = int(MK)
+    work = np.ascontiguousarray(kern[:MK, :MK, :3], dtype=np.float32)
+    _native.Context.get().normalize_kernel(work, MK)
+    kern[:MK, :MK, :3] = work
+
+
+def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
+                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0):
+    """Richardson-Lucy blind / non-blind deconvolution by majorisation-minimisation
+    (lib/deconvolution.pyx:341-675), executed on the GPU.  See the module docstring."""
+    _check_buffer("image", image)
+    _check_buffer("u", u)
+    _check_buffer("psf", psf)
+    M, N, MK = int(M), int(N), int(MK)
+    u_M, u_N = u.shape[0], u.shape[1]
+    pad = (u_M - M) // 2                                                       # pyx:376
+    if u.shape != (M + 2 * (MK // 2), N + 2 * (MK // 2), 3) or image.shape != (M, N, 3) or psf.shape != (MK, MK, 3):
+        # the reference does not validate shapes (it would read out of bounds); the GPU path cannot do that
+        raise ValueError("expected image (%d,%d,3), u (%d,%d,3), psf (%d,%d,3); got %s, %s, %s" %
+                         (M, N, M + 2 * (MK // 2), N + 2 * (MK // 2), MK, MK, image.shape, u.shape, psf.shape))
+    job = _get_job(M, N, MK)
+    job.upload(image, u, psf)
+    params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C)
+    st = job.run(params)
+    u_new, _psf_local, psf_caller = job.download()
+    u[...] = u_new                                                             # in place, any strides
+    if blind:
+        psf[...] = psf_caller
+    # the reference's stdout (pyx:593,648,658-672)
+    for it in range(st.trace_len):
+        print("DoF : min = %f | max = %f" % (st.trace_dof_min[it], st.trace_dof_max[it]))
+        if st.stopped and it == st.iterations_done - 1:
+            print("white autocorellation condition met")
+        if (it + 1) % 50 == 0:
+            print("%i iterations completed" % (it + 1))
+    if st.stopped:
+        print("Convergence after %i iterations." % st.iterations_done)
+    else:
+        print("Did not converge after %i iterations. Don't use the result." % st.iterations_done)
+    print("Stats : autocovariance = %.6f | lamdba = %.0f | residual = %.6f | variance/noise = %.6f" % (
+        1000 * st.M_r / ((bottom - top) * (right - left) * 3), np.float32(lambd), st.Hu, st.varu))
+    if st.has_nan:
+        print("has NaN after DoF correction")
+    richardson_lucy_MM.last = st
+    return u[pad:pad + M, pad:pad + N, ...]                                    # pyx:675 (view)
+
+
+richardson_lucy_MM.last = None

@@ -1,0 +1,166 @@
+/*
+ * ics_hip.h -- C ABI of libics_hip.so: the MI355X (gfx950) implementation of the
+ * Richardson-Lucy / MM deconvolution hot path of aurelienpierre/Image-Cases-Studies.
+ *
+ * This is the drop-in boundary.  Everything is `extern "C"`, plain pointers and sizes; host
+ * arrays are float32, C-contiguous, HWC (channel fastest, 3 channels) exactly as the reference
+ * passes numpy buffers to lib/deconvolution.pyx.  Every entry point returns 0 on success or a
+ * negative ICS_E* code; ics_last_error() returns a thread-local description (HIP error string
+ * included).  No entry point falls back to a CPU path: without a usable gfx950 device every
+ * compute call fails with ICS_ENODEV.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   ics_rl_*               lib/deconvolution.pyx:341-675   richardson_lucy_MM (cpdef, :341-342)
+ *   ics_normalize_kernel   lib/deconvolution.pyx:47-75     normalize_kernel (cpdef, :73-75)
+ *   ics_tv                 lib/deconvolution.pyx:137-239   TV (cdef)
+ *   ics_conv2d_symm        lib/utils.py:237-264            bessel_blur / gaussian_blur
+ *                                                          (scipy.signal.convolve2d same/symm)
+ *   ics_usm                lib/utils.py:267-277            USM
+ *   ics_bilateral          lib/utils.py:173-234            bilateral_filter
+ * The Python side that binds these (ctypes) is image-cases-studies_amd/lib/_native.py; the
+ * reference-side binding a maintainer would add is shown in INTEGRATION.md.
+ */
+#ifndef ICS_HIP_H
+#define ICS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICS_ABI_VERSION 1
+
+/* error codes */
+#define ICS_OK 0
+#define ICS_EINVAL (-1)  /* bad argument                                        */
+#define ICS_ENODEV (-2)  /* no usable HIP device / wrong architecture            */
+#define ICS_EHIP (-3)    /* a HIP runtime call failed (see ics_last_error)       */
+#define ICS_ENOMEM (-4)  /* device or host allocation failed                     */
+#define ICS_ESTATE (-5)  /* call sequence error (e.g. run before upload)         */
+#define ICS_ENOSUP (-6)  /* unsupported size (e.g. stop-test window too large)   */
+
+typedef struct ics_ctx ics_ctx; /* one per (process, device): stream, events, scratch   */
+typedef struct ics_rl ics_rl;   /* one deconvolution job: device-resident frames        */
+
+/* ---- library / device ------------------------------------------------------------------ */
+int ics_abi_version(void);
+const char *ics_last_error(void);
+int ics_device_count(int *count);
+/* Creates a context on `device` (hipSetDevice + one non-blocking stream).  Fails with
+ * ICS_ENODEV when the device is not gfx950. */
+int ics_ctx_create(int device, ics_ctx **out);
+void ics_ctx_destroy(ics_ctx *ctx);
+int ics_ctx_synchronize(ics_ctx *ctx);
+/* Device description: name (<=255 chars), compute units, HBM bytes. */
+int ics_ctx_info(ics_ctx *ctx, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes);
+
+/* ---- Richardson-Lucy / MM job (lib/deconvolution.pyx:341-675) --------------------------- */
+
+/* Arguments of richardson_lucy_MM that are scalars (pyx:341-342).  `p, norm, order, priority,
+ * refocus` are accepted and ignored by the reference and therefore absent. */
+typedef struct ics_rl_params {
+  int top, bottom, left, right; /* stats window, image coordinates (pyx:600-601,627)      */
+  float tau;                    /* non-blind stop threshold (pyx:652)                      */
+  int iterations;               /* max OUTER iterations, 5 inner each (pyx:375,460)        */
+  float step_factor;            /* pyx:524,574                                             */
+  float lambd;                  /* pyx:519                                                 */
+  int blind;                    /* pyx:434,501,555                                         */
+  int correlation;              /* pyx:584-585 (channel tie + caller-array rebinding quirk)*/
+  int channels;                 /* `C`: bounds the blind channel loops (pyx:557,570); 3    */
+  int tv_mode;                  /* ICS_TV_*: 0 = shipped behaviour (TV term dead)          */
+  int stop_test;                /* 1 = evaluate the residual-whiteness stop test (pyx:623-654)
+                                   on device every outer iteration (the reference always
+                                   does); 0 = never stop early, M_r not computed           */
+  int profile;                  /* 1 = bracket every kernel launch with HIP events on the job's
+                                   stream and report per-kernel averages in ics_rl_stats    */
+  int reserved[3];
+} ics_rl_params;
+
+#define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
+
+/* Scalars the reference only prints (pyx:593,648,659,665-669).  Arrays are per outer iteration
+ * and hold at most ICS_MAX_TRACE entries (later iterations overwrite the last slot). */
+#define ICS_MAX_TRACE 1024
+typedef struct ics_rl_stats {
+  int iterations_done; /* `it` at exit                                                    */
+  int stopped;         /* stop_flag                                                       */
+  int has_nan;         /* np.any(np.isnan(u)) (pyx:671)                                   */
+  float M_r, Hu, varu; /* values at exit (pyx:669)                                        */
+  float dof_min, dof_max;
+  int trace_len;
+  float trace_M_r[ICS_MAX_TRACE];
+  float trace_Hu[ICS_MAX_TRACE];
+  float trace_varu[ICS_MAX_TRACE];
+  float trace_dof_min[ICS_MAX_TRACE];
+  float trace_dof_max[ICS_MAX_TRACE];
+  /* timing of the last ics_rl_run, measured with HIP events on the job's stream */
+  float ms_total;      /* whole run (first launch -> last kernel), device time             */
+  int inner_iterations;/* inner iterations executed                                       */
+  /* params.profile = 1: average milliseconds per launch and launch count per kernel class */
+  float ms_kernel[8];
+  int launches[8];
+} ics_rl_stats;
+
+/* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, >= 3):
+ * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376. */
+int ics_rl_create(ics_ctx *ctx, int M, int N, int MK, ics_rl **out);
+void ics_rl_destroy(ics_rl *job);
+/* Host -> device.  image: M*N*3, u: uM*uN*3, psf: MK*MK*3 floats, C-contiguous HWC. */
+int ics_rl_upload(ics_rl *job, const float *image, const float *u, const float *psf);
+/* Device -> host; any pointer may be NULL.  `psf_caller` is what the reference leaves in the
+ * CALLER's psf array (differs from the local psf when correlation != 0, pyx:585). */
+int ics_rl_download(ics_rl *job, float *u, float *psf_local, float *psf_caller);
+/* Runs the whole loop (pyx:460-659) on the device.  Host synchronisation happens once per outer
+ * iteration (to read the stop-test scalars), never inside the 5 inner iterations. */
+int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
+
+/* Stage-level entry points (parity tests, profiling).  They operate on the job's device frames. */
+#define ICS_STAGE_SYNTH_RESIDUAL 1 /* A1+A2: error = conv_valid(u, psf) - image   (pyx:477-488)   */
+#define ICS_STAGE_BACKPROJECT 2    /* A3 (+A7 reductions): gradu = corr_full(error, psf) (:490-491) */
+#define ICS_STAGE_UPDATE 3         /* A5,A6,A8,A10: u update + DoF blend          (pyx:499-552)   */
+#define ICS_STAGE_PSF_GRADIENT 4   /* A13: gradk                                   (pyx:567-571)   */
+#define ICS_STAGE_PSF_UPDATE 5     /* A14-A17: psf step, tie, normalise, rotate    (pyx:574-589)   */
+#define ICS_STAGE_MAJORIZE 6       /* ut = u                                       (pyx:462)       */
+#define ICS_STAGE_STATS 7          /* A18+A19 on device -> stats scalars           (pyx:593-638)   */
+int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
+
+/* Reads one device frame back in the reference's shape. */
+#define ICS_BUF_U 0      /* uM x uN x 3  */
+#define ICS_BUF_UT 1     /* uM x uN x 3  */
+#define ICS_BUF_GRADU 2  /* uM x uN x 3 : raw back-projection (A3), before A6 */
+#define ICS_BUF_IMAGE 3  /* M x N x 3    */
+#define ICS_BUF_ERROR 4  /* M x N x 3    */
+#define ICS_BUF_PSF 5    /* MK x MK x 3  */
+#define ICS_BUF_GRADK 6  /* MK x MK x 3  */
+#define ICS_BUF_SCALARS 7 /* 16 floats: dt[3], maxu[3], maxg[3], dtpsf, M_r, Hu, varu, dof_min, dof_max, 0 */
+int ics_rl_read(ics_rl *job, int which, float *host, size_t count);
+int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
+
+/* Kernel classes indexing ics_rl_stats.ms_kernel / launches. */
+#define ICS_K_SYNTH 0        /* A1+A2 convolution kernel        */
+#define ICS_K_BACKPROJECT 1  /* A3 correlation kernel (+A7)     */
+#define ICS_K_UPDATE 2       /* A5/A6/A8/A10 elementwise kernel */
+#define ICS_K_PSF_GRADIENT 3 /* A13 MFMA kernel (+ reduction)   */
+#define ICS_K_PSF_UPDATE 4   /* A14-A17                         */
+#define ICS_K_MAJORIZE 5     /* ut = u copy                     */
+#define ICS_K_STATS 6        /* A18/A19 window statistics + FFT */
+#define ICS_KERNEL_COUNT 8
+
+/* ---- small standalone operators ---------------------------------------------------------- */
+/* lib/deconvolution.pyx:73-75 -- in place on a host MK*MK*3 float32 array, computed on device. */
+int ics_normalize_kernel(ics_ctx *ctx, float *kern, int MK);
+/* lib/deconvolution.pyx:137-239 -- u: M*N*3 -> out, div (borders untouched = 0). */
+int ics_tv(ics_ctx *ctx, const float *u, int M, int N, float epsilon, int order, int norm, float *out, float *div);
+/* lib/utils.py:237-264 -- scipy.signal.convolve2d(src, kern, mode="same", boundary="symm"), float64. */
+int ics_conv2d_symm(ics_ctx *ctx, const double *src, int H, int W, const double *kern, int KH, int KW, double *out);
+/* lib/utils.py:267-277 -- src + (src - conv2d_symm(src, kern)) * amount. */
+int ics_usm(ics_ctx *ctx, const double *src, int H, int W, const double *kern, int KH, int KW, double amount, double *out);
+/* lib/utils.py:173-234 -- bilateral filter, symmetric padding, gaussian(x, s) = exp(-x^2/(2 s^2)). */
+int ics_bilateral(ics_ctx *ctx, const double *src, int H, int W, int radius, double std_i, double std_s, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICS_HIP_H */

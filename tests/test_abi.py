@@ -1,0 +1,80 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/ics_hip.h declares, the
+ctypes structs match the C layout, and -- on a machine without a GPU -- the product path fails
+loudly instead of falling back to anything."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ics_hip.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ics_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lib import _native
+    lib = _native.load()
+    names = declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libics_hip.so does not export %s" % n
+    assert lib.ics_abi_version() == 1
+
+
+def test_struct_layout_matches_the_header(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
+    from lib import _native
+    c = tmp_path / "layout.c"
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ics_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+                 'sizeof(ics_rl_params), sizeof(ics_rl_stats), offsetof(ics_rl_params, stop_test),'
+                 'offsetof(ics_rl_stats, ms_total), offsetof(ics_rl_stats, launches));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals == [ctypes.sizeof(_native.RLParams), ctypes.sizeof(_native.RLStats), _native.RLParams.stop_test.offset,
+                    _native.RLStats.ms_total.offset, _native.RLStats.launches.offset]
+
+
+def test_no_silent_cpu_fallback_without_gpu():
+    from lib import _native
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.NativeError) as ei:
+        _native.Context(0)
+    assert ei.value.code == _native.ICS_ENODEV
+    from lib import deconvolution as dc
+    img = np.zeros((9, 9, 3), np.float32)
+    u = np.zeros((11, 11, 3), np.float32)
+    psf = np.full((3, 3, 3), 1 / 9, np.float32)
+    with pytest.raises(_native.NativeError):
+        dc.richardson_lucy_MM(img, u, psf, 1, 8, 1, 8, 0.0, 9, 9, 3, 3, 1, 1e-3, 1.0, blind=False)
+    with pytest.raises(_native.NativeError):
+        dc.normalize_kernel(psf, 3)
+
+
+def test_argument_validation_mirrors_cython_buffer_errors():
+    from lib import deconvolution as dc
+    a = np.zeros((9, 9, 3), np.float64)
+    with pytest.raises(ValueError, match="Buffer dtype mismatch, expected 'DTYPE_t' but got 'double'"):
+        dc.richardson_lucy_MM(a, a, a, 0, 1, 0, 1, 0, 9, 9, 3, 3, 1, 1e-3, 1.0)
+    b = np.zeros((9, 9), np.float32)
+    with pytest.raises(ValueError, match=r"Buffer has wrong number of dimensions \(expected 3, got 2\)"):
+        dc.normalize_kernel(b, 3)
+    assert dc.DTYPE is np.float32
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "image-cases-studies_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f)).read()
+                assert "rl_mm_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, os.path.join(d, f)

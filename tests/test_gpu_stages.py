@@ -1,0 +1,141 @@
+"""GPU parity, stage by stage, through the C ABI (ics_rl_stage / ics_rl_read).
+
+Each stage of one inner iteration (lib/deconvolution.pyx:473-591) is compared with the oracle on the
+same inputs ("teacher forcing": the inputs of a stage are what the device holds).  Convolutions are
+checked against float64 direct sums (tolerance 2e-6 relative: fp32 accumulation of <= 31*31 terms);
+the elementwise stages reproduce the reference's rounding exactly and are checked bit for bit.
+"""
+import numpy as np
+import pytest
+
+import rl_mm_oracle as orc
+from helpers import conv_valid64, corr_full64, gradk64, psf_step_f32, rel_err, update_f32
+
+pytestmark = pytest.mark.gpu
+
+CONV_TOL = 2e-6
+
+
+def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
+    from lib import _native
+    case = orc.synth_case(M, N, MK, seed=seed, blind=blind, per_channel_psf=per_channel_psf)
+    rng = np.random.default_rng(seed + 1)
+    # a PSF without symmetry so that flips / transposes are detected
+    psf = (case["psf0"] * (0.5 + rng.random(case["psf0"].shape, dtype=np.float32))).astype(np.float32)
+    orc.normalize_kernel(psf, MK)
+    job = _native.RLJob(M, N, MK)
+    job.upload(case["image"], case["u0"], psf)
+    return job, case, psf
+
+
+@pytest.mark.parametrize("MK", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
+def test_synth_residual_and_backprojection_all_psf_sizes(MK):
+    from lib import _native as nv
+    M, N = 70 + MK, 131
+    job, case, psf = make_job(M, N, MK, seed=MK)
+    # perturb u so that it is not just the padded image
+    rng = np.random.default_rng(7)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    e_ref = conv_valid64(u, psf) - case["image"]
+    scale = np.max(np.abs(conv_valid64(u, psf)))
+    assert np.max(np.abs(e - e_ref)) / scale < CONV_TOL
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    g_ref = corr_full64(e.astype(np.float64), psf)
+    assert g.shape == g_ref.shape
+    assert rel_err(g, g_ref) < CONV_TOL
+    job.close()
+
+
+@pytest.mark.parametrize("M,N,MK,blind", [(64, 64, 15, False), (65, 191, 15, False), (130, 67, 9, True), (257, 300, 15, True), (40, 50, 31, False)])
+def test_one_inner_iteration_stage_by_stage(M, N, MK, blind):
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=M + N, blind=blind)
+    pad = MK // 2
+    step, lambd = 1e-3, 10000.0
+    rng = np.random.default_rng(3)
+    u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    ut = case["u0"]
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, ut)
+    win = orc.default_window(M, N, MK)
+    p = job.params(*win, 1e9, 1, step, lambd, blind=blind)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g_raw = job.read(nv.BUF_GRADU)
+    job.stage(nv.STAGE_UPDATE, p)
+    u_dev = job.read(nv.BUF_U)
+    sc = job.scalars()
+    u_ref, dt, DoF = update_f32(u, ut, g_raw, case["image"], step, lambd, blind, pad)
+    # reductions (A7) and the step size are exact
+    for k in range(3):
+        assert sc["maxu%d" % k] == np.amax(u[..., k])
+        assert sc["dt%d" % k] == dt[k]
+    assert np.array_equal(u_dev, u_ref, equal_nan=True), "A5-A10 must reproduce the reference's float32 rounding bit for bit"
+    if blind:
+        job.stage(nv.STAGE_SYNTH_RESIDUAL, p)       # A11 on the updated u
+        e2 = job.read(nv.BUF_ERROR)
+        job.stage(nv.STAGE_PSF_GRADIENT, p)
+        gk = job.read(nv.BUF_GRADK)
+        gk_ref = gradk64(u_dev.astype(np.float64), e2.astype(np.float64))
+        assert rel_err(gk, gk_ref) < 1e-5
+        for correlation in (0,):
+            job.stage(nv.STAGE_PSF_UPDATE, p)
+            psf_dev = job.read(nv.BUF_PSF)
+            psf_ref, _caller, dtpsf = psf_step_f32(psf, gk, step, MK, correlation)
+            assert sc is not None
+            assert np.array_equal(psf_dev, psf_ref), "A14-A17 must be bit exact given the device's gradk"
+            assert job.scalars()["dtpsf"] == dtpsf
+    job.close()
+
+
+def test_psf_update_correlation_quirk():
+    """pyx:584-585: with correlation the local psf is tied across channels and the caller's array only
+    receives the first gradient step."""
+    from lib import _native as nv
+    M, N, MK = 90, 70, 7
+    job, case, psf = make_job(M, N, MK, seed=11, blind=True)
+    p = job.params(*orc.default_window(M, N, MK), 0.0, 1, 1e-3, 10000.0, blind=True, correlation=1)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    job.stage(nv.STAGE_PSF_UPDATE, p)
+    _, psf_local, psf_caller = job.download()
+    ref_local, ref_caller, _ = psf_step_f32(psf, gk, 1e-3, MK, 1)
+    assert np.array_equal(psf_local, ref_local)
+    assert np.array_equal(psf_caller, ref_caller)
+    # a second step moves the local psf but not the caller's copy
+    job.stage(nv.STAGE_PSF_UPDATE, p)
+    _, psf_local2, psf_caller2 = job.download()
+    assert np.array_equal(psf_caller2, ref_caller)
+    assert not np.array_equal(psf_local2, psf_local)
+    job.close()
+
+
+@pytest.mark.parametrize("M,N,MK,win", [(129, 129, 15, (8, 119, 8, 119)), (300, 280, 9, (5, 250, 5, 250)), (65, 49, 9, (5, 42, 5, 42))])
+def test_window_statistics_and_whiteness_metric(M, N, MK, win):
+    """A18/A19 on device (FFT autocorrelation) vs the oracle's numpy/scipy evaluation."""
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=5)
+    pad = MK // 2
+    p = job.params(*win, 1e9, 1, 1e-3, 10000.0, blind=False)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    u = job.read(nv.BUF_U)
+    job.stage(nv.STAGE_STATS, p)
+    sc = job.scalars()
+    top, bottom, left, right = win
+    ew = e[top:bottom, left:right]
+    M_r = orc.residual_whiteness(ew, orc.stop_weights(*win), orc._conv_scipy)
+    Hu = np.linalg.norm(ew) ** 2 / ((bottom - top) * (right - left) * 3)
+    varu = np.std(u[top + pad:bottom - pad, left + pad:right - pad]) ** 2
+    assert abs(sc["M_r"] - M_r) / M_r < 2e-4
+    assert abs(sc["Hu"] - Hu) / Hu < 1e-5
+    assert abs(sc["varu"] - varu) / varu < 1e-5
+    job.close()
