@@ -436,7 +436,7 @@ static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.wsc = j->wsc;
   a.z = j->z; a.tw = j->tw; a.weights = j->weights;
   a.top = p->top; a.bottom = p->bottom; a.left = p->left; a.right = p->right;
-  a.P = j->P; a.logP = j->logP; a.do_mr = p->stop_test; a.geo = j->g;
+  a.P = j->P; a.logP = j->logP; a.do_mr = p->stop_test != 0; a.geo = j->g;
   RC(pr.begin(ICS_K_STATS));
   HIPCHK(ics_launch_stats(a, j->ctx->stream));
   RC(pr.end());
@@ -503,7 +503,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     st->trace_M_r[slot] = M_r; st->trace_Hu[slot] = Hu; st->trace_varu[slot] = varu;
     st->trace_dof_min[slot] = dmin; st->trace_dof_max[slot] = dmax;
     st->trace_len = slot + 1;
-    if (it > 1 && p->stop_test) {                             // pyx:643-654
+    if (it > 1 && p->stop_test == 1) {                        // pyx:643-654 (stop_test 2: evaluate only)
       if (p->blind) { if (M_r > M_r_prev) stop = 1; }
       else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
     }

@@ -72,7 +72,9 @@ typedef struct ics_rl_params {
   int tv_mode;                  /* ICS_TV_*: 0 = shipped behaviour (TV term dead)          */
   int stop_test;                /* 1 = evaluate the residual-whiteness stop test (pyx:623-654)
                                    on device every outer iteration (the reference always
-                                   does); 0 = never stop early, M_r not computed           */
+                                   does); 0 = never stop early, M_r not computed;
+                                   2 = compute M_r every outer iteration but never stop
+                                   (fixed-length benchmark runs with the full workload)    */
   int profile;                  /* 1 = bracket every kernel launch with HIP events on the job's
                                    stream and report per-kernel averages in ics_rl_stats    */
   int reserved[3];

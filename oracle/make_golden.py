@@ -40,11 +40,16 @@ CASES = [
     dict(name="bl_129x129_k15", M=129, N=129, MK=15, blind=1, corr=0, snaps=[1, 2, 5], step=1e-3),
     dict(name="bl_65x65_k7_corr", M=65, N=65, MK=7, blind=1, corr=1, snaps=[1, 3], step=1e-3),
     dict(name="bl_101x101_k11_s1e-4", M=101, N=101, MK=11, blind=1, corr=0, snaps=[20], step=1e-4),
+    # chain of calls with iterations=2: `it > 1` (pyx:643) never holds, so no stop decision is involved
+    # and the chain is a 20-outer-iteration (100 inner) blind trajectory free of the fragile M_r test
+    dict(name="bl_101x101_k11_chain", M=101, N=101, MK=11, blind=1, corr=0, snaps=[2], chain=10, step=1e-3),
 ]
 
 
-def run_ref(ref, case, c, iters, strided=False):
+def run_ref(ref, case, c, iters, strided=False, u_start=None, psf_start=None):
     image, u, psf = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    if u_start is not None:
+        u, psf = u_start.copy(), psf_start.copy()
     if strided:  # non-contiguous views, as deconvolve.py:278-279 passes them
         big_i = np.zeros((image.shape[0] + 4, image.shape[1] + 6, 3), np.float32); big_i[2:-2, 3:-3] = image; image = big_i[2:-2, 3:-3]
         big_u = np.zeros((u.shape[0] + 2, u.shape[1] + 10, 3), np.float32); big_u[1:-1, 5:-5] = u; u = big_u[1:-1, 5:-5]
@@ -57,13 +62,20 @@ def run_ref(ref, case, c, iters, strided=False):
     return np.ascontiguousarray(image), np.ascontiguousarray(u), psf, buf.getvalue()
 
 
-def run_orc(case, c, iters):
+def run_orc(case, c, iters, conv="scipy", u_start=None, psf_start=None):
     image, u, psf = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    if u_start is not None:
+        u, psf = u_start.copy(), psf_start.copy()
     M, N = image.shape[:2]
     tr = orc.Trace()
     orc.richardson_lucy_MM(image, u, psf, *c["window"], c["tau"], M, N, 3, c["MK"], iters, c["step"], c["lambd"],
-                           blind=c["blind"], correlation=c["corr"], trace=tr, quiet=True)
+                           blind=c["blind"], correlation=c["corr"], trace=tr, quiet=True, conv=conv)
     return image, u, psf, tr
+
+
+def rel(a, b):
+    den = float(np.max(np.abs(b.astype(np.float64))))
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) / (den if den > 0 else 1.0))
 
 
 def main():
@@ -82,6 +94,7 @@ def main():
         meta = dict(c)
         meta["versions"] = versions
         logs = {}
+        noise = {}
         for n in c["snaps"]:
             img_r, u_r, psf_r, log_r = run_ref(ref, case, c, n)
             img_o, u_o, psf_o, tr = run_orc(case, c, n)
@@ -93,6 +106,19 @@ def main():
             payload["psf_local_%d" % n] = tr.psf_final
             logs[str(n)] = log_r
             last = tr
+            # noise floor: the same loop with float64 direct sums instead of scipy's complex64 FFT
+            _, u_d, psf_d, tr_d = run_orc(case, c, n, conv="direct")
+            noise[str(n)] = [rel(u_d, u_r), rel(psf_d, psf_r), tr_d.iterations]
+        if c.get("chain"):
+            u_c, psf_c = payload["u_2"], payload["psf_2"]
+            u_o, psf_o = u_c, psf_c
+            for k in range(2, c["chain"] + 1):
+                _, u_c, psf_c, _ = run_ref(ref, case, c, 2, u_start=u_c, psf_start=psf_c)
+                _, u_o, psf_o, _ = run_orc(case, c, 2, u_start=u_o, psf_start=psf_o)
+                assert np.array_equal(u_c, u_o) and np.array_equal(psf_c, psf_o)
+                if k in (c["chain"] // 2, c["chain"]):
+                    payload["u_chain_%d" % k] = u_c
+                    payload["psf_chain_%d" % k] = psf_c
         # strided-view run must equal the contiguous one
         _, u_s, psf_s, _ = run_ref(ref, case, c, c["snaps"][0], strided=True)
         assert np.array_equal(u_s, payload["u_%d" % c["snaps"][0]], equal_nan=True)
@@ -106,6 +132,7 @@ def main():
         meta["iterations_done"] = last.iterations
         meta["stopped"] = last.stopped
         meta["logs"] = logs
+        meta["noise_floor"] = noise  # per snapshot: [rel err u, rel err psf, iterations] of the f64-direct oracle vs reference
         payload["meta"] = np.array(json.dumps(meta))
         path = os.path.join(OUT, "rl_%s.npz" % c["name"])
         np.savez_compressed(path, **payload)

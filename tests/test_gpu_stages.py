@@ -2,7 +2,7 @@
 
 Each stage of one inner iteration (lib/deconvolution.pyx:473-591) is compared with the oracle on the
 same inputs ("teacher forcing": the inputs of a stage are what the device holds).  Convolutions are
-checked against float64 direct sums (tolerance 2e-6 relative: fp32 accumulation of <= 31*31 terms);
+checked against float64 direct sums (tolerance 5e-6 relative: sequential fp32 accumulation of up to 31*31 = 961 terms);
 the elementwise stages reproduce the reference's rounding exactly and are checked bit for bit.
 """
 import numpy as np
@@ -13,7 +13,7 @@ from helpers import conv_valid64, corr_full64, gradk64, psf_step_f32, rel_err, u
 
 pytestmark = pytest.mark.gpu
 
-CONV_TOL = 2e-6
+CONV_TOL = 5e-6
 
 
 def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):

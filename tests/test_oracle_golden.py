@@ -49,6 +49,15 @@ def test_direct_float64_convolution_noise_floor(golden_dir, name):
     assert rel_err(psf, z["psf_%d" % n]) < 1e-5
 
 
+def test_noise_floor_recorded_in_fixtures(golden_dir):
+    """Every fixture carries the float64-direct noise floor; short runs sit far below the 1e-4 bar."""
+    for name in CASES:
+        z, meta = load_golden(golden_dir, name)
+        first = meta["snaps"][0]
+        if first <= 2:
+            assert meta["noise_floor"][str(first)][0] < 1e-5, name
+
+
 def test_oracle_long_run_small_step(golden_dir):
     z, meta = load_golden(golden_dir, "nb_129x129_k15_s1e-4")
     _, u, _, tr = run_oracle(z, meta, 50)
