@@ -130,11 +130,13 @@ extern "C" int ics_ctx_info(ics_ctx* c, char* name, size_t name_len, int* cus, u
 }
 
 // -------------------------------------------------------------------------------------------------
+// Device allocation, zero-filled ON THE GIVEN STREAM: the job's stream is non-blocking, so a
+// null-stream hipMemset would not be ordered with the uploads/kernels that follow on it.
 template <typename T>
-static int dalloc(T** p, size_t count, bool zero = true) {
+static int dalloc(T** p, size_t count, hipStream_t s, bool zero = true) {
   *p = nullptr;
   HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
-  if (zero) HIPCHK(hipMemset(*p, 0, count * sizeof(T)));
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), s));
   return ICS_OK;
 }
 
@@ -169,17 +171,20 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   j->gradk_blocks = ics_gradk_blocks(j->g, c->cus);
   int rc;
 #define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
-  TRY(dalloc(&j->u, j->frame_floats)); TRY(dalloc(&j->ut, j->frame_floats)); TRY(dalloc(&j->gr, j->frame_floats));
-  TRY(dalloc(&j->f, j->frame_floats)); TRY(dalloc(&j->e, j->frame_floats));
-  TRY(dalloc(&j->psf, n)); TRY(dalloc(&j->gradk, n)); TRY(dalloc(&j->psf_caller, n));
-  TRY(dalloc(&j->wconv, (size_t)MK * j->g.wrow)); TRY(dalloc(&j->wcorr, (size_t)MK * j->g.wrow));
-  TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt));
-  TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE)); TRY(dalloc(&j->dofkeys, (size_t)4));
-  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT)); TRY(dalloc(&j->wsc, (size_t)8)); TRY(dalloc(&j->flags, (size_t)4));
+  hipStream_t s = c->stream;
+  TRY(dalloc(&j->u, j->frame_floats, s)); TRY(dalloc(&j->ut, j->frame_floats, s)); TRY(dalloc(&j->gr, j->frame_floats, s));
+  TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
+  TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
+  TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
+  TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt, s));
+  TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE, s)); TRY(dalloc(&j->dofkeys, (size_t)4, s));
+  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->wsc, (size_t)8, s)); TRY(dalloc(&j->flags, (size_t)4, s));
 #undef TRY
   hipError_t e = hipHostMalloc((void**)&j->h_scal, (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);
   if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
   hipEventCreate(&j->ev_begin); hipEventCreate(&j->ev_end);
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e)); }
   *out = j;
   return ICS_OK;
 }
@@ -315,9 +320,9 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
   if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
   if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
   int rc;
-  if ((rc = dalloc(&j->z, (size_t)3 * P * P, false)) != ICS_OK) return rc;
-  if ((rc = dalloc(&j->tw, (size_t)P / 2 + 1, false)) != ICS_OK) return rc;
-  if ((rc = dalloc(&j->weights, (size_t)H * W, false)) != ICS_OK) return rc;
+  if ((rc = dalloc(&j->z, (size_t)3 * P * P, j->ctx->stream, false)) != ICS_OK) return rc;
+  if ((rc = dalloc(&j->tw, (size_t)P / 2 + 1, j->ctx->stream, false)) != ICS_OK) return rc;
+  if ((rc = dalloc(&j->weights, (size_t)H * W, j->ctx->stream, false)) != ICS_OK) return rc;
   std::vector<float2> tw(P / 2 + 1);
   for (int k = 0; k < P / 2; ++k) {
     const double ang = -2.0 * M_PI * (double)k / (double)P;
@@ -343,8 +348,9 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
     for (int c = 0; c < W; ++c) { w[(size_t)r * W + c] = sqrtf(wi[r] * he[c]); sum += w[(size_t)r * W + c]; }
   const float fs = (float)sum;
   for (auto& v : w) v = v / fs;
-  HIPCHK(hipMemcpy(j->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(j->weights, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpyAsync(j->tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice, j->ctx->stream));
+  HIPCHK(hipMemcpyAsync(j->weights, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, j->ctx->stream));
+  HIPCHK(hipStreamSynchronize(j->ctx->stream));  // tw / w are stack-owned host vectors
   j->P = P; j->logP = logP; j->wt = p->top; j->wb = p->bottom; j->wl = p->left; j->wr = p->right;
   return ICS_OK;
 }

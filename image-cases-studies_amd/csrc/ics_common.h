@@ -31,7 +31,7 @@ struct IcsGeom {
   int pitch;     // floats per row
   int rows;      // allocated rows
   int tiles_x, tiles_y;
-  int wrow;      // floats per packed PSF row = round_up(3*K, 4)
+  int wrow;      // floats per packed weight row = round_up(6*K, 4); K+1 rows (see IcsConvArgs::w)
 };
 
 static inline IcsGeom ics_make_geom(int M, int N, int K) {
@@ -48,7 +48,7 @@ static inline IcsGeom ics_make_geom(int M, int N, int K) {
   int px = g.ax + g.tiles_x * ICS_TILE + g.ax;
   g.pitch = ((3 * px + 63) / 64) * 64;
   g.rows = g.ay + g.tiles_y * ICS_TILE + g.ay + 1;  // +1: slack row for tiles that over-read
-  g.wrow = (3 * K + 3) & ~3;
+  g.wrow = (6 * K + 3) & ~3;
   return g;
 }
 static inline size_t ics_frame_floats(const IcsGeom& g) { return (size_t)g.rows * g.pitch; }
@@ -86,7 +86,8 @@ __host__ __device__ static inline float ics_key2f(uint32_t k) {
 // ---- launchers implemented in the .hip translation units ------------------------------------
 struct IcsConvArgs {
   const float* in;   // frame origin of the convolved array (u for A1, error for A3)
-  const float* w;    // packed PSF, correlation orientation, [K][wrow]
+  const float* w;    // packed weights, correlation orientation W[a][b][c], as ROW PAIRS for v_pk_fma_f32:
+                     // w[ap][ (3b+c)*2 + h ] = W[ap - h][b][c]  (ap = 0..K, h = 0/1, W[-1] = W[K] = 0)
   float* out;        // frame origin of the output (error for A1, gradu for A3)
   const float* f;    // A1: image frame origin
   const float* u;    // A3: u frame origin   (for the fused A6/A7 reductions)

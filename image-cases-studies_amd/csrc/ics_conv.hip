@@ -11,14 +11,20 @@
 // zero apron of the frames supplies the zero extension that `full` needs.
 //
 // Kernel shape (CDNA4): one 256-thread workgroup (4 waves) per 64 x (16*R) pixel tile.  The tile
-// plus halo is staged once in LDS (dwordx4 global loads, HWC rows are contiguous so a 64-px row
-// segment is one 768-B run).  Each lane owns R output rows x 4 pixels (12 floats of the flattened
+// plus halo is staged once in LDS (dwordx4 global loads, HWC rows are contiguous so a 78-px row
+// segment is one 936-B run).  Each lane owns R output rows x 4 pixels (12 floats of the flattened
 // x*3+c axis, so the channel of a register is a compile-time constant) and walks the input rows
 // once: an LDS row strip is read with ds_read_b128 into registers and feeds all R output rows
-// (kernel row a = i - r), i.e. K*12 FMAs per output row per strip.  PSF weights are wave-uniform
-// and come through the scalar cache into SGPRs (v_fmac_f32 with an SGPR operand), so the VALU
-// stream is almost pure FMA.  fp32 throughout; the dense formulation needed for MFMA would waste
-// >= 50 % of the matrix pipe on the Toeplitz band, so this path is VALU by design.
+// (kernel row a = i - r).  The FMA stream is packed (v_pk_fma_f32, the only way to the fp32 vector
+// peak on CDNA4: measured 135 TF/s vs 65 TF/s for v_fmac_f32, csrc/tools/ubench_fma.hip): the two
+// halves of an accumulator pair are the SAME pixel/channel of two consecutive output rows, so both
+// halves take the same input value (op_sel broadcast of one strip register, no shuffles) and the
+// weight operand is the pair (W[a][b][c], W[a-1][b][c]) of two consecutive kernel rows, which is
+// wave-uniform and arrives through the scalar cache as an aligned SGPR pair.  The VALU stream is
+// therefore pure v_pk_fma_f32 acc, s[w:w+1], v_strip(op_sel), acc.  Each row pair walks K+1 input
+// rows (the first/last with one zero weight), a (K+1)/K overhead.  fp32 throughout; the dense
+// formulation needed for MFMA would waste >= 50 % of the matrix pipe on the Toeplitz band
+// (DESIGN.md), so this path is VALU by design.
 #include "ics_common.h"
 
 namespace {
@@ -26,20 +32,26 @@ namespace {
 template <int K, int R>
 struct ConvCfg {
   static constexpr int PAD = K / 2;
-  static constexpr int AX = (PAD + 3) & ~3;
   static constexpr int TW = ICS_TILE;
   static constexpr int TH = 16 * R;
   static constexpr int LROWS = TH + K - 1;
-  static constexpr int LW_USED = 3 * (TW + 2 * AX);  // floats staged per LDS row (multiple of 4)
-  static constexpr int LALIGN = 64 / R;               // R*LWF % 64 == 0 keeps ds_read_b128 conflict-free
+  // LDS row = pixels [x0 - PAD, x0 + TW + PAD): a lane's strip then starts at float 12*tx, 16-B aligned,
+  // and is read with ds_read_b128.  (The matching global address is only 4-B aligned: 3*PAD floats.)
+  static constexpr int LW_USED = (3 * (TW + 2 * PAD) + 3) & ~3;  // floats staged per LDS row
+  static constexpr int LALIGN = 64 / R;                           // R*LWF % 64 == 0: conflict-free b128 strips
   static constexpr int LWF = ((LW_USED + LALIGN - 1) / LALIGN) * LALIGN;
-  static constexpr int OFF0 = 3 * (AX - PAD);
-  static constexpr int STRIP = (OFF0 + 12 + 3 * (K - 1) + 3) & ~3;
-  static constexpr int WROW = (3 * K + 3) & ~3;
+  static constexpr int STRIP = (12 + 3 * (K - 1) + 3) & ~3;
+  static constexpr int WROW2 = (6 * K + 3) & ~3;      // floats per packed row-pair weight row (ics_common.h)
   static constexpr size_t LDS_BYTES = (size_t)LROWS * LWF * 4;
   static_assert(12 * 15 + STRIP <= LWF, "strip overruns the LDS row");
   static_assert(ICS_TILE % TH == 0, "tile height must divide the frame granularity");
+  static_assert(R % 2 == 0, "output rows are processed in pairs");
 };
+
+// 16-byte vector with 4-byte alignment: global_load_dwordx4 only needs dword alignment
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
@@ -57,7 +69,7 @@ __device__ __forceinline__ uint32_t key_of(float f) {
 }
 
 template <int K, int R, int MODE>
-__global__ __launch_bounds__(256) void k_conv(IcsConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv(IcsConvArgs a) {
   using C = ConvCfg<K, R>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -66,54 +78,87 @@ __global__ __launch_bounds__(256) void k_conv(IcsConvArgs a) {
   const int x0 = txi * C::TW, y0 = tyi * C::TH;
   const int pitch = a.g.pitch;
 
-  // ---- stage tile + halo -------------------------------------------------------------------
+  // ---- stage tile + halo: all global loads of a batch are in flight before the LDS writes ----------
   {
-    const float* src = a.in + (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::AX);
+    const float* src = a.in + (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::PAD);
     constexpr int LW4 = C::LW_USED / 4;
-    for (int v = tid; v < C::LROWS * LW4; v += 256) {
-      const int row = v / LW4, c4 = v - row * LW4;
-      const float4 val = *reinterpret_cast<const float4*>(src + (ptrdiff_t)row * pitch + 4 * c4);
-      *reinterpret_cast<float4*>(lds + row * C::LWF + 4 * c4) = val;
-    }
-  }
-  __syncthreads();
-
-  float acc[R][12];
+    constexpr int NV = C::LROWS * LW4;
+    constexpr int NIT = (NV + 255) / 256;
+    constexpr int BATCH = NIT;  // one batch: every load of the tile is in flight before the first LDS write
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+    for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+      f32x4u val[BATCH];
 #pragma unroll
-    for (int f = 0; f < 12; ++f) acc[r][f] = 0.f;
-
-  const float* lrow0 = lds + (ty * R) * C::LWF + 12 * tx;
-  const float* __restrict__ wbase = a.w;
-
-#pragma unroll 1
-  for (int i = 0; i < R + K - 1; ++i) {
-    float strip[C::STRIP];
-    const float4* lp = reinterpret_cast<const float4*>(lrow0 + i * C::LWF);
+      for (int k = 0; k < BATCH; ++k) {
+        if (it0 + k < NIT) {
+          int v = tid + (it0 + k) * 256;
+          v = v < NV ? v : NV - 1;  // clamp instead of predicating the load
+          const int row = v / LW4, c4 = v - row * LW4;
+          val[k] = *reinterpret_cast<const f32x4u*>(src + (ptrdiff_t)row * pitch + 4 * c4);
+        }
+      }
 #pragma unroll
-    for (int j = 0; j < C::STRIP / 4; ++j) {
-      const float4 t = lp[j];
-      strip[4 * j + 0] = t.x; strip[4 * j + 1] = t.y; strip[4 * j + 2] = t.z; strip[4 * j + 3] = t.w;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int arow = i - r;  // wave-uniform kernel row feeding output row r from input row i
-      if (arow >= 0 && arow < K) {
-        const float* __restrict__ wr = wbase + arow * C::WROW;
-#pragma unroll
-        for (int b = 0; b < K; ++b) {
-          const float w0 = wr[3 * b + 0], w1 = wr[3 * b + 1], w2 = wr[3 * b + 2];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            acc[r][3 * p + 0] = __builtin_fmaf(w0, strip[C::OFF0 + 3 * (p + b) + 0], acc[r][3 * p + 0]);
-            acc[r][3 * p + 1] = __builtin_fmaf(w1, strip[C::OFF0 + 3 * (p + b) + 1], acc[r][3 * p + 1]);
-            acc[r][3 * p + 2] = __builtin_fmaf(w2, strip[C::OFF0 + 3 * (p + b) + 2], acc[r][3 * p + 2]);
+      for (int k = 0; k < BATCH; ++k) {
+        if (it0 + k < NIT) {
+          const int v = tid + (it0 + k) * 256;
+          if (v < NV) {
+            const int row = v / LW4, c4 = v - row * LW4;
+            *reinterpret_cast<float4*>(lds + row * C::LWF + 4 * c4) = make_float4(val[k].x, val[k].y, val[k].z, val[k].w);
           }
         }
       }
     }
   }
+  __syncthreads();
+
+  // accumulator pairs: A[rp][f] = (output row 2rp, output row 2rp+1) at flat column f
+  f32x2 A[R / 2][12];
+#pragma unroll
+  for (int rp = 0; rp < R / 2; ++rp)
+#pragma unroll
+    for (int f = 0; f < 12; ++f) A[rp][f] = (f32x2){0.f, 0.f};
+
+  const float* lrow0 = lds + (ty * R) * C::LWF + 12 * tx;
+  const f32x2* __restrict__ wbase = reinterpret_cast<const f32x2*>(a.w);
+
+  // Loop over packed weight rows ap = 0..K.  Row ap holds the pairs (W[ap], W[ap-1]) (W[-1] = W[K] = 0)
+  // and serves EVERY row pair of the lane: pair rp (output rows 2rp, 2rp+1) takes its input from LDS
+  // row ap + 2rp.  The body is branch-free: (R/2) strips, one weight row, (R/2)*K*12 packed FMAs.
+#pragma unroll 1
+  for (int ap = 0; ap <= K; ++ap) {
+    float strip[R / 2][C::STRIP];
+#pragma unroll
+    for (int rp = 0; rp < R / 2; ++rp) {
+      const float4* lp = reinterpret_cast<const float4*>(lrow0 + (ap + 2 * rp) * C::LWF);
+#pragma unroll
+      for (int j = 0; j < C::STRIP / 4; ++j) {
+        const float4 t = lp[j];
+        strip[rp][4 * j + 0] = t.x; strip[rp][4 * j + 1] = t.y; strip[rp][4 * j + 2] = t.z; strip[rp][4 * j + 3] = t.w;
+      }
+    }
+    const f32x2* __restrict__ wr = wbase + ap * (C::WROW2 / 2);
+#pragma unroll
+    for (int b = 0; b < K; ++b) {
+      const f32x2 w0 = wr[3 * b + 0], w1 = wr[3 * b + 1], w2 = wr[3 * b + 2];
+#pragma unroll
+      for (int rp = 0; rp < R / 2; ++rp) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float s0 = strip[rp][3 * (p + b) + 0];
+          const float s1 = strip[rp][3 * (p + b) + 1];
+          const float s2 = strip[rp][3 * (p + b) + 2];
+          A[rp][3 * p + 0] = __builtin_elementwise_fma(w0, (f32x2){s0, s0}, A[rp][3 * p + 0]);
+          A[rp][3 * p + 1] = __builtin_elementwise_fma(w1, (f32x2){s1, s1}, A[rp][3 * p + 1]);
+          A[rp][3 * p + 2] = __builtin_elementwise_fma(w2, (f32x2){s2, s2}, A[rp][3 * p + 2]);
+        }
+      }
+    }
+  }
+  float acc[R][12];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int f = 0; f < 12; ++f) acc[r][f] = (r & 1) ? A[r / 2][f].y : A[r / 2][f].x;
 
   // ---- epilogue ----------------------------------------------------------------------------
   const int xp = x0 + 4 * tx;  // first of this lane's 4 pixels (u-frame x)

@@ -34,8 +34,8 @@ hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gra
 struct IcsPsfArgs {
   float* psf;          // [K][K][3] local psf (pyx: the name `psf` inside the function)
   const float* gradk;  // [K][K][3]
-  float* wconv;        // [K][wrow] rot180(psf): weights of A1 in correlation orientation
-  float* wcorr;        // [K][wrow] psf:         weights of A3 in correlation orientation
+  float* wconv;        // [K+1][wrow] row-pair packed rot180(psf): weights of A1 (correlation orientation)
+  float* wcorr;        // [K+1][wrow] row-pair packed psf:         weights of A3
   float* psf_caller;   // what the caller's array holds (correlation quirk, pyx:585)
   float* scal;         // ICS_SC_DTPSF recorded
   int* frozen;         // device flag: caller array detached (pyx:585 rebinding)

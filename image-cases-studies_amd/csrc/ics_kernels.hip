@@ -297,14 +297,19 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     if (tid == 0 && detach) *a.frozen = 1;
     __syncthreads();
   }
-  // pack: wcorr[a][3b+c] = psf[a][b][c];  wconv[a][3b+c] = psf[K-1-a][K-1-b][c]; row padding zeroed
-  for (int i = tid; i < K * a.wrow; i += 256) {
-    const int ra = i / a.wrow, rc = i - ra * a.wrow;
+  // pack the row-pair weights of the convolution kernels (ics_common.h, IcsConvArgs::w):
+  //   W_corr[a][b][c] = psf[a][b][c] (A3),  W_conv[a][b][c] = psf[K-1-a][K-1-b][c] (A1, = psf_rotated, pyx:589)
+  //   w[ap][(3b+c)*2 + h] = W[ap - h][b][c], ap = 0..K, W[-1] = W[K] = 0; row padding zeroed
+  for (int i = tid; i < (K + 1) * a.wrow; i += 256) {
+    const int ap = i / a.wrow, rc = i - ap * a.wrow;
     float v1 = 0.f, v2 = 0.f;
-    if (rc < 3 * K) {
-      const int b = rc / 3, c = rc - 3 * b;
-      v1 = p[(ra * K + b) * 3 + c];
-      v2 = p[((K - 1 - ra) * K + (K - 1 - b)) * 3 + c];
+    if (rc < 6 * K) {
+      const int h = rc & 1, bc = rc >> 1, b = bc / 3, c = bc - 3 * b;
+      const int ra = ap - h;
+      if (ra >= 0 && ra < K) {
+        v1 = p[(ra * K + b) * 3 + c];
+        v2 = p[((K - 1 - ra) * K + (K - 1 - b)) * 3 + c];
+      }
     }
     a.wcorr[i] = v1; a.wconv[i] = v2;
   }
