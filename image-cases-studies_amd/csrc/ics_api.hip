@@ -53,7 +53,8 @@ struct ics_rl {
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
   uint32_t* dofkeys;                    // 4 words
   float* scal;                          // ICS_SC_COUNT
-  float* wsc;                           // 8
+  double* dacc;                         // 8 accumulators of the window statistics
+  uint32_t* ukey;                       // 2
   int* flags;                           // [0] frozen, [1] hasnan
   // stop-test scratch (allocated for the window of the last run)
   float2* z; float2* tw; float* weights;
@@ -145,7 +146,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->u, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
-                  j->red, j->dofkeys, j->scal, j->wsc, j->flags, j->z, j->tw, j->weights};
+                  j->red, j->dofkeys, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
   for (hipEvent_t e : j->ev) hipEventDestroy(e);
@@ -178,7 +179,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
   TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt, s));
   TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE, s)); TRY(dalloc(&j->dofkeys, (size_t)4, s));
-  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->wsc, (size_t)8, s)); TRY(dalloc(&j->flags, (size_t)4, s));
+  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->dacc, (size_t)8, s)); TRY(dalloc(&j->ukey, (size_t)2, s)); TRY(dalloc(&j->flags, (size_t)4, s));
 #undef TRY
   hipError_t e = hipHostMalloc((void**)&j->h_scal, (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);
   if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -439,7 +440,7 @@ static int do_majorize(ics_rl* j, Prof& pr) {
 
 static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   IcsStatsArgs a;
-  a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.wsc = j->wsc;
+  a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.dacc = j->dacc; a.ukey = j->ukey;
   a.z = j->z; a.tw = j->tw; a.weights = j->weights;
   a.top = p->top; a.bottom = p->bottom; a.left = p->left; a.right = p->right;
   a.P = j->P; a.logP = j->logP; a.do_mr = p->stop_test != 0; a.geo = j->g;

@@ -124,8 +124,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // Loop over packed weight rows ap = 0..K.  Row ap holds the pairs (W[ap], W[ap-1]) (W[-1] = W[K] = 0)
   // and serves EVERY row pair of the lane: pair rp (output rows 2rp, 2rp+1) takes its input from LDS
   // row ap + 2rp.  The body is branch-free: (R/2) strips, one weight row, (R/2)*K*12 packed FMAs.
+  // a wave owns 4*R consecutive output rows; border tiles have waves with no row to produce
+  const int wy0 = y0 + __builtin_amdgcn_readfirstlane(tid >> 6) * 4 * R;
+  const bool wave_has_rows = (MODE == 0) ? (wy0 < C::PAD + a.g.M && wy0 + 4 * R > C::PAD) : (wy0 < a.g.uM);
 #pragma unroll 1
-  for (int ap = 0; ap <= K; ++ap) {
+  for (int ap = 0; ap <= (wave_has_rows ? K : -1); ++ap) {
     float strip[R / 2][C::STRIP];
 #pragma unroll
     for (int rp = 0; rp < R / 2; ++rp) {

@@ -52,7 +52,8 @@ struct IcsStatsArgs {
   const float* u;      // u frame origin
   float* scal;         // ICS_SC_MR / HU / VARU written
   const uint32_t* dofkeys;
-  float* wsc;          // work scalars (8 floats)
+  double* dacc;        // 8 double accumulators (zeroed by the launcher)
+  uint32_t* ukey;      // 2 keys (max |t|)
   float2* z;           // [3][P][P] complex scratch
   const float2* tw;    // [P/2] twiddles exp(-2 pi i k / P)
   const float* weights;// [H][W] Gaussian window (pyx:393-404)

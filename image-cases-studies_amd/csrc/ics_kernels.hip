@@ -113,11 +113,12 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
 // with the long pixel axis as K, so it runs on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact
 // fp32 == an fmaf chain) at (K/16)^2 = 88 % useful work for a 15x15 PSF.  rot180(u) (A12, pyx:567)
 // is never materialised: the flip is the minus sign in the indices.
-// Workgroups are persistent (grid-stride over 64x32-px tiles) and keep their 16x16 accumulators in
-// registers across tiles; one partial block per workgroup is written at the end and reduced in
+// Workgroups are persistent (grid-stride over 64x32-px tiles, next tile prefetched into registers
+// during the MFMA phase) and keep their 16x16 accumulators in registers across tiles; one partial block per workgroup is written at the end and reduced in
 // double, in a fixed order, by k_gradk_reduce (deterministic, no float atomics).
 // =================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NB>
 struct GradkCfg {
@@ -151,28 +152,63 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) acc[c][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
-    const int x0 = (t % ntx) * C::TW, y0 = (t / ntx) * C::TH;
+  // Staging is split (issue early / write late): the global loads of tile t+1 are issued right after
+  // the LDS image of tile t is complete and stay in flight during its MFMA phase; they are written to
+  // LDS only after the barrier that ends the phase.  The kernel needs few registers besides, so the
+  // ~70 staging VGPRs are free and HBM/L2 latency disappears behind the matrix pipe.
+  constexpr int W4 = 3 * C::TW / 4, NU4 = C::UROWS * W4, NUIT = (NU4 + 255) / 256;
+  constexpr int E4 = C::LWE / 4, NE4 = C::TH * E4, NEIT = (NE4 + 255) / 256;
+  f32x4 pu[NUIT], pe[NEIT];  // native vectors (HIP's float4 struct kept the array in scratch)
+  // (macros, not lambdas: capturing the register arrays by reference would push them to scratch)
+#define GK_PREFETCH(T)                                                                              \
+  {                                                                                                 \
+    const int px0 = ((T) % ntx) * C::TW, py0 = ((T) / ntx) * C::TH;                                 \
+    /* U rows [y0 + pad - NT + 1, y0 + pad + TH), px [x0, x0 + 64) */                               \
+    const float* src = a.u + (ptrdiff_t)(py0 + pad - C::NT + 1) * pitch + 3 * px0;                  \
+    _Pragma("unroll") for (int k = 0; k < NUIT; ++k) {                                              \
+      int v = tid + k * 256; v = v < NU4 ? v : NU4 - 1;                                             \
+      const int row = v / W4, c4 = v - row * W4;                                                    \
+      pu[k] = *reinterpret_cast<const f32x4*>(src + (ptrdiff_t)row * pitch + 4 * c4);               \
+    }                                                                                               \
+    /* E rows [y0, y0 + TH), px [x0 - 8NB, x0 + 64 + 16NB) */                                       \
+    const float* srce = a.e + (ptrdiff_t)py0 * pitch + 3 * (px0 - 8 * NB);                          \
+    _Pragma("unroll") for (int k = 0; k < NEIT; ++k) {                                              \
+      int v = tid + k * 256; v = v < NE4 ? v : NE4 - 1;                                             \
+      const int row = v / E4, c4 = v - row * E4;                                                    \
+      pe[k] = *reinterpret_cast<const f32x4*>(srce + (ptrdiff_t)row * pitch + 4 * c4);              \
+    }                                                                                               \
+  }
+
+  const int ntiles = ntx * nty;
+  {
+    const int tfirst = (int)blockIdx.x < ntiles ? (int)blockIdx.x : ntiles - 1;
+    GK_PREFETCH(tfirst)
+  }
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     __syncthreads();  // previous tile fully consumed
-    {  // U rows [y0 + pad - NT + 1, y0 + pad + TH), px [x0, x0 + 64)
-      const float* src = a.u + (ptrdiff_t)(y0 + pad - C::NT + 1) * pitch + 3 * x0;
-      constexpr int W4 = 3 * C::TW / 4;
-      for (int v = tid; v < C::UROWS * W4; v += 256) {
+#pragma unroll
+    for (int k = 0; k < NUIT; ++k) {
+      const int v = tid + k * 256;
+      if (v < NU4) {
         const int row = v / W4, c4 = v - row * W4;
-        const float4 val = *reinterpret_cast<const float4*>(src + (ptrdiff_t)row * pitch + 4 * c4);
-        float2* d = reinterpret_cast<float2*>(ul + row * C::LWU + 4 * c4);  // LWU rows are only 8-B aligned
-        d[0] = make_float2(val.x, val.y); d[1] = make_float2(val.z, val.w);
+        f32x2* d = reinterpret_cast<f32x2*>(ul + row * C::LWU + 4 * c4);  // LWU rows are only 8-B aligned
+        d[0] = pu[k].xy; d[1] = pu[k].zw;
       }
-      // E rows [y0, y0 + TH), px [x0 - 8NB, x0 + 64 + 16NB)
-      const float* srce = a.e + (ptrdiff_t)y0 * pitch + 3 * (x0 - 8 * NB);
-      constexpr int E4 = C::LWE / 4;
-      for (int v = tid; v < C::TH * E4; v += 256) {
+    }
+#pragma unroll
+    for (int k = 0; k < NEIT; ++k) {
+      const int v = tid + k * 256;
+      if (v < NE4) {
         const int row = v / E4, c4 = v - row * E4;
-        *reinterpret_cast<float4*>(el + row * C::LWE + 4 * c4) =
-            *reinterpret_cast<const float4*>(srce + (ptrdiff_t)row * pitch + 4 * c4);
+        *reinterpret_cast<f32x4*>(el + row * C::LWE + 4 * c4) = pe[k];
       }
     }
     __syncthreads();
+    {  // unconditional (clamped) so that the staging registers stay plain SSA values, not scratch
+      const int tnext = t + (int)gridDim.x < ntiles ? t + (int)gridDim.x : ntiles - 1;
+      GK_PREFETCH(tnext)
+    }
+#undef GK_PREFETCH
     // wave w owns tile rows [8w, 8w+8)
     for (int yy = wave * (C::TH / 4); yy < (wave + 1) * (C::TH / 4); ++yy) {
       const float* arow = ul + (yy + C::NT - 1 - m) * C::LWU + 3 * q;           // + 12*xk + c, - 16*ab rows

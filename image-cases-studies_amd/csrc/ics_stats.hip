@@ -35,74 +35,75 @@ __device__ __forceinline__ float block_maxf(float v, float* sh) {
   return s;
 }
 
-// wsc: [0]=mean_e [1]=std_e [2]=max|t| [3]=Hu [4]=varu
-__global__ __launch_bounds__(1024) void k_win_moments(IcsStatsArgs a) {
-  __shared__ double shd[16];
-  __shared__ float shf[16];
-  const IcsGeom& G = a.geo;
-  const int H = a.bottom - a.top, W = a.right - a.left, pad = G.pad;
-  const int ne = H * W * 3;
-  // error window [top:bottom, left:right] (image coords -> u-frame +pad)
-  double s = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    const int r = i / (3 * W), c = i - r * 3 * W;
-    const float v = a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c];
-    s += v; s2 += (double)v * v;
-  }
-  s = block_sum(s, shd); s2 = block_sum(s2, shd);
-  const float mean_e = (float)(s / ne);
-  const float Hu = (float)(s2 / ((double)H * W * 3));
-  double d2 = 0.0;
-  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    const int r = i / (3 * W), c = i - r * 3 * W;
-    const float v = __fsub_rn(a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_e);
-    d2 += (double)v * v;
-  }
-  d2 = block_sum(d2, shd);
-  const float std_e = sqrtf((float)(d2 / ne));
+// ---- window moments, three grid-wide passes (double atomics; <= 200k elements) ------------------
+// dacc: [0]=sum e  [1]=sum e^2  [2]=sum u  [3]=sum (e-mean_e)^2  [4]=sum (u-mean_u)^2  [5]=sum ac^2 w
+// ukey: [0] = key of max |(e-mean)/std|
+struct Win {
+  int H, W, Hu, Wu, ne, nu;
+};
+__device__ __forceinline__ Win make_win(const IcsStatsArgs& a) {
+  Win w;
+  w.H = a.bottom - a.top; w.W = a.right - a.left;
+  w.Hu = (a.bottom - a.geo.pad) - (a.top + a.geo.pad); w.Wu = (a.right - a.geo.pad) - (a.left + a.geo.pad);
+  if (w.Hu < 0) w.Hu = 0;
+  if (w.Wu < 0) w.Wu = 0;
+  w.ne = w.H * w.W * 3; w.nu = w.Hu * w.Wu * 3;
+  return w;
+}
+// error window [top:bottom, left:right] in image coordinates -> u-frame (+pad)
+__device__ __forceinline__ float win_e(const IcsStatsArgs& a, const Win& w, int i) {
+  const int r = i / (3 * w.W), c = i - r * 3 * w.W;
+  return a.e[(ptrdiff_t)(a.top + a.geo.pad + r) * a.geo.pitch + 3 * (a.left + a.geo.pad) + c];
+}
+// u window [top+pad : bottom-pad, left+pad : right-pad] in u coordinates (pyx:600)
+__device__ __forceinline__ float win_u(const IcsStatsArgs& a, const Win& w, int i) {
+  const int r = i / (3 * w.Wu), c = i - r * 3 * w.Wu;
+  return a.u[(ptrdiff_t)(a.top + a.geo.pad + r) * a.geo.pitch + 3 * (a.left + a.geo.pad) + c];
+}
+__device__ __forceinline__ float mean_of(double s, int n) { return (float)(s / n); }
+__device__ __forceinline__ float std_of(double d2, int n) { return sqrtf((float)(d2 / n)); }
+
+__global__ __launch_bounds__(256) void k_mom1(IcsStatsArgs a) {
+  __shared__ double shd[4];
+  const Win w = make_win(a);
+  double s = 0.0, s2 = 0.0, su = 0.0;
+  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  for (int i = t0; i < w.ne; i += stride) { const float v = win_e(a, w, i); s += v; s2 += (double)v * v; }
+  for (int i = t0; i < w.nu; i += stride) su += win_u(a, w, i);
+  s = block_sum(s, shd); s2 = block_sum(s2, shd); su = block_sum(su, shd);
+  if (threadIdx.x == 0) { atomicAdd(a.dacc + 0, s); atomicAdd(a.dacc + 1, s2); atomicAdd(a.dacc + 2, su); }
+}
+__global__ __launch_bounds__(256) void k_mom2(IcsStatsArgs a) {
+  __shared__ double shd[4];
+  const Win w = make_win(a);
+  const float mean_e = mean_of(a.dacc[0], w.ne), mean_u = w.nu ? mean_of(a.dacc[2], w.nu) : 0.f;
+  double d2 = 0.0, du = 0.0;
+  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  for (int i = t0; i < w.ne; i += stride) { const float v = __fsub_rn(win_e(a, w, i), mean_e); d2 += (double)v * v; }
+  for (int i = t0; i < w.nu; i += stride) { const float v = __fsub_rn(win_u(a, w, i), mean_u); du += (double)v * v; }
+  d2 = block_sum(d2, shd); du = block_sum(du, shd);
+  if (threadIdx.x == 0) { atomicAdd(a.dacc + 3, d2); atomicAdd(a.dacc + 4, du); }
+}
+__global__ __launch_bounds__(256) void k_mom3(IcsStatsArgs a) {
+  __shared__ float shf[4];
+  const Win w = make_win(a);
+  const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
   float mx = 0.f;
-  for (int i = threadIdx.x; i < ne; i += blockDim.x) {
-    const int r = i / (3 * W), c = i - r * 3 * W;
-    const float v = __fdiv_rn(__fsub_rn(a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_e), std_e);
-    const float av = __builtin_fabsf(v);
+  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+  for (int i = t0; i < w.ne; i += stride) {
+    const float av = __builtin_fabsf(__fdiv_rn(__fsub_rn(win_e(a, w, i), mean_e), std_e));
     mx = (mx > av || mx != mx) ? mx : av;
   }
   mx = block_maxf(mx, shf);
-  // u window [top+pad : bottom-pad, left+pad : right-pad] in u coordinates (pyx:600)
-  const int Hu_r = (a.bottom - pad) - (a.top + pad), Wu = (a.right - pad) - (a.left + pad);
-  float varu = __builtin_nanf("");
-  if (Hu_r > 0 && Wu > 0) {
-    const int nu = Hu_r * Wu * 3;
-    double su = 0.0;
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
-      const int r = i / (3 * Wu), c = i - r * 3 * Wu;
-      su += a.u[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c];
-    }
-    su = block_sum(su, shd);
-    const float mean_u = (float)(su / nu);
-    double du = 0.0;
-    for (int i = threadIdx.x; i < nu; i += blockDim.x) {
-      const int r = i / (3 * Wu), c = i - r * 3 * Wu;
-      const float v = __fsub_rn(a.u[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad) + c], mean_u);
-      du += (double)v * v;
-    }
-    du = block_sum(du, shd);
-    const float sd = sqrtf((float)(du / nu));
-    varu = __fmul_rn(sd, sd);
-  }
-  if (threadIdx.x == 0) {
-    a.wsc[0] = mean_e; a.wsc[1] = std_e; a.wsc[2] = mx; a.wsc[3] = Hu; a.wsc[4] = varu;
-    a.scal[ICS_SC_HU] = Hu; a.scal[ICS_SC_VARU] = varu;
-    a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[0]);
-    a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[1]);
-  }
+  if (threadIdx.x == 0) atomicMax(a.ukey, (mx != mx) ? 0xFFC00000u : ics_f2key(mx));
 }
 
 // z[c][i][j] = ((e - mean)/std)/max|t| inside the window, 0 elsewhere (zero padding to P x P)
 __global__ __launch_bounds__(256) void k_win_fill(IcsStatsArgs a) {
   const IcsGeom& G = a.geo;
-  const int H = a.bottom - a.top, W = a.right - a.left, P = a.P, pad = G.pad;
-  const float mean_e = a.wsc[0], std_e = a.wsc[1], mx = a.wsc[2];
+  const Win w = make_win(a);
+  const int H = w.H, W = w.W, P = a.P, pad = G.pad;
+  const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne), mx = ics_key2f(a.ukey[0]);
   const long total = 3L * P * P;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int j = (int)(i % P), r = (int)((i / P) % P), c = (int)(i / ((long)P * P));
@@ -151,21 +152,33 @@ __global__ __launch_bounds__(256) void k_abs2(float2* z, long total) {
   }
 }
 
-// M_r = mean over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
-__global__ __launch_bounds__(1024) void k_mr(IcsStatsArgs a) {
-  __shared__ double shd[16];
+// sum over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
+__global__ __launch_bounds__(256) void k_mr(IcsStatsArgs a) {
+  __shared__ double shd[4];
   const int H = a.bottom - a.top, W = a.right - a.left, P = a.P;
   const float inv = 1.0f / ((float)P * (float)P);
   double s = 0.0;
   const int n = H * W * 3;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int b = i % W, r = (i / W) % H, c = i / (W * H);
     const int zr = (r - H / 2 + P) & (P - 1), zc = (b - W / 2 + P) & (P - 1);
     const float ac = a.z[((long)c * P + zr) * P + zc].x * inv;
     s += (double)__fmul_rn(__fmul_rn(ac, ac), a.weights[r * W + b]);
   }
   s = block_sum(s, shd);
-  if (threadIdx.x == 0) a.scal[ICS_SC_MR] = (float)(s / n);
+  if (threadIdx.x == 0) atomicAdd(a.dacc + 5, s);
+}
+
+// scalars of the outer iteration (pyx:593-638) from the accumulators
+__global__ void k_stats_final(IcsStatsArgs a) {
+  const Win w = make_win(a);
+  a.scal[ICS_SC_HU] = (float)(a.dacc[1] / ((double)w.H * w.W * 3));
+  float varu = __builtin_nanf("");
+  if (w.nu > 0) { const float sd = std_of(a.dacc[4], w.nu); varu = __fmul_rn(sd, sd); }
+  a.scal[ICS_SC_VARU] = varu;
+  a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[0]);
+  a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[1]);
+  if (a.do_mr) a.scal[ICS_SC_MR] = (float)(a.dacc[5] / w.ne);
 }
 
 __global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* flag) {
@@ -185,8 +198,16 @@ __global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* 
 }  // namespace
 
 hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_win_moments, dim3(1), dim3(1024), 0, s, a);
+  hipError_t e = hipMemsetAsync(a.dacc, 0, 8 * sizeof(double), s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(a.ukey, 0, 2 * sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  const int ne = (a.bottom - a.top) * (a.right - a.left) * 3;
+  int gb = (ne + 256 * 8 - 1) / (256 * 8); if (gb < 1) gb = 1; if (gb > 512) gb = 512;
+  hipLaunchKernelGGL(k_mom1, dim3(gb), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_mom2, dim3(gb), dim3(256), 0, s, a);
   if (a.do_mr) {
+    hipLaunchKernelGGL(k_mom3, dim3(gb), dim3(256), 0, s, a);
     const int P = a.P;
     const long total = 3L * P * P;
     long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
@@ -199,8 +220,9 @@ hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_abs2, dim3((unsigned)blocks), dim3(256), 0, s, a.z, total);
     hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, (long)P, 1L, P, plane, 1, a.tw);
     hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, 1L, (long)P, P, plane, 1, a.tw);
-    hipLaunchKernelGGL(k_mr, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);
   }
+  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);
   return hipGetLastError();
 }
 
