@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t key_of(float f) {
 }
 
 template <int K, int R, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv(IcsConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv(IcsConvArgs a) {
   using C = ConvCfg<K, R>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -273,7 +273,9 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
 
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
-  constexpr int R = (K <= 15) ? 4 : 2;
+  // R = 2 (64x32-px tiles): 44 KB of LDS at K = 15 -> 3 workgroups per CU; measured 3-6 % faster than
+  // R = 4 (64x64 tiles, 2 workgroups per CU) at 4096^2 despite the larger halo (profiles/)
+  constexpr int R = 2;
   return mode == 0 ? launch_one<K, R, 0>(a, s) : launch_one<K, R, 1>(a, s);
 }
 

@@ -136,10 +136,12 @@ def TV(u, M, N, epsilon, order, norm):
     out = np.zeros_like(u)
     div = np.zeros_like(u)
     dxdy = F32(np.power(F32(2), F32(0.5)))
+    # pyx:149-152: `4. * (1 + 1/dxdy)`: 1/dxdy and 1 + ... are C float operations (dxdy is a float),
+    # the product with the double literal is exact (x4 / x2) and is stored into the C float `adjust`
     if norm == 1:
-        adjust = F32(4.0 * (1 + 1 / float(dxdy)))  # double expression stored into a C float
+        adjust = F32(4.0) * F32(F32(1) + F32(F32(1) / dxdy))
     else:
-        adjust = F32(2.0 * (1 + float(dxdy)))
+        adjust = F32(2.0) * F32(F32(1) + dxdy)
     eps = F32(epsilon)
     c = u[1:M - 1, 1:N - 1]
 
