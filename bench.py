@@ -73,7 +73,7 @@ def cpu_baseline(mode, MK, budget_s=20.0):
     """The oracle (numpy/scipy port of lib/deconvolution.pyx, same FFT call pattern) on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rl_mm_oracle as orc  # cpu_baseline leg only
-    S = 1024 if mode == "blind" else 1024
+    S = 2048
     image, u0, psf_true, psf_uniform = synth_frame(S, S, MK, seed=0)
     psf = (psf_uniform if mode == "blind" else psf_true).copy()
     win = (MK // 2 + 1, 255 - MK // 2 - 1, MK // 2 + 1, 255 - MK // 2 - 1)
@@ -84,7 +84,7 @@ def cpu_baseline(mode, MK, budget_s=20.0):
         orc.richardson_lucy_MM(image, u, psf, *win, 1e9, S, S, 3, MK, 1, 1e-3, 10000.0, blind=(mode == "blind"), quiet=True)
         outer += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s * 0.6 or outer >= 4:
+        if dt > budget_s * 0.5 or outer >= 8:
             break
     inner = 5 * outer
     return {"value": round(S * S * inner / dt / 1e6, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port",
@@ -146,12 +146,20 @@ def main():
         names = _native.KERNEL_NAMES
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(7) if st.launches[k]}
         roof = None
+        traffic = None
+        try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if tj["workload"] == {"size": M, "psf": MK}:
+                traffic = tj["kernels"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         if kern:
             dom = max((k for k in kern if k in BYTES_PER_PX), key=lambda k: kern[k]["ms"] * kern[k]["launches"])
             bytes_launch = BYTES_PER_PX[dom] * M * N
             ach = bytes_launch / (kern[dom]["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": (traffic[dom]["hbm_bytes"] if traffic and dom in traffic else None),
                     "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kern[dom]["ms"]}
         it_gbps = ITER_BYTES_PER_PX[args.mode] * M * N / (ms_per_step * 1e-3) / 1e9
         out = {

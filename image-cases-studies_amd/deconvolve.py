@@ -1,0 +1,222 @@
+# -*- coding: utf-8 -*-
+"""Driver with the call surface of the reference's `deconvolve.py` (pad_image :24-37, build_pyramid
+:40-60, deblur_module :65-368), feeding the GPU solver in `lib.deconvolution`.
+
+What is kept from the reference: argument names/defaults of `deblur_module`, the validation errors
+(:117-120, :145-148), gamma and bit-depth scaling (:97-103, :346-352), odd-size padding (:164-175), the
+pyramid schedule, the mask-window arithmetic (:209-230) and the three call shapes into
+`richardson_lucy_MM` (:277-313) including their positional arguments.
+
+What differs, and why:
+  * `skimage.transform.resize(order=3, mode="edge")` (:245-249) is an un-vendored dependency that is
+    not installed in this image; `resize_bicubic` below (scipy.ndimage cubic spline + the Gaussian
+    anti-aliasing skimage applies when shrinking) stands in for it.  PARITY UNPINNED for the pyramid
+    levels below 1.0; with `pyramid=False` (one level, scale 1) no resize is involved.
+  * matplotlib pop-ups (:331-336) only when `display=True` and matplotlib is importable.
+  * the 16-bit TIFF is written by `lib.utils.save` (own minimal writer instead of the vendored tifffile).
+"""
+import numpy as np
+
+from lib import utils
+from lib import deconvolution as dc
+
+
+def pad_image(image, pad, mode="edge"):
+    """deconvolve.py:24-37 -- pad the two spatial axes of an H x W x 3 image, float32 C-contiguous."""
+    R = np.pad(image[..., 0], pad, mode=mode)
+    G = np.pad(image[..., 1], pad, mode=mode)
+    B = np.pad(image[..., 2], pad, mode=mode)
+    u = np.dstack((R, G, B))
+    return np.ascontiguousarray(u, np.float32)
+
+
+def build_pyramid(psf_size, lambd):
+    """deconvolve.py:40-60 -- scales 1, 1/sqrt2, ... and the odd kernel sizes >= 3 that go with them."""
+    images = [1.]
+    kernels = [psf_size]
+    while kernels[-1] > 3:
+        kernels.append(int(np.ceil(kernels[-1] / np.sqrt(2))))
+        images.append(images[-1] / np.sqrt(2))
+        if kernels[-1] % 2 == 0:
+            kernels[-1] -= 1
+        if kernels[-1] < 3:
+            kernels[-1] = 3
+    return images, kernels
+
+
+def resize_bicubic(img, shape):
+    """Stand-in for skimage.transform.resize(img, shape, order=3, mode="edge", preserve_range=True)."""
+    from scipy import ndimage
+    img = np.asarray(img, dtype=np.float64)
+    out_h, out_w = int(shape[0]), int(shape[1])
+    in_h, in_w = img.shape[0], img.shape[1]
+    if (in_h, in_w) == (out_h, out_w):
+        return img.copy()
+    fy, fx = in_h / out_h, in_w / out_w
+    sy, sx = max(0.0, (fy - 1) / 2), max(0.0, (fx - 1) / 2)       # skimage's anti-aliasing sigma
+    if sy > 0 or sx > 0:
+        img = ndimage.gaussian_filter(img, (sy, sx, 0), mode="nearest")
+    ys = (np.arange(out_h) + 0.5) * fy - 0.5
+    xs = (np.arange(out_w) + 0.5) * fx - 0.5
+    yy, xx = np.meshgrid(ys, xs, indexing="ij")
+    out = np.empty((out_h, out_w, img.shape[2]))
+    for c in range(img.shape[2]):
+        out[..., c] = ndimage.map_coordinates(img[..., c], [yy, xx], order=3, mode="nearest")
+    return out
+
+
+def mask_window(i, top, bottom, left, right):
+    """deconvolve.py:209-230 -- scale the mask box to pyramid level `i` and make it odd and square,
+    with the reference's exact (and slightly odd) tie-breaking."""
+    temp_top, temp_bottom = int(i * top), int(i * bottom)
+    temp_left, temp_right = int(i * left), int(i * right)
+    if int(temp_bottom - temp_top) % 2 == 0:
+        if int(temp_bottom - temp_top) < int(temp_right - temp_left):
+            temp_bottom += 1
+        elif int(temp_bottom - temp_top) > int(temp_right - temp_left):
+            temp_top += 1
+        else:
+            temp_top -= 1
+    if int(temp_right - temp_left) % 2 == 0:
+        if int(temp_bottom - temp_top) < int(temp_right - temp_left):
+            temp_left += 1
+        elif int(temp_bottom - temp_top) > int(temp_bottom - temp_top):   # (sic) never true, deconvolve.py:227
+            temp_right += 1
+        else:
+            temp_right -= -1                                              # (sic) deconvolve.py:230
+    return temp_top, temp_bottom, temp_left, temp_right
+
+
+@utils.timeit
+def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance=1, quality="normal", bits=8,
+                  mask=None, display=True, blur="static", preview=False, p=1, order=2, norm=1, priority=0, mask_size=255,
+                  iterations=200, refocus=False, pyramid=True, solver=None, save=True):
+    """deconvolve.py:65-368.  Extra keyword arguments (not in the reference): `pyramid=False` runs the
+    single scale-1 level only, `solver` replaces `dc.richardson_lucy_MM` (tests record the calls),
+    `save=False` returns the float image instead of writing the TIFF."""
+    rl = solver if solver is not None else dc.richardson_lucy_MM
+    pic = np.ascontiguousarray(pic, dtype=np.float32)
+    pic = pad_image(pic, (1, 1)).astype(np.float32)                       # :94
+    samples = 2 ** bits - 1                                               # :97
+    pic = pic / samples
+    pic = pic ** (1 / 2.2)                                                # :103
+    step = {"normal": 1e-3, "high": 5e-4, "veryhigh": 1e-4, "low": 5e-3}[quality]   # :106-113
+    if blur_width < 3:
+        raise ValueError("The blur width should be at least 3 pixels.")
+    elif blur_width % 2 == 0:
+        raise ValueError("The blur width should be odd. You can use %i." % (blur_width + 1))
+    M, N = pic.shape[0], pic.shape[1]
+    if mask is None:
+        mask = [M // 2, N // 2]
+    top, bottom = mask[0] - mask_size // 2, mask[0] + mask_size // 2       # :138-141
+    left, right = mask[1] - mask_size // 2, mask[1] + mask_size // 2
+    print("Mask size :", (bottom - top + 1), "×", (right - left + 1))
+    if not (top > 0 and bottom < M and left > 0 and right < N):
+        raise ValueError("The mask is outside the picture boundaries. Move its center inside or reduce the blur size.")
+    correlation = {"static": False, "motion": True}[blur]                 # :154-157
+    tolerance /= 100.
+    odd_vert = odd_hor = False
+    if pic.shape[0] % 2 == 0:                                             # :167-175
+        pic = pad_image(pic, ((1, 0), (0, 0))).astype(np.float32)
+        odd_vert = True
+        print("Padded vertically")
+    if pic.shape[1] % 2 == 0:
+        pic = pad_image(pic, ((0, 0), (1, 0))).astype(np.float32)
+        odd_hor = True
+        print("Padded horizontally")
+    M, N = pic.shape[0], pic.shape[1]
+    psf = utils.uniform_kernel(blur_width)                                # :178-179
+    psf = np.dstack((psf, psf, psf))
+    images, kernels = build_pyramid(blur_width, confidence)               # :182
+    if not pyramid:
+        images, kernels = images[:1], kernels[:1]
+    deblured_image = pic
+    try:
+        for case in ["blind", "non-blind"]:                               # :193
+            print("\n===== %s DECONVOLUTION =====" % case)
+            deblured_image = pic.copy()
+            lambd = confidence * 1000                                     # :200
+            for i, k in zip(reversed(images), reversed(kernels)):        # :204
+                print("======== Pyramid step %1.3f ========" % i)
+                temp_top, temp_bottom, temp_left, temp_right = mask_window(i, top, bottom, left, right)
+                temp_width, temp_height = int(np.floor(i * N)), int(np.floor(i * M))
+                if temp_width % 2 == 0:
+                    temp_width += 1
+                if temp_height % 2 == 0:
+                    temp_height += 1
+                shape = (temp_height, temp_width, 3)
+                temp_blurry_image = resize_bicubic(pic, shape).astype(np.float32)              # :245
+                deblured_image = resize_bicubic(deblured_image, shape).astype(np.float32)      # :246
+                if case == "blind":
+                    psf_copy = np.ascontiguousarray(resize_bicubic(psf, (k, k, 3)).astype(np.float32))   # :249
+                    dc.normalize_kernel(psf_copy, k)
+                else:
+                    psf_copy = np.ascontiguousarray(psf, dtype=np.float32).copy()
+                    k = kernels[0]
+                temp_blurry_image = pad_image(temp_blurry_image, (1, 1)).astype(np.float32)    # :256-257
+                deblured_image = pad_image(deblured_image, (1, 1)).astype(np.float32)
+                pad = int(np.floor(k / 2))
+                print("Image size", temp_blurry_image.shape)
+                print("u size", deblured_image.shape)
+                print("Mask size", (temp_bottom - temp_top), (temp_right - temp_left))
+                print("PSF size", psf_copy.shape)
+                tolerance_temp = tolerance if i == 1. else 0
+                win = (pad + 1, temp_bottom - temp_top - pad - 1, pad + 1, temp_bottom - temp_top - pad - 1)
+                if case == "blind":                                       # :277-288
+                    deblured_image[temp_top - 1:temp_bottom + 1, temp_left - 1:temp_right + 1, ...] = rl(
+                        temp_blurry_image[temp_top - 1:temp_bottom + 1, temp_left - 1:temp_right + 1, ...],
+                        deblured_image[temp_top - pad - 1:temp_bottom + pad + 1, temp_left - pad - 1:temp_right + pad + 1, ...],
+                        psf_copy, *win, 0, temp_bottom - temp_top + 2, temp_right - temp_left + 2, 3,
+                        k, iterations, step, lambd, blind=True, p=p, correlation=correlation, order=order, norm=2,
+                        priority=0, refocus=refocus)
+                    psf = psf_copy.copy()
+                elif preview:                                             # :290-300
+                    deblured_image[temp_top - 1:temp_bottom + 1, temp_left - 1:temp_right + 1, ...] = rl(
+                        temp_blurry_image[temp_top - 1:temp_bottom + 1, temp_left - 1:temp_right + 1, ...],
+                        deblured_image[temp_top - pad - 1:temp_bottom + pad + 1, temp_left - pad - 1:temp_right + pad + 1, ...],
+                        psf_copy, *win, tolerance_temp, temp_bottom - temp_top + 2, temp_right - temp_left + 2, 3,
+                        k, iterations, step, lambd, blind=False, p=p, order=order, norm=2, priority=priority, refocus=refocus)
+                else:                                                     # :301-316
+                    deblured_image = pad_image(deblured_image, (pad, pad)).astype(np.float32)
+                    deblured_image[pad:-pad, pad:-pad, ...] = rl(
+                        temp_blurry_image, deblured_image, psf_copy, *win, tolerance_temp,
+                        temp_height + 2, temp_width + 2, 3,
+                        k, iterations, step, lambd, blind=False, p=p, order=order, norm=2, priority=priority, refocus=refocus)
+                    deblured_image = deblured_image[pad:-pad, pad:-pad, ...]
+                temp_blurry_image = temp_blurry_image[1:-1, 1:-1, ...]    # :322-323
+                deblured_image = deblured_image[1:-1, 1:-1, ...]
+            if display and case == "blind":                               # :331-336
+                try:
+                    import matplotlib.pyplot as plt
+                    psf_check = (psf - np.amin(psf)) / (np.amax(psf) - np.amin(psf))
+                    plt.imshow(psf_check, interpolation="lanczos", aspect="equal", vmin=0, vmax=1)
+                    plt.show()
+                except ImportError:
+                    pass
+    except KeyboardInterrupt:                                             # :338-342
+        pass
+    deblured_image = np.clip(deblured_image, 0., 1.)                      # :346
+    deblured_image = deblured_image ** 2.2
+    deblured_image = deblured_image * (2 ** 16 - 1)
+    if preview:
+        filename = filename + "-preview"
+        deblured_image = deblured_image[top:bottom, left:right, ...]
+    else:
+        if odd_hor:
+            deblured_image = deblured_image[:, 1:, ...]
+        if odd_vert:
+            deblured_image = deblured_image[1:, :, ...]
+        deblured_image = deblured_image[1:-1, 1:-1, ...]
+    if save:
+        utils.save(deblured_image, filename, dest_path)
+    return deblured_image, psf
+
+
+if __name__ == '__main__':
+    import sys
+    from PIL import Image
+    if len(sys.argv) < 4:
+        raise SystemExit("usage: python deconvolve.py <picture> <dest_dir> <blur_width> [mask_y mask_x]")
+    with Image.open(sys.argv[1]) as pic:
+        mask = [int(sys.argv[4]), int(sys.argv[5])] if len(sys.argv) >= 6 else None
+        deblur_module(pic, sys.argv[1].rsplit("/", 1)[-1] + "-ics", sys.argv[2], int(sys.argv[3]), mask=mask, display=False)

@@ -1,0 +1,86 @@
+"""deconvolve.py call surface (SURVEY.md 8c 'deconve.py' row): pyramid schedule pinned to the integers
+the reference's build_pyramid produces, mask-window arithmetic, validation errors, and the arguments the
+driver passes to richardson_lucy_MM (recorded with a stub solver; no GPU needed)."""
+import numpy as np
+import pytest
+
+
+def test_build_pyramid_matches_reference_integers():
+    import deconvolve as dv
+    assert dv.build_pyramid(9, 10)[1] == [9, 7, 5, 3]
+    assert dv.build_pyramid(15, 10)[1] == [15, 11, 7, 5, 3]
+    assert dv.build_pyramid(31, 10)[1] == [31, 21, 15, 11, 7, 5, 3]
+    images, kernels = dv.build_pyramid(7, 10)
+    assert kernels == [7, 5, 3] and np.allclose(images, [1, 2 ** -0.5, 0.5])
+    assert dv.build_pyramid(3, 1) == ([1.], [3])
+
+
+def test_pad_image_is_edge_replication_float32():
+    import deconvolve as dv
+    img = np.arange(2 * 3 * 3, dtype=np.float64).reshape(2, 3, 3)
+    out = dv.pad_image(img, (1, 1))
+    assert out.shape == (4, 5, 3) and out.dtype == np.float32 and out.flags.c_contiguous
+    assert np.array_equal(out[0, 0], img[0, 0]) and np.array_equal(out[-1, -1], img[-1, -1])
+    assert dv.pad_image(img, ((1, 0), (0, 0))).shape == (3, 3, 3)
+
+
+def test_validation_errors():
+    import deconvolve as dv
+    pic = np.full((64, 64, 3), 128, np.uint8)
+    with pytest.raises(ValueError, match="at least 3"):
+        dv.deblur_module(pic, "x", ".", 1, save=False)
+    with pytest.raises(ValueError, match="should be odd. You can use 5"):
+        dv.deblur_module(pic, "x", ".", 4, save=False)
+    with pytest.raises(ValueError, match="mask is outside"):
+        dv.deblur_module(pic, "x", ".", 3, mask=[5, 5], mask_size=31, save=False)
+
+
+def test_driver_call_shapes_recorded(capsys, monkeypatch):
+    """Blind call on the mask window (deconvolve.py:277-286) then the full-frame non-blind call (:304-313)."""
+    import deconvolve as dv
+    import rl_mm_oracle as orc
+    monkeypatch.setattr(dv.dc, "normalize_kernel", orc.normalize_kernel)   # no GPU in this test: oracle as stand-in
+    calls = []
+
+    def solver(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step, lambd, **kw):
+        calls.append(dict(image=image.shape, u=u.shape, psf=psf.shape, win=(top, bottom, left, right), tau=tau, M=M, N=N, C=C, MK=MK,
+                          it=iterations, step=step, lambd=lambd, kw=kw, contiguous=(image.flags.c_contiguous, u.flags.c_contiguous)))
+        assert u.shape == (M + 2 * (MK // 2), N + 2 * (MK // 2), 3) and image.shape == (M, N, 3) and psf.shape == (MK, MK, 3)
+        pad = (u.shape[0] - M) // 2
+        return u[pad:pad + M, pad:pad + N]
+
+    rng = np.random.default_rng(0)
+    pic = (rng.random((90, 100, 3)) * 255).astype(np.uint8)
+    out, psf = dv.deblur_module(pic, "x", ".", 5, mask=[46, 50], mask_size=41, display=False, pyramid=False, solver=solver,
+                                save=False, iterations=7, tolerance=2, confidence=10)
+    assert len(calls) == 2
+    blind, full = calls
+    # picture 90x100 -> +1 px each side = 92x102 -> made odd: 93x103; mask box 46+-20 / 50+-20 -> 40 wide -> made odd 41
+    assert blind["kw"]["blind"] is True and blind["MK"] == 5 and blind["M"] == 43 and blind["N"] == 43
+    assert blind["win"] == (3, 38, 3, 38) and blind["tau"] == 0 and blind["it"] == 7 and blind["step"] == 1e-3 and blind["lambd"] == 10000
+    assert blind["contiguous"] == (False, False)                       # window views, as deconvolve.py:278-279
+    assert full["kw"]["blind"] is False and full["M"] == 95 and full["N"] == 105 and full["tau"] == pytest.approx(0.02)
+    assert full["win"] == blind["win"] and full["contiguous"] == (True, True)
+    assert out.shape == (90, 100, 3) and psf.shape == (5, 5, 3)
+    assert out.min() >= 0 and out.max() <= 65535
+
+
+def test_mask_window_reference_tie_breaking():
+    import deconvolve as dv
+    assert dv.mask_window(1.0, 26, 66, 30, 70) == (25, 66, 30, 71)
+    assert dv.mask_window(1.0, 10, 51, 10, 51) == (10, 51, 10, 51)
+    t = dv.mask_window(2 ** -0.5, 100, 354, 120, 374)
+    assert (t[1] - t[0]) % 2 == 1
+
+
+@pytest.mark.gpu
+def test_deblur_module_end_to_end_on_gpu(tmp_path):
+    """Full driver on a synthetic blurred picture: blind estimate on the mask window then non-blind pass."""
+    import deconvolve as dv
+    import rl_mm_oracle as orc
+    case = orc.synth_case(120, 140, 5, seed=1)
+    pic = np.clip(case["image"] ** 2.2 * 255, 0, 255).astype(np.uint8)
+    out, psf = dv.deblur_module(pic, "gpu", str(tmp_path), 5, mask=[60, 70], mask_size=61, display=False, iterations=4,
+                                pyramid=True)
+    assert out.shape == (120, 140, 3) and np.isfinite(out).all() and (tmp_path / "gpu.tif").exists()
+    assert np.all(psf >= 0) and np.allclose(psf.sum(axis=(0, 1)), 1, atol=1e-4)
