@@ -32,7 +32,8 @@ sys.path.insert(0, os.path.join(ROOT, "image-cases-studies_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic bytes per pixel and launch (one fp32 x 3 frame transit T = 12 B/px)
-BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "psf_gradient": 24.0}
+BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "psf_gradient": 24.0,
+                "update_synth": 72.0}  # fused update + convolution: 4 reads + 2 writes
 ITER_BYTES_PER_PX = {"nonblind": 144.0, "blind": 204.0}
 
 
@@ -102,6 +103,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--psf", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
@@ -124,7 +126,7 @@ def main():
     win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)  # 255-px stats window as deconvolve.py:281 passes it
 
     def run(n_inner, profile):
-        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile)
+        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse))
         return job.run(p)
 
     if warm:
@@ -144,7 +146,7 @@ def main():
         ms_per_step = elapsed * 1e3 / steps
         value = grp.size * M * N * steps / elapsed / 1e6
         names = _native.KERNEL_NAMES
-        kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(7) if st.launches[k]}
+        kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(8) if st.launches[k]}
         roof = None
         traffic = None
         try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/)

@@ -47,7 +47,7 @@ struct ics_rl {
   ics_ctx* ctx;
   IcsGeom g;
   size_t frame_floats, origin;
-  float *u, *ut, *gr, *f, *e;          // frame bases (origin = base + origin)
+  float *u, *u2, *ut, *gr, *f, *e;     // frame bases (origin = base + origin); u2 = ping-pong partner of u
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   int gradk_blocks;
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
@@ -145,7 +145,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->u, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
+  void* ptrs[] = {j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
                   j->red, j->dofkeys, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -173,7 +173,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   int rc;
 #define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
   hipStream_t s = c->stream;
-  TRY(dalloc(&j->u, j->frame_floats, s)); TRY(dalloc(&j->ut, j->frame_floats, s)); TRY(dalloc(&j->gr, j->frame_floats, s));
+  TRY(dalloc(&j->u, j->frame_floats, s)); TRY(dalloc(&j->u2, j->frame_floats, s)); TRY(dalloc(&j->ut, j->frame_floats, s)); TRY(dalloc(&j->gr, j->frame_floats, s));
   TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
   TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
@@ -390,16 +390,19 @@ struct Prof {
 
 #define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
 
-static int do_conv(ics_rl* j, int mode, float lambd, int slot, Prof& pr) {
+static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   IcsConvArgs a;
-  a.g = j->g; a.lambd = lambd;
-  if (mode == 0) { a.in = org(j, j->u); a.w = j->wconv; a.out = org(j, j->e); }
-  else { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
+  a.g = j->g; a.lambd = p->lambd;
+  if (mode == 1) { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
+  else { a.in = org(j, j->u); a.w = j->wconv; a.out = org(j, j->e); }
   a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, j->ut);
   a.red = j->red + slot * ICS_RED_STRIDE;
-  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
+  a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
+  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
   HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
   RC(pr.end());
+  if (mode == 2) { float* t = j->u; j->u = j->u2; j->u2 = t; }  // the updated frame is now `u`
   return ICS_OK;
 }
 
@@ -487,14 +490,23 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     RC(do_majorize(j, pr));                                   // pyx:462
     HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
     RC(reset_dofkeys(j));
+    const bool fuse = p->fuse != 0;
+    bool have_e = false;  // error already produced by a fused update+synth kernel
     for (int itt = 0; itt < INNER; ++itt) {                   // pyx:473
-      RC(do_conv(j, 0, p->lambd, itt, pr));                   // A1+A2
-      RC(do_conv(j, 1, p->lambd, itt, pr));                   // A3 (+A7)
-      RC(do_update(j, p, itt, itt == INNER - 1, pr));         // A5,A6,A8,A10
+      const int last = itt == INNER - 1;
+      if (!have_e) RC(do_conv(j, 0, p, itt, 0, pr));          // A1+A2
+      have_e = false;
+      RC(do_conv(j, 1, p, itt, 0, pr));                       // A3 (+A7)
       if (p->blind) {                                         // pyx:555
-        RC(do_conv(j, 0, p->lambd, itt, pr));                 // A11
+        if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
+        else { RC(do_update(j, p, itt, last, pr)); RC(do_conv(j, 0, p, itt, 0, pr)); }
         RC(do_gradk(j, pr));                                  // A12+A13
         RC(do_psf(j, p, pr));                                 // A14-A17
+      } else if (fuse && !last) {
+        RC(do_conv(j, 2, p, itt, 0, pr));                     // A5-A10 fused with A1+A2 of itt+1
+        have_e = true;
+      } else {
+        RC(do_update(j, p, itt, last, pr));                   // A5,A6,A8,A10 (outer boundary: stats need u and e)
       }
       ++inner_done;
     }
@@ -541,16 +553,21 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   switch (stage) {
     case ICS_STAGE_SYNTH_RESIDUAL:
       RC(pack_weights(j, 0, 0.f, 0, s));
-      RC(do_conv(j, 0, p->lambd, 0, pr));
+      RC(do_conv(j, 0, p, 0, 0, pr));
       break;
     case ICS_STAGE_BACKPROJECT:
       RC(pack_weights(j, 0, 0.f, 0, s));
       HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
-      RC(do_conv(j, 1, p->lambd, 0, pr));
+      RC(do_conv(j, 1, p, 0, 0, pr));
       break;
     case ICS_STAGE_UPDATE:
       RC(reset_dofkeys(j));
       RC(do_update(j, p, 0, 1, pr));
+      break;
+    case ICS_STAGE_UPDATE_SYNTH:
+      RC(pack_weights(j, 0, 0.f, 0, s));
+      RC(reset_dofkeys(j));
+      RC(do_conv(j, 2, p, 0, 1, pr));
       break;
     case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, pr)); break;
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;

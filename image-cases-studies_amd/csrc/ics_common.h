@@ -92,10 +92,18 @@ struct IcsConvArgs {
   const float* f;    // A1: image frame origin
   const float* u;    // A3: u frame origin   (for the fused A6/A7 reductions)
   const float* ut;   // A3: ut frame origin
-  uint32_t* red;     // A3: reduction keys (ICS_RED_*)
+  uint32_t* red;     // A3: reduction keys (ICS_RED_*) written; mode 2: keys of the finished back-projection read
   float lambd;
+  // mode 2 only (update of the previous inner iteration fused in front of the convolution):
+  const float* gr;   // raw back-projection frame (A3 output)
+  float* u_out;      // frame that receives the updated u (ping-pong partner of `in`)
+  float* scal;       // device scalar block: dt / maxu / maxg recorded
+  uint32_t* dofkeys; // DoF min/max/NaN keys (when want_dof)
+  float step;
+  int blind, want_dof;
   IcsGeom g;
 };
-// mode 0 = A1+A2 (valid convolution + residual), mode 1 = A3 (+A6/A7 reductions)
+// mode 0 = A1+A2 (valid convolution + residual), mode 1 = A3 (+A6/A7 reductions),
+// mode 2 = A5/A6/A8/A10 (update, recomputed on the halo) + A1+A2 on the updated u
 hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_supported(int K);

@@ -74,10 +74,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
-  const int txi = blockIdx.x, tyi = blockIdx.y;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), each XCD has its own L2.
+  // Remap so that every XCD owns one contiguous band of tile rows and the halos shared by neighbouring
+  // tiles hit in that XCD's L2 (bijective for any tile count; affects speed only, never results).
+  const int gx = a.g.tiles_x, nwg = gridDim.x;
+  int lin = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = lin & 7;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+  }
+  const int tyi = lin / gx, txi = lin - tyi * gx;
   const int x0 = txi * C::TW, y0 = tyi * C::TH;
   const int pitch = a.g.pitch;
 
+  if (MODE != 2) {
   // ---- stage tile + halo: all global loads of a batch are in flight before the LDS writes ----------
   {
     const float* src = a.in + (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::PAD);
@@ -109,6 +119,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
   }
+  } else {
+    // ---- mode 2: the image update of the finished inner iteration (A5/A6/A8/A10, pyx:499-552) is applied
+    // while staging: every staged element (tile + halo) is computed from u_old, ut, gradu, image with the
+    // reference's float32 rounding, written to LDS, and the tile's own elements are stored to `u_out`.
+    // u_old stays intact for the neighbouring tiles' halos (ping-pong), so no grid-wide dependency arises.
+    float dt[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float maxu = ics_key2f(a.red[ICS_RED_MAXU + c]);
+      const float maxg = ics_key2f(a.red[ICS_RED_MAXG + c]);
+      dt[c] = __fdiv_rn(__fmul_rn(a.step, maxu), __fadd_rn(maxg, 1e-15f));
+      if (blockIdx.x == 0 && tid == 0) {
+        a.scal[ICS_SC_DT + c] = dt[c]; a.scal[ICS_SC_MAXU + c] = maxu; a.scal[ICS_SC_MAXG + c] = maxg;
+      }
+    }
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, knan = 0u;
+    const float lambd = a.lambd;
+    const ptrdiff_t base = (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::PAD);
+    constexpr int LW4 = C::LW_USED / 4;
+    constexpr int NV = C::LROWS * LW4;
+    constexpr int NIT = (NV + 255) / 256;
+    constexpr int BATCH = 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+      f32x4u pu[BATCH], pt[BATCH], pg[BATCH], pf[BATCH];
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        int v = tid + (it0 + k) * 256;
+        v = v < NV ? v : NV - 1;
+        const int row = v / LW4, c4 = v - row * LW4;
+        const ptrdiff_t o = base + (ptrdiff_t)row * pitch + 4 * c4;
+        pu[k] = *reinterpret_cast<const f32x4u*>(a.in + o);
+        pt[k] = *reinterpret_cast<const f32x4u*>(a.ut + o);
+        pg[k] = *reinterpret_cast<const f32x4u*>(a.gr + o);
+        pf[k] = *reinterpret_cast<const f32x4u*>(a.f + o);
+      }
+#pragma unroll
+      for (int k = 0; k < BATCH; ++k) {
+        const int v = tid + (it0 + k) * 256;
+        if (v < NV) {
+          const int row = v / LW4, c4 = v - row * LW4;
+          const int y = y0 - C::PAD + row;
+          const bool yin = (y >= C::PAD) && (y < C::PAD + a.g.M);
+          const bool yown = (row >= C::PAD) && (row < C::PAD + C::TH) && (y < a.g.uM);
+          float un4[4];
+          bool own[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int fi = 4 * c4 + jj;          // float index inside the LDS row
+            const int pxr = fi / 3, c = fi - 3 * pxr;
+            const int x = x0 - C::PAD + pxr;
+            const float uo = pu[k][jj], to = pt[k][jj], go = pg[k][jj], fo = pf[k][jj];
+            const float dtc = c == 0 ? dt[0] : (c == 1 ? dt[1] : dt[2]);
+            const float g = __fadd_rn(__fmul_rn(lambd, go), __fmul_rn(__fsub_rn(uo, to), 0.5f));
+            float un = __fsub_rn(uo, __fmul_rn(dtc, g));
+            own[jj] = yown && (pxr >= C::PAD) && (pxr < C::PAD + C::TW) && (x < a.g.uN);
+            if (yin && (x >= C::PAD) && (x < C::PAD + a.g.N)) {
+              const float d = __fdiv_rn(__fsub_rn(go, fo), __fadd_rn(go, fo));
+              float D = __fmul_rn(d, d);
+              if (!a.blind) D = __fdiv_rn(D, lambd);
+              un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fo));
+              if (a.want_dof && own[jj]) {
+                if (D != D) knan = 1u;
+                else { const uint32_t kk = ics_f2key(D); kmin = kmin < kk ? kmin : kk; kmax = kmax > kk ? kmax : kk; }
+              }
+            }
+            un4[jj] = un;
+          }
+          *reinterpret_cast<float4*>(lds + row * C::LWF + 4 * c4) = make_float4(un4[0], un4[1], un4[2], un4[3]);
+          float* dst = a.u_out + base + (ptrdiff_t)row * pitch + 4 * c4;
+          if (own[0] && own[3]) {
+            f32x4u w4 = {un4[0], un4[1], un4[2], un4[3]};
+            *reinterpret_cast<f32x4u*>(dst) = w4;
+          } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) if (own[jj]) dst[jj] = un4[jj];
+          }
+        }
+      }
+    }
+    if (a.want_dof) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o1 = (uint32_t)__shfl_xor((int)kmin, off, 64); kmin = kmin < o1 ? kmin : o1;
+        const uint32_t o2 = (uint32_t)__shfl_xor((int)kmax, off, 64); kmax = kmax > o2 ? kmax : o2;
+        const uint32_t o3 = (uint32_t)__shfl_xor((int)knan, off, 64); knan = knan > o3 ? knan : o3;
+      }
+      if ((tid & 63) == 0) {
+        if (kmin < a.dofkeys[0]) atomicMin(a.dofkeys + 0, kmin);
+        if (kmax > a.dofkeys[1]) atomicMax(a.dofkeys + 1, kmax);
+        if (knan) atomicOr(a.dofkeys + 2, 1u);
+      }
+    }
+  }
   __syncthreads();
 
   // accumulator pairs: A[rp][f] = (output row 2rp, output row 2rp+1) at flat column f
@@ -126,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // row ap + 2rp.  The body is branch-free: (R/2) strips, one weight row, (R/2)*K*12 packed FMAs.
   // a wave owns 4*R consecutive output rows; border tiles have waves with no row to produce
   const int wy0 = y0 + __builtin_amdgcn_readfirstlane(tid >> 6) * 4 * R;
-  const bool wave_has_rows = (MODE == 0) ? (wy0 < C::PAD + a.g.M && wy0 + 4 * R > C::PAD) : (wy0 < a.g.uM);
+  const bool wave_has_rows = (MODE != 1) ? (wy0 < C::PAD + a.g.M && wy0 + 4 * R > C::PAD) : (wy0 < a.g.uM);
 #pragma unroll 1
   for (int ap = 0; ap <= (wave_has_rows ? K : -1); ++ap) {
     float strip[R / 2][C::STRIP];
@@ -139,6 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         strip[rp][4 * j + 0] = t.x; strip[rp][4 * j + 1] = t.y; strip[rp][4 * j + 2] = t.z; strip[rp][4 * j + 3] = t.w;
       }
     }
+    // (every strip element is consumed through op_sel as the low or high half of an aligned VGPR pair)
     const f32x2* __restrict__ wr = wbase + ap * (C::WROW2 / 2);
 #pragma unroll
     for (int b = 0; b < K; ++b) {
@@ -165,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // ---- epilogue ----------------------------------------------------------------------------
   const int xp = x0 + 4 * tx;  // first of this lane's 4 pixels (u-frame x)
-  if (MODE == 0) {
+  if (MODE != 1) {
     // error = synth - image on the M x N interior (pyx:488); the border ring of the frame stays 0
     const int lo_x = C::PAD, hi_x = C::PAD + a.g.N, lo_y = C::PAD, hi_y = C::PAD + a.g.M;
 #pragma unroll
@@ -195,7 +300,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   } else {
     // gradu (raw back-projection) over the whole u-frame + reductions for the step size:
     //   g = lambd*gradu + (u-ut)/2.  (pyx:519, float product + exact halving, one rounding)
-    uint32_t kg[3] = {0u, 0u, 0u}, ku[3] = {0u, 0u, 0u};
+    // float maxima + a NaN flag per lane (2 VALU per value); converted to order-preserving keys once
+    float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    bool nan_g[3] = {false, false, false}, nan_u[3] = {false, false, false}, any = false;
     const float lambd = a.lambd;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -216,10 +323,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const float g = __fadd_rn(__fmul_rn(lambd, acc[r][3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
-            const uint32_t k1 = key_of(__builtin_fabsf(g));
-            const uint32_t k2 = key_of(uv[3*p+c]);
-            kg[c] = kg[c] > k1 ? kg[c] : k1;
-            ku[c] = ku[c] > k2 ? ku[c] : k2;
+            mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
+            mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
+            nan_g[c] |= (g != g); nan_u[c] |= (uv[3*p+c] != uv[3*p+c]);
+            any = true;
           }
         }
       }
@@ -236,8 +343,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
     }
     // wave shuffle reduction -> LDS -> one atomic per value per workgroup
+    uint32_t kg[3], ku[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]); }
+    for (int c = 0; c < 3; ++c) {
+      kg[c] = nan_g[c] ? 0xFFC00000u : (any ? ics_f2key(mg[c]) : 0u);   // NaN propagates like np.amax
+      ku[c] = nan_u[c] ? 0xFFC00000u : (any ? ics_f2key(mu[c]) : 0u);
+      kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]);
+    }
     __syncthreads();  // all waves are done reading the tile
     uint32_t* red_lds = reinterpret_cast<uint32_t*>(lds);
     const int wave = tid >> 6, lane = tid & 63;
@@ -251,7 +363,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int w = 1; w < 4; ++w) { const uint32_t o = red_lds[w * 8 + tid]; m = m > o ? m : o; }
       const int slot = tid < 3 ? ICS_RED_MAXG + tid : ICS_RED_MAXU + (tid - 3);
-      atomicMax(a.red + slot, m);
+      // the running maximum only grows: a (possibly stale, hence lower) read lets most of the ~8000
+      // workgroups skip their atomic instead of serialising on six L2 words
+      if (m > a.red[slot]) atomicMax(a.red + slot, m);
     }
   }
 }
@@ -266,13 +380,14 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     configured = true;
   }
-  dim3 grid(a.g.tiles_x, a.g.tiles_y * (ICS_TILE / C::TH));
+  dim3 grid(a.g.tiles_x * a.g.tiles_y * (ICS_TILE / C::TH));
   hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
+  if (mode == 2) return launch_one<K, 2, 2>(a, s);
   // R = 2 (64x32-px tiles): 44 KB of LDS at K = 15 -> 3 workgroups per CU; measured 3-6 % faster than
   // R = 4 (64x64 tiles, 2 workgroups per CU) at 4096^2 despite the larger halo (profiles/)
   constexpr int R = 2;

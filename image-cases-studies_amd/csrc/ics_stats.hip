@@ -227,6 +227,6 @@ hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
 }
 
 hipError_t ics_launch_hasnan(const float* u, const IcsGeom& g, int* flag, hipStream_t s) {
-  hipLaunchKernelGGL(k_hasnan, dim3(2048), dim3(256), 0, s, u, g, flag);
+  hipLaunchKernelGGL(k_hasnan, dim3(512), dim3(256), 0, s, u, g, flag);
   return hipGetLastError();
 }

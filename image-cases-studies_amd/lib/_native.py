@@ -16,13 +16,13 @@ LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ICS_MAX_TRACE = 1024
 ICS_KERNEL_COUNT = 8
-KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "-")
+KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth")
 
 # error codes (include/ics_hip.h)
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
 
 # stages / buffers
-STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS = range(1, 8)
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH = range(1, 9)
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS = range(8)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
                 "dof_min", "dof_max", "_")
@@ -32,7 +32,7 @@ class RLParams(C.Structure):
     _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
                 ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
                 ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
-                ("stop_test", C.c_int), ("profile", C.c_int), ("reserved", C.c_int * 3)]
+                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class RLStats(C.Structure):
@@ -238,12 +238,12 @@ class RLJob:
 
     @staticmethod
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
-               stop_test=1, profile=0):
+               stop_test=1, profile=0, fuse=0):
         p = RLParams()
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
         p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), 0
-        p.stop_test, p.profile = int(stop_test), int(profile)
+        p.stop_test, p.profile, p.fuse = int(stop_test), int(profile), int(fuse)
         return p
 
     def run(self, params):

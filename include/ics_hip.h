@@ -77,7 +77,12 @@ typedef struct ics_rl_params {
                                    (fixed-length benchmark runs with the full workload)    */
   int profile;                  /* 1 = bracket every kernel launch with HIP events on the job's
                                    stream and report per-kernel averages in ics_rl_stats    */
-  int reserved[3];
+  int fuse;                     /* 1: the image update of inner iteration i is fused in front of the next
+                                   convolution (one kernel, u ping-pong, bit-identical results).  Default 0:
+                                   measured SLOWER on MI355X at 4096^2/15x15 (0.67 ms vs 0.28 + 0.19 ms),
+                                   the 1.8x halo recompute with two IEEE divisions per element outweighs
+                                   the saved frame pass                            */
+  int reserved[2];
 } ics_rl_params;
 
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
@@ -126,6 +131,7 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 #define ICS_STAGE_PSF_UPDATE 5     /* A14-A17: psf step, tie, normalise, rotate    (pyx:574-589)   */
 #define ICS_STAGE_MAJORIZE 6       /* ut = u                                       (pyx:462)       */
 #define ICS_STAGE_STATS 7          /* A18+A19 on device -> stats scalars           (pyx:593-638)   */
+#define ICS_STAGE_UPDATE_SYNTH 8   /* ICS_STAGE_UPDATE fused with ICS_STAGE_SYNTH_RESIDUAL (one kernel) */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -148,6 +154,7 @@ int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
 #define ICS_K_PSF_UPDATE 4   /* A14-A17                         */
 #define ICS_K_MAJORIZE 5     /* ut = u copy                     */
 #define ICS_K_STATS 6        /* A18/A19 window statistics + FFT */
+#define ICS_K_UPDATE_SYNTH 7 /* fused A5-A10 + A1/A2 (or A11) kernel */
 #define ICS_KERNEL_COUNT 8
 
 /* ---- small standalone operators ---------------------------------------------------------- */

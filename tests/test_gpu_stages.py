@@ -139,3 +139,32 @@ def test_window_statistics_and_whiteness_metric(M, N, MK, win):
     assert abs(sc["Hu"] - Hu) / Hu < 1e-5
     assert abs(sc["varu"] - varu) / varu < 1e-5
     job.close()
+
+
+@pytest.mark.parametrize("M,N,MK,blind", [(64, 64, 15, False), (97, 191, 15, True), (130, 67, 9, False), (50, 45, 3, True), (70, 90, 31, False)])
+def test_fused_update_synth_equals_separate_kernels(M, N, MK, blind):
+    """ICS_STAGE_UPDATE_SYNTH (update recomputed on the halo while staging + convolution, u ping-pong) must
+    give bit-identical u, error, dt and DoF extrema to ICS_STAGE_UPDATE followed by ICS_STAGE_SYNTH_RESIDUAL."""
+    from lib import _native as nv
+    res = []
+    for fused in (False, True):
+        job, case, psf = make_job(M, N, MK, seed=M * 3 + N, blind=blind)
+        rng = np.random.default_rng(9)
+        u = (case["u0"] + 0.03 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        job.write(nv.BUF_U, u)
+        job.write(nv.BUF_UT, case["u0"])
+        p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=blind)
+        job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+        job.stage(nv.STAGE_BACKPROJECT, p)
+        if fused:
+            job.stage(nv.STAGE_UPDATE_SYNTH, p)
+        else:
+            job.stage(nv.STAGE_UPDATE, p)
+            job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+        job.stage(nv.STAGE_STATS, job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=blind, stop_test=0))
+        sc = job.scalars()
+        res.append((job.read(nv.BUF_U), job.read(nv.BUF_ERROR), [sc[k] for k in ("dt0", "dt1", "dt2", "dof_min", "dof_max")]))
+        job.close()
+    assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+    assert np.array_equal(res[0][1], res[1][1], equal_nan=True)
+    assert res[0][2] == res[1][2]
