@@ -118,7 +118,8 @@ def main():
     warm = ((args.warmup + 4) // 5) * 5
     blind = args.mode == "blind"
 
-    ctx = _native.Context.get(grp.local_rank)
+    ndev = max(1, _native.device_count())
+    ctx = _native.Context.get(grp.local_rank % ndev)  # (% ndev only matters when ranks share a GPU in tests)
     image, u0, psf_true, psf_uniform = synth_frame(M, N, MK, seed=grp.rank)
     job = _native.RLJob(M, N, MK, ctx)
     job.upload(image, u0, psf_uniform if blind else psf_true)

@@ -27,13 +27,18 @@
 // (DESIGN.md), so this path is VALU by design.
 #include "ics_common.h"
 
+#ifndef ICS_CONV_NTY32
+#define ICS_CONV_NTY32 1
+#endif
+
 namespace {
 
-template <int K, int R>
+template <int K, int R, int NTY = 16>
 struct ConvCfg {
   static constexpr int PAD = K / 2;
   static constexpr int TW = ICS_TILE;
-  static constexpr int TH = 16 * R;
+  static constexpr int NT = 16 * NTY;   // threads per workgroup: 16 lanes across x, NTY across y
+  static constexpr int TH = NTY * R;
   static constexpr int LROWS = TH + K - 1;
   // LDS row = pixels [x0 - PAD, x0 + TW + PAD): a lane's strip then starts at float 12*tx, 16-B aligned,
   // and is read with ds_read_b128.  (The matching global address is only 4-B aligned: 3*PAD floats.)
@@ -68,9 +73,46 @@ __device__ __forceinline__ uint32_t key_of(float f) {
   return ics_f2key(f);
 }
 
-template <int K, int R, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_conv(IcsConvArgs a) {
-  using C = ConvCfg<K, R>;
+// LDS row (ap + 2*rp) -> strip registers of row pair rp (ds_read_b128, 16-B aligned by construction)
+template <typename C, int R>
+__device__ __forceinline__ void load_strips(float (&strip)[R / 2][C::STRIP], const float* lrow0, int ap) {
+#pragma unroll
+  for (int rp = 0; rp < R / 2; ++rp) {
+    const float4* lp = reinterpret_cast<const float4*>(lrow0 + (ap + 2 * rp) * C::LWF);
+#pragma unroll
+    for (int j = 0; j < C::STRIP / 4; ++j) {
+      const float4 t = lp[j];
+      strip[rp][4 * j + 0] = t.x; strip[rp][4 * j + 1] = t.y; strip[rp][4 * j + 2] = t.z; strip[rp][4 * j + 3] = t.w;
+    }
+  }
+}
+
+// One packed weight row against the strips of every row pair: (R/2)*K*12 v_pk_fma_f32.
+// (every strip element is consumed through op_sel as the low or high half of an aligned VGPR pair)
+template <typename C, int K, int R>
+__device__ __forceinline__ void fma_row(f32x2 (&A)[R / 2][12], const float (&strip)[R / 2][C::STRIP], const f32x2* __restrict__ wr) {
+#pragma unroll
+  for (int b = 0; b < K; ++b) {
+    const f32x2 w0 = wr[3 * b + 0], w1 = wr[3 * b + 1], w2 = wr[3 * b + 2];
+#pragma unroll
+    for (int rp = 0; rp < R / 2; ++rp) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float s0 = strip[rp][3 * (p + b) + 0];
+        const float s1 = strip[rp][3 * (p + b) + 1];
+        const float s2 = strip[rp][3 * (p + b) + 2];
+        A[rp][3 * p + 0] = __builtin_elementwise_fma(w0, (f32x2){s0, s0}, A[rp][3 * p + 0]);
+        A[rp][3 * p + 1] = __builtin_elementwise_fma(w1, (f32x2){s1, s1}, A[rp][3 * p + 1]);
+        A[rp][3 * p + 2] = __builtin_elementwise_fma(w2, (f32x2){s2, s2}, A[rp][3 * p + 2]);
+      }
+    }
+  }
+}
+
+template <int K, int R, int MODE, int WPE, int NTY>
+__global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_conv(IcsConvArgs a) {
+  using C = ConvCfg<K, R, NTY>;
+  constexpr int NT = C::NT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
@@ -93,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float* src = a.in + (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::PAD);
     constexpr int LW4 = C::LW_USED / 4;
     constexpr int NV = C::LROWS * LW4;
-    constexpr int NIT = (NV + 255) / 256;
+    constexpr int NIT = (NV + NT - 1) / NT;
     constexpr int BATCH = NIT;  // one batch: every load of the tile is in flight before the first LDS write
 #pragma unroll
     for (int it0 = 0; it0 < NIT; it0 += BATCH) {
@@ -101,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
         if (it0 + k < NIT) {
-          int v = tid + (it0 + k) * 256;
+          int v = tid + (it0 + k) * NT;
           v = v < NV ? v : NV - 1;  // clamp instead of predicating the load
           const int row = v / LW4, c4 = v - row * LW4;
           val[k] = *reinterpret_cast<const f32x4u*>(src + (ptrdiff_t)row * pitch + 4 * c4);
@@ -110,7 +152,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
         if (it0 + k < NIT) {
-          const int v = tid + (it0 + k) * 256;
+          const int v = tid + (it0 + k) * NT;
           if (v < NV) {
             const int row = v / LW4, c4 = v - row * LW4;
             *reinterpret_cast<float4*>(lds + row * C::LWF + 4 * c4) = make_float4(val[k].x, val[k].y, val[k].z, val[k].w);
@@ -139,14 +181,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const ptrdiff_t base = (ptrdiff_t)(y0 - C::PAD) * pitch + 3 * (x0 - C::PAD);
     constexpr int LW4 = C::LW_USED / 4;
     constexpr int NV = C::LROWS * LW4;
-    constexpr int NIT = (NV + 255) / 256;
+    constexpr int NIT = (NV + NT - 1) / NT;
     constexpr int BATCH = 4;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += BATCH) {
       f32x4u pu[BATCH], pt[BATCH], pg[BATCH], pf[BATCH];
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
-        int v = tid + (it0 + k) * 256;
+        int v = tid + (it0 + k) * NT;
         v = v < NV ? v : NV - 1;
         const int row = v / LW4, c4 = v - row * LW4;
         const ptrdiff_t o = base + (ptrdiff_t)row * pitch + 4 * c4;
@@ -157,7 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       }
 #pragma unroll
       for (int k = 0; k < BATCH; ++k) {
-        const int v = tid + (it0 + k) * 256;
+        const int v = tid + (it0 + k) * NT;
         if (v < NV) {
           const int row = v / LW4, c4 = v - row * LW4;
           const int y = y0 - C::PAD + row;
@@ -231,35 +273,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   // a wave owns 4*R consecutive output rows; border tiles have waves with no row to produce
   const int wy0 = y0 + __builtin_amdgcn_readfirstlane(tid >> 6) * 4 * R;
   const bool wave_has_rows = (MODE != 1) ? (wy0 < C::PAD + a.g.M && wy0 + 4 * R > C::PAD) : (wy0 < a.g.uM);
+  // Software pipeline: K is odd, so the K+1 weight rows are walked in pairs with two strip register sets
+  // (ping-pong): the LDS reads of row ap+1 are issued before the FMAs of row ap and land behind them.
+  // (Only when both sets fit the VGPR budget of 3 waves/SIMD; otherwise single-buffered.)
+  constexpr bool PINGPONG = (WPE == 2) && ((R / 2) * C::STRIP * 2 + 12 * R <= 200);
+  if (PINGPONG) {
+    float sa[R / 2][C::STRIP], sb[R / 2][C::STRIP];
+    if (wave_has_rows) load_strips<C, R>(sa, lrow0, 0);
 #pragma unroll 1
-  for (int ap = 0; ap <= (wave_has_rows ? K : -1); ++ap) {
-    float strip[R / 2][C::STRIP];
-#pragma unroll
-    for (int rp = 0; rp < R / 2; ++rp) {
-      const float4* lp = reinterpret_cast<const float4*>(lrow0 + (ap + 2 * rp) * C::LWF);
-#pragma unroll
-      for (int j = 0; j < C::STRIP / 4; ++j) {
-        const float4 t = lp[j];
-        strip[rp][4 * j + 0] = t.x; strip[rp][4 * j + 1] = t.y; strip[rp][4 * j + 2] = t.z; strip[rp][4 * j + 3] = t.w;
-      }
+    for (int ap = 0; ap <= (wave_has_rows ? K : -1); ap += 2) {
+      load_strips<C, R>(sb, lrow0, ap + 1);
+      fma_row<C, K, R>(A, sa, wbase + ap * (C::WROW2 / 2));
+      if (ap + 2 <= K) load_strips<C, R>(sa, lrow0, ap + 2);
+      fma_row<C, K, R>(A, sb, wbase + (ap + 1) * (C::WROW2 / 2));
     }
-    // (every strip element is consumed through op_sel as the low or high half of an aligned VGPR pair)
-    const f32x2* __restrict__ wr = wbase + ap * (C::WROW2 / 2);
-#pragma unroll
-    for (int b = 0; b < K; ++b) {
-      const f32x2 w0 = wr[3 * b + 0], w1 = wr[3 * b + 1], w2 = wr[3 * b + 2];
-#pragma unroll
-      for (int rp = 0; rp < R / 2; ++rp) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float s0 = strip[rp][3 * (p + b) + 0];
-          const float s1 = strip[rp][3 * (p + b) + 1];
-          const float s2 = strip[rp][3 * (p + b) + 2];
-          A[rp][3 * p + 0] = __builtin_elementwise_fma(w0, (f32x2){s0, s0}, A[rp][3 * p + 0]);
-          A[rp][3 * p + 1] = __builtin_elementwise_fma(w1, (f32x2){s1, s1}, A[rp][3 * p + 1]);
-          A[rp][3 * p + 2] = __builtin_elementwise_fma(w2, (f32x2){s2, s2}, A[rp][3 * p + 2]);
-        }
-      }
+  } else {
+#pragma unroll 1
+    for (int ap = 0; ap <= (wave_has_rows ? K : -1); ++ap) {
+      float strip[R / 2][C::STRIP];
+      load_strips<C, R>(strip, lrow0, ap);
+      fma_row<C, K, R>(A, strip, wbase + ap * (C::WROW2 / 2));
     }
   }
   float acc[R][12];
@@ -361,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (tid < 6) {
       uint32_t m = red_lds[tid];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) { const uint32_t o = red_lds[w * 8 + tid]; m = m > o ? m : o; }
+      for (int w = 1; w < NT / 64; ++w) { const uint32_t o = red_lds[w * 8 + tid]; m = m > o ? m : o; }
       const int slot = tid < 3 ? ICS_RED_MAXG + tid : ICS_RED_MAXU + (tid - 3);
       // the running maximum only grows: a (possibly stale, hence lower) read lets most of the ~8000
       // workgroups skip their atomic instead of serialising on six L2 words
@@ -370,28 +403,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
 }
 
-template <int K, int R, int MODE>
+template <int K, int R, int MODE, int NTY>
 hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
-  using C = ConvCfg<K, R>;
+  using C = ConvCfg<K, R, NTY>;
   static bool configured = false;
-  auto kern = k_conv<K, R, MODE>;
+  // waves per SIMD the kernel is compiled for: 3 (<= 168 VGPRs, single-buffered strips) when three
+  // workgroups fit the LDS, else 2 (<= 256 VGPRs, ping-pong strips)
+  constexpr int WPE = (NTY == 32) ? 4 : ((3 * C::LDS_BYTES <= 160 * 1024) ? 3 : 2);
+  auto kern = k_conv<K, R, MODE, WPE, NTY>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
     configured = true;
   }
   dim3 grid(a.g.tiles_x * a.g.tiles_y * (ICS_TILE / C::TH));
-  hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
-  if (mode == 2) return launch_one<K, 2, 2>(a, s);
+  // NTY = 32 (512 threads, 64x64-px tile, 2 workgroups = 16 waves per CU) when its LDS image fits twice
+  constexpr int NTY = (2 * ConvCfg<K, 2, 32>::LDS_BYTES <= 160 * 1024 && ICS_CONV_NTY32) ? 32 : 16;
+  if (mode == 2) return launch_one<K, 2, 2, NTY>(a, s);
   // R = 2 (64x32-px tiles): 44 KB of LDS at K = 15 -> 3 workgroups per CU; measured 3-6 % faster than
   // R = 4 (64x64 tiles, 2 workgroups per CU) at 4096^2 despite the larger halo (profiles/)
   constexpr int R = 2;
-  return mode == 0 ? launch_one<K, R, 0>(a, s) : launch_one<K, R, 1>(a, s);
+  return mode == 0 ? launch_one<K, R, 0, NTY>(a, s) : launch_one<K, R, 1, NTY>(a, s);
 }
 
 }  // namespace

@@ -32,8 +32,8 @@ class Group:
         if self.size > 1:
             import torch
             import torch.distributed as dist
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:  # ICS_DIST_BACKEND=gloo lets several ranks share one GPU (testing only)
+                backend = os.environ.get("ICS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device("cuda", self.local_rank)
