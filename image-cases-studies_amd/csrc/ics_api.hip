@@ -48,6 +48,7 @@ struct ics_rl {
   IcsGeom g;
   size_t frame_floats, origin;
   float *u, *u2, *ut, *gr, *f, *e;     // frame bases (origin = base + origin); u2 = ping-pong partner of u
+  float* tvf;                           // TV term frame (tv_mode 1, allocated on first use)
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   int gradk_blocks;
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
@@ -145,7 +146,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
+  void* ptrs[] = {j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
                   j->red, j->dofkeys, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -254,6 +255,7 @@ static int frame_of(ics_rl* j, int which, float** frame, int* rows, int* cols, i
     case ICS_BUF_GRADU: *frame = j->gr; break;
     case ICS_BUF_IMAGE: *frame = j->f; break;
     case ICS_BUF_ERROR: *frame = j->e; break;
+    case ICS_BUF_TV: if (!j->tvf) return -1; *frame = j->tvf; break;
     default: return -1;
   }
   if (which == ICS_BUF_IMAGE || which == ICS_BUF_ERROR) { *rows = g.M; *cols = g.N; *oy = g.pad; *ox = g.pad; }
@@ -398,6 +400,7 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, j->ut);
   a.red = j->red + slot * ICS_RED_STRIDE;
   a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.tv = (p->tv_mode == ICS_TV_MM_ACTIVE && j->tvf) ? org(j, j->tvf) : nullptr;
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
   HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
@@ -410,9 +413,26 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
   IcsUpdateArgs a;
   a.u = org(j, j->u); a.ut = org(j, j->ut); a.g = org(j, j->gr); a.f = org(j, j->f);
   a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.tv = (p->tv_mode == ICS_TV_MM_ACTIVE && j->tvf) ? org(j, j->tvf) : nullptr; a.f_rw = org(j, j->f);
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));
   HIPCHK(ics_launch_update(a, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
+static int ensure_tv(ics_rl* j) {
+  if (j->tvf) return ICS_OK;
+  int rc = dalloc(&j->tvf, j->frame_floats, j->ctx->stream);
+  return rc;
+}
+
+static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
+  IcsTvTermArgs a;
+  a.u = org(j, j->u); a.ut = org(j, j->ut); a.f = org(j, j->f); a.tv = org(j, j->tvf);
+  a.red = j->red + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.geo = j->g;
+  RC(pr.begin(ICS_K_UPDATE));   // accounted with the elementwise class
+  HIPCHK(ics_launch_tvterm(a, j->ctx->stream));
   RC(pr.end());
   return ICS_OK;
 }
@@ -461,7 +481,9 @@ static int reset_dofkeys(ics_rl* j) {
 
 static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (!j || !p) return fail(ICS_EINVAL, "NULL argument");
-  if (p->tv_mode != ICS_TV_SHIPPED) return fail(ICS_ENOSUP, "tv_mode %d not implemented (only ICS_TV_SHIPPED)", p->tv_mode);
+  if (p->tv_mode != ICS_TV_SHIPPED && p->tv_mode != ICS_TV_MM_ACTIVE)
+    return fail(ICS_ENOSUP, "tv_mode %d not implemented (ICS_TV_SHIPPED, ICS_TV_MM_ACTIVE)", p->tv_mode);
+  if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
 }
@@ -473,6 +495,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   HIPCHK(hipSetDevice(j->ctx->device));
   hipStream_t s = j->ctx->stream;
   RC(ensure_window(j, p));
+  const bool tv = p->tv_mode == ICS_TV_MM_ACTIVE;
+  if (tv) RC(ensure_tv(j));
   memset(st, 0, sizeof *st);
   Prof pr{j, p->profile != 0};
   j->ev_used = 0;
@@ -496,6 +520,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       const int last = itt == INNER - 1;
       if (!have_e) RC(do_conv(j, 0, p, itt, 0, pr));          // A1+A2
       have_e = false;
+      if (tv) RC(do_tvterm(j, p, itt, pr));                   // pyx:495-496 (live only in tv_mode 1)
       RC(do_conv(j, 1, p, itt, 0, pr));                       // A3 (+A7)
       if (p->blind) {                                         // pyx:555
         if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
@@ -557,12 +582,20 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       break;
     case ICS_STAGE_BACKPROJECT:
       RC(pack_weights(j, 0, 0.f, 0, s));
-      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      // (in tv_mode 1 ICS_STAGE_TVTERM runs first and owns the reset: its keys live in the same slot)
+      if (p->tv_mode == ICS_TV_SHIPPED) HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      else RC(ensure_tv(j));
       RC(do_conv(j, 1, p, 0, 0, pr));
       break;
     case ICS_STAGE_UPDATE:
       RC(reset_dofkeys(j));
       RC(do_update(j, p, 0, 1, pr));
+      break;
+    case ICS_STAGE_TVTERM:
+      if (p->tv_mode != ICS_TV_MM_ACTIVE) return fail(ICS_EINVAL, "ICS_STAGE_TVTERM needs tv_mode = ICS_TV_MM_ACTIVE");
+      RC(ensure_tv(j));
+      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      RC(do_tvterm(j, p, 0, pr));
       break;
     case ICS_STAGE_UPDATE_SYNTH:
       RC(pack_weights(j, 0, 0.f, 0, s));

@@ -69,7 +69,9 @@ __host__ __device__ static inline float ics_key2f(uint32_t k) {
 // Reduction slots written by the back-projection kernel (one set per inner iteration).
 #define ICS_RED_MAXG 0 /* 3 keys: max |gradu_k| after A6 (pyx:524)  */
 #define ICS_RED_MAXU 3 /* 3 keys: max u_k                (pyx:524)  */
-#define ICS_RED_STRIDE 8
+#define ICS_RED_MAXT 6 /* 3 keys: max |T_k|  (active MM-TV: gradu of pyx:543)          */
+#define ICS_RED_MAXF 9 /* 3 keys: max image_k                (pyx:548)          */
+#define ICS_RED_STRIDE 16
 
 // Device scalar block (floats), mirrored by ICS_BUF_SCALARS in include/ics_hip.h.
 #define ICS_SC_DT 0
@@ -92,6 +94,7 @@ struct IcsConvArgs {
   const float* f;    // A1: image frame origin
   const float* u;    // A3: u frame origin   (for the fused A6/A7 reductions)
   const float* ut;   // A3: ut frame origin
+  const float* tv;   // A3, active MM-TV only: T frame (else NULL), see k_tvterm
   uint32_t* red;     // A3: reduction keys (ICS_RED_*) written; mode 2: keys of the finished back-projection read
   float lambd;
   // mode 2 only (update of the previous inner iteration fused in front of the convolution):

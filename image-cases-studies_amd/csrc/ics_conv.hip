@@ -355,7 +355,11 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (xp + p < a.g.uN) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const float g = __fadd_rn(__fmul_rn(lambd, acc[r][3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
+            float g;
+            if (a.tv && y >= 1 && y <= a.g.uM - 2 && xp + p >= 1 && xp + p <= a.g.uN - 2)   // active MM-TV, pyx:517
+              g = (float)(((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, acc[r][3*p+c])) + (double)__fsub_rn(uv[3*p+c], tv[3*p+c]) / 4.0);
+            else
+              g = __fadd_rn(__fmul_rn(lambd, acc[r][3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
             mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
             mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
             nan_g[c] |= (g != g); nan_u[c] |= (uv[3*p+c] != uv[3*p+c]);

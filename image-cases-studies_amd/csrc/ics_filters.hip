@@ -4,6 +4,7 @@
 // neighbours served by L1/L2 (3x3 .. (2r+1)^2 taps, rows are contiguous so a wave reads 64
 // consecutive elements per tap).
 #include "ics_kernels.h"
+#include "ics_tv.h"
 
 namespace {
 
@@ -13,46 +14,19 @@ namespace {
 // order 1: backward and forward first differences, four norms.
 // norm 1: |x|+|y|+eps, adjust = 4(1+1/sqrt2);  norm 2: sqrt(x^2+y^2+eps^2), adjust = 2(1+sqrt2).
 // Borders are left untouched (pyx:239).  Separately rounded float32 operations, reference order.
-__device__ __forceinline__ float nrm(float x, float y, float eps, int norm) {
-  if (norm == 1) return __fadd_rn(__fadd_rn(__builtin_fabsf(x), __builtin_fabsf(y)), eps);
-  return __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(eps, eps)));
-}
-
 __global__ __launch_bounds__(256) void k_tv(const float* __restrict__ u, int M, int N, float eps, int order, int norm,
                                            float* __restrict__ out, float* __restrict__ dv) {
   const long total = (long)(M - 2) * (N - 2) * 3;
-  const float dxdy = 1.41421354f;  // powf(2, 0.5) as a float
-  const float adjust = (norm == 1) ? __fmul_rn(4.0f, __fadd_rn(1.0f, __fdiv_rn(1.0f, dxdy)))
-                                   : __fmul_rn(2.0f, __fadd_rn(1.0f, dxdy));
   const long rs = (long)N * 3;
   for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
     const int k = (int)(t % 3);
     const int j = 1 + (int)((t / 3) % (N - 2));
     const int i = 1 + (int)(t / (3L * (N - 2)));
     const long o = (long)i * rs + 3L * j + k;
-    const float c = u[o], up = u[o - rs], dn = u[o + rs], lf = u[o - 3], rt = u[o + 3];
-    const float ul = u[o - rs - 3], dr = u[o + rs + 3], ur = u[o - rs + 3], dl = u[o + rs - 3];
-    float d, r;
-    if (order == 2) {
-      const float m2c = __fmul_rn(-2.0f, c);
-      const float udx = __fadd_rn(__fadd_rn(m2c, up), dn);
-      const float udy = __fadd_rn(__fadd_rn(m2c, lf), rt);
-      const float udxdy = __fdiv_rn(__fadd_rn(__fadd_rn(m2c, ul), dr), dxdy);
-      const float udydx = __fdiv_rn(__fadd_rn(__fadd_rn(m2c, ur), dl), dxdy);
-      d = __fsub_rn(__fsub_rn(__fsub_rn(-udx, udy), udxdy), udydx);
-      r = __fadd_rn(nrm(udx, udy, eps, norm), nrm(udxdy, udydx, eps, norm));
-    } else {
-      const float udx_b = __fsub_rn(c, up), udy_b = __fsub_rn(c, lf);
-      const float udx_f = __fadd_rn(-c, dn), udy_f = __fadd_rn(-c, rt);
-      const float udxdy_b = __fdiv_rn(__fsub_rn(c, ul), dxdy), udydx_b = __fdiv_rn(__fsub_rn(c, ur), dxdy);
-      const float udydx_f = __fdiv_rn(__fadd_rn(-c, dl), dxdy), udxdy_f = __fdiv_rn(__fadd_rn(-c, dr), dxdy);
-      d = __fadd_rn(udx_b, udy_b); d = __fsub_rn(d, udx_f); d = __fsub_rn(d, udy_f);
-      d = __fadd_rn(d, udxdy_b); d = __fadd_rn(d, udydx_b); d = __fsub_rn(d, udxdy_f); d = __fsub_rn(d, udydx_f);
-      r = __fadd_rn(__fadd_rn(__fadd_rn(nrm(udx_b, udy_b, eps, norm), nrm(udx_f, udy_f, eps, norm)),
-                              nrm(udxdy_b, udydx_b, eps, norm)), nrm(udxdy_f, udydx_f, eps, norm));
-    }
-    dv[o] = __fdiv_rn(d, adjust);
-    out[o] = __fdiv_rn(r, adjust);
+    const IcsTvOut r = ics_tv_point(u[o], u[o - rs], u[o + rs], u[o - 3], u[o + 3], u[o - rs - 3], u[o + rs + 3],
+                                    u[o - rs + 3], u[o + rs - 3], eps, order, norm);
+    dv[o] = r.div;
+    out[o] = r.out;
   }
 }
 

@@ -8,6 +8,8 @@ struct IcsUpdateArgs {
   const float* ut;     // majoriser (pyx:462)
   const float* g;      // raw back-projection (A3)
   const float* f;      // image
+  const float* tv;     // active MM-TV: T frame (NULL in the shipped mode)
+  float* f_rw;         // active MM-TV: the image frame is updated in place (pyx:549)
   const uint32_t* red; // reduction keys of this inner iteration (ICS_RED_*)
   float* scal;         // device scalar block (ICS_SC_*): dt, maxu, maxg are recorded
   uint32_t* dofkeys;   // [0] = min key, [1] = max key, [2] = NaN flag (only when want_dof)
@@ -17,6 +19,18 @@ struct IcsUpdateArgs {
   IcsGeom geo;
 };
 hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s);
+
+// ---- active MM-TV (build-defined extension, pyx:517/:543 made reachable): TV term of u against ut ---
+struct IcsTvTermArgs {
+  const float* u;      // frame origin
+  const float* ut;     // majoriser
+  const float* f;      // image (for max image_k, pyx:548)
+  float* tv;           // T frame written
+  uint32_t* red;       // ICS_RED_MAXT / ICS_RED_MAXF keys of this inner iteration
+  float epsilon;       // 1e-2 blind / 1e-6 non-blind (pyx:434-437)
+  IcsGeom geo;
+};
+hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s);
 
 // ---- A13 (pyx:567-571): PSF gradient, fp32 MFMA ------------------------------------------------
 struct IcsGradkArgs {

@@ -2,6 +2,7 @@
 #include <stdlib.h>
 
 #include "ics_kernels.h"
+#include "ics_tv.h"
 
 namespace {
 
@@ -48,6 +49,12 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
       a.scal[ICS_SC_DT + c] = dt[c]; a.scal[ICS_SC_MAXU + c] = maxu; a.scal[ICS_SC_MAXG + c] = maxg;
     }
   }
+  float dt2[3] = {0.f, 0.f, 0.f};
+  if (a.tv) {  // pyx:548: dt = step*(max image_k + 0)/(max|gradu_k| + 1e-15) with gradu = T
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dt2[c] = __fdiv_rn(__fmul_rn(a.step, ics_key2f(a.red[ICS_RED_MAXF + c])), __fadd_rn(ics_key2f(a.red[ICS_RED_MAXT + c]), 1e-15f));
+  }
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, knan = 0u;
   const float lambd = a.lambd;
   for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
@@ -55,7 +62,7 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
     const int xp = 4 * (int)(gid - (long)y * ngx);
     if (xp >= G.uN) continue;
     const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
-    float uv[12], tv[12], gv[12], fv[12];
+    float uv[12], tv[12], gv[12], fv[12], Tv[12];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const f32x4 p = reinterpret_cast<const f32x4*>(a.u + o)[j];
@@ -64,6 +71,7 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
       const f32x4 s = reinterpret_cast<const f32x4*>(a.f + o)[j];
       uv[4*j] = p.x; uv[4*j+1] = p.y; uv[4*j+2] = p.z; uv[4*j+3] = p.w;
       tv[4*j] = q.x; tv[4*j+1] = q.y; tv[4*j+2] = q.z; tv[4*j+3] = q.w;
+      if (a.tv) { const f32x4 w = reinterpret_cast<const f32x4*>(a.tv + o)[j]; Tv[4*j] = w.x; Tv[4*j+1] = w.y; Tv[4*j+2] = w.z; Tv[4*j+3] = w.w; }
       gv[4*j] = r.x; gv[4*j+1] = r.y; gv[4*j+2] = r.z; gv[4*j+3] = r.w;
       fv[4*j] = s.x; fv[4*j+1] = s.y; fv[4*j+2] = s.z; fv[4*j+3] = s.w;
     }
@@ -75,12 +83,20 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int i = 3 * p + c;
-        const float g = __fadd_rn(__fmul_rn(lambd, gv[i]), __fmul_rn(__fsub_rn(uv[i], tv[i]), 0.5f));
+        float g;
+        if (a.tv && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
+          g = (float)(((double)Tv[i] + (double)__fmul_rn(lambd, gv[i])) + (double)__fsub_rn(uv[i], tv[i]) / 4.0);
+        else
+          g = __fadd_rn(__fmul_rn(lambd, gv[i]), __fmul_rn(__fsub_rn(uv[i], tv[i]), 0.5f));
         float un = __fsub_rn(uv[i], __fmul_rn(dt[c], g));
         if (inside) {
           const float d = __fdiv_rn(__fsub_rn(gv[i], fv[i]), __fadd_rn(gv[i], fv[i]));
           float D = __fmul_rn(d, d);
           if (!a.blind) D = __fdiv_rn(D, lambd);
+          if (a.tv) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
+            fv[i] = __fsub_rn(fv[i], __fdiv_rn(__fmul_rn(dt2[c], Tv[i]), lambd));
+            a.f_rw[o + i] = fv[i];
+          }
           un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fv[i]));
           if (a.want_dof) {
             if (D != D) knan = 1u;
@@ -107,6 +123,95 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
     if ((threadIdx.x & 63) == 0) {
       atomicMin(a.dofkeys + 0, kmin); atomicMax(a.dofkeys + 1, kmax);
       if (knan) atomicOr(a.dofkeys + 2, 1u);
+    }
+  }
+}
+
+// =================================================================================================
+// Active MM-TV (build-defined extension; oracle/rl_ext_oracle.py): the regulariser term of pyx:517/:543,
+//   T = float( div/TV_u_L1/TV_ut_L1/2. + div/TV_u_L2/TV_ut_L2/2. )  on the interior of the u-frame, 0 on its border,
+// with TV(.) the order-2 stencil of pyx:137-189 (norm 1 and 2), `div` in its norm-2 scaling (the second TV call of
+// pyx:495-496 overwrites it) and TV_ut evaluated from the majoriser ut.  Also reduces max|T_k| and max image_k
+// for the image step of pyx:548.  One lane = 4 pixels; the 3x6-px neighbourhoods of u and ut come as 3 rows of
+// 5 unaligned dwordx4 loads each (served by L1/L2).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
+  const IcsGeom& G = a.geo;
+  const int ngx = G.tiles_x * 16;
+  const long total = (long)G.uM * ngx;
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  float mt[3] = {0.f, 0.f, 0.f}, mf[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  bool nan_t[3] = {false, false, false}, nan_f[3] = {false, false, false}, any_f = false;
+  const float eps = a.epsilon;
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int y = (int)(gid / ngx);
+    const int xp = 4 * (int)(gid - (long)y * ngx);
+    if (xp >= G.uN) continue;
+    float nu[3][20], nt[3][20];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const ptrdiff_t o = (ptrdiff_t)(y - 1 + r) * G.pitch + 3 * (xp - 1);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const f32x4u p = *reinterpret_cast<const f32x4u*>(a.u + o + 4 * j);
+        const f32x4u q = *reinterpret_cast<const f32x4u*>(a.ut + o + 4 * j);
+        nu[r][4*j] = p.x; nu[r][4*j+1] = p.y; nu[r][4*j+2] = p.z; nu[r][4*j+3] = p.w;
+        nt[r][4*j] = q.x; nt[r][4*j+1] = q.y; nt[r][4*j+2] = q.z; nt[r][4*j+3] = q.w;
+      }
+    }
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
+    float T[12];
+    const bool yact = (y >= 1) && (y <= G.uM - 2);
+    const bool yin = (y >= G.pad) && (y < G.pad + G.M);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int x = xp + p;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int i = 3 * (p + 1) + c;
+        float t = 0.f;
+        if (yact && x >= 1 && x <= G.uN - 2) {
+          const IcsTvOut u1 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 1);
+          const IcsTvOut u2 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 2);
+          const IcsTvOut t1 = ics_tv_point(nt[1][i], nt[0][i], nt[2][i], nt[1][i-3], nt[1][i+3], nt[0][i-3], nt[2][i+3], nt[0][i+3], nt[2][i-3], eps, 2, 1);
+          const IcsTvOut t2 = ics_tv_point(nt[1][i], nt[0][i], nt[2][i], nt[1][i-3], nt[1][i+3], nt[0][i-3], nt[2][i+3], nt[0][i+3], nt[2][i-3], eps, 2, 2);
+          const double d1 = (double)__fdiv_rn(__fdiv_rn(u2.div, u1.out), t1.out) / 2.0;
+          const double d2 = (double)__fdiv_rn(__fdiv_rn(u2.div, u2.out), t2.out) / 2.0;
+          t = (float)(d1 + d2);
+        }
+        T[3*p+c] = t;
+        if (x < G.uN) { mt[c] = __builtin_fmaxf(mt[c], __builtin_fabsf(t)); nan_t[c] |= (t != t); }
+      }
+    }
+    if (yin) {  // max image_k over the M x N image
+      float fv[12];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { const f32x4 q = reinterpret_cast<const f32x4*>(a.f + o)[j]; fv[4*j] = q.x; fv[4*j+1] = q.y; fv[4*j+2] = q.z; fv[4*j+3] = q.w; }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (xp + p >= G.pad && xp + p < G.pad + G.N) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { mf[c] = __builtin_fmaxf(mf[c], fv[3*p+c]); nan_f[c] |= (fv[3*p+c] != fv[3*p+c]); }
+          any_f = true;
+        }
+    }
+    if (xp + 3 < G.uN) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { const f32x4 w = {T[4*j], T[4*j+1], T[4*j+2], T[4*j+3]}; reinterpret_cast<f32x4*>(a.tv + o)[j] = w; }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (xp + p < G.uN) { a.tv[o + 3*p] = T[3*p]; a.tv[o + 3*p + 1] = T[3*p+1]; a.tv[o + 3*p + 2] = T[3*p+2]; }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint32_t kt = nan_t[c] ? 0xFFC00000u : ics_f2key(mt[c]);
+    uint32_t kf = nan_f[c] ? 0xFFC00000u : (any_f ? ics_f2key(mf[c]) : 0u);
+    kt = wave_max_u32(kt); kf = wave_max_u32(kf);
+    if ((threadIdx.x & 63) == 0) {
+      if (kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
+      if (kf > a.red[ICS_RED_MAXF + c]) atomicMax(a.red + ICS_RED_MAXF + c, kf);
     }
   }
 }
@@ -357,6 +462,11 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
 }
 
 }  // namespace
+
+hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_tvterm, dim3(1024), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 
 hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   const long total = (long)a.geo.uM * a.geo.tiles_x * 16;

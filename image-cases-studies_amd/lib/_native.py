@@ -22,8 +22,8 @@ KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
 
 # stages / buffers
-STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH = range(1, 9)
-BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS = range(8)
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM = range(1, 10)
+BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV = range(9)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
                 "dof_min", "dof_max", "_")
 
@@ -200,7 +200,7 @@ class RLJob:
             pass
 
     def _shape(self, which):
-        if which in (BUF_U, BUF_UT, BUF_GRADU):
+        if which in (BUF_U, BUF_UT, BUF_GRADU, BUF_TV):
             return (self.uM, self.uN, 3)
         if which in (BUF_IMAGE, BUF_ERROR):
             return (self.M, self.N, 3)
@@ -238,11 +238,11 @@ class RLJob:
 
     @staticmethod
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
-               stop_test=1, profile=0, fuse=0):
+               stop_test=1, profile=0, fuse=0, tv_mode=0):
         p = RLParams()
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
-        p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), 0
+        p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), int(tv_mode)
         p.stop_test, p.profile, p.fuse = int(stop_test), int(profile), int(fuse)
         return p
 

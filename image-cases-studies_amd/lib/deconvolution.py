@@ -67,9 +67,13 @@ def normalize_kernel(kern, MK):
 
 
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
-                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0):
+                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0):
     """Richardson-Lucy blind / non-blind deconvolution by majorisation-minimisation
-    (lib/deconvolution.pyx:341-675), executed on the GPU.  See the module docstring."""
+    (lib/deconvolution.pyx:341-675), executed on the GPU.  See the module docstring.
+
+    `tv_mode` (keyword-only, not in the reference): 0 = the shipped behaviour (TV term dead); 1 = the
+    build-defined active MM-TV mode (include/ics_hip.h ICS_TV_MM_ACTIVE, oracle/rl_ext_oracle.py; parity
+    unpinned), in which `image` is also updated in place as pyx:549 intends."""
     _check_buffer("image", image)
     _check_buffer("u", u)
     _check_buffer("psf", psf)
@@ -82,12 +86,15 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
                          (M, N, M + 2 * (MK // 2), N + 2 * (MK // 2), MK, MK, image.shape, u.shape, psf.shape))
     job = _get_job(M, N, MK)
     job.upload(image, u, psf)
-    params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C)
+    params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
+                        tv_mode=tv_mode)
     st = job.run(params)
     u_new, _psf_local, psf_caller = job.download()
     u[...] = u_new                                                             # in place, any strides
     if blind:
         psf[...] = psf_caller
+    if tv_mode:
+        image[...] = job.read(_native.BUF_IMAGE)                               # pyx:549 (live in this mode)
     # the reference's stdout (pyx:593,648,658-672)
     for it in range(st.trace_len):
         print("DoF : min = %f | max = %f" % (st.trace_dof_min[it], st.trace_dof_max[it]))

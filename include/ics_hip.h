@@ -86,6 +86,9 @@ typedef struct ics_rl_params {
 } ics_rl_params;
 
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
+#define ICS_TV_MM_ACTIVE 1 /* BUILD-DEFINED extension, parity unpinned: the if-branches :517/:543 made
+                              reachable (TV_ut from the majoriser, image denoising step :547-549 live);
+                              exact definition in oracle/rl_ext_oracle.py.  `image` is modified.      */
 
 /* Scalars the reference only prints (pyx:593,648,659,665-669).  Arrays are per outer iteration
  * and hold at most ICS_MAX_TRACE entries (later iterations overwrite the last slot). */
@@ -132,6 +135,7 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 #define ICS_STAGE_MAJORIZE 6       /* ut = u                                       (pyx:462)       */
 #define ICS_STAGE_STATS 7          /* A18+A19 on device -> stats scalars           (pyx:593-638)   */
 #define ICS_STAGE_UPDATE_SYNTH 8   /* ICS_STAGE_UPDATE fused with ICS_STAGE_SYNTH_RESIDUAL (one kernel) */
+#define ICS_STAGE_TVTERM 9         /* tv_mode 1: TV term T of u against ut (+ max|T_k|, max image_k)     */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -142,6 +146,7 @@ int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 #define ICS_BUF_ERROR 4  /* M x N x 3    */
 #define ICS_BUF_PSF 5    /* MK x MK x 3  */
 #define ICS_BUF_GRADK 6  /* MK x MK x 3  */
+#define ICS_BUF_TV 8      /* uM x uN x 3 : TV term T (tv_mode 1) */
 #define ICS_BUF_SCALARS 7 /* 16 floats: dt[3], maxu[3], maxg[3], dtpsf, M_r, Hu, varu, dof_min, dof_max, 0 */
 int ics_rl_read(ics_rl *job, int which, float *host, size_t count);
 int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);

@@ -1,0 +1,87 @@
+"""Active MM-TV mode (tv_mode = 1): BUILD-DEFINED extension, PARITY UNPINNED (the reference holds this
+arithmetic only as unreachable code).  The HIP path is validated against the build's own
+CPU restatement (oracle/rl_ext_oracle.py, <= 1e-5) and through properties."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import rl_ext_oracle as ext
+import rl_mm_oracle as orc
+from helpers import rel_err
+
+
+def test_tv_term_properties_cpu():
+    rng = np.random.default_rng(0)
+    flat = np.full((12, 14, 3), 0.3, np.float32)
+    T, act = ext.tv_term(flat, flat, 1e-2)
+    assert np.all(T == 0) and act[1:-1, 1:-1].all() and not act[0].any() and not act[:, -1].any()
+    u = rng.random((15, 17, 3), dtype=np.float32)
+    ut = rng.random((15, 17, 3), dtype=np.float32)
+    T, act = ext.tv_term(u, ut, 1e-6)
+    assert np.all(T[0] == 0) and np.all(T[:, 0] == 0) and np.isfinite(T).all() and np.abs(T[1:-1, 1:-1]).max() > 0
+    # T is -grad of a TV-like energy: a single bright pixel is pushed down (T > 0 there means u decreases)
+    spike = np.full((9, 9, 3), 0.5, np.float32); spike[4, 4] = 0.9
+    T, _ = ext.tv_term(spike, spike, 1e-2)
+    assert np.all(T[4, 4] > 0)
+
+
+def test_ext_oracle_differs_from_shipped_and_modifies_image():
+    # (lambd = 100: with lambd = 1e4 the image step dt*T/lambd of pyx:549 is below float32 resolution)
+    case = orc.synth_case(40, 36, 5, seed=4)
+    args = (*orc.default_window(40, 36, 5), 1e9, 40, 36, 3, 5, 2, 1e-3, 100.0)
+    img1, u1 = case["image"].copy(), case["u0"].copy()
+    orc.richardson_lucy_MM(img1, u1, case["psf0"].copy(), *args, blind=False, quiet=True, conv="direct")
+    img2, u2 = case["image"].copy(), case["u0"].copy()
+    ext.richardson_lucy_MM_tv(img2, u2, case["psf0"].copy(), *args, blind=False)
+    assert np.array_equal(img1, case["image"]) and not np.array_equal(img2, case["image"])
+    assert rel_err(u2, u1) > 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,MK,blind", [(70, 131, 9, False), (64, 64, 15, True), (33, 37, 3, False)])
+def test_gpu_tv_term_stage_matches_oracle(M, N, MK, blind):
+    from lib import _native as nv
+    case = orc.synth_case(M, N, MK, seed=M + 1, blind=blind)
+    rng = np.random.default_rng(5)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job = nv.RLJob(M, N, MK)
+    job.upload(case["image"], u, case["psf0"])
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=blind, tv_mode=1)
+    job.stage(nv.STAGE_TVTERM, p)
+    T = job.read(nv.BUF_TV)
+    T_ref, act = ext.tv_term(u, case["u0"], 1e-2 if blind else 1e-6)
+    scale = np.abs(T_ref).max()
+    assert np.max(np.abs(T - T_ref)) / scale < 1e-5          # sqrtf vs powf(x, 0.5): <= 1 ulp apart
+    assert np.all(T[~act] == 0)
+    job.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,MK,blind,outer,lambd", [(65, 49, 9, False, 2, 1e4), (97, 81, 7, True, 2, 1e4), (129, 129, 15, False, 2, 200.0),
+                                                       (80, 70, 5, True, 3, 50.0)])
+def test_gpu_tv_mode_run_matches_ext_oracle(M, N, MK, blind, outer, lambd):
+    from lib import deconvolution as dc
+    case = orc.synth_case(M, N, MK, seed=M + MK, blind=blind)
+    win = orc.default_window(M, N, MK)
+    args = (*win, 1e9, M, N, 3, MK, outer, 1e-3, lambd)
+    img_r, u_r, psf_r = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    ext.richardson_lucy_MM_tv(img_r, u_r, psf_r, *args, blind=blind)
+    img, u, psf = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = dc.richardson_lucy_MM(img, u, psf, *args, blind=blind, tv_mode=1)
+    assert np.shares_memory(out, u)
+    eu, ei, ep = rel_err(u, u_r), rel_err(img, img_r), rel_err(psf, psf_r)
+    print("tv_mode=1 %dx%d k%d blind=%d: rel err u=%.2e image=%.2e psf=%.2e" % (M, N, MK, blind, eu, ei, ep))
+    assert eu < 1e-5 and ei < 1e-5 and ep < 1e-5
+    if lambd < 1e3 or blind:
+        assert not np.array_equal(img, case["image"])                   # pyx:549 is live in this mode
+    if blind:
+        assert np.all(psf >= 0) and np.allclose(psf.sum(axis=(0, 1)), 1, atol=1e-5)   # PSF stays on the simplex
+    # and it is a different algorithm from the shipped one
+    u_s = case["u0"].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dc.richardson_lucy_MM(case["image"].copy(), u_s, case["psf0"].copy(), *args, blind=blind)
+    assert rel_err(u, u_s) > 1e-6
