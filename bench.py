@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--psf", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tv-mode", type=int, default=0, help="0 = shipped loop (TV term dead, the parity-pinned path); 1 = build-defined active MM-TV")
     ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
@@ -127,7 +128,7 @@ def main():
     win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)  # 255-px stats window as deconvolve.py:281 passes it
 
     def run(n_inner, profile):
-        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse))
+        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse), tv_mode=args.tv_mode)
         return job.run(p)
 
     if warm:
@@ -172,7 +173,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
                                    "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", M, N, MK, MK),
-                       "mode": args.mode, "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size},
+                       "mode": args.mode, "tv_mode": args.tv_mode, "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size},
             "hbm_roofline_iteration": {"algorithmic_bytes_per_px": ITER_BYTES_PER_PX[args.mode], "achieved_GBps": round(it_gbps, 1),
                                        "frac_of_8TBps": round(it_gbps / HBM_PEAK_GBPS, 4)},
             "kernels_ms": kern, "device_ms_total_rank0": round(st.ms_total, 3),

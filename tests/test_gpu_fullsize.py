@@ -1,0 +1,136 @@
+"""Size-independent properties at BASELINE.json's full sizes (configs[2]: 4096x4096x3 / 15x15, configs[3]:
+6144x6144x3 / 31x31), where the oracle is too slow to run: adjointness of the two convolutions, linearity,
+constant-image fixed point, the PSF gradient against direct dot products, the update formula on crops
+(teacher-forced with the device's own back-projection and step size), simplex constraint of the PSF, and
+agreement of a full blind run's window statistics with numpy evaluated on the downloaded frames."""
+import numpy as np
+import pytest
+
+import rl_mm_oracle as orc
+from helpers import update_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_psf(MK, seed):
+    rng = np.random.default_rng(seed)
+    psf = (orc.gaussian_psf(MK) * (0.5 + rng.random((MK, MK, 3), dtype=np.float32))).astype(np.float32)
+    orc.normalize_kernel(psf, MK)
+    return psf
+
+
+def dot64(a, b):
+    return float(np.sum(a.astype(np.float64) * b.astype(np.float64)))
+
+
+@pytest.mark.parametrize("S,MK", [(4096, 15), (6144, 31)])
+def test_full_size_convolution_properties(S, MK):
+    from lib import _native as nv
+    rng = np.random.default_rng(S)
+    pad = MK // 2
+    job = nv.RLJob(S, S, MK)
+    psf = rand_psf(MK, 1)
+    u = rng.random((S + 2 * pad, S + 2 * pad, 3), dtype=np.float32)
+    zero_img = np.zeros((S, S, 3), np.float32)
+    job.upload(zero_img, u, psf)
+    p = job.params(pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1, 1e9, 1, 1e-3, 10000.0, blind=True)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    synth = job.read(nv.BUF_ERROR)                       # image = 0  ->  error = conv(u, psf)
+    # (1) spot check against direct float64 sums on three crops (corner, centre, far corner)
+    for (y, x) in [(0, 0), (S // 2 - 8, S // 2 + 3), (S - 16, S - 16)]:
+        ref = np.stack([orc._conv_direct(u[y:y + 16 + 2 * pad, x:x + 16 + 2 * pad, c], psf[..., c], "valid") for c in range(3)], -1)
+        assert np.max(np.abs(synth[y:y + 16, x:x + 16] - ref)) < 5e-6 * np.max(np.abs(ref))
+    # (2) adjointness: <conv(u), e> == <u, corr_full(e)>
+    e = rng.standard_normal((S, S, 3), dtype=np.float32)
+    job.write(nv.BUF_ERROR, e)
+    job.write(nv.BUF_UT, u)
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    lhs, rhs = dot64(synth, e), dot64(u, g)
+    assert abs(lhs - rhs) <= 2e-6 * (np.sqrt(dot64(synth, synth) * dot64(e, e)))
+    # (3) the fused reductions saw the whole frame: max u per channel is exact
+    job.stage(nv.STAGE_UPDATE, p)
+    sc = job.scalars()
+    for k in range(3):
+        assert sc["maxu%d" % k] == float(np.max(u[..., k]))
+    # (4) PSF gradient: gradk[a, b, c] = <e, u shifted>, a few taps against float64 dot products
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_ERROR, e)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    for (a, b, c) in [(0, 0, 0), (MK - 1, MK - 1, 2), (pad, pad, 1), (1, MK - 2, 0)]:
+        ref = dot64(e[..., c], u[MK - 1 - a:MK - 1 - a + S, MK - 1 - b:MK - 1 - b + S, c])
+        assert abs(gk[a, b, c] - ref) < 2e-5 * np.sqrt(dot64(e[..., c], e[..., c]) * S * S / 3), (a, b, c)
+    # (5) linearity: conv(2u) = 2 conv(u) exactly in binary floating point
+    job.write(nv.BUF_U, (2.0 * u).astype(np.float32))
+    job.write(nv.BUF_IMAGE, zero_img)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    assert np.array_equal(job.read(nv.BUF_ERROR), 2.0 * synth)
+    # (6) a constant image is a fixed point of a normalised PSF
+    job.write(nv.BUF_U, np.full_like(u, 0.375))
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    c = job.read(nv.BUF_ERROR)
+    assert np.max(np.abs(c - 0.375)) < 3e-6
+    job.close()
+
+
+def test_config3_blind_4096_one_outer_iteration_consistency():
+    """BASELINE.json configs[2] shape: one full outer iteration (5 inner) of the blind loop at 4096^2/15x15,
+    then every quantity that can be re-derived from the downloaded frames is re-derived with numpy."""
+    from lib import _native as nv
+    import bench
+    S, MK = 4096, 15
+    pad = MK // 2
+    image, u0, psf_true, psf_uniform = bench.synth_frame(S, S, MK, seed=3)
+    job = nv.RLJob(S, S, MK)
+    job.upload(image, u0, psf_uniform)
+    win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)
+    st = job.run(job.params(*win, 0.0, 1, 1e-3, 10000.0, blind=True, stop_test=1))
+    assert st.iterations_done == 1 and st.inner_iterations == 5 and not st.has_nan
+    u, psf, psf_caller = job.download()
+    e = job.read(nv.BUF_ERROR)
+    assert np.array_equal(psf, psf_caller)
+    assert np.all(psf >= 0) and np.allclose(psf.astype(np.float64).sum(axis=(0, 1)), 1, atol=2e-6)   # simplex (A16)
+    assert not np.allclose(psf, psf_uniform)                                                          # PSF was refined
+    # residual consistency: error == conv(u, psf) - image on crops (A11 ran on the final u with the previous psf,
+    # so re-run A11 with the final psf through the stage API and compare that)
+    p = job.params(*win, 0.0, 1, 1e-3, 10000.0, blind=True)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e2 = job.read(nv.BUF_ERROR)
+    for (y, x) in [(5, 9), (2000, 2100), (4070, 4060)]:
+        ref = np.stack([orc._conv_direct(u[y:y + 20 + 2 * pad, x:x + 20 + 2 * pad, c], psf[..., c], "valid") for c in range(3)], -1) - image[y:y + 20, x:x + 20]
+        assert np.max(np.abs(e2[y:y + 20, x:x + 20] - ref)) < 5e-6
+    # window statistics of the run (A18/A19) against numpy on the frames of the run
+    top, bottom, left, right = win
+    ew = e[top:bottom, left:right]
+    M_r = orc.residual_whiteness(ew, orc.stop_weights(*win), orc._conv_scipy)
+    Hu = np.linalg.norm(ew) ** 2 / ((bottom - top) * (right - left) * 3)
+    varu = np.std(u[top + pad:bottom - pad, left + pad:right - pad]) ** 2
+    assert abs(st.M_r - M_r) / M_r < 1e-3 and abs(st.Hu - Hu) / Hu < 1e-4 and abs(st.varu - varu) / varu < 1e-4
+    job.close()
+
+
+def test_update_formula_on_crops_at_4096():
+    """A5-A10 at full size: teacher-forced with the device's own back-projection and step size, crops are
+    compared bit for bit with the numpy float32 restatement."""
+    from lib import _native as nv
+    import bench
+    S, MK = 4096, 15
+    pad = MK // 2
+    image, u0, psf_true, _ = bench.synth_frame(S, S, MK, seed=5)
+    rng = np.random.default_rng(0)
+    u = (u0 + np.float32(0.02) * rng.standard_normal(u0.shape, dtype=np.float32)).astype(np.float32)
+    job = nv.RLJob(S, S, MK)
+    job.upload(image, u, psf_true)
+    job.write(nv.BUF_UT, u0)
+    p = job.params(pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1, 1e9, 1, 1e-3, 10000.0, blind=False)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g_raw = job.read(nv.BUF_GRADU)
+    job.stage(nv.STAGE_UPDATE, p)
+    u_dev = job.read(nv.BUF_U)
+    u_ref, dt, DoF = update_f32(u, u0, g_raw, image, 1e-3, 10000.0, False, pad)
+    sc = job.scalars()
+    assert [sc["dt0"], sc["dt1"], sc["dt2"]] == [float(x) for x in dt]
+    assert np.array_equal(u_dev, u_ref, equal_nan=True)
+    job.close()
