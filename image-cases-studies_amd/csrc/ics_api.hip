@@ -400,7 +400,7 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, j->ut);
   a.red = j->red + slot * ICS_RED_STRIDE;
   a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
-  a.tv = (p->tv_mode == ICS_TV_MM_ACTIVE && j->tvf) ? org(j, j->tvf) : nullptr;
+  a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0;
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
   HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
@@ -413,7 +413,7 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
   IcsUpdateArgs a;
   a.u = org(j, j->u); a.ut = org(j, j->ut); a.g = org(j, j->gr); a.f = org(j, j->f);
   a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
-  a.tv = (p->tv_mode == ICS_TV_MM_ACTIVE && j->tvf) ? org(j, j->tvf) : nullptr; a.f_rw = org(j, j->f);
+  a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0; a.f_rw = org(j, j->f);
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));
   HIPCHK(ics_launch_update(a, j->ctx->stream));
@@ -430,7 +430,7 @@ static int ensure_tv(ics_rl* j) {
 static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   IcsTvTermArgs a;
   a.u = org(j, j->u); a.ut = org(j, j->ut); a.f = org(j, j->f); a.tv = org(j, j->tvf);
-  a.red = j->red + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.geo = j->g;
+  a.red = j->red + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.kind = p->tv_mode; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));   // accounted with the elementwise class
   HIPCHK(ics_launch_tvterm(a, j->ctx->stream));
   RC(pr.end());
@@ -481,8 +481,8 @@ static int reset_dofkeys(ics_rl* j) {
 
 static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (!j || !p) return fail(ICS_EINVAL, "NULL argument");
-  if (p->tv_mode != ICS_TV_SHIPPED && p->tv_mode != ICS_TV_MM_ACTIVE)
-    return fail(ICS_ENOSUP, "tv_mode %d not implemented (ICS_TV_SHIPPED, ICS_TV_MM_ACTIVE)", p->tv_mode);
+  if (p->tv_mode < ICS_TV_SHIPPED || p->tv_mode > ICS_TV_PAM_COLLAB)
+    return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
@@ -495,7 +495,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   HIPCHK(hipSetDevice(j->ctx->device));
   hipStream_t s = j->ctx->stream;
   RC(ensure_window(j, p));
-  const bool tv = p->tv_mode == ICS_TV_MM_ACTIVE;
+  const bool tv = p->tv_mode != ICS_TV_SHIPPED;
   if (tv) RC(ensure_tv(j));
   memset(st, 0, sizeof *st);
   Prof pr{j, p->profile != 0};
@@ -592,7 +592,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       RC(do_update(j, p, 0, 1, pr));
       break;
     case ICS_STAGE_TVTERM:
-      if (p->tv_mode != ICS_TV_MM_ACTIVE) return fail(ICS_EINVAL, "ICS_STAGE_TVTERM needs tv_mode = ICS_TV_MM_ACTIVE");
+      if (p->tv_mode == ICS_TV_SHIPPED) return fail(ICS_EINVAL, "ICS_STAGE_TVTERM needs tv_mode != ICS_TV_SHIPPED");
       RC(ensure_tv(j));
       HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
       RC(do_tvterm(j, p, 0, pr));

@@ -94,7 +94,8 @@ struct IcsConvArgs {
   const float* f;    // A1: image frame origin
   const float* u;    // A3: u frame origin   (for the fused A6/A7 reductions)
   const float* ut;   // A3: ut frame origin
-  const float* tv;   // A3, active MM-TV only: T frame (else NULL), see k_tvterm
+  const float* tv;   // A3, extended modes only: T frame (else NULL), see k_tvterm
+  int tv_kind;       // 0 shipped, 1 active MM-TV, 2/3 PAM (isotropic / collaborative TV)
   uint32_t* red;     // A3: reduction keys (ICS_RED_*) written; mode 2: keys of the finished back-projection read
   float lambd;
   // mode 2 only (update of the previous inner iteration fused in front of the convolution):

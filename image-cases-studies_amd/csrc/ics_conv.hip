@@ -356,7 +356,9 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             float g;
-            if (a.tv && y >= 1 && y <= a.g.uM - 2 && xp + p >= 1 && xp + p <= a.g.uN - 2)   // active MM-TV, pyx:517
+            if (a.tv_kind >= 2)                                                                  // PAM: G = T + lambd*gradu
+              g = (float)((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, acc[r][3*p+c]));
+            else if (a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && xp + p >= 1 && xp + p <= a.g.uN - 2)   // active MM-TV, pyx:517
               g = (float)(((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, acc[r][3*p+c])) + (double)__fsub_rn(uv[3*p+c], tv[3*p+c]) / 4.0);
             else
               g = __fadd_rn(__fmul_rn(lambd, acc[r][3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));

@@ -8,7 +8,8 @@ struct IcsUpdateArgs {
   const float* ut;     // majoriser (pyx:462)
   const float* g;      // raw back-projection (A3)
   const float* f;      // image
-  const float* tv;     // active MM-TV: T frame (NULL in the shipped mode)
+  const float* tv;     // extended modes: T frame (NULL in the shipped mode)
+  int tv_kind;         // 0 shipped, 1 active MM-TV, 2/3 PAM
   float* f_rw;         // active MM-TV: the image frame is updated in place (pyx:549)
   const uint32_t* red; // reduction keys of this inner iteration (ICS_RED_*)
   float* scal;         // device scalar block (ICS_SC_*): dt, maxu, maxg are recorded
@@ -28,6 +29,7 @@ struct IcsTvTermArgs {
   float* tv;           // T frame written
   uint32_t* red;       // ICS_RED_MAXT / ICS_RED_MAXF keys of this inner iteration
   float epsilon;       // 1e-2 blind / 1e-6 non-blind (pyx:434-437)
+  int kind;            // 1 MM-TV term, 2 isotropic TV gradient, 3 collaborative L-inf,1,1 TV gradient
   IcsGeom geo;
 };
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s);

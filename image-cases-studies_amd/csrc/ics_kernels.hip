@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
     }
   }
   float dt2[3] = {0.f, 0.f, 0.f};
-  if (a.tv) {  // pyx:548: dt = step*(max image_k + 0)/(max|gradu_k| + 1e-15) with gradu = T
+  if (a.tv_kind == 1) {  // pyx:548: dt = step*(max image_k + 0)/(max|gradu_k| + 1e-15) with gradu = T
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       dt2[c] = __fdiv_rn(__fmul_rn(a.step, ics_key2f(a.red[ICS_RED_MAXF + c])), __fadd_rn(ics_key2f(a.red[ICS_RED_MAXT + c]), 1e-15f));
@@ -84,16 +84,18 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
       for (int c = 0; c < 3; ++c) {
         const int i = 3 * p + c;
         float g;
-        if (a.tv && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
+        if (a.tv_kind >= 2)                                                    // PAM: G = T + lambd*gradu, no majoriser term
+          g = (float)((double)Tv[i] + (double)__fmul_rn(lambd, gv[i]));
+        else if (a.tv_kind == 1 && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
           g = (float)(((double)Tv[i] + (double)__fmul_rn(lambd, gv[i])) + (double)__fsub_rn(uv[i], tv[i]) / 4.0);
         else
           g = __fadd_rn(__fmul_rn(lambd, gv[i]), __fmul_rn(__fsub_rn(uv[i], tv[i]), 0.5f));
         float un = __fsub_rn(uv[i], __fmul_rn(dt[c], g));
-        if (inside) {
+        if (inside && a.tv_kind < 2) {   // (PAM has no DoF blend)
           const float d = __fdiv_rn(__fsub_rn(gv[i], fv[i]), __fadd_rn(gv[i], fv[i]));
           float D = __fmul_rn(d, d);
           if (!a.blind) D = __fdiv_rn(D, lambd);
-          if (a.tv) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
+          if (a.tv_kind == 1) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
             fv[i] = __fsub_rn(fv[i], __fdiv_rn(__fmul_rn(dt2[c], Tv[i]), lambd));
             a.f_rw[o + i] = fv[i];
           }
@@ -125,6 +127,48 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
       if (knan) atomicOr(a.dofkeys + 2, 1u);
     }
   }
+}
+
+// PAM total-variation gradient (oracle/rl_ext_oracle.py pam_tv_term): T = -div(p) at one float.
+// n = the 3 x 6-px neighbourhood rows (y-1, y, y+1) of u, i = index of the centre float, c = its channel.
+//   forward differences d_x = u[y+1]-u[y], d_y = u[x+1]-u[x]; backward-difference divergence
+//   isotropic:      p = d / sqrt(dx^2 + dy^2 + eps^2)            (per channel)
+//   collaborative:  p_d,c = [c == first argmax_c' |d_d u_c'|] * d / sqrt(d^2 + eps^2)   (L-inf over channels)
+__device__ __forceinline__ float pam_term(const float (&n)[3][20], int i, int c, float eps, bool collaborative) {
+  const float e2 = __fmul_rn(eps, eps);
+  if (!collaborative) {
+    const float dx0 = __fsub_rn(n[2][i], n[1][i]), dy0 = __fsub_rn(n[1][i + 3], n[1][i]);          // at (y, x)
+    const float dxu = __fsub_rn(n[1][i], n[0][i]), dyu = __fsub_rn(n[0][i + 3], n[0][i]);          // at (y-1, x)
+    const float dxl = __fsub_rn(n[2][i - 3], n[1][i - 3]), dyl = __fsub_rn(n[1][i], n[1][i - 3]);  // at (y, x-1)
+    const float n0 = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dx0, dx0), __fmul_rn(dy0, dy0)), e2));
+    const float nu_ = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dxu, dxu), __fmul_rn(dyu, dyu)), e2));
+    const float nl = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(dxl, dxl), __fmul_rn(dyl, dyl)), e2));
+    const float div = __fadd_rn(__fsub_rn(__fdiv_rn(dx0, n0), __fdiv_rn(dxu, nu_)), __fsub_rn(__fdiv_rn(dy0, n0), __fdiv_rn(dyl, nl)));
+    return -div;
+  }
+  const int b = i - c;  // channel 0 of this pixel
+  float px0 = 0.f, pxu = 0.f, py0 = 0.f, pyl = 0.f;
+  {  // x-direction at (y, x) and (y-1, x)
+    float d[3], du[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d[k] = __fsub_rn(n[2][b + k], n[1][b + k]); du[k] = __fsub_rn(n[1][b + k], n[0][b + k]); }
+    int s = 0, su = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) { if (__builtin_fabsf(d[k]) > __builtin_fabsf(d[s])) s = k; if (__builtin_fabsf(du[k]) > __builtin_fabsf(du[su])) su = k; }
+    if (s == c) px0 = __fdiv_rn(d[c], __fsqrt_rn(__fadd_rn(__fmul_rn(d[c], d[c]), e2)));
+    if (su == c) pxu = __fdiv_rn(du[c], __fsqrt_rn(__fadd_rn(__fmul_rn(du[c], du[c]), e2)));
+  }
+  {  // y-direction at (y, x) and (y, x-1)
+    float d[3], dl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { d[k] = __fsub_rn(n[1][b + k + 3], n[1][b + k]); dl[k] = __fsub_rn(n[1][b + k], n[1][b + k - 3]); }
+    int s = 0, sl = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) { if (__builtin_fabsf(d[k]) > __builtin_fabsf(d[s])) s = k; if (__builtin_fabsf(dl[k]) > __builtin_fabsf(dl[sl])) sl = k; }
+    if (s == c) py0 = __fdiv_rn(d[c], __fsqrt_rn(__fadd_rn(__fmul_rn(d[c], d[c]), e2)));
+    if (sl == c) pyl = __fdiv_rn(dl[c], __fsqrt_rn(__fadd_rn(__fmul_rn(dl[c], dl[c]), e2)));
+  }
+  return -__fadd_rn(__fsub_rn(px0, pxu), __fsub_rn(py0, pyl));
 }
 
 // =================================================================================================
@@ -170,7 +214,9 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
       for (int c = 0; c < 3; ++c) {
         const int i = 3 * (p + 1) + c;
         float t = 0.f;
-        if (yact && x >= 1 && x <= G.uN - 2) {
+        if (a.kind >= 2) {
+          if (yact && x >= 1 && x <= G.uN - 2) t = pam_term(nu, i, c, eps, a.kind == 3);
+        } else if (yact && x >= 1 && x <= G.uN - 2) {
           const IcsTvOut u1 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 1);
           const IcsTvOut u2 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 2);
           const IcsTvOut t1 = ics_tv_point(nt[1][i], nt[0][i], nt[2][i], nt[1][i-3], nt[1][i+3], nt[0][i-3], nt[2][i+3], nt[0][i+3], nt[2][i-3], eps, 2, 1);

@@ -176,8 +176,9 @@ __global__ void k_stats_final(IcsStatsArgs a) {
   float varu = __builtin_nanf("");
   if (w.nu > 0) { const float sd = std_of(a.dacc[4], w.nu); varu = __fmul_rn(sd, sd); }
   a.scal[ICS_SC_VARU] = varu;
-  a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[0]);
-  a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : ics_key2f(a.dofkeys[1]);
+  const bool no_dof = a.dofkeys[0] == 0xFFFFFFFFu && a.dofkeys[1] == 0u;   // modes without a DoF blend (PAM)
+  a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : (no_dof ? 0.f : ics_key2f(a.dofkeys[0]));
+  a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : (no_dof ? 0.f : ics_key2f(a.dofkeys[1]));
   if (a.do_mr) a.scal[ICS_SC_MR] = (float)(a.dacc[5] / w.ne);
 }
 

@@ -89,6 +89,10 @@ typedef struct ics_rl_params {
 #define ICS_TV_MM_ACTIVE 1 /* BUILD-DEFINED extension, parity unpinned: the if-branches :517/:543 made
                               reachable (TV_ut from the majoriser, image denoising step :547-549 live);
                               exact definition in oracle/rl_ext_oracle.py.  `image` is modified.      */
+#define ICS_TV_PAM_ISO 2   /* BUILD-DEFINED, parity unpinned: PAM u-step (Perrone & Favaro 2014; reference
+                              README.md:42,106 prose only) with an isotropic TV gradient, PSF step as
+                              pyx:555-589; no majoriser term, no DoF blend (oracle/rl_ext_oracle.py)  */
+#define ICS_TV_PAM_COLLAB 3 /* same with the collaborative L-inf,1,1 RGB TV gradient (README.md:113-114) */
 
 /* Scalars the reference only prints (pyx:593,648,659,665-669).  Arrays are per outer iteration
  * and hold at most ICS_MAX_TRACE entries (later iterations overwrite the last slot). */

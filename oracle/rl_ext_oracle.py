@@ -116,3 +116,99 @@ def richardson_lucy_MM_tv(image, u, psf, top, bottom, left, right, tau, M, N, C,
         it += 1
     tr.iterations, tr.stopped, tr.psf_final = it, stop_flag, psf.copy()
     return u[pad:pad + M, pad:pad + N, ...]
+
+
+# =================================================================================================
+# tv_mode = 2 / 3: PAM (projected alternating minimisation, Perrone & Favaro 2014; README.md:42,106 of the
+# reference describe it in prose only) with an isotropic (2) or collaborative L-inf,1,1 (3; Duran, Moeller,
+# Sbert, Cremers, IPOL 2016, README.md:113-114) total-variation gradient.  BUILD-DEFINED, PARITY UNPINNED.
+#
+#   u-step :  G = lambd * k_ (*) (k * u - f)  -  div(p),      u <- u - dt_k * G,
+#             dt_k = step * max(u_k) / (max|G_k| + 1e-15)     (the reference's max-normalised step, pyx:524)
+#             no majoriser term, no DoF blend, image untouched
+#   p      :  forward differences  dx u = u[i+1,j] - u[i,j],  dy u = u[i,j+1] - u[i,j]   (float32)
+#             isotropic     p_d,c = d_d u_c / sqrt(dx u_c^2 + dy u_c^2 + eps^2)
+#             collaborative p_d,c = [c == argmax_c' |d_d u_c'|] * d_d u_c / sqrt(d_d u_c^2 + eps^2)
+#                           (first maximal channel wins ties), i.e. the (sub)gradient of sum_px sum_d max_c |d_d u_c|
+#   div    :  backward differences  (p_x[i,j] - p_x[i-1,j]) + (p_y[i,j] - p_y[i,j-1]);  the stored term is
+#             T = -div(p) on the interior of the u-frame and 0 on its 1-px border, G = float32(T + lambd*gradu)
+#   PSF    :  gradient step, clamp, normalise exactly as lib/deconvolution.pyx:555-589
+# =================================================================================================
+def pam_tv_term(u, epsilon, collaborative):
+    u = np.asarray(u, np.float32)
+    M, N = u.shape[:2]
+    eps = F32(epsilon)
+    px = np.zeros_like(u)
+    py = np.zeros_like(u)
+    dx = np.zeros_like(u); dx[:-1] = u[1:] - u[:-1]
+    dy = np.zeros_like(u); dy[:, :-1] = u[:, 1:] - u[:, :-1]
+    if not collaborative:
+        nrm = np.sqrt(dx * dx + dy * dy + eps * eps).astype(np.float32)
+        px, py = dx / nrm, dy / nrm
+    else:
+        for d, p in ((dx, px), (dy, py)):
+            sel = np.argmax(np.abs(d), axis=2)                      # first maximal channel
+            mask = np.zeros(d.shape, bool)
+            np.put_along_axis(mask, sel[..., None], True, axis=2)
+            p[...] = np.where(mask, d / np.sqrt(d * d + eps * eps).astype(np.float32), F32(0))
+    div = np.zeros_like(u)
+    div[1:] += px[1:] - px[:-1]
+    div[:, 1:] += py[:, 1:] - py[:, :-1]
+    T = np.zeros_like(u)
+    T[1:M - 1, 1:N - 1] = -div[1:M - 1, 1:N - 1]
+    return T
+
+
+def richardson_lucy_PAM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
+                        blind=True, correlation=False, *, collaborative=False, conv="direct", trace: Trace | None = None):
+    cv = base._conv_scipy if conv == "scipy" else base._conv_direct
+    tr = trace if trace is not None else Trace()
+    step_factor, lambd, tau = F32(step_factor), F32(lambd), F32(tau)
+    u_M, u_N = u.shape[:2]
+    pad = (u_M - M) // 2
+    epsilon = 1e-2 if blind else 1e-6
+    gradk = np.zeros((MK, MK, 3), np.float32)
+    gradu = np.zeros_like(u)
+    error = np.zeros((M, N, 3), np.float32)
+    weights = stop_weights(top, bottom, left, right)
+    psf_rotated = rotate_180(psf)
+    it, stop_flag = 0, False
+    M_r = M_r_prev = F32(0)
+    while it < iterations and not stop_flag:
+        for _ in range(INNER_ITER):
+            synth = np.stack([cv(u[..., c], psf[..., c], "valid") for c in range(3)], axis=-1).astype(np.float32)
+            error[:] = synth - image
+            for k in range(3):
+                gradu[..., k] = cv(error[..., k], psf_rotated[..., k], "full")
+            T = pam_tv_term(u, epsilon, collaborative)
+            gradu[:] = (T.astype(np.float64) + (lambd * gradu).astype(np.float64)).astype(np.float32)
+            for k in range(3):
+                dt = F32(step_factor * F32(np.amax(u[..., k]))) / F32(np.amax(np.abs(gradu[..., k])) + F32(1e-15))
+                u[..., k] -= dt * gradu[..., k]
+            if blind:
+                for c in range(C):
+                    error[..., c] = cv(u[..., c], psf[..., c], "valid")
+                error -= image
+                u_rot = rotate_180(u)
+                for c in range(C):
+                    gradk[..., c] = cv(u_rot[..., c], error[..., c], "valid")
+                dtpsf = F32(F32(step_factor / F32(MK)) * F32(np.amax(psf))) / F32(np.amax(np.abs(gradk)) + F32(1e-15))
+                psf -= dtpsf * gradk
+                if correlation:
+                    m = np.mean(psf, axis=2)
+                    psf = np.dstack((m, m, m))
+                normalize_kernel(psf, MK)
+                psf_rotated = rotate_180(psf)
+        if it > 0:
+            M_r_prev = M_r
+        M_r = residual_whiteness(error[top:bottom, left:right, ...], weights, base._conv_scipy)
+        tr.M_r.append(M_r)
+        if it > 1:
+            if blind:
+                stop_flag = bool(M_r > M_r_prev)
+            else:
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    stop_flag = bool(F32(M_r - M_r_prev) / F32(M_r + M_r_prev) > tau)
+        it += 1
+    tr.iterations, tr.stopped, tr.psf_final = it, stop_flag, psf.copy()
+    return u[pad:pad + M, pad:pad + N, ...]

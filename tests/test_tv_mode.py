@@ -85,3 +85,67 @@ def test_gpu_tv_mode_run_matches_ext_oracle(M, N, MK, blind, outer, lambd):
     with contextlib.redirect_stdout(io.StringIO()):
         dc.richardson_lucy_MM(case["image"].copy(), u_s, case["psf0"].copy(), *args, blind=blind)
     assert rel_err(u, u_s) > 1e-6
+
+
+# ---- tv_mode 2 / 3: PAM with isotropic / collaborative L-inf,1,1 TV (build-defined, parity unpinned) ---------
+def tv_energy(u, eps, collaborative):
+    u = u.astype(np.float64)
+    dx = np.zeros_like(u); dx[:-1] = u[1:] - u[:-1]
+    dy = np.zeros_like(u); dy[:, :-1] = u[:, 1:] - u[:, :-1]
+    if collaborative:
+        return float(np.sum(np.sqrt(np.max(np.abs(dx), axis=2) ** 2 + eps ** 2) + np.sqrt(np.max(np.abs(dy), axis=2) ** 2 + eps ** 2)))
+    return float(np.sum(np.sqrt(dx ** 2 + dy ** 2 + eps ** 2)))
+
+
+@pytest.mark.parametrize("collaborative", [False, True])
+def test_pam_tv_term_is_the_gradient_of_the_tv_energy(collaborative):
+    """finite differences on a 9x11 frame ('gradient check by finite differences on 9x9')"""
+    u = np.random.default_rng(3).random((9, 11, 3), dtype=np.float32)
+    T = ext.pam_tv_term(u, 1e-2, collaborative).astype(np.float64)
+    for (i, j, c) in [(4, 5, 0), (3, 3, 2), (6, 8, 1), (2, 7, 0), (1, 1, 1), (7, 9, 2)]:
+        h = 1e-5
+        up, um = u.astype(np.float64).copy(), u.astype(np.float64).copy()
+        up[i, j, c] += h; um[i, j, c] -= h
+        fd = (tv_energy(up, 1e-2, collaborative) - tv_energy(um, 1e-2, collaborative)) / (2 * h)
+        assert abs(fd - T[i, j, c]) < 1e-5
+    flat = np.full((8, 8, 3), 0.4, np.float32)
+    assert np.all(ext.pam_tv_term(flat, 1e-2, collaborative) == 0)      # TV gradient of a constant image vanishes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [2, 3])
+def test_gpu_pam_tv_term_stage_matches_oracle(kind):
+    from lib import _native as nv
+    M, N, MK = 70, 131, 9
+    case = orc.synth_case(M, N, MK, seed=8, blind=True)
+    rng = np.random.default_rng(6)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job = nv.RLJob(M, N, MK)
+    job.upload(case["image"], u, case["psf0"])
+    p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=True, tv_mode=kind)
+    job.stage(nv.STAGE_TVTERM, p)
+    T = job.read(nv.BUF_TV)
+    T_ref = ext.pam_tv_term(u, 1e-2, kind == 3)
+    assert np.max(np.abs(T - T_ref)) < 2e-6 * np.abs(T_ref).max()
+    job.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,MK,blind,kind", [(65, 49, 9, False, 2), (97, 81, 7, True, 2), (80, 70, 5, True, 3), (129, 129, 15, True, 3)])
+def test_gpu_pam_run_matches_ext_oracle(M, N, MK, blind, kind):
+    # (collaborative TV with the non-blind epsilon = 1e-6 is not trajectory-comparable: the arg-max channel of an
+    #  almost flat pixel flips on 1e-7 differences; that mode is covered by the teacher-forced stage test above)
+    from lib import deconvolution as dc
+    case = orc.synth_case(M, N, MK, seed=M + MK + kind, blind=blind)
+    args = (*orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 2, 1e-3, 50.0)
+    img_r, u_r, psf_r = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    ext.richardson_lucy_PAM(img_r, u_r, psf_r, *args, blind=blind, collaborative=(kind == 3))
+    img, u, psf = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dc.richardson_lucy_MM(img, u, psf, *args, blind=blind, tv_mode=kind)
+    eu, ep = rel_err(u, u_r), rel_err(psf, psf_r)
+    print("tv_mode=%d %dx%d k%d blind=%d: rel err u=%.2e psf=%.2e" % (kind, M, N, MK, blind, eu, ep))
+    assert eu < 1e-5 and ep < 1e-5
+    assert np.array_equal(img, case["image"])                           # PAM leaves the blurry image alone
+    if blind:
+        assert np.all(psf >= 0) and np.allclose(psf.sum(axis=(0, 1)), 1, atol=1e-5)
