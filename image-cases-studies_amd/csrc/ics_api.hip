@@ -62,6 +62,7 @@ struct ics_rl {
   int P, logP, wt, wb, wl, wr;
   float* h_scal;                        // pinned host mirror of scal (+ flags)
   bool uploaded;
+  bool ut_is_u;                         // majoriser aliased to u (first inner iteration of an outer one, no copy made yet)
   // profiling
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_class;
@@ -70,6 +71,9 @@ struct ics_rl {
 };
 
 static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
+// majoriser frame: pyx:462 `ut = u.copy()` is realised without a copy -- until the first update of the outer
+// iteration ut IS u; that update writes out of place and the old u frame becomes ut (buffer rotation)
+static inline float* ut_of(ics_rl* j) { return j->ut_is_u ? j->u : j->ut; }
 
 // -------------------------------------------------------------------------------------------------
 extern "C" int ics_abi_version(void) { return ICS_ABI_VERSION; }
@@ -397,7 +401,7 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.g = j->g; a.lambd = p->lambd;
   if (mode == 1) { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
   else { a.in = org(j, j->u); a.w = j->wconv; a.out = org(j, j->e); }
-  a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, j->ut);
+  a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, ut_of(j));
   a.red = j->red + slot * ICS_RED_STRIDE;
   a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0;
@@ -411,13 +415,19 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
 
 static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   IcsUpdateArgs a;
-  a.u = org(j, j->u); a.ut = org(j, j->ut); a.g = org(j, j->gr); a.f = org(j, j->f);
+  a.u = org(j, j->u); a.ut = org(j, ut_of(j)); a.g = org(j, j->gr); a.f = org(j, j->f);
+  a.u_out = org(j, j->ut_is_u ? j->u2 : j->u);
   a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0; a.f_rw = org(j, j->f);
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));
   HIPCHK(ics_launch_update(a, j->ctx->stream));
   RC(pr.end());
+  if (j->ut_is_u) {  // rotate: the untouched old u is the majoriser now, the stale ut frame becomes the spare
+    float* old_ut = j->ut;
+    j->ut = j->u; j->u = j->u2; j->u2 = old_ut;
+    j->ut_is_u = false;
+  }
   return ICS_OK;
 }
 
@@ -429,7 +439,7 @@ static int ensure_tv(ics_rl* j) {
 
 static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   IcsTvTermArgs a;
-  a.u = org(j, j->u); a.ut = org(j, j->ut); a.f = org(j, j->f); a.tv = org(j, j->tvf);
+  a.u = org(j, j->u); a.ut = org(j, ut_of(j)); a.f = org(j, j->f); a.tv = org(j, j->tvf);
   a.red = j->red + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.kind = p->tv_mode; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));   // accounted with the elementwise class
   HIPCHK(ics_launch_tvterm(a, j->ctx->stream));
@@ -455,6 +465,7 @@ static int do_psf(ics_rl* j, const ics_rl_params* p, Prof& pr) {
 }
 
 static int do_majorize(ics_rl* j, Prof& pr) {
+  j->ut_is_u = false;
   RC(pr.begin(ICS_K_MAJORIZE));
   HIPCHK(hipMemcpyAsync(j->ut, j->u, j->frame_floats * 4, hipMemcpyDeviceToDevice, j->ctx->stream));
   RC(pr.end());
@@ -511,7 +522,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   RC(pack_weights(j, 0, 0.f, 0, s));
   HIPCHK(hipEventRecord(j->ev_begin, s));
   while (it < p->iterations && !stop) {                       // pyx:460
-    RC(do_majorize(j, pr));                                   // pyx:462
+    if (p->fuse) RC(do_majorize(j, pr));                      // pyx:462 (explicit copy only for the fused path)
+    else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
     HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
     RC(reset_dofkeys(j));
     const bool fuse = p->fuse != 0;

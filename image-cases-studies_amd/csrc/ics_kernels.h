@@ -4,7 +4,8 @@
 
 // ---- A5/A6/A8/A10 (lib/deconvolution.pyx:499-552): image update + DoF blend -------------------
 struct IcsUpdateArgs {
-  float* u;            // frame origin, updated in place
+  const float* u;      // frame origin of the current u
+  float* u_out;        // frame that receives the updated u (== u for an in-place update)
   const float* ut;     // majoriser (pyx:462)
   const float* g;      // raw back-projection (A3)
   const float* f;      // image

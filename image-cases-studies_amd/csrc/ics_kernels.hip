@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const f32x4 w = {uv[4*j], uv[4*j+1], uv[4*j+2], uv[4*j+3]};
-        reinterpret_cast<f32x4*>(a.u + o)[j] = w;
+        reinterpret_cast<f32x4*>(a.u_out + o)[j] = w;
       }
     } else {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
-        if (xp + p < G.uN) { a.u[o + 3*p] = uv[3*p]; a.u[o + 3*p + 1] = uv[3*p+1]; a.u[o + 3*p + 2] = uv[3*p+2]; }
+        if (xp + p < G.uN) { a.u_out[o + 3*p] = uv[3*p]; a.u_out[o + 3*p + 1] = uv[3*p+1]; a.u_out[o + 3*p + 2] = uv[3*p+2]; }
     }
   }
   if (a.want_dof) {  // wave shuffle -> one atomic per wave (grid is capped, so a few thousand atomics)
