@@ -4,6 +4,10 @@
 #include "ics_kernels.h"
 #include "ics_tv.h"
 
+#ifndef ICS_GRADK_WAVES
+#define ICS_GRADK_WAVES 4   /* waves per k_gradk workgroup (4 or 8: measured equal, 0.28 ms at 4096^2) */
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -276,21 +280,23 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
 // double, in a fixed order, by k_gradk_reduce (deterministic, no float atomics).
 // =================================================================================================
 
-template <int NB>
+template <int NB, int NW = 4>
 struct GradkCfg {
   static constexpr int TW = 64, TH = 32, NT = 16 * NB;
+  static constexpr int NTH = 64 * NW;              // threads per workgroup (NW waves, TH/NW tile rows each)
   static constexpr int UROWS = TH + NT - 1;
   static constexpr int LWU = 3 * TW + 2;          // == 2 (mod 32): the 16 rows x 2 k of an A read hit 32 banks
   static constexpr int EPX = TW + 24 * NB;        // E pixels staged per row: [x0 - 8NB, x0 + 64 + 16NB)
   static constexpr int LWE = 3 * EPX;
   static constexpr size_t LDS_FLOATS = (size_t)UROWS * LWU + (size_t)TH * LWE;
-  static constexpr size_t RED_FLOATS = 4 * 3 * NB * NB * 256;
+  static constexpr size_t RED_FLOATS = (size_t)NW * 3 * NB * NB * 256;
   static constexpr size_t LDS_BYTES = 4 * (LDS_FLOATS > RED_FLOATS ? LDS_FLOATS : RED_FLOATS);
 };
 
-template <int NB>
-__global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
-  using C = GradkCfg<NB>;
+template <int NB, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
+  using C = GradkCfg<NB, NW>;
+  constexpr int NTH = C::NTH;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* ul = lds;
   float* el = lds + C::UROWS * C::LWU;
@@ -312,8 +318,8 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
   // the LDS image of tile t is complete and stay in flight during its MFMA phase; they are written to
   // LDS only after the barrier that ends the phase.  The kernel needs few registers besides, so the
   // ~70 staging VGPRs are free and HBM/L2 latency disappears behind the matrix pipe.
-  constexpr int W4 = 3 * C::TW / 4, NU4 = C::UROWS * W4, NUIT = (NU4 + 255) / 256;
-  constexpr int E4 = C::LWE / 4, NE4 = C::TH * E4, NEIT = (NE4 + 255) / 256;
+  constexpr int W4 = 3 * C::TW / 4, NU4 = C::UROWS * W4, NUIT = (NU4 + NTH - 1) / NTH;
+  constexpr int E4 = C::LWE / 4, NE4 = C::TH * E4, NEIT = (NE4 + NTH - 1) / NTH;
   f32x4 pu[NUIT], pe[NEIT];  // native vectors (HIP's float4 struct kept the array in scratch)
   // (macros, not lambdas: capturing the register arrays by reference would push them to scratch)
 #define GK_PREFETCH(T)                                                                              \
@@ -322,14 +328,14 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
     /* U rows [y0 + pad - NT + 1, y0 + pad + TH), px [x0, x0 + 64) */                               \
     const float* src = a.u + (ptrdiff_t)(py0 + pad - C::NT + 1) * pitch + 3 * px0;                  \
     _Pragma("unroll") for (int k = 0; k < NUIT; ++k) {                                              \
-      int v = tid + k * 256; v = v < NU4 ? v : NU4 - 1;                                             \
+      int v = tid + k * NTH; v = v < NU4 ? v : NU4 - 1;                                             \
       const int row = v / W4, c4 = v - row * W4;                                                    \
       pu[k] = *reinterpret_cast<const f32x4*>(src + (ptrdiff_t)row * pitch + 4 * c4);               \
     }                                                                                               \
     /* E rows [y0, y0 + TH), px [x0 - 8NB, x0 + 64 + 16NB) */                                       \
     const float* srce = a.e + (ptrdiff_t)py0 * pitch + 3 * (px0 - 8 * NB);                          \
     _Pragma("unroll") for (int k = 0; k < NEIT; ++k) {                                              \
-      int v = tid + k * 256; v = v < NE4 ? v : NE4 - 1;                                             \
+      int v = tid + k * NTH; v = v < NE4 ? v : NE4 - 1;                                             \
       const int row = v / E4, c4 = v - row * E4;                                                    \
       pe[k] = *reinterpret_cast<const f32x4*>(srce + (ptrdiff_t)row * pitch + 4 * c4);              \
     }                                                                                               \
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int k = 0; k < NUIT; ++k) {
-      const int v = tid + k * 256;
+      const int v = tid + k * NTH;
       if (v < NU4) {
         const int row = v / W4, c4 = v - row * W4;
         f32x2* d = reinterpret_cast<f32x2*>(ul + row * C::LWU + 4 * c4);  // LWU rows are only 8-B aligned
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < NEIT; ++k) {
-      const int v = tid + k * 256;
+      const int v = tid + k * NTH;
       if (v < NE4) {
         const int row = v / E4, c4 = v - row * E4;
         *reinterpret_cast<f32x4*>(el + row * C::LWE + 4 * c4) = pe[k];
@@ -365,8 +371,8 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
       GK_PREFETCH(tnext)
     }
 #undef GK_PREFETCH
-    // wave w owns tile rows [8w, 8w+8)
-    for (int yy = wave * (C::TH / 4); yy < (wave + 1) * (C::TH / 4); ++yy) {
+    // wave w owns tile rows [w*TH/NW, (w+1)*TH/NW)
+    for (int yy = wave * (C::TH / NW); yy < (wave + 1) * (C::TH / NW); ++yy) {
       const float* arow = ul + (yy + C::NT - 1 - m) * C::LWU + 3 * q;           // + 12*xk + c, - 16*ab rows
       const float* brow = el + yy * C::LWE + 3 * (q + m + 8 * NB - pad);       // + 12*xk + c, + 48*bb
 #pragma unroll 4
@@ -402,8 +408,10 @@ __global__ __launch_bounds__(256) void k_gradk(IcsGradkArgs a) {
   __syncthreads();
   constexpr int PER = 3 * NB * NB * 256;
   float* dst = a.partial + (size_t)blockIdx.x * (3 * C::NT * C::NT);
-  for (int v = tid; v < PER; v += 256) {
-    const float s = ((red[v] + red[PER + v]) + red[2 * PER + v]) + red[3 * PER + v];
+  for (int v = tid; v < PER; v += NTH) {
+    float s = red[v];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s += red[w * PER + v];   // fixed order -> deterministic
     // v = ((c*NB + i)*NB + j)*256 + r*64 + l  ->  a = 16 i + 4 (l>>4) + r, b = 16 j + (l & 15)
     const int l = v & 63, r = (v >> 6) & 3, blk = v >> 8;
     const int j = blk % NB, i = (blk / NB) % NB, c = blk / (NB * NB);
@@ -535,15 +543,16 @@ int ics_gradk_blocks(const IcsGeom& g, int cus) {
 
 template <int NB>
 static hipError_t launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
-  using C = GradkCfg<NB>;
+  constexpr int NW = ICS_GRADK_WAVES;
+  using C = GradkCfg<NB, NW>;
   static bool configured = false;
-  auto kern = k_gradk<NB>;
+  auto kern = k_gradk<NB, NW>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) return e;
     configured = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(256), C::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
