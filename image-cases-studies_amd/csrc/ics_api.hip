@@ -165,7 +165,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   *out = nullptr;
   if (M < 1 || N < 1) return fail(ICS_EINVAL, "image size %dx%d", M, N);
   if (MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "MK must be odd and >= 3 (got %d)", MK);
-  if (!ics_conv_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..31)", MK);
+  if (!ics_conv_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..63)", MK);
   HIPCHK(hipSetDevice(c->device));
   ics_rl* j = new ics_rl();  // value-initialised: every pointer/flag starts at 0
   j->ctx = c;
@@ -495,6 +495,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->tv_mode < ICS_TV_SHIPPED || p->tv_mode > ICS_TV_PAM_COLLAB)
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
+  if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
 }

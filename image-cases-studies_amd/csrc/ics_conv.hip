@@ -419,7 +419,7 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   auto kern = k_conv<K, R, MODE, WPE, NTY>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }  // do not leave a sticky error behind
     configured = true;
   }
   dim3 grid(a.g.tiles_x * a.g.tiles_y * (ICS_TILE / C::TH));
@@ -431,7 +431,10 @@ template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
   // NTY = 32 (512 threads, 64x64-px tile, 2 workgroups = 16 waves per CU) when its LDS image fits twice
   constexpr int NTY = (2 * ConvCfg<K, 2, 32>::LDS_BYTES <= 160 * 1024 && ICS_CONV_NTY32) ? 32 : 16;
-  if (mode == 2) return launch_one<K, 2, 2, NTY>(a, s);
+  if (mode == 2) {
+    if constexpr (K <= 31) return launch_one<K, 2, 2, NTY>(a, s);
+    else return hipErrorInvalidValue;  // the opt-in fused kernel is only built for PSF sizes <= 31
+  }
   // R = 2 (64x32-px tiles): 44 KB of LDS at K = 15 -> 3 workgroups per CU; measured 3-6 % faster than
   // R = 4 (64x64 tiles, 2 workgroups per CU) at 4096^2 despite the larger halo (profiles/)
   constexpr int R = 2;
@@ -440,7 +443,7 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool ics_conv_supported(int K) { return K >= 3 && K <= 31 && (K & 1); }
+bool ics_conv_supported(int K) { return K >= 3 && K <= 63 && (K & 1); }
 
 hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s) {
   switch (a.g.K) {
@@ -459,6 +462,22 @@ hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 27: return launch_k<27>(mode, a, s);
     case 29: return launch_k<29>(mode, a, s);
     case 31: return launch_k<31>(mode, a, s);
+    case 33: return launch_k<33>(mode, a, s);
+    case 35: return launch_k<35>(mode, a, s);
+    case 37: return launch_k<37>(mode, a, s);
+    case 39: return launch_k<39>(mode, a, s);
+    case 41: return launch_k<41>(mode, a, s);
+    case 43: return launch_k<43>(mode, a, s);
+    case 45: return launch_k<45>(mode, a, s);
+    case 47: return launch_k<47>(mode, a, s);
+    case 49: return launch_k<49>(mode, a, s);
+    case 51: return launch_k<51>(mode, a, s);
+    case 53: return launch_k<53>(mode, a, s);
+    case 55: return launch_k<55>(mode, a, s);
+    case 57: return launch_k<57>(mode, a, s);
+    case 59: return launch_k<59>(mode, a, s);
+    case 61: return launch_k<61>(mode, a, s);
+    case 63: return launch_k<63>(mode, a, s);
     default: return hipErrorInvalidValue;
   }
 }

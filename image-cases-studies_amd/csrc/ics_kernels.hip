@@ -289,7 +289,7 @@ struct GradkCfg {
   static constexpr int EPX = TW + 24 * NB;        // E pixels staged per row: [x0 - 8NB, x0 + 64 + 16NB)
   static constexpr int LWE = 3 * EPX;
   static constexpr size_t LDS_FLOATS = (size_t)UROWS * LWU + (size_t)TH * LWE;
-  static constexpr size_t RED_FLOATS = (size_t)NW * 3 * NB * NB * 256;
+  static constexpr size_t RED_FLOATS = (size_t)NW * NB * NB * 256;   // one channel at a time
   static constexpr size_t LDS_BYTES = 4 * (LDS_FLOATS > RED_FLOATS ? LDS_FLOATS : RED_FLOATS);
 };
 
@@ -393,30 +393,31 @@ __global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
       }
     }
   }
-  // ---- cross-wave reduction (fixed order) and partial write -----------------------------------
-  __syncthreads();
-  float* red = lds;  // [wave][c][ab][bb][256]: element (row = 4*q + j, col = m) at [j*64 + lane]
+  // ---- cross-wave reduction (fixed order) and partial write, one channel per pass (bounds the LDS) --------
+  float* red = lds;  // [wave][ab][bb][256]: element (row = 4*q + j, col = m) at [j*64 + lane]
+  constexpr int PER = NB * NB * 256;
+  float* dst = a.partial + (size_t)blockIdx.x * (3 * C::NT * C::NT);
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < 3; ++c) {
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll
       for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          red[(((wave * 3 + c) * NB + i) * NB + j) * 256 + r * 64 + lane] = acc[c][i][j][r];
-  __syncthreads();
-  constexpr int PER = 3 * NB * NB * 256;
-  float* dst = a.partial + (size_t)blockIdx.x * (3 * C::NT * C::NT);
-  for (int v = tid; v < PER; v += NTH) {
-    float s = red[v];
+          red[((wave * NB + i) * NB + j) * 256 + r * 64 + lane] = acc[c][i][j][r];
+    __syncthreads();
+    for (int v = tid; v < PER; v += NTH) {
+      float s = red[v];
 #pragma unroll
-    for (int w = 1; w < NW; ++w) s += red[w * PER + v];   // fixed order -> deterministic
-    // v = ((c*NB + i)*NB + j)*256 + r*64 + l  ->  a = 16 i + 4 (l>>4) + r, b = 16 j + (l & 15)
-    const int l = v & 63, r = (v >> 6) & 3, blk = v >> 8;
-    const int j = blk % NB, i = (blk / NB) % NB, c = blk / (NB * NB);
-    const int ta = 16 * i + 4 * (l >> 4) + r, tb = 16 * j + (l & 15);
-    dst[(c * C::NT + ta) * C::NT + tb] = s;
+      for (int w = 1; w < NW; ++w) s += red[w * PER + v];   // fixed order -> deterministic
+      // v = (i*NB + j)*256 + r*64 + l  ->  a = 16 i + 4 (l>>4) + r, b = 16 j + (l & 15)
+      const int l = v & 63, r = (v >> 6) & 3, blk = v >> 8;
+      const int j = blk % NB, i = blk / NB;
+      const int ta = 16 * i + 4 * (l >> 4) + r, tb = 16 * j + (l & 15);
+      dst[(c * C::NT + ta) * C::NT + tb] = s;
+    }
   }
 }
 
@@ -549,7 +550,7 @@ static hipError_t launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s
   auto kern = k_gradk<NB, NW>;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }  // do not leave a sticky error behind
     configured = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
@@ -560,6 +561,8 @@ hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
   const int nb = (a.geo.K + 15) / 16;
   if (nb == 1) return launch_gradk<1>(a, nblocks, s);
   if (nb == 2) return launch_gradk<2>(a, nblocks, s);
+  if (nb == 3) return launch_gradk<3>(a, nblocks, s);
+  if (nb == 4) return launch_gradk<4>(a, nblocks, s);
   return hipErrorInvalidValue;
 }
 

@@ -117,7 +117,7 @@ typedef struct ics_rl_stats {
   int launches[8];
 } ics_rl_stats;
 
-/* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, >= 3):
+/* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 63):
  * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376. */
 int ics_rl_create(ics_ctx *ctx, int M, int N, int MK, ics_rl **out);
 void ics_rl_destroy(ics_rl *job);

@@ -13,7 +13,7 @@ from helpers import conv_valid64, corr_full64, gradk64, psf_step_f32, rel_err, u
 
 pytestmark = pytest.mark.gpu
 
-CONV_TOL = 5e-6
+CONV_TOL = 5e-6   # K <= 31; larger PSFs scale it with the number of accumulated terms
 
 
 def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
@@ -28,7 +28,7 @@ def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
     return job, case, psf
 
 
-@pytest.mark.parametrize("MK", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31])
+@pytest.mark.parametrize("MK", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 39, 45, 55, 63])
 def test_synth_residual_and_backprojection_all_psf_sizes(MK):
     from lib import _native as nv
     M, N = 70 + MK, 131
@@ -43,16 +43,17 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK):
     e = job.read(nv.BUF_ERROR)
     e_ref = conv_valid64(u, psf) - case["image"]
     scale = np.max(np.abs(conv_valid64(u, psf)))
-    assert np.max(np.abs(e - e_ref)) / scale < CONV_TOL
+    tol = CONV_TOL * max(1.0, (MK / 31.0) ** 2)
+    assert np.max(np.abs(e - e_ref)) / scale < tol
     job.stage(nv.STAGE_BACKPROJECT, p)
     g = job.read(nv.BUF_GRADU)
     g_ref = corr_full64(e.astype(np.float64), psf)
     assert g.shape == g_ref.shape
-    assert rel_err(g, g_ref) < CONV_TOL
+    assert rel_err(g, g_ref) < tol
     job.close()
 
 
-@pytest.mark.parametrize("M,N,MK,blind", [(64, 64, 15, False), (65, 191, 15, False), (130, 67, 9, True), (257, 300, 15, True), (40, 50, 31, False)])
+@pytest.mark.parametrize("M,N,MK,blind", [(64, 64, 15, False), (65, 191, 15, False), (130, 67, 9, True), (257, 300, 15, True), (40, 50, 31, False), (100, 90, 45, True), (80, 120, 63, True), (70, 70, 21, True)])
 def test_one_inner_iteration_stage_by_stage(M, N, MK, blind):
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=M + N, blind=blind)
