@@ -75,8 +75,9 @@ typedef struct ics_rl_params {
                                    does); 0 = never stop early, M_r not computed;
                                    2 = compute M_r every outer iteration but never stop
                                    (fixed-length benchmark runs with the full workload)    */
-  int profile;                  /* 1 = bracket every kernel launch with HIP events on the job's
-                                   stream and report per-kernel averages in ics_rl_stats    */
+  int profile;                  /* k > 0: bracket the kernel launches of every k-th inner iteration (k = 1:
+                                   all) and the per-outer kernels with HIP events on the job's stream;
+                                   per-kernel averages are reported in ics_rl_stats         */
   int fuse;                     /* 1: the image update of inner iteration i is fused in front of the next
                                    convolution (one kernel, u ping-pong, bit-identical results).  Default 0:
                                    measured SLOWER on MI355X at 4096^2/15x15 (0.67 ms vs 0.28 + 0.19 ms),
