@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--psf", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary (untimed for `value`) run of the other mode")
     ap.add_argument("--tv-mode", type=int, default=0, help="0 = shipped loop (TV term dead, the parity-pinned path); 1 = build-defined active MM-TV")
     ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -146,6 +147,22 @@ def main():
     elapsed = grp.max(elapsed)
     assert st.inner_iterations == steps, (st.inner_iterations, steps)
 
+    # secondary measurement (not `value`): the other mode on the same resident frame, same schedule
+    other = None
+    if grp.size == 1 and not args.no_other_mode:
+        omode = "nonblind" if blind else "blind"
+        job.upload(image, u0, psf_true if blind else psf_uniform)
+        po = job.params(*win, 1e9, steps // 5, 1e-3, 10000.0, not blind, 0, 3, stop_test=2, profile=0, fuse=int(args.fuse), tv_mode=args.tv_mode)
+        job.run(job.params(*win, 1e9, max(1, warm // 5), 1e-3, 10000.0, not blind, 0, 3, stop_test=2))
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        job.run(po)
+        ctx.synchronize()
+        e2 = time.perf_counter() - t1
+        ogb = ITER_BYTES_PER_PX[omode] * M * N / (e2 / steps) / 1e9
+        other = {"mode": omode, "ms_per_step": round(e2 * 1e3 / steps, 4), "MPixels_per_s_per_iter": round(M * N * steps / e2 / 1e6, 1),
+                 "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[omode], "frac_of_8TBps": round(ogb / HBM_PEAK_GBPS, 4)}
+
     per_rank = grp.gather([st.ms_total, float(st.iterations_done), float(st.M_r), float(st.has_nan)])
     if grp.rank == 0:
         ms_per_step = elapsed * 1e3 / steps
@@ -182,6 +199,7 @@ def main():
             "kernels_ms": kern, "device_ms_total_rank0": round(st.ms_total, 3),
             "per_rank": [{"device_ms": round(r[0], 3), "outer_done": int(r[1])} for r in per_rank],
             "roofline": roof,
+            "other_mode_same_frame": other,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.mode, MK)
