@@ -510,6 +510,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   const bool tv = p->tv_mode != ICS_TV_SHIPPED;
   if (tv) RC(ensure_tv(j));
   memset(st, 0, sizeof *st);
+  j->ut_is_u = false;
   Prof pr_on{j, p->profile != 0};       // (per-outer kernels are always bracketed when profiling)
   Prof pr_off{j, false};
   Prof& pr = pr_on;

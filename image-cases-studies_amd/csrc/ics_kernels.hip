@@ -546,12 +546,14 @@ template <int NB>
 static hipError_t launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
   constexpr int NW = ICS_GRADK_WAVES;
   using C = GradkCfg<NB, NW>;
-  static bool configured = false;
+  static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   auto kern = k_gradk<NB, NW>;
-  if (!configured) {
+  if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }  // do not leave a sticky error behind
-    configured = true;
+    configured[dev] = true;
   }
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
