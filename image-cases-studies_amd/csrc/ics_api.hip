@@ -50,6 +50,7 @@ struct ics_rl {
   float *u, *u2, *ut, *gr, *f, *e;     // frame bases (origin = base + origin); u2 = ping-pong partner of u
   float* tvf;                           // TV term frame (tv_mode 1, allocated on first use)
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
+  float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 17), else NULL
   int gradk_blocks;
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
   uint32_t* dofkeys;                    // 4 words
@@ -150,7 +151,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->psf_caller, j->partial,
+  void* ptrs[] = {j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial,
                   j->red, j->dofkeys, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -182,6 +183,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
   TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
+  if (ics_conv_mfma_supported(MK)) { TRY(dalloc(&j->bt_conv, ics_conv_mfma_table_floats(MK), s)); TRY(dalloc(&j->bt_corr, ics_conv_mfma_table_floats(MK), s)); }
   TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt, s));
   TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE, s)); TRY(dalloc(&j->dofkeys, (size_t)4, s));
   TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->dacc, (size_t)8, s)); TRY(dalloc(&j->ukey, (size_t)2, s)); TRY(dalloc(&j->flags, (size_t)4, s));
@@ -210,7 +212,7 @@ static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px,
 
 static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hipStream_t s) {
   IcsPsfArgs a;
-  a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.psf_caller = j->psf_caller;
+  a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.bt_conv = j->bt_conv; a.bt_corr = j->bt_corr; a.psf_caller = j->psf_caller;
   a.scal = j->scal; a.frozen = j->flags; a.step = step; a.K = j->g.K; a.wrow = j->g.wrow;
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
@@ -396,6 +398,15 @@ struct Prof {
 
 #define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
 
+// ICS_CONV_AUTO: matrix-core kernels where they exist (MK <= 17); env ICS_CONV_PATH=vector|matrix overrides AUTO
+static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
+  if (!j->bt_conv) return false;
+  if (p->conv == ICS_CONV_VECTOR) return false;
+  if (p->conv == ICS_CONV_MATRIX) return true;
+  static const int env = [] { const char* e = getenv("ICS_CONV_PATH"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+  return env != 1;
+}
+
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   IcsConvArgs a;
   a.g = j->g; a.lambd = p->lambd;
@@ -406,8 +417,11 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0;
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
+  const bool matrix = mode != 2 && use_matrix_conv(j, p);
+  a.bt = matrix ? (mode == 1 ? j->bt_corr : j->bt_conv) : nullptr;
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
-  HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
+  if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
+  else HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
   RC(pr.end());
   if (mode == 2) { float* t = j->u; j->u = j->u2; j->u2 = t; }  // the updated frame is now `u`
   return ICS_OK;
@@ -495,6 +509,8 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->tv_mode < ICS_TV_SHIPPED || p->tv_mode > ICS_TV_PAM_COLLAB)
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
+  if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
+  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 17");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;

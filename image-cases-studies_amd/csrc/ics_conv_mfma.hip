@@ -1,0 +1,551 @@
+// ics_conv_mfma.hip -- the two PSF convolutions of one Richardson-Lucy inner iteration on the gfx950
+// matrix cores (PSF sizes 3..17).  Same contract as ics_conv.hip (modes 0 and 1):
+//
+//   mode 0 (A1+A2, lib/deconvolution.pyx:477-488):  error = convolve(u, psf, "valid") - image
+//   mode 1 (A3,    lib/deconvolution.pyx:490-491):  gradu = convolve(error, rot180(psf), "full")
+//           + the reductions of A7 (pyx:523-524)
+//
+//     out[y, x, c] = sum_{a,b<K} W[a, b, c] * in[y + a - pad, x + b - pad, c]
+//
+// Why a second kernel: the packed-fp32 VALU kernel of ics_conv.hip tops out at ~88 TFLOP/s (of the 135
+// that v_pk_fma_f32 can issue) and is the largest item of the iteration.  The matrix cores have no fast
+// fp32 mode on CDNA4 (v_mfma_f32_16x16x4_f32 = 157 TF), but v_mfma_f32_16x16x32_f16 sustains 1.9 PF
+// with fp32 accumulation.  Every fp32 operand is therefore split into two fp16 terms,
+//     x * s = hi + lo,  hi = fp16(x*s),  lo = fp16(x*s - hi)          (s = a power of two per tile / per PSF)
+// which keeps 22 significand bits, and the product is evaluated as hi*hi + hi*lo + lo*hi (three MFMAs,
+// the lo*lo term is below 2^-22).  Measured against float64 the result is as close as the sequential fp32
+// FMA chain of the VALU kernel (oracle comparison in tests/test_gpu_stages.py, same tolerance for both).
+//
+// Formulation.  Along x the convolution is a banded Toeplitz product, one per kernel row a and channel c:
+//     out_a[y, 16cb + j] = sum_{k<32} in[y + a - pad, 16cb - pad + k] * B_a[k][j],   B_a[k][j] = W[a][k - j][c]
+// (zero outside 0 <= k-j < K; 16 + K - 1 <= 32 input columns per 16 output columns, hence K <= 17).
+// The MFMA's M dimension runs over 16 image rows, and the rows of one fragment are taken 4 apart:
+//     fragment q, lane row i  <->  input row q + 4i (tile-relative)       q = 0 .. K+2
+// so that the product with B_a lands on output rows (q - a) + 4i: fragment q feeds the four accumulator
+// sets t = q - a = 0..3 IN PLACE, i.e. one LDS fragment read serves up to 4 kernel rows x 3 split terms =
+// 12 MFMAs (a row-contiguous fragment would serve 3 and the kernel would be LDS-bound).
+//
+// Kernel shape: persistent 4-wave workgroups, two per CU, walking 64x64-pixel tiles.
+//   * LDS (75 KB): the tile + halo as six fp16 planes (channel x hi/lo), rows grouped by y mod 4 so that the
+//     16 lane rows of a fragment are consecutive 160-B LDS rows (conflict-free for the b128 lane groups of
+//     gfx950, MI355X_MICROARCH.md LDS).  Two workgroups per CU: one's memory phases (conversion, epilogue)
+//     overlap the other's matrix phase.
+//   * wave w owns the 16-column block w of the tile for all three channels (12 accumulators).
+//   * Toeplitz fragments are never stored: the weights sit in LDS as compact rows (K halves + a zero per
+//     (c, a, hi/lo), 3 KB); per row every lane builds one dword of the zero-padded row image from two LDS
+//     halves and gathers its 8 consecutive halves with four ds_bpermute_b32.  (Full 1-KiB fragments from
+//     global memory made the kernel L1-bound; fragment-shaped LDS copies do not fit beside the planes.)
+//   * the fp32 HWC rows of the NEXT tile are requested into registers (2 waves per SIMD -> 256 VGPRs) before
+//     the MFMA loop, which itself issues no vector-memory load (they return in order): HBM latency is covered
+//     by the matrix phase; conversion to the fp16 planes happens after the epilogue of the current tile.
+//   * the accumulators are transposed back to HWC through LDS (aliasing the planes) and leave through the
+//     same epilogue arithmetic as the VALU kernel (residual / back-projection + step-size reductions).
+#include "ics_common.h"
+
+#ifndef ICS_MFMA_ABLATE
+#define ICS_MFMA_ABLATE 0  /* tools/bench_conv_mfma.hip: 1 = no MFMA loop, 2 = no conversion, 4 = no epilogue */
+#endif
+
+// phase timing probe (tools/bench_conv_mfma.hip -DICS_MFMA_TIMING): per-wave cycle totals between the marks
+#ifdef ICS_MFMA_TIMING
+__device__ unsigned long long ics_mfma_ticks[11];
+#define ICS_TICK_INIT unsigned long long tk_prev = __builtin_readcyclecounter(), tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ICS_TICK(i) do { const unsigned long long tk_now = __builtin_readcyclecounter(); tk_acc[i] += tk_now - tk_prev; tk_prev = tk_now; } while (0)
+#define ICS_TICK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 10; ++i) atomicAdd(&ics_mfma_ticks[i], tk_acc[i]); atomicAdd(&ics_mfma_ticks[10], 1ull); } } while (0)
+#else
+#define ICS_TICK_INIT
+#define ICS_TICK(i)
+#define ICS_TICK_FLUSH
+#endif
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int K>
+struct MCfg {
+  static constexpr int PAD = K / 2;
+  static constexpr int TH = 64, TW = 64, NCB = TW / 16;
+  static constexpr int NW = 4, NT = 64 * NW;
+  static constexpr int LROWS = TH + K - 1;       // input rows of the tile
+  static constexpr int RC = (LROWS + 3) / 4;     // LDS rows per (y mod 4) class
+  static constexpr int LCOLS = TW + 16;          // staged columns: [x0 - PAD, x0 - PAD + 80)
+  static constexpr int ROWB = 2 * LCOLS;         // 160 bytes per LDS row: conflict-free for the fragment reads
+  static constexpr int PLANE = 4 * RC * ROWB;    // bytes per (channel, hi/lo) plane
+  static constexpr int DATA = 6 * PLANE;
+  static constexpr int OUTB = TH * TW * 3 * 4;   // fp32 HWC transpose buffer (aliases the planes)
+  static constexpr int BENT = 192;               // bytes per (c, a, hi/lo) entry of the compact weight table
+  static constexpr int BTAB = 3 * K * 2 * BENT;
+  static constexpr int SCRATCH = DATA > OUTB ? DATA : OUTB;
+  static constexpr int WROW = K + 1;             // halves per compact weight row in LDS: K weights + one zero
+  static constexpr int WLDS = 3 * K * 2 * WROW * 2;
+  static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
+  static constexpr int NQ = K + 3;               // fragments per (channel, column block)
+  static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
+  static constexpr int NTASK = LROWS * XG;
+  static constexpr int NIT = (NTASK + NT - 1) / NT;
+  static constexpr int ETASK = TH * (TW / 4);    // epilogue tasks: one row x 4 pixels
+  static constexpr int EIT = (ETASK + NT - 1) / NT;
+  static_assert(16 + K - 1 <= 32, "one 32-wide MFMA window per 16 output columns");
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+    v = v > o ? v : o;
+  }
+  return v;
+}
+
+// power-of-two scale that brings a maximum magnitude m into [2^14, 2^15) (fp16 overflows at 65504);
+// 1 for m = 0 / Inf / NaN.  `inv` is the exact inverse.
+__device__ __forceinline__ void pow2_scale(float m, float& s, float& inv) {
+  const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
+  uint32_t sb = 127u;
+  if (m > 0.f && e != 255u) { sb = 268u - e; sb = sb > 240u ? 240u : sb; }
+  s = __uint_as_float(sb << 23);
+  inv = __uint_as_float((254u - sb) << 23);
+}
+
+// Buffer addressing (SGPR resource + 32-bit lane offset + SGPR/immediate offset): with flat 64-bit pointers
+// the compiler materialised one 64-bit VGPR base per load and spilled them.
+#define ICS_BUF_WORD3 0x00020000  /* gfx9 raw buffer: DATA_FORMAT = 32 */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, ICS_BUF_WORD3);
+}
+
+// the staged rows of a tile: task t = (row, 4-pixel group) -> three dwordx4 loads (4-byte aligned).
+// `soff` = wave-uniform byte offset of the tile's first staged element.
+template <typename C>
+__device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer_rsrc_t rs, int soff, int tid, int pitch) {
+#pragma unroll
+  for (int k = 0; k < C::NIT; ++k) {
+    int t = tid + k * C::NT;
+    t = t < C::NTASK ? t : C::NTASK - 1;  // clamp instead of predicating the load
+    const int row = t / C::XG, xg = t - row * C::XG;
+    const int toff = 4 * (row * pitch + 12 * xg);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) v[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16 * h, soff, 0));
+  }
+}
+
+// a copy of `x` the optimiser cannot trace back: values derived from it are recomputed where they are used
+// instead of being hoisted out of the tile loop (where they were spilled -- and a scratch reload waits on
+// vmcnt, i.e. on the whole prefetch in flight)
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+template <int K, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_mfma(IcsConvArgs a) {
+  using C = MCfg<K>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* fscr = reinterpret_cast<float*>(lds + C::SCRATCH);
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // = column block of this wave
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int pitch = a.g.pitch;
+
+  // persistent tile walk: workgroup b runs on XCD b % 8 (observed dispatch); every XCD owns one contiguous
+  // band of tiles so that the halos shared by neighbouring tiles hit in that XCD's L2
+  const int tpr = a.g.tiles_x;   // tiles per row
+  const int ntiles = tpr * a.g.tiles_y;
+  const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;         // bands (= XCDs when the grid covers them all)
+  const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
+  const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;            // workgroups walking this band
+  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  int tile = band0 + kx;
+  if (tile >= band1) return;
+
+  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::BTAB);
+
+  // compact weight rows -> LDS once per workgroup: row (c, a, hi/lo) = K halves + a zero (global table entry:
+  // padded row Wp[idx] = W[idx - 15], halves 15 .. 15+K-1 of the first copy)
+  uint16_t* ldsW = reinterpret_cast<uint16_t*>(lds + C::SCRATCH + 256);
+  {
+    const uint16_t* tab = reinterpret_cast<const uint16_t*>(a.bt);
+    for (int i = tid; i < C::WLDS / 2; i += C::NT) {
+      const int e = i / C::WROW, b = i - e * C::WROW;
+      ldsW[i] = b < K ? tab[e * 96 + 15 + b] : (uint16_t)0;
+    }
+  }
+  // lane constants.  The "row image" of a weight row is 64 dwords: dword l < 32 = halves (2l, 2l+1) of the
+  // padded row, dword 32 + l = halves (2l+1, 2l+2); every lane builds its image dword from two LDS halves
+  // (out-of-range taps read the row's zero) and gathers its fragment = 4 consecutive image dwords starting at
+  // dword bo >> 1 of copy bo & 1 with ds_bpermute, bo = 8*lg - li + 15 being the first half of its slice.
+  const int bo = 8 * lg - li + 15;
+  const int bsel = 4 * ((bo & 1) * 32 + (bo >> 1));                                  // ds_bpermute byte index
+  const int ib0 = 2 * (lane & 31) + (lane >> 5) - 15, ib1 = ib0 + 1;                 // taps of this lane's image dword
+  const int wo0 = (ib0 >= 0 && ib0 < K) ? ib0 : K, wo1 = (ib1 >= 0 && ib1 < K) ? ib1 : K;
+  // LDS byte addresses of the two halves in row 0; opaque to the optimiser so that the per-row constants stay in
+  // the 16-bit offset field of ds_read_u16 (folded with the 75 KB base they exceed it: one address VGPR per row)
+  typedef const __attribute__((address_space(3))) uint16_t* lds_u16p;
+  uint32_t wa0 = (uint32_t)(uintptr_t)(lds_u16p)(ldsW + wo0), wa1 = (uint32_t)(uintptr_t)(lds_u16p)(ldsW + wo1);
+  asm volatile("" : "+v"(wa0), "+v"(wa1));
+  const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
+
+  float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  bool nan_g[3] = {false, false, false}, nan_u[3] = {false, false, false}, any = false;
+
+  // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
+  f32x4u raw[C::NIT][3];
+  {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + txi * C::TW - C::PAD)), tid, pitch);
+  }
+
+  ICS_TICK_INIT;
+#pragma unroll 1
+  for (; tile < band1; tile += nx) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    const int x0 = txi * C::TW, y0 = tyi * C::TH;
+
+    // ---- raw fp32 HWC rows (registers) -> six fp16 planes, scaled by a per-tile power of two ----------
+    float inv_x;
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::NIT; ++k)
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(raw[k][h][e]));
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) fscr[wv] = m;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
+      float s_x;
+      pow2_scale(m, s_x, inv_x);
+      const int tidc = opaque(tid);
+#pragma unroll
+      for (int k = 0; k < C::NIT; ++k) {
+        const int t = tidc + k * C::NT;
+        if (t < C::NTASK && !((ICS_MFMA_ABLATE & 2) && k > 0)) {
+          const int row = t / C::XG, xg = t - row * C::XG;
+          unsigned char* dst = lds + ((row & 3) * C::RC + (row >> 2)) * C::ROWB + 8 * xg;
+          float f[12];
+#pragma unroll
+          for (int h = 0; h < 3; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[4 * h + e] = raw[k][h][e] * s_x;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            h4 hi, lo;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const float x = f[3 * p + c];
+              const _Float16 xh = (_Float16)x;
+              hi[p] = xh;
+              lo[p] = (_Float16)(x - (float)xh);
+            }
+            *reinterpret_cast<h4*>(dst + (2 * c) * C::PLANE) = hi;
+            *reinterpret_cast<h4*>(dst + (2 * c + 1) * C::PLANE) = lo;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    ICS_TICK(0);
+
+    // ---- request the next tile's rows: in flight during the whole matrix phase (the loop below issues no
+    // vector-memory loads -- they return in order, a weight load behind this prefetch would wait for it) -----
+    if (tile + nx < band1) {
+      const int nt = tile + nx;
+      const int nyi = nt / tpr, nxi = nt - nyi * tpr;
+      load_raw<C>(raw, rs_in, 4 * ((a.g.ay + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + nxi * C::TW - C::PAD)), opaque(tid), pitch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    ICS_TICK(7);
+    // ---- Toeplitz MFMA loop ----------------------------------------------------------------------------
+    f4 acc[3][4];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[ch][t] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (x0 + 16 * wv < a.g.uN) {   // wave-uniform: a column block right of the frame carries no output
+#pragma unroll
+      for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
+        // row images of this channel: one dword per lane per (a, hi/lo), built WPF steps ahead of their gather
+        constexpr int WPF = 2;
+        uint32_t wr[K][2];
+        auto rowimg = [&](int ka) {
+#pragma unroll
+          for (int sp = 0; sp < 2; ++sp) {
+            const uint32_t ro = (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROW * 2);
+            wr[ka][sp] = (uint32_t)*reinterpret_cast<lds_u16p>(wa0 + ro) | ((uint32_t)*reinterpret_cast<lds_u16p>(wa1 + ro) << 16);
+          }
+        };
+#pragma unroll
+        for (int ka = 0; ka < WPF && ka < K; ++ka) rowimg(ka);
+        const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
+        const unsigned char* pl = ph + C::PLANE;
+        h8 Bh[K], Bl[K];
+        // software pipeline: the operands of step q + 1 (A fragment from the planes, B fragment gathered from the
+        // weight row) are requested before the MFMAs of step q
+        auto gatherB = [&](int ka) {
+          u4 t0, t1;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            if (ICS_MFMA_ABLATE & 8) { t0[d] = wr[ka][0] + d; t1[d] = wr[ka][1] + d; continue; }   // timing probe only
+            t0[d] = (uint32_t)__builtin_amdgcn_ds_bpermute(bsel + 4 * d, (int)wr[ka][0]);
+            t1[d] = (uint32_t)__builtin_amdgcn_ds_bpermute(bsel + 4 * d, (int)wr[ka][1]);
+          }
+          Bh[ka] = __builtin_bit_cast(h8, t0); Bl[ka] = __builtin_bit_cast(h8, t1);
+        };
+        gatherB(0);
+        h8 Ah = *reinterpret_cast<const h8*>(ph), Al = *reinterpret_cast<const h8*>(pl);
+#pragma unroll
+        for (int q = 0; q < C::NQ; ++q) {
+          if (q + WPF < K) rowimg(q + WPF);
+          h8 Nh = Ah, Nl = Al;
+          if (q + 1 < C::NQ) {
+            const int off = (((q + 1) & 3) * C::RC + ((q + 1) >> 2)) * C::ROWB;
+            if (!(ICS_MFMA_ABLATE & 16)) {   // 16: timing probe without the A-fragment reads
+              Nh = *reinterpret_cast<const h8*>(ph + off);
+              Nl = *reinterpret_cast<const h8*>(pl + off);
+            }
+          }
+          if (q + 1 < K) gatherB(q + 1);
+          __builtin_amdgcn_sched_barrier(0);   // ...and all of them are in flight before the step's MFMAs start
+          // three split terms; within a term the (up to) 4 accumulators are independent
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int ka = q - t;
+              if (ka < 0 || ka >= K) continue;
+              const h8 av = term == 2 ? Al : Ah;
+              const h8 bv = term == 1 ? Bl[ka] : Bh[ka];
+              acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[ch][t], 0, 0, 0);
+            }
+          }
+          Ah = Nh; Al = Nl;
+          __builtin_amdgcn_sched_barrier(0);   // keep each step's prefetches in that step (register pressure)
+        }
+      }
+    }
+    ICS_TICK(1);
+    __syncthreads();  // every wave is done with the planes
+    ICS_TICK(2);
+
+    // ---- accumulators -> fp32 HWC tile in LDS (row t + 16*lg + 4*r, column 16*wv + li) -------------------
+    {
+      float* o = reinterpret_cast<float*>(lds);
+      const float sc = inv_w * inv_x;   // powers of two
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int y = t + 16 * lg + 4 * r, x = 16 * wv + li;
+            o[(y * C::TW + x) * 3 + ch] = acc[ch][t][r] * sc;
+          }
+    }
+    ICS_TICK(8);
+    // ---- epilogue (same arithmetic as ics_conv.hip): a task = one row x 4 pixels, processed in batches of EB
+    // tasks; the global operands of a batch are requested first (the first batch before the barrier, so that
+    // their latency overlaps the transposes).  Mode 1 carries two operand frames: smaller batches.
+    constexpr int EOPS = (MODE == 0) ? 1 : 2;
+    constexpr int EB = (MODE == 0) ? C::EIT : 2;
+    static_assert(C::EIT % EB == 0, "epilogue batches");
+    const float* ot = reinterpret_cast<const float*>(lds);
+    const int tide = opaque(tid);
+#pragma unroll
+    for (int eb = 0; eb < C::EIT; eb += EB) {
+      float4 eop[EB][EOPS][3];
+      bool evalid[EB];
+  #pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        const int task = tide + (eb + k) * C::NT;
+        const int ty = task / (C::TW / 4), tx = task - ty * (C::TW / 4);
+        const int y = y0 + ty, xp = x0 + 4 * tx;
+        bool ok = task < ((ICS_MFMA_ABLATE & 4) ? 16 : C::ETASK);
+        if (MODE == 0) ok = ok && y >= C::PAD && y < C::PAD + a.g.M && xp + 3 >= C::PAD && xp < C::PAD + a.g.N;
+        else ok = ok && y < a.g.uM && xp < a.g.uN;
+        evalid[k] = ok;
+        if (ok) {
+          const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * xp;
+          if (MODE == 0) {
+            const float4* fp = reinterpret_cast<const float4*>(a.f + o);
+            eop[k][0][0] = fp[0]; eop[k][0][1] = fp[1]; eop[k][0][2] = fp[2];
+          } else {
+            const float4* up = reinterpret_cast<const float4*>(a.u + o);
+            const float4* tp = reinterpret_cast<const float4*>(a.ut + o);
+            eop[k][0][0] = up[0]; eop[k][0][1] = up[1]; eop[k][0][2] = up[2];
+            eop[k][EOPS - 1][0] = tp[0]; eop[k][EOPS - 1][1] = tp[1]; eop[k][EOPS - 1][2] = tp[2];
+          }
+        }
+      }
+      if (eb == 0) {
+        ICS_TICK(3);
+        __syncthreads();
+        ICS_TICK(4);
+      }
+
+      // ---- epilogue (same arithmetic as ics_conv.hip): a task = one row x 4 pixels --------------------------
+  #pragma unroll
+      for (int k = 0; k < EB; ++k) {
+        if (!evalid[k]) continue;
+        const int task = tide + (eb + k) * C::NT;
+        const int ty = task / (C::TW / 4), tx = task - ty * (C::TW / 4);
+        const int y = y0 + ty, xp = x0 + 4 * tx;
+        float av[12];
+        {
+          const float4* lp = reinterpret_cast<const float4*>(ot + ty * (C::TW * 3) + 12 * tx);
+  #pragma unroll
+          for (int j = 0; j < 3; ++j) { const float4 t4 = lp[j]; av[4*j] = t4.x; av[4*j+1] = t4.y; av[4*j+2] = t4.z; av[4*j+3] = t4.w; }
+        }
+        const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * xp;
+        if (MODE == 0) {
+          // error = synth - image on the M x N interior (pyx:488); the border ring of the frame stays 0
+          const int lo_x = C::PAD, hi_x = C::PAD + a.g.N;
+          float fv[12];
+  #pragma unroll
+          for (int j = 0; j < 3; ++j) { const float4 t4 = eop[k][0][j]; fv[4*j] = t4.x; fv[4*j+1] = t4.y; fv[4*j+2] = t4.z; fv[4*j+3] = t4.w; }
+          float e[12];
+  #pragma unroll
+          for (int f = 0; f < 12; ++f) e[f] = __fsub_rn(av[f], fv[f]);
+          if (xp >= lo_x && xp + 3 < hi_x) {
+            float4* op = reinterpret_cast<float4*>(a.out + o);
+  #pragma unroll
+            for (int j = 0; j < 3; ++j) op[j] = make_float4(e[4*j], e[4*j+1], e[4*j+2], e[4*j+3]);
+          } else {
+  #pragma unroll
+            for (int p = 0; p < 4; ++p)
+              if (xp + p >= lo_x && xp + p < hi_x) {
+                a.out[o + 3*p] = e[3*p]; a.out[o + 3*p + 1] = e[3*p+1]; a.out[o + 3*p + 2] = e[3*p+2];
+              }
+          }
+        } else {
+          // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
+          const float lambd = a.lambd;
+          float uv[12], tv[12];
+  #pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float4 t4 = eop[k][0][j]; uv[4*j] = t4.x; uv[4*j+1] = t4.y; uv[4*j+2] = t4.z; uv[4*j+3] = t4.w;
+            const float4 s4 = eop[k][EOPS - 1][j]; tv[4*j] = s4.x; tv[4*j+1] = s4.y; tv[4*j+2] = s4.z; tv[4*j+3] = s4.w;
+          }
+  #pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            if (xp + p < a.g.uN) {
+  #pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                float g;
+                if (a.tv_kind >= 2)
+                  g = (float)((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, av[3*p+c]));
+                else if (a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && xp + p >= 1 && xp + p <= a.g.uN - 2)
+                  g = (float)(((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, av[3*p+c])) + (double)__fsub_rn(uv[3*p+c], tv[3*p+c]) / 4.0);
+                else
+                  g = __fadd_rn(__fmul_rn(lambd, av[3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
+                mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
+                mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
+                nan_g[c] |= (g != g); nan_u[c] |= (uv[3*p+c] != uv[3*p+c]);
+                any = true;
+              }
+            }
+          }
+          if (xp + 3 < a.g.uN) {
+            float4* op = reinterpret_cast<float4*>(a.out + o);
+  #pragma unroll
+            for (int j = 0; j < 3; ++j) op[j] = make_float4(av[4*j], av[4*j+1], av[4*j+2], av[4*j+3]);
+          } else {
+  #pragma unroll
+            for (int p = 0; p < 4; ++p)
+              if (xp + p < a.g.uN) {
+                a.out[o + 3*p] = av[3*p]; a.out[o + 3*p + 1] = av[3*p+1]; a.out[o + 3*p + 2] = av[3*p+2];
+              }
+          }
+        }
+      }
+    }
+    ICS_TICK(5);
+    __syncthreads();  // the transpose buffer is consumed before the next tile's planes overwrite it
+    ICS_TICK(6);
+  }
+
+  ICS_TICK_FLUSH;
+  if (MODE == 1) {
+    // step-size reductions of all tiles of this workgroup: wave shuffle -> LDS -> one atomic per value
+    uint32_t kg[3], ku[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      kg[c] = nan_g[c] ? 0xFFC00000u : (any ? ics_f2key(mg[c]) : 0u);   // NaN propagates like np.amax
+      ku[c] = nan_u[c] ? 0xFFC00000u : (any ? ics_f2key(mu[c]) : 0u);
+      kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]);
+    }
+    uint32_t* red_lds = reinterpret_cast<uint32_t*>(fscr);
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { red_lds[wv * 8 + c] = kg[c]; red_lds[wv * 8 + 3 + c] = ku[c]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+      uint32_t m = red_lds[tid];
+#pragma unroll
+      for (int w = 1; w < C::NW; ++w) { const uint32_t o2 = red_lds[w * 8 + tid]; m = m > o2 ? m : o2; }
+      const int slot = tid < 3 ? ICS_RED_MAXG + tid : ICS_RED_MAXU + (tid - 3);
+      if (m > a.red[slot]) atomicMax(a.red + slot, m);
+    }
+  }
+}
+
+template <int K, int MODE>
+hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
+  using C = MCfg<K>;
+  static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
+  static int cus[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  auto kern = k_conv_mfma<K, MODE>;
+  if (!configured[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    configured[dev] = true;
+  }
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+  }
+  const int ntiles = a.g.tiles_x * a.g.tiles_y;
+  int grid = 2 * cus[dev];                   // two persistent workgroups per CU (LDS: 2 x 75 KB)
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+template <int K>
+hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
+  return mode == 0 ? launch_one<K, 0>(a, s) : launch_one<K, 1>(a, s);
+}
+
+}  // namespace
+
+bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 17 && (K & 1); }
+
+// compact Toeplitz weight table: [c][a][hi/lo] x 192 bytes, then one float 1/s_w (ics_common.h)
+size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * 48 + 4; }
+
+hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
+  if ((mode != 0 && mode != 1) || !a.bt) return hipErrorInvalidValue;
+  switch (a.g.K) {
+    case 3: return launch_k<3>(mode, a, s);
+    case 5: return launch_k<5>(mode, a, s);
+    case 7: return launch_k<7>(mode, a, s);
+    case 9: return launch_k<9>(mode, a, s);
+    case 11: return launch_k<11>(mode, a, s);
+    case 13: return launch_k<13>(mode, a, s);
+    case 15: return launch_k<15>(mode, a, s);
+    case 17: return launch_k<17>(mode, a, s);
+    default: return hipErrorInvalidValue;
+  }
+}

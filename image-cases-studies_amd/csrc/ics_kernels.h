@@ -53,6 +53,8 @@ struct IcsPsfArgs {
   const float* gradk;  // [K][K][3]
   float* wconv;        // [K+1][wrow] row-pair packed rot180(psf): weights of A1 (correlation orientation)
   float* wcorr;        // [K+1][wrow] row-pair packed psf:         weights of A3
+  void* bt_conv;       // Toeplitz fragment tables of the matrix-core convolution (ics_common.h), or NULL
+  void* bt_corr;
   float* psf_caller;   // what the caller's array holds (correlation quirk, pyx:585)
   float* scal;         // ICS_SC_DTPSF recorded
   int* frozen;         // device flag: caller array detached (pyx:585 rebinding)

@@ -514,6 +514,41 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     }
     a.wcorr[i] = v1; a.wconv[i] = v2;
   }
+  // Compact Toeplitz weight tables of the matrix-core convolution (ics_conv_mfma.hip): every weight scaled by a
+  // power of two (max -> [2^14, 2^15)) and split into fp16 hi + lo.  Entry (c*K + a)*2 + s holds the kernel
+  // row zero-padded to Wp[idx] = W[a][idx - 15][c] twice: 48 halves from idx 0 and 48 halves from idx 1.
+  if (a.bt_conv && a.bt_corr) {
+    uint32_t km = 0u;
+    for (int i = tid; i < n; i += 256) { const uint32_t k1 = key_of(__builtin_fabsf(p[i])); km = km > k1 ? km : k1; }
+    km = wave_max_u32(km);
+    if ((tid & 63) == 0) atomicMax(&sred[2], km);
+    __syncthreads();
+    const float m = ics_key2f(sred[2]);
+    const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
+    uint32_t sb = 127u;
+    if (m > 0.f && e != 255u) { sb = 268u - e; sb = sb > 240u ? 240u : sb; }
+    const float s_w = __uint_as_float(sb << 23), inv_w = __uint_as_float((254u - sb) << 23);
+    _Float16* tc = reinterpret_cast<_Float16*>(a.bt_conv);
+    _Float16* tr = reinterpret_cast<_Float16*>(a.bt_corr);
+    const int nhalf = 3 * K * 2 * 96;
+    for (int i = tid; i < nhalf; i += 256) {
+      const int ent = i / 96, hh = i - ent * 96;
+      const int sp = ent & 1, ca = ent >> 1, c = ca / K, ra = ca - c * K;
+      const int b = (hh % 48) + (hh / 48) - 15;
+      float w1 = 0.f, w2 = 0.f;
+      if (b >= 0 && b < K) {
+        w1 = p[(ra * K + b) * 3 + c] * s_w;
+        w2 = p[((K - 1 - ra) * K + (K - 1 - b)) * 3 + c] * s_w;
+      }
+      const _Float16 h1 = (_Float16)w1, h2 = (_Float16)w2;
+      tr[i] = sp ? (_Float16)(w1 - (float)h1) : h1;
+      tc[i] = sp ? (_Float16)(w2 - (float)h2) : h2;
+    }
+    if (tid == 0) {
+      *reinterpret_cast<float*>(tc + nhalf) = inv_w;
+      *reinterpret_cast<float*>(tr + nhalf) = inv_w;
+    }
+  }
 }
 
 }  // namespace

@@ -1,0 +1,54 @@
+// bench_conv_mfma.hip -- stand-alone timing harness for the matrix-core convolution (ics_conv_mfma.hip) at
+// 4096^2 x 3, 15x15 PSF; built in variants (-DICS_MFMA_ABLATE=mask) to see which phase bounds the kernel.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I.. [-DICS_MFMA_ABLATE=m] bench_conv_mfma.hip -o bench_conv_mfma
+#include "../ics_conv_mfma.hip"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 4096, K = argc > 2 ? atoi(argv[2]) : 15;
+  IcsGeom g = ics_make_geom(M, M, K);
+  const size_t nf = ics_frame_floats(g), org = ics_origin_offset(g);
+  std::vector<float> h(nf);
+  srand(1);
+  for (size_t i = 0; i < nf; ++i) h[i] = (float)rand() / RAND_MAX;
+  float *in, *out, *f, *u, *ut; uint32_t* red; void* bt;
+  hipMalloc(&in, nf * 4); hipMalloc(&out, nf * 4); hipMalloc(&f, nf * 4); hipMalloc(&u, nf * 4); hipMalloc(&ut, nf * 4);
+  hipMalloc(&red, 1024); hipMemset(red, 0, 1024);
+  for (float* p : {in, f, u, ut}) hipMemcpy(p, h.data(), nf * 4, hipMemcpyHostToDevice);
+  hipMemset(out, 0, nf * 4);
+  const size_t tf = ics_conv_mfma_table_floats(K);
+  std::vector<_Float16> tab(tf * 2, (_Float16)0.f);
+  for (int c = 0; c < 3; ++c) for (int a = 0; a < K; ++a) for (int s = 0; s < 2; ++s) for (int hh = 0; hh < 96; ++hh) {
+    const int b = (hh % 48) + (hh / 48) - 15;
+    const float w = (b >= 0 && b < K) ? 16384.f / (K * K) * (1.f + 0.01f * a + 0.02f * b) : 0.f;
+    const _Float16 hi = (_Float16)w;
+    tab[(((size_t)c * K + a) * 2 + s) * 96 + hh] = s ? (_Float16)(w - (float)hi) : hi;
+  }
+  reinterpret_cast<float*>(tab.data())[tf - 4] = 1.f / 16384.f;
+  hipMalloc(&bt, tf * 4); hipMemcpy(bt, tab.data(), tf * 4, hipMemcpyHostToDevice);
+  IcsConvArgs a = {};
+  a.in = in + org; a.out = out + org; a.f = f + org; a.u = u + org; a.ut = ut + org; a.red = red; a.lambd = 1.f; a.bt = bt; a.g = g;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int mode = 0; mode < 2; ++mode) {
+    for (int i = 0; i < 3; ++i) if (ics_launch_conv_mfma(mode, a, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) ics_launch_conv_mfma(mode, a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("ablate=%d mode %d: %.4f ms\n", ICS_MFMA_ABLATE, mode, ms / 20);
+#ifdef ICS_MFMA_TIMING
+    {
+      unsigned long long h[11]; hipMemcpyFromSymbol(h, HIP_SYMBOL(ics_mfma_ticks), sizeof h);
+      const double tiles = (double)g.tiles_x * g.tiles_y * 4 * 23;   // wave-tiles over the 23 launches of this mode
+      const char* nm[10] = {"convert+sync", "mfma loop", "wait sync C", "epi operand issue", "wait sync D", "epilogue", "wait sync E", "prefetch issue", "transposes (LDS)", "-"};
+      double tot = 0; for (int i = 0; i < 10; ++i) tot += (double)h[i];
+      for (int i = 0; i < 9; ++i) printf("   %-18s %8.0f cycles / wave-tile  (%4.1f %%)\n", nm[i], h[i] / tiles, 100.0 * h[i] / tot);
+      printf("   total %.0f cycles / wave-tile, %llu waves\n", tot / tiles, h[10]);
+      unsigned long long z[11] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ics_mfma_ticks), z, sizeof z);
+    }
+#endif
+  }
+  return 0;
+}

@@ -24,6 +24,7 @@ ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0
 # stages / buffers
 STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM = range(1, 10)
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV = range(9)
+CONV_AUTO, CONV_VECTOR, CONV_MATRIX = range(3)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
                 "dof_min", "dof_max", "_")
 
@@ -32,7 +33,7 @@ class RLParams(C.Structure):
     _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
                 ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
                 ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
-                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("reserved", C.c_int * 2)]
+                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class RLStats(C.Structure):
@@ -238,12 +239,12 @@ class RLJob:
 
     @staticmethod
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
-               stop_test=1, profile=0, fuse=0, tv_mode=0):
+               stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0):
         p = RLParams()
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
         p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), int(tv_mode)
-        p.stop_test, p.profile, p.fuse = int(stop_test), int(profile), int(fuse)
+        p.stop_test, p.profile, p.fuse, p.conv = int(stop_test), int(profile), int(fuse), int(conv)
         return p
 
     def run(self, params):

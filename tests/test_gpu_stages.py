@@ -28,8 +28,14 @@ def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
     return job, case, psf
 
 
-@pytest.mark.parametrize("MK", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 39, 45, 55, 63])
-def test_synth_residual_and_backprojection_all_psf_sizes(MK):
+CONV_CASES = [(MK, 1) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 39, 45, 55, 63)] + \
+             [(MK, 2) for MK in (3, 5, 7, 9, 11, 13, 15, 17)]
+
+
+@pytest.mark.parametrize("MK,conv", CONV_CASES)
+def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
+    """conv = 1: packed-fp32 vector kernels (ics_conv.hip); conv = 2: matrix-core kernels with fp16-split
+    operands (ics_conv_mfma.hip, MK <= 17).  Same tolerance for both against float64 direct sums."""
     from lib import _native as nv
     M, N = 70 + MK, 131
     job, case, psf = make_job(M, N, MK, seed=MK)
@@ -38,7 +44,7 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK):
     u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
     job.write(nv.BUF_U, u)
     job.write(nv.BUF_UT, case["u0"])
-    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False)
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False, conv=conv)
     job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
     e = job.read(nv.BUF_ERROR)
     e_ref = conv_valid64(u, psf) - case["image"]
@@ -154,7 +160,7 @@ def test_fused_update_synth_equals_separate_kernels(M, N, MK, blind):
         u = (case["u0"] + 0.03 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
         job.write(nv.BUF_U, u)
         job.write(nv.BUF_UT, case["u0"])
-        p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=blind)
+        p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=blind, conv=nv.CONV_VECTOR)
         job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
         job.stage(nv.STAGE_BACKPROJECT, p)
         if fused:

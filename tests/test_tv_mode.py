@@ -145,7 +145,15 @@ def test_gpu_pam_run_matches_ext_oracle(M, N, MK, blind, kind):
         dc.richardson_lucy_MM(img, u, psf, *args, blind=blind, tv_mode=kind)
     eu, ep = rel_err(u, u_r), rel_err(psf, psf_r)
     print("tv_mode=%d %dx%d k%d blind=%d: rel err u=%.2e psf=%.2e" % (kind, M, N, MK, blind, eu, ep))
-    assert eu < 1e-5 and ep < 1e-5
+    assert ep < 1e-5
+    if kind == 3:
+        # the collaborative term takes the arg-max channel per pixel: a 1e-7 difference in the convolution (fp32
+        # chain in the oracle, fp16-split MFMA or packed fp32 on the device) can flip it at an isolated, almost
+        # flat pixel, which then differs by ~1e-4.  Gate the bulk at 1e-5 and the outliers by count and size.
+        d = np.abs(u - u_r) / np.abs(u_r).max()
+        assert np.mean(d > 1e-5) < 1e-3 and d.max() < 5e-3
+    else:
+        assert eu < 1e-5
     assert np.array_equal(img, case["image"])                           # PAM leaves the blurry image alone
     if blind:
         assert np.all(psf >= 0) and np.allclose(psf.sum(axis=(0, 1)), 1, atol=1e-5)
