@@ -97,6 +97,8 @@ def cpu_baseline(mode, MK, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--conv", choices=["auto", "vector", "matrix"], default="auto",
+                    help="convolution kernels: auto = matrix-core (fp16-split MFMA) for PSF <= 17, else packed-fp32 vector")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["blind", "nonblind"], default="blind")
@@ -119,6 +121,10 @@ def main():
     steps = ((args.steps + 4) // 5) * 5
     warm = ((args.warmup + 4) // 5) * 5
     blind = args.mode == "blind"
+    conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
+    if conv == 0 and os.environ.get("ICS_CONV_PATH", "")[:1] == "v":
+        conv = 1
+    matrix = conv != 1 and MK <= 17   # which kernels ICS_CONV_AUTO resolves to (include/ics_hip.h)
 
     ndev = max(1, _native.device_count())
     ctx = _native.Context.get(grp.local_rank % ndev)  # (% ndev only matters when ranks share a GPU in tests)
@@ -129,7 +135,7 @@ def main():
     win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)  # 255-px stats window as deconvolve.py:281 passes it
 
     def run(n_inner, profile):
-        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse), tv_mode=args.tv_mode)
+        p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse), tv_mode=args.tv_mode, conv=conv)
         return job.run(p)
 
     if warm:
@@ -152,8 +158,8 @@ def main():
     if grp.size == 1 and not args.no_other_mode:
         omode = "nonblind" if blind else "blind"
         job.upload(image, u0, psf_true if blind else psf_uniform)
-        po = job.params(*win, 1e9, steps // 5, 1e-3, 10000.0, not blind, 0, 3, stop_test=2, profile=0, fuse=int(args.fuse), tv_mode=args.tv_mode)
-        job.run(job.params(*win, 1e9, max(1, warm // 5), 1e-3, 10000.0, not blind, 0, 3, stop_test=2))
+        po = job.params(*win, 1e9, steps // 5, 1e-3, 10000.0, not blind, 0, 3, stop_test=2, profile=0, fuse=int(args.fuse), tv_mode=args.tv_mode, conv=conv)
+        job.run(job.params(*win, 1e9, max(1, warm // 5), 1e-3, 10000.0, not blind, 0, 3, stop_test=2, conv=conv))
         ctx.synchronize()
         t1 = time.perf_counter()
         job.run(po)
@@ -174,7 +180,7 @@ def main():
         try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/)
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
             if tj["workload"] == {"size": M, "psf": MK}:
-                traffic = tj["kernels"]
+                traffic = tj["kernels_matrix" if matrix and not args.fuse else "kernels_vector"]
         except (OSError, ValueError, KeyError):
             traffic = None
         if kern:
@@ -191,9 +197,12 @@ def main():
             "value": round(value, 1), "unit": "MPixels/s/iter", "n_gpus": grp.size, "steps": steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": ("frames, sums and every elementwise step in fp32; the two PSF convolutions run on the matrix cores with each "
+                           "fp32 operand split into two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation"
+                           if matrix and not args.fuse else "fp32 throughout (packed-fp32 vector convolutions)"),
             "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
                                    "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", M, N, MK, MK),
-                       "mode": args.mode, "tv_mode": args.tv_mode, "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size},
+                       "mode": args.mode, "tv_mode": args.tv_mode, "conv": "matrix" if matrix and not args.fuse else "vector", "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size},
             "hbm_roofline_iteration": {"algorithmic_bytes_per_px": ITER_BYTES_PER_PX[args.mode], "achieved_GBps": round(it_gbps, 1),
                                        "frac_of_8TBps": round(it_gbps / HBM_PEAK_GBPS, 4)},
             "kernels_ms": kern, "device_ms_total_rank0": round(st.ms_total, 3),

@@ -189,10 +189,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
 
   float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  bool nan_g[3] = {false, false, false}, nan_u[3] = {false, false, false}, any = false;
+  uint32_t rflags = 0u;   // bit c: NaN seen in g_c, bit 3+c: NaN seen in u_c, bit 6: any element reduced (one register)
 
   // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
+  // epilogue operands and output through buffer addressing as well (frame origins; offsets are >= 0 there)
+  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
   f32x4u raw[C::NIT][3];
   {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
       float s_x;
-      pow2_scale(m, s_x, inv_x);
+      pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);   // uniform: SGPRs
       const int tidc = opaque(tid);
 #pragma unroll
       for (int k = 0; k < C::NIT; ++k) {
@@ -276,11 +279,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // row images of this channel: one dword per lane per (a, hi/lo), built WPF steps ahead of their gather
         constexpr int WPF = 2;
         uint32_t wr[K][2];
+        // (re-hidden per tile and channel: the row images are tile-invariant and would otherwise be hoisted out of
+        //  the tile loop, 90 live registers that push the prefetched rows into scratch)
+        uint32_t wb0 = wa0, wb1 = wa1;
+        asm volatile("" : "+v"(wb0), "+v"(wb1));
         auto rowimg = [&](int ka) {
 #pragma unroll
           for (int sp = 0; sp < 2; ++sp) {
             const uint32_t ro = (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROW * 2);
-            wr[ka][sp] = (uint32_t)*reinterpret_cast<lds_u16p>(wa0 + ro) | ((uint32_t)*reinterpret_cast<lds_u16p>(wa1 + ro) << 16);
+            wr[ka][sp] = (uint32_t)*reinterpret_cast<lds_u16p>(wb0 + ro) | ((uint32_t)*reinterpret_cast<lds_u16p>(wb1 + ro) << 16);
           }
         };
 #pragma unroll
@@ -350,12 +357,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             o[(y * C::TW + x) * 3 + ch] = acc[ch][t][r] * sc;
           }
     }
+    __builtin_amdgcn_sched_barrier(0);   // the accumulators are dead before the epilogue operands are requested
     ICS_TICK(8);
     // ---- epilogue (same arithmetic as ics_conv.hip): a task = one row x 4 pixels, processed in batches of EB
     // tasks; the global operands of a batch are requested first (the first batch before the barrier, so that
     // their latency overlaps the transposes).  Mode 1 carries two operand frames: smaller batches.
     constexpr int EOPS = (MODE == 0) ? 1 : 2;
-    constexpr int EB = (MODE == 0) ? C::EIT : 2;
+    constexpr int EB = (MODE == 0) ? 2 : 1;
     static_assert(C::EIT % EB == 0, "epilogue batches");
     const float* ot = reinterpret_cast<const float*>(lds);
     const int tide = opaque(tid);
@@ -373,15 +381,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         else ok = ok && y < a.g.uM && xp < a.g.uN;
         evalid[k] = ok;
         if (ok) {
-          const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * xp;
-          if (MODE == 0) {
-            const float4* fp = reinterpret_cast<const float4*>(a.f + o);
-            eop[k][0][0] = fp[0]; eop[k][0][1] = fp[1]; eop[k][0][2] = fp[2];
-          } else {
-            const float4* up = reinterpret_cast<const float4*>(a.u + o);
-            const float4* tp = reinterpret_cast<const float4*>(a.ut + o);
-            eop[k][0][0] = up[0]; eop[k][0][1] = up[1]; eop[k][0][2] = up[2];
-            eop[k][EOPS - 1][0] = tp[0]; eop[k][EOPS - 1][1] = tp[1]; eop[k][EOPS - 1][2] = tp[2];
+          const int ob = 4 * (ty * pitch + 12 * tx);      // byte offset inside the tile; the tile origin is uniform
+          const int sb = 4 * (y0 * pitch + 3 * x0);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            eop[k][0][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f, ob + 16 * j, sb, 0));
+            if (MODE == 1) eop[k][EOPS - 1][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, ob + 16 * j, sb, 0));
           }
         }
       }
@@ -448,8 +453,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                   g = __fadd_rn(__fmul_rn(lambd, av[3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
                 mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
                 mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
-                nan_g[c] |= (g != g); nan_u[c] |= (uv[3*p+c] != uv[3*p+c]);
-                any = true;
+                rflags |= ((g != g) ? (1u << c) : 0u) | ((uv[3*p+c] != uv[3*p+c]) ? (8u << c) : 0u) | 64u;
               }
             }
           }
@@ -478,8 +482,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     uint32_t kg[3], ku[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      kg[c] = nan_g[c] ? 0xFFC00000u : (any ? ics_f2key(mg[c]) : 0u);   // NaN propagates like np.amax
-      ku[c] = nan_u[c] ? 0xFFC00000u : (any ? ics_f2key(mu[c]) : 0u);
+      kg[c] = (rflags & (1u << c)) ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(mg[c]) : 0u);   // NaN propagates like np.amax
+      ku[c] = (rflags & (8u << c)) ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(mu[c]) : 0u);
       kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]);
     }
     uint32_t* red_lds = reinterpret_cast<uint32_t*>(fscr);
