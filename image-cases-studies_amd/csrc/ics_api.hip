@@ -461,11 +461,12 @@ static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   return ICS_OK;
 }
 
-static int do_gradk(ics_rl* j, Prof& pr) {
+static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   IcsGradkArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
   RC(pr.begin(ICS_K_PSF_GRADIENT));
-  HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
+  if (use_matrix_conv(j, p) && ics_gradk_mfma_supported(j->g.K)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
+  else HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
   HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
   RC(pr.end());
   return ICS_OK;
@@ -560,7 +561,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       if (p->blind) {                                         // pyx:555
         if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
         else { RC(do_update(j, p, itt, last, pr)); RC(do_conv(j, 0, p, itt, 0, pr)); }
-        RC(do_gradk(j, pr));                                  // A12+A13
+        RC(do_gradk(j, p, pr));                               // A12+A13
         RC(do_psf(j, p, pr));                                 // A14-A17
       } else if (fuse && !last) {
         RC(do_conv(j, 2, p, itt, 0, pr));                     // A5-A10 fused with A1+A2 of itt+1
@@ -637,7 +638,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       RC(reset_dofkeys(j));
       RC(do_conv(j, 2, p, 0, 1, pr));
       break;
-    case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, pr)); break;
+    case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, p, pr)); break;
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
     case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;
     case ICS_STAGE_STATS:

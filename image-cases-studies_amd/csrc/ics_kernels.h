@@ -44,6 +44,9 @@ struct IcsGradkArgs {
 };
 int ics_gradk_blocks(const IcsGeom& g, int cus);  // grid size (persistent workgroups)
 hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s);
+// matrix-core variant for PSF sizes <= 15 (ics_gradk_mfma.hip): fp16-split operands, same partial layout
+bool ics_gradk_mfma_supported(int K);
+hipError_t ics_launch_gradk_mfma(const IcsGradkArgs& a, int nblocks, hipStream_t s);
 // gradk[a][b][c] = sum over workgroups (double accumulation, fixed order)
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s);
 
