@@ -1,5 +1,5 @@
 // ics_conv_mfma.hip -- the two PSF convolutions of one Richardson-Lucy inner iteration on the gfx950
-// matrix cores (PSF sizes 3..17).  Same contract as ics_conv.hip (modes 0 and 1):
+// matrix cores (PSF sizes 3..15).  Same contract as ics_conv.hip (modes 0 and 1):
 //
 //   mode 0 (A1+A2, lib/deconvolution.pyx:477-488):  error = convolve(u, psf, "valid") - image
 //   mode 1 (A3,    lib/deconvolution.pyx:490-491):  gradu = convolve(error, rot180(psf), "full")
@@ -18,7 +18,7 @@
 //
 // Formulation.  Along x the convolution is a banded Toeplitz product, one per kernel row a and channel c:
 //     out_a[y, 16cb + j] = sum_{k<32} in[y + a - pad, 16cb - pad + k] * B_a[k][j],   B_a[k][j] = W[a][k - j][c]
-// (zero outside 0 <= k-j < K; 16 + K - 1 <= 32 input columns per 16 output columns, hence K <= 17).
+// (zero outside 0 <= k-j < K; 16 + K - 1 <= 32 input columns per 16 output columns, hence K <= 17; built for K <= 15, where the weight rows still fit in LDS beside the planes).
 // The MFMA's M dimension runs over 16 image rows, and the rows of one fragment are taken 4 apart:
 //     fragment q, lane row i  <->  input row q + 4i (tile-relative)       q = 0 .. K+2
 // so that the product with B_a lands on output rows (q - a) + 4i: fragment q feeds the four accumulator
@@ -31,10 +31,10 @@
 //     gfx950, MI355X_MICROARCH.md LDS).  Two workgroups per CU: one's memory phases (conversion, epilogue)
 //     overlap the other's matrix phase.
 //   * wave w owns the 16-column block w of the tile for all three channels (12 accumulators).
-//   * Toeplitz fragments are never stored: the weights sit in LDS as compact rows (K halves + a zero per
-//     (c, a, hi/lo), 3 KB); per row every lane builds one dword of the zero-padded row image from two LDS
-//     halves and gathers its 8 consecutive halves with four ds_bpermute_b32.  (Full 1-KiB fragments from
-//     global memory made the kernel L1-bound; fragment-shaped LDS copies do not fit beside the planes.)
+//   * Toeplitz fragments are never stored: the weights sit in LDS as zero-padded rows (64 B per (c, a, hi/lo),
+//     5.6 KB at K = 15); a lane's 8 consecutive halves start at half 8g - j + 15 of the row: it reads the five
+//     dwords that contain them and funnel-shifts by the parity.  (Full 1-KiB fragments from global memory made
+//     the kernel L1-bound; a ds_bpermute gather from a row image cost ~5 LDS cycles per bpermute.)
 //   * the fp32 HWC rows of the NEXT tile are requested into registers (2 waves per SIMD -> 256 VGPRs) before
 //     the MFMA loop, which itself issues no vector-memory load (they return in order): HBM latency is covered
 //     by the matrix phase; conversion to the fp16 planes happens after the epilogue of the current tile.
@@ -72,17 +72,23 @@ struct MCfg {
   static constexpr int TH = 64, TW = 64, NCB = TW / 16;
   static constexpr int NW = 4, NT = 64 * NW;
   static constexpr int LROWS = TH + K - 1;       // input rows of the tile
-  static constexpr int RC = (LROWS + 3) / 4;     // LDS rows per (y mod 4) class
+  // LDS rows are grouped by (y mod 4): class c holds rows c, c+4, ... contiguously, classes back to back
+  static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
+  static constexpr int cls_base(int c) { return c == 0 ? 0 : cls_base(c - 1) + cls_rows(c - 1); }
   static constexpr int LCOLS = TW + 16;          // staged columns: [x0 - PAD, x0 - PAD + 80)
   static constexpr int ROWB = 2 * LCOLS;         // 160 bytes per LDS row: conflict-free for the fragment reads
-  static constexpr int PLANE = 4 * RC * ROWB;    // bytes per (channel, hi/lo) plane
+  static constexpr int PLANE = LROWS * ROWB;     // bytes per (channel, hi/lo) plane
   static constexpr int DATA = 6 * PLANE;
   static constexpr int OUTB = TH * TW * 3 * 4;   // fp32 HWC transpose buffer (aliases the planes)
-  static constexpr int BENT = 192;               // bytes per (c, a, hi/lo) entry of the compact weight table
+  static constexpr int BENT = 192;               // bytes per (c, a, hi/lo) entry of the global weight table
   static constexpr int BTAB = 3 * K * 2 * BENT;
   static constexpr int SCRATCH = DATA > OUTB ? DATA : OUTB;
-  static constexpr int WROW = K + 1;             // halves per compact weight row in LDS: K weights + one zero
-  static constexpr int WLDS = 3 * K * 2 * WROW * 2;
+  // weight rows in LDS: halves 8 .. K+24 of the zero-padded row Wp[idx] = W[idx - 15] (the taps sit at local
+  // halves 7 .. K+6, at least ten zeros follow): every 8-half window that meets a tap lies inside, and the
+  // all-zero windows are redirected to the zero tail
+  static constexpr int WROWB = (2 * (K + 17) + 3) & ~3;
+  static constexpr int WZERO = (K + 7) / 2;      // first all-zero dword of a row
+  static constexpr int WLDS = 3 * K * 2 * WROWB;
   static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
   static constexpr int NQ = K + 3;               // fragments per (channel, column block)
   static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
@@ -163,29 +169,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::BTAB);
 
-  // compact weight rows -> LDS once per workgroup: row (c, a, hi/lo) = K halves + a zero (global table entry:
-  // padded row Wp[idx] = W[idx - 15], halves 15 .. 15+K-1 of the first copy)
-  uint16_t* ldsW = reinterpret_cast<uint16_t*>(lds + C::SCRATCH + 256);
+  // weight rows -> LDS once per workgroup (global table entry: padded row Wp[0..47], then the shifted copy)
   {
+    uint16_t* ldsW = reinterpret_cast<uint16_t*>(lds + C::SCRATCH + 256);
     const uint16_t* tab = reinterpret_cast<const uint16_t*>(a.bt);
+    constexpr int RH = C::WROWB / 2;
     for (int i = tid; i < C::WLDS / 2; i += C::NT) {
-      const int e = i / C::WROW, b = i - e * C::WROW;
-      ldsW[i] = b < K ? tab[e * 96 + 15 + b] : (uint16_t)0;
+      const int e = i / RH, h = i - e * RH;
+      ldsW[i] = (h < K + 7) ? tab[e * 96 + 8 + h] : (uint16_t)0;
     }
   }
-  // lane constants.  The "row image" of a weight row is 64 dwords: dword l < 32 = halves (2l, 2l+1) of the
-  // padded row, dword 32 + l = halves (2l+1, 2l+2); every lane builds its image dword from two LDS halves
-  // (out-of-range taps read the row's zero) and gathers its fragment = 4 consecutive image dwords starting at
-  // dword bo >> 1 of copy bo & 1 with ds_bpermute, bo = 8*lg - li + 15 being the first half of its slice.
+  // lane constants of the B operand: this lane's 8 consecutive halves start at half bo = 8*lg - li + 15 of the
+  // padded row; it reads the five dwords that contain them and funnel-shifts by the parity (v_alignbit).
+  // (Gathering them from a row image with ds_bpermute cost ~5 LDS cycles per bpermute, 8 per fragment pair.)
   const int bo = 8 * lg - li + 15;
-  const int bsel = 4 * ((bo & 1) * 32 + (bo >> 1));                                  // ds_bpermute byte index
-  const int ib0 = 2 * (lane & 31) + (lane >> 5) - 15, ib1 = ib0 + 1;                 // taps of this lane's image dword
-  const int wo0 = (ib0 >= 0 && ib0 < K) ? ib0 : K, wo1 = (ib1 >= 0 && ib1 < K) ? ib1 : K;
-  // LDS byte addresses of the two halves in row 0; opaque to the optimiser so that the per-row constants stay in
-  // the 16-bit offset field of ds_read_u16 (folded with the 75 KB base they exceed it: one address VGPR per row)
-  typedef const __attribute__((address_space(3))) uint16_t* lds_u16p;
-  uint32_t wa0 = (uint32_t)(uintptr_t)(lds_u16p)(ldsW + wo0), wa1 = (uint32_t)(uintptr_t)(lds_u16p)(ldsW + wo1);
-  asm volatile("" : "+v"(wa0), "+v"(wa1));
+  const bool bzero = bo < 8 || bo > K + 14;                         // window entirely in the zero padding
+  const uint32_t bsh = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
+  // LDS byte address of the first dword in row 0; opaque to the optimiser so that the per-row constants stay in
+  // the 16-bit offset field of the ds_read (folded with the 75 KB base they exceed it: one address VGPR per row)
+  typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
+  uint32_t wa0 = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 4u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+  asm volatile("" : "+v"(wa0));
   const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
 
   float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -232,7 +236,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int t = tidc + k * C::NT;
         if (t < C::NTASK && !((ICS_MFMA_ABLATE & 2) && k > 0)) {
           const int row = t / C::XG, xg = t - row * C::XG;
-          unsigned char* dst = lds + ((row & 3) * C::RC + (row >> 2)) * C::ROWB + 8 * xg;
+          const int rc = row & 3;
+          const int crow = (rc == 0 ? 0 : (rc == 1 ? C::cls_base(1) : (rc == 2 ? C::cls_base(2) : C::cls_base(3)))) + (row >> 2);
+          unsigned char* dst = lds + crow * C::ROWB + 8 * xg;
           float f[12];
 #pragma unroll
           for (int h = 0; h < 3; ++h)
@@ -276,45 +282,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (x0 + 16 * wv < a.g.uN) {   // wave-uniform: a column block right of the frame carries no output
 #pragma unroll
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
-        // row images of this channel: one dword per lane per (a, hi/lo), built WPF steps ahead of their gather
-        constexpr int WPF = 2;
-        uint32_t wr[K][2];
-        // (re-hidden per tile and channel: the row images are tile-invariant and would otherwise be hoisted out of
-        //  the tile loop, 90 live registers that push the prefetched rows into scratch)
-        uint32_t wb0 = wa0, wb1 = wa1;
-        asm volatile("" : "+v"(wb0), "+v"(wb1));
-        auto rowimg = [&](int ka) {
-#pragma unroll
-          for (int sp = 0; sp < 2; ++sp) {
-            const uint32_t ro = (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROW * 2);
-            wr[ka][sp] = (uint32_t)*reinterpret_cast<lds_u16p>(wb0 + ro) | ((uint32_t)*reinterpret_cast<lds_u16p>(wb1 + ro) << 16);
-          }
-        };
-#pragma unroll
-        for (int ka = 0; ka < WPF && ka < K; ++ka) rowimg(ka);
+        // (re-hidden per tile and channel: the weight reads are tile-invariant and would otherwise be hoisted out
+        //  of the tile loop, hundreds of live registers)
+        uint32_t wb0 = wa0;
+        asm volatile("" : "+v"(wb0));
         const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
         const unsigned char* pl = ph + C::PLANE;
         h8 Bh[K], Bl[K];
-        // software pipeline: the operands of step q + 1 (A fragment from the planes, B fragment gathered from the
-        // weight row) are requested before the MFMAs of step q
+        // software pipeline: the operands of step q + 1 (A fragment from the planes, B fragment from the weight
+        // rows) are requested before the MFMAs of step q
         auto gatherB = [&](int ka) {
-          u4 t0, t1;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            if (ICS_MFMA_ABLATE & 8) { t0[d] = wr[ka][0] + d; t1[d] = wr[ka][1] + d; continue; }   // timing probe only
-            t0[d] = (uint32_t)__builtin_amdgcn_ds_bpermute(bsel + 4 * d, (int)wr[ka][0]);
-            t1[d] = (uint32_t)__builtin_amdgcn_ds_bpermute(bsel + 4 * d, (int)wr[ka][1]);
+          for (int sp = 0; sp < 2; ++sp) {
+            const lds_u32p r = reinterpret_cast<lds_u32p>(wb0 + (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROWB));
+            const uint32_t d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4];
+            u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh), __builtin_amdgcn_alignbit(d2, d1, bsh),
+                    __builtin_amdgcn_alignbit(d3, d2, bsh), __builtin_amdgcn_alignbit(d4, d3, bsh)};
+            (sp ? Bl[ka] : Bh[ka]) = __builtin_bit_cast(h8, w);
           }
-          Bh[ka] = __builtin_bit_cast(h8, t0); Bl[ka] = __builtin_bit_cast(h8, t1);
         };
         gatherB(0);
         h8 Ah = *reinterpret_cast<const h8*>(ph), Al = *reinterpret_cast<const h8*>(pl);
 #pragma unroll
         for (int q = 0; q < C::NQ; ++q) {
-          if (q + WPF < K) rowimg(q + WPF);
           h8 Nh = Ah, Nl = Al;
           if (q + 1 < C::NQ) {
-            const int off = (((q + 1) & 3) * C::RC + ((q + 1) >> 2)) * C::ROWB;
+            const int off = (C::cls_base((q + 1) & 3) + ((q + 1) >> 2)) * C::ROWB;
             if (!(ICS_MFMA_ABLATE & 16)) {   // 16: timing probe without the A-fragment reads
               Nh = *reinterpret_cast<const h8*>(ph + off);
               Nl = *reinterpret_cast<const h8*>(pl + off);
@@ -534,7 +527,7 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 17 && (K & 1); }
+bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 15 && (K & 1); }   // K = 17: no LDS room for its weight rows
 
 // compact Toeplitz weight table: [c][a][hi/lo] x 192 bytes, then one float 1/s_w (ics_common.h)
 size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * 48 + 4; }
@@ -549,7 +542,6 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 11: return launch_k<11>(mode, a, s);
     case 13: return launch_k<13>(mode, a, s);
     case 15: return launch_k<15>(mode, a, s);
-    case 17: return launch_k<17>(mode, a, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -83,15 +83,15 @@ typedef struct ics_rl_params {
                                    measured SLOWER on MI355X at 4096^2/15x15 (0.67 ms vs 0.28 + 0.19 ms),
                                    the 1.8x halo recompute with two IEEE divisions per element outweighs
                                    the saved frame pass                            */
-  int conv;                     /* ICS_CONV_*: which convolution kernels run A1/A3 (default ICS_CONV_AUTO)        */
+  int conv;                     /* ICS_CONV_*: which kernels run the convolutions A1/A3 and the PSF gradient A13    */
   int reserved[1];
 } ics_rl_params;
 
-#define ICS_CONV_AUTO 0   /* matrix-core kernels for MK <= 17, vector kernels above (env ICS_CONV_PATH=vector|matrix
+#define ICS_CONV_AUTO 0   /* matrix-core kernels for MK <= 15, vector kernels above (env ICS_CONV_PATH=vector|matrix
                              overrides the choice of AUTO)                                                */
-#define ICS_CONV_VECTOR 1 /* packed-fp32 VALU kernels (ics_conv.hip): every product and sum in fp32           */
-#define ICS_CONV_MATRIX 2 /* MFMA kernels (ics_conv_mfma.hip), MK <= 17: operands split into two fp16 terms
-                             (22 significand bits), three fp16 MFMAs with fp32 accumulation per product      */
+#define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip) + fp32-MFMA PSF gradient: fp32 products */
+#define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip, ics_gradk_mfma.hip), MK <= 15: operands split
+                             into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
 
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
 #define ICS_TV_MM_ACTIVE 1 /* BUILD-DEFINED extension, parity unpinned: the if-branches :517/:543 made
