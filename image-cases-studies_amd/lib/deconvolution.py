@@ -67,13 +67,16 @@ def normalize_kernel(kern, MK):
 
 
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
-                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0):
+                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0, conv=0):
     """Richardson-Lucy blind / non-blind deconvolution by majorisation-minimisation
     (lib/deconvolution.pyx:341-675), executed on the GPU.  See the module docstring.
 
     `tv_mode` (keyword-only, not in the reference): 0 = the shipped behaviour (TV term dead); 1 = the
     build-defined active MM-TV mode (include/ics_hip.h ICS_TV_MM_ACTIVE, oracle/rl_ext_oracle.py; parity
-    unpinned), in which `image` is also updated in place as pyx:549 intends."""
+    unpinned), in which `image` is also updated in place as pyx:549 intends.
+
+    `conv` (keyword-only, not in the reference): include/ics_hip.h ICS_CONV_*: 0 = auto (matrix-core kernels with
+    fp16-split operands for MK <= 15), 1 = fp32 products everywhere, 2 = force the matrix-core kernels."""
     _check_buffer("image", image)
     _check_buffer("u", u)
     _check_buffer("psf", psf)
@@ -87,7 +90,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     job = _get_job(M, N, MK)
     job.upload(image, u, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
-                        tv_mode=tv_mode)
+                        tv_mode=tv_mode, conv=conv)
     st = job.run(params)
     u_new, _psf_local, psf_caller = job.download()
     u[...] = u_new                                                             # in place, any strides

@@ -28,7 +28,7 @@ CASES = ["nb_33x37_k3", "nb_65x65_k7", "nb_65x81_k9_pcpsf", "nb_129x129_k15", "n
          "bl_65x49_k9", "bl_129x129_k15", "bl_65x65_k7_corr", "bl_101x101_k11_s1e-4"]
 
 
-def run_gpu(z, meta, iters, u_start=None, psf_start=None, strided=False):
+def run_gpu(z, meta, iters, u_start=None, psf_start=None, strided=False, conv=0):
     from lib import deconvolution as dc
     image = z["image"].copy()
     u = (z["u0"] if u_start is None else u_start).copy()
@@ -40,7 +40,7 @@ def run_gpu(z, meta, iters, u_start=None, psf_start=None, strided=False):
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         out = dc.richardson_lucy_MM(image, u, psf, *meta["window"], meta["tau"], M, N, 3, MK, iters, meta["step"], meta["lambd"],
-                                    blind=meta["blind"], correlation=meta["corr"])
+                                    blind=meta["blind"], correlation=meta["corr"], conv=conv)
     assert np.shares_memory(out, u) and out.shape == (M, N, 3)
     return np.ascontiguousarray(u), psf, buf.getvalue(), dc.richardson_lucy_MM.last
 
@@ -65,12 +65,13 @@ def fragile_decisions(z, blind, tau):
     return out
 
 
+@pytest.mark.parametrize("conv", [0, 1], ids=["auto", "fp32"])   # 0: matrix-core kernels (MK <= 15), 1: fp32 products
 @pytest.mark.parametrize("name", CASES)
-def test_trajectory_matches_reference_golden(golden_dir, name):
+def test_trajectory_matches_reference_golden(golden_dir, name, conv):
     z, meta = load_golden(golden_dir, name)
     fragile = fragile_decisions(z, meta["blind"], meta["tau"])
     for n in meta["snaps"]:
-        u, psf, log, st = run_gpu(z, meta, n)
+        u, psf, log, st = run_gpu(z, meta, n, conv=conv)
         eu = rel_err(u, z["u_%d" % n])
         ep = rel_err(psf, z["psf_%d" % n])
         (tu, lim_u), (tp, lim_p) = gate(meta, n, 0), gate(meta, n, 1)
