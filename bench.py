@@ -98,7 +98,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--conv", choices=["auto", "vector", "matrix"], default="auto",
-                    help="convolution kernels: auto = matrix-core (fp16-split MFMA) for PSF <= 15, else packed-fp32 vector")
+                    help="convolution kernels: auto = matrix-core (fp16-split MFMA) where built and faster (PSF <= 17, 23..37), else packed-fp32 vector")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["blind", "nonblind"], default="blind")
@@ -124,7 +124,8 @@ def main():
     conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
     if conv == 0 and os.environ.get("ICS_CONV_PATH", "")[:1] == "v":
         conv = 1
-    matrix = conv != 1 and MK <= 15   # which kernels ICS_CONV_AUTO resolves to (include/ics_hip.h)
+    # which convolution kernels the run resolves to (include/ics_hip.h ICS_CONV_*, csrc ics_conv_mfma_preferred)
+    matrix = (conv == 2 and MK <= 37) or (conv == 0 and (MK <= 17 or 23 <= MK <= 37))
 
     ndev = max(1, _native.device_count())
     ctx = _native.Context.get(grp.local_rank % ndev)  # (% ndev only matters when ranks share a GPU in tests)

@@ -50,7 +50,7 @@ struct ics_rl {
   float *u, *u2, *ut, *gr, *f, *e;     // frame bases (origin = base + origin); u2 = ping-pong partner of u
   float* tvf;                           // TV term frame (tv_mode 1, allocated on first use)
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
-  float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 15), else NULL
+  float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
   uint32_t* dofkeys;                    // 4 words
@@ -398,13 +398,14 @@ struct Prof {
 
 #define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
 
-// ICS_CONV_AUTO: matrix-core kernels where they exist (MK <= 15); env ICS_CONV_PATH=vector|matrix overrides AUTO
+// ICS_CONV_AUTO: matrix-core kernels where they exist and win (ics_conv_mfma_preferred); env ICS_CONV_PATH=vector|matrix
+// overrides AUTO
 static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
   if (!j->bt_conv) return false;
   if (p->conv == ICS_CONV_VECTOR) return false;
   if (p->conv == ICS_CONV_MATRIX) return true;
   static const int env = [] { const char* e = getenv("ICS_CONV_PATH"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
-  return env != 1;
+  return env == 2 || (env == 0 && ics_conv_mfma_preferred(j->g.K));
 }
 
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
@@ -511,7 +512,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
-  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 15");
+  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 37");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;

@@ -112,10 +112,11 @@ struct IcsConvArgs {
 // mode 2 = A5/A6/A8/A10 (update, recomputed on the halo) + A1+A2 on the updated u
 hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_supported(int K);
-// Matrix-core variant (ics_conv_mfma.hip): modes 0 and 1, odd K <= 15, operands split into two fp16 terms.
-// Weight table (built by k_psf): entry (c*K + a)*2 + s (s = 0 hi, 1 lo) = 96 halves: the scaled kernel row
-// zero-padded to Wp[idx] = s_w * W[a][idx - 15][c], stored as Wp[0..47] followed by Wp[1..48]; one float
-// 1/s_w behind the last entry.
+// Matrix-core variant (ics_conv_mfma.hip): modes 0 and 1, odd K <= 37, operands split into two fp16 terms.
+// Weight table (built by k_psf, = the kernel's LDS image): row (c*K + a)*2 + s (s = 0 hi, 1 lo) of
+// WROWB = round4(2*(K+17)) bytes holds halves 8.. of the scaled zero-padded kernel row Wp[idx] = s_w * W[a][idx - 15][c]
+// (taps at local halves 7 .. K+6); one float 1/s_w behind the last row.
 hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_mfma_supported(int K);
+bool ics_conv_mfma_preferred(int K);   // what ICS_CONV_AUTO picks
 size_t ics_conv_mfma_table_floats(int K);

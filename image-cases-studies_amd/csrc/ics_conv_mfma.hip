@@ -75,29 +75,30 @@ struct MCfg {
   // LDS rows are grouped by (y mod 4): class c holds rows c, c+4, ... contiguously, classes back to back
   static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
   static constexpr int cls_base(int c) { return c == 0 ? 0 : cls_base(c - 1) + cls_rows(c - 1); }
-  static constexpr int LCOLS = TW + 16;          // staged columns: [x0 - PAD, x0 - PAD + 80)
-  static constexpr int ROWB = 2 * LCOLS;         // 160 bytes per LDS row: conflict-free for the fragment reads
+  // 16 output columns need 16 + K - 1 input columns: one 32-wide MFMA window (NCH = 1, K <= 17) or two (K <= 49)
+  static constexpr int NCH = (16 + K - 1 <= 32) ? 1 : 2;
+  static constexpr int LCOLS = TW + 32 * NCH - 16;   // staged columns: [x0 - PAD, x0 - PAD + 80 / 112)
+  static constexpr int ROWB = 2 * LCOLS;             // 160 / 224 bytes per LDS row: conflict-free for the fragment reads
   static constexpr int PLANE = LROWS * ROWB;     // bytes per (channel, hi/lo) plane
   static constexpr int DATA = 6 * PLANE;
   static constexpr int OUTB = TH * TW * 3 * 4;   // fp32 HWC transpose buffer (aliases the planes)
-  static constexpr int BENT = 192;               // bytes per (c, a, hi/lo) entry of the global weight table
-  static constexpr int BTAB = 3 * K * 2 * BENT;
   static constexpr int SCRATCH = DATA > OUTB ? DATA : OUTB;
   // weight rows in LDS: halves 8 .. K+24 of the zero-padded row Wp[idx] = W[idx - 15] (the taps sit at local
   // halves 7 .. K+6, at least ten zeros follow): every 8-half window that meets a tap lies inside, and the
   // all-zero windows are redirected to the zero tail
   static constexpr int WROWB = (2 * (K + 17) + 3) & ~3;
   static constexpr int WZERO = (K + 7) / 2;      // first all-zero dword of a row
-  static constexpr int WLDS = 3 * K * 2 * WROWB;
+  static constexpr int WLDS = 3 * K * 2 * WROWB; // = the global weight table built by k_psf (ics_common.h), copied verbatim
   static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
+  static constexpr int WGS = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;   // workgroups (of 4 waves) per CU
   static constexpr int NQ = K + 3;               // fragments per (channel, column block)
   static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
   static constexpr int NTASK = LROWS * XG;
   static constexpr int NIT = (NTASK + NT - 1) / NT;
   static constexpr int ETASK = TH * (TW / 4);    // epilogue tasks: one row x 4 pixels
   static constexpr int EIT = (ETASK + NT - 1) / NT;
-  static_assert(16 + K - 1 <= 32, "one 32-wide MFMA window per 16 output columns");
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert(16 + K - 1 <= 32 * NCH, "MFMA windows cover the taps of 16 output columns");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -147,7 +148,7 @@ __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 template <int K, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_conv_mfma(IcsConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WGS, MCfg<K>::WGS))) void k_conv_mfma(IcsConvArgs a) {
   using C = MCfg<K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* fscr = reinterpret_cast<float*>(lds + C::SCRATCH);
@@ -167,29 +168,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int tile = band0 + kx;
   if (tile >= band1) return;
 
-  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::BTAB);
+  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
-  // weight rows -> LDS once per workgroup (global table entry: padded row Wp[0..47], then the shifted copy)
+  // weight rows -> LDS once per workgroup (the global table is the LDS image)
   {
-    uint16_t* ldsW = reinterpret_cast<uint16_t*>(lds + C::SCRATCH + 256);
-    const uint16_t* tab = reinterpret_cast<const uint16_t*>(a.bt);
-    constexpr int RH = C::WROWB / 2;
-    for (int i = tid; i < C::WLDS / 2; i += C::NT) {
-      const int e = i / RH, h = i - e * RH;
-      ldsW[i] = (h < K + 7) ? tab[e * 96 + 8 + h] : (uint16_t)0;
-    }
+    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::SCRATCH + 256);
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
+    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
   }
-  // lane constants of the B operand: this lane's 8 consecutive halves start at half bo = 8*lg - li + 15 of the
-  // padded row; it reads the five dwords that contain them and funnel-shifts by the parity (v_alignbit).
-  // (Gathering them from a row image with ds_bpermute cost ~5 LDS cycles per bpermute, 8 per fragment pair.)
-  const int bo = 8 * lg - li + 15;
-  const bool bzero = bo < 8 || bo > K + 14;                         // window entirely in the zero padding
-  const uint32_t bsh = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
-  // LDS byte address of the first dword in row 0; opaque to the optimiser so that the per-row constants stay in
-  // the 16-bit offset field of the ds_read (folded with the 75 KB base they exceed it: one address VGPR per row)
+  // lane constants of the B operand: in window h this lane's 8 consecutive halves start at half
+  // bo = 32h + 8*lg - li + 15 of the zero-padded row; it reads the five dwords that contain them and funnel-shifts
+  // by the parity (v_alignbit).  (Gathering them from a row image with ds_bpermute cost ~5 LDS cycles per bpermute.)
+  // wa0 = LDS byte address of the first dword in row 0; opaque to the optimiser so that the per-row constants stay in
+  // the 16-bit offset field of the ds_read (folded with the plane base they exceed it: one address VGPR per row)
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
-  uint32_t wa0 = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 4u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
-  asm volatile("" : "+v"(wa0));
+  uint32_t wa0[C::NCH], bsh[C::NCH];
+#pragma unroll
+  for (int h = 0; h < C::NCH; ++h) {
+    const int bo = 32 * h + 8 * lg - li + 15;
+    const bool bzero = bo < 8 || bo > K + 14;                       // window entirely in the zero padding
+    bsh[h] = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
+    wa0[h] = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 4u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+    asm volatile("" : "+v"(wa0[h]));
+  }
   const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
 
   float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
@@ -284,50 +285,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
         // (re-hidden per tile and channel: the weight reads are tile-invariant and would otherwise be hoisted out
         //  of the tile loop, hundreds of live registers)
-        uint32_t wb0 = wa0;
-        asm volatile("" : "+v"(wb0));
+        uint32_t wb[C::NCH];
+#pragma unroll
+        for (int h = 0; h < C::NCH; ++h) { wb[h] = wa0[h]; asm volatile("" : "+v"(wb[h])); }
         const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
         const unsigned char* pl = ph + C::PLANE;
-        h8 Bh[K], Bl[K];
-        // software pipeline: the operands of step q + 1 (A fragment from the planes, B fragment from the weight
+        h8 Bh[K][C::NCH], Bl[K][C::NCH];
+        // software pipeline: the operands of step q + 1 (A fragments from the planes, B fragments from the weight
         // rows) are requested before the MFMAs of step q
         auto gatherB = [&](int ka) {
 #pragma unroll
-          for (int sp = 0; sp < 2; ++sp) {
-            const lds_u32p r = reinterpret_cast<lds_u32p>(wb0 + (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROWB));
-            const uint32_t d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4];
-            u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh), __builtin_amdgcn_alignbit(d2, d1, bsh),
-                    __builtin_amdgcn_alignbit(d3, d2, bsh), __builtin_amdgcn_alignbit(d4, d3, bsh)};
-            (sp ? Bl[ka] : Bh[ka]) = __builtin_bit_cast(h8, w);
-          }
+          for (int h = 0; h < C::NCH; ++h)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              const lds_u32p r = reinterpret_cast<lds_u32p>(wb[h] + (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROWB));
+              const uint32_t d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4];
+              u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh[h]), __builtin_amdgcn_alignbit(d2, d1, bsh[h]),
+                      __builtin_amdgcn_alignbit(d3, d2, bsh[h]), __builtin_amdgcn_alignbit(d4, d3, bsh[h])};
+              (sp ? Bl[ka][h] : Bh[ka][h]) = __builtin_bit_cast(h8, w);
+            }
         };
         gatherB(0);
-        h8 Ah = *reinterpret_cast<const h8*>(ph), Al = *reinterpret_cast<const h8*>(pl);
+        h8 Ah[C::NCH], Al[C::NCH];
+#pragma unroll
+        for (int h = 0; h < C::NCH; ++h) { Ah[h] = *reinterpret_cast<const h8*>(ph + 64 * h); Al[h] = *reinterpret_cast<const h8*>(pl + 64 * h); }
 #pragma unroll
         for (int q = 0; q < C::NQ; ++q) {
-          h8 Nh = Ah, Nl = Al;
+          h8 Nh[C::NCH], Nl[C::NCH];
+#pragma unroll
+          for (int h = 0; h < C::NCH; ++h) { Nh[h] = Ah[h]; Nl[h] = Al[h]; }
           if (q + 1 < C::NQ) {
             const int off = (C::cls_base((q + 1) & 3) + ((q + 1) >> 2)) * C::ROWB;
             if (!(ICS_MFMA_ABLATE & 16)) {   // 16: timing probe without the A-fragment reads
-              Nh = *reinterpret_cast<const h8*>(ph + off);
-              Nl = *reinterpret_cast<const h8*>(pl + off);
+#pragma unroll
+              for (int h = 0; h < C::NCH; ++h) {
+                Nh[h] = *reinterpret_cast<const h8*>(ph + off + 64 * h);
+                Nl[h] = *reinterpret_cast<const h8*>(pl + off + 64 * h);
+              }
             }
           }
           if (q + 1 < K) gatherB(q + 1);
           __builtin_amdgcn_sched_barrier(0);   // ...and all of them are in flight before the step's MFMAs start
-          // three split terms; within a term the (up to) 4 accumulators are independent
+          // three split terms x windows; the (up to) 4 accumulators of a pass are independent
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int ka = q - t;
-              if (ka < 0 || ka >= K) continue;
-              const h8 av = term == 2 ? Al : Ah;
-              const h8 bv = term == 1 ? Bl[ka] : Bh[ka];
-              acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[ch][t], 0, 0, 0);
+            for (int h = 0; h < C::NCH; ++h) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const int ka = q - t;
+                if (ka < 0 || ka >= K) continue;
+                const h8 av = term == 2 ? Al[h] : Ah[h];
+                const h8 bv = term == 1 ? Bl[ka][h] : Bh[ka][h];
+                acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[ch][t], 0, 0, 0);
+              }
             }
           }
-          Ah = Nh; Al = Nl;
+#pragma unroll
+          for (int h = 0; h < C::NCH; ++h) { Ah[h] = Nh[h]; Al[h] = Nl[h]; }
           __builtin_amdgcn_sched_barrier(0);   // keep each step's prefetches in that step (register pressure)
         }
       }
@@ -514,7 +529,7 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
     cus[dev] = n;
   }
   const int ntiles = a.g.tiles_x * a.g.tiles_y;
-  int grid = 2 * cus[dev];                   // two persistent workgroups per CU (LDS: 2 x 75 KB)
+  int grid = C::WGS * cus[dev];              // persistent workgroups: as many as fit the LDS of a CU
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();
@@ -527,10 +542,14 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 15 && (K & 1); }   // K = 17: no LDS room for its weight rows
+bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   // K = 39: planes + weights exceed 160 KB
 
-// compact Toeplitz weight table: [c][a][hi/lo] x 192 bytes, then one float 1/s_w (ics_common.h)
-size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * 48 + 4; }
+// Measured on MI355X at 4096^2: with two 32-wide windows per column block (K >= 19) only K/64 of the MACs
+// are useful and the 126 KB of planes leave room for one workgroup per CU; the packed-fp32 kernels win at K = 19, 21.
+bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K) && K != 19 && K != 21; }
+
+// weight table: [c][a][hi/lo] rows of WROWB bytes (the LDS image), then one float 1/s_w (ics_common.h)
+size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * (((2 * (K + 17) + 3) & ~3) / 4) + 4; }
 
 hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
   if ((mode != 0 && mode != 1) || !a.bt) return hipErrorInvalidValue;
@@ -542,6 +561,17 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 11: return launch_k<11>(mode, a, s);
     case 13: return launch_k<13>(mode, a, s);
     case 15: return launch_k<15>(mode, a, s);
+    case 17: return launch_k<17>(mode, a, s);
+    case 19: return launch_k<19>(mode, a, s);
+    case 21: return launch_k<21>(mode, a, s);
+    case 23: return launch_k<23>(mode, a, s);
+    case 25: return launch_k<25>(mode, a, s);
+    case 27: return launch_k<27>(mode, a, s);
+    case 29: return launch_k<29>(mode, a, s);
+    case 31: return launch_k<31>(mode, a, s);
+    case 33: return launch_k<33>(mode, a, s);
+    case 35: return launch_k<35>(mode, a, s);
+    case 37: return launch_k<37>(mode, a, s);
     default: return hipErrorInvalidValue;
   }
 }

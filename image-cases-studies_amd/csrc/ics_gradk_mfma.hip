@@ -27,20 +27,24 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+template <int NB>
 struct GCfg {
-  static constexpr int TH = 32, TW = 64, NT = 16;    // tile: residual rows x U columns; taps per axis (padded)
+  static constexpr int TW = 64, NT = 16 * NB;        // U columns per tile; taps per axis (padded to 16 NB)
+  static constexpr int TH = NB == 1 ? 32 : 16;       // residual rows per tile
   static constexpr int NW = 4, NTH = 64 * NW;
   static constexpr int UROWS = TH + NT - 1;          // 47
-  static constexpr int ECOLS = TW + 16;              // E columns [x0 - 8, x0 + 72)
-  static constexpr int ROWB = 160;                   // bytes per LDS row (both operands)
-  static constexpr int UPLANE = UROWS * ROWB, EPLANE = TH * ROWB;
+  static constexpr int ECOLS = TW + 16 * NB;         // E columns [x0 - 8 NB, x0 + 64 + 8 NB)
+  static constexpr int UROWB = 160;                  // bytes per LDS row of U: conflict-free for the 16 descending lane rows
+  static constexpr int EROWB = 2 * ECOLS;
+  static constexpr int UPLANE = UROWS * UROWB, EPLANE = TH * EROWB;
   static constexpr int UOFF = 0, EOFF = 6 * UPLANE;
-  static constexpr int DATA = 6 * UPLANE + 6 * EPLANE + 64;   // + slack: lanes of unused taps may over-read a row
-  static constexpr size_t LDS_BYTES = DATA + 256;
+  static constexpr int DATA = 6 * UPLANE + 6 * EPLANE + 64;   // + slack: the five-dword B read may overshoot a row
+  static constexpr size_t RED_BYTES = (size_t)NW * NB * NB * 256 * 4;   // cross-wave reduction, one channel at a time
+  static constexpr size_t LDS_BYTES = (DATA > (int)RED_BYTES ? DATA : (int)RED_BYTES) + 256;
+  static constexpr int SCR = (int)LDS_BYTES - 256;
   static constexpr int UXG = TW / 4, EXG = ECOLS / 4;         // 4-pixel groups per staged row
-  static constexpr int UTASK = UROWS * UXG, ETASK = TH * EXG; // 752 + 640
+  static constexpr int UTASK = UROWS * UXG, ETASK = TH * EXG;
   static constexpr int UIT = (UTASK + NTH - 1) / NTH, EIT = (ETASK + NTH - 1) / NTH;
-  static constexpr size_t RED_FLOATS = (size_t)NW * 256;      // cross-wave reduction, one channel at a time
   static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 };
 
@@ -63,7 +67,7 @@ __device__ __forceinline__ float wg_max(float m, float* scr, int wave, int lane)
   if (lane == 0) scr[wave] = m;
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < GCfg::NW; ++w) m = __builtin_fmaxf(m, scr[w]);
+  for (int w = 0; w < 4; ++w) m = __builtin_fmaxf(m, scr[w]);
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
 }
 
@@ -89,11 +93,12 @@ __device__ __forceinline__ void split_store(const f32x4u (&v)[3], float s, unsig
   }
 }
 
-// requests the staged rows of tile t: U rows [y0 + pad - 15, y0 + pad + 32) x [x0, x0 + 64) and E rows [y0, y0 + 32) x
-// [x0 - 8, x0 + 72), one 4-pixel group (three dwordx4) per task
-__device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg::UIT][3], f32x4u (&pe)[GCfg::EIT][3], __amdgpu_buffer_rsrc_t rs_u,
+// requests the staged rows of tile t: U rows [y0 + pad - NT + 1, y0 + pad + TH) x [x0, x0 + 64) and E rows [y0, y0 + TH) x
+// [x0 - 8 NB, x0 + 64 + 8 NB), one 4-pixel group (three dwordx4) per task
+template <int NB>
+__device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg<NB>::UIT][3], f32x4u (&pe)[GCfg<NB>::EIT][3], __amdgpu_buffer_rsrc_t rs_u,
                                           __amdgpu_buffer_rsrc_t rs_e, const IcsGeom& G, int t, int tid) {
-  using C = GCfg;
+  using C = GCfg<NB>;
   const int x0 = (t % G.tiles_x) * C::TW, y0 = (t / G.tiles_x) * C::TH, pitch = G.pitch;
   const int su = 4 * ((G.ay + y0 + G.pad - (C::NT - 1)) * pitch + 3 * (G.ax + x0));
 #pragma unroll
@@ -104,7 +109,7 @@ __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg::UIT][3], f32x4u (&p
     for (int h = 0; h < 3; ++h)
       pu[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_u, 4 * (row * pitch + 12 * xg) + 16 * h, su, 0));
   }
-  const int se = 4 * ((G.ay + y0) * pitch + 3 * (G.ax + x0 - 8));
+  const int se = 4 * ((G.ay + y0) * pitch + 3 * (G.ax + x0 - 8 * NB));
 #pragma unroll
   for (int k = 0; k < C::EIT; ++k) {
     int v = tid + k * C::NTH; v = v < C::ETASK ? v : C::ETASK - 1;
@@ -117,10 +122,11 @@ __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg::UIT][3], f32x4u (&p
 
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
+template <int NB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gradk_mfma(IcsGradkArgs a) {
-  using C = GCfg;
+  using C = GCfg<NB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  float* fscr = reinterpret_cast<float*>(lds + C::DATA);
+  float* fscr = reinterpret_cast<float*>(lds + C::SCR);
   const IcsGeom& G = a.geo;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,17 +139,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const ptrdiff_t org = (ptrdiff_t)G.ay * pitch + 3 * G.ax;
   const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.u - org), rs_e = make_rsrc(a.e - org);
 
-  // lane constants of the B gather: first half of this lane's slice inside the 48-half segment
-  const int jb = li < G.K ? li : G.K - 1;                       // lanes of unused taps repeat the last one
-  const int bo = 8 * lg + jb + 8 - pad;
-  const uint32_t bsh = (bo & 1) * 16;
-
-  f4 tot[3];
+  // lane constants of the B operand: for tap block jb this lane's 8 halves start at half bo of the row segment that
+  // begins at column 32X (plane column 0 = frame column x0 - 8 NB); lanes of unused taps repeat the last one
+  uint32_t boff[NB], bsh[NB];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) tot[c] = (f4){0.f, 0.f, 0.f, 0.f};
+  for (int jb = 0; jb < NB; ++jb) {
+    const int tap = 16 * jb + li < G.K ? 16 * jb + li : G.K - 1;
+    const int bo = 8 * lg + tap + 8 * NB - pad;
+    boff[jb] = 4u * (uint32_t)(bo >> 1);
+    bsh[jb] = (uint32_t)(bo & 1) * 16u;
+  }
+
+  f4 tot[3][NB][NB];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) tot[c][ia][jb] = (f4){0.f, 0.f, 0.f, 0.f};
 
   f32x4u pu[C::UIT][3], pe[C::EIT][3];
-  if ((int)blockIdx.x < ntiles) load_tile(pu, pe, rs_u, rs_e, G, blockIdx.x, tid);
+  if ((int)blockIdx.x < ntiles) load_tile<NB>(pu, pe, rs_u, rs_e, G, blockIdx.x, tid);
 #pragma unroll 1
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     // ---- the rows of this tile are in registers (requested during the previous tile's MFMA phase) ----------
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int v = tid + k * C::NTH;
       if (v < C::UTASK) {
         const int row = v / C::UXG, xg = v - row * C::UXG;
-        split_store(pu[k], s_u, lds + C::UOFF + row * C::ROWB + 8 * xg, C::UPLANE);
+        split_store(pu[k], s_u, lds + C::UOFF + row * C::UROWB + 8 * xg, C::UPLANE);
       }
     }
 #pragma unroll
@@ -179,96 +195,132 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int v = tid + k * C::NTH;
       if (v < C::ETASK) {
         const int row = v / C::EXG, xg = v - row * C::EXG;
-        split_store(pe[k], s_e, lds + C::EOFF + row * C::ROWB + 8 * xg, C::EPLANE);
+        split_store(pe[k], s_e, lds + C::EOFF + row * C::EROWB + 8 * xg, C::EPLANE);
       }
     }
     __syncthreads();
 
     // next tile's rows: in flight during the whole MFMA phase (which issues no vector-memory load)
-    if (t + (int)gridDim.x < ntiles) load_tile(pu, pe, rs_u, rs_e, G, t + (int)gridDim.x, opaque(tid));
+    if (t + (int)gridDim.x < ntiles) load_tile<NB>(pu, pe, rs_u, rs_e, G, t + (int)gridDim.x, opaque(tid));
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- MFMA phase: wave w owns residual rows 8w .. 8w+7 ---------------------------------------------------
-    // six independent accumulators (channel x chunk): the three split terms of one product never follow each
-    // other on the same accumulator
-    f4 acc[3][C::TW / 32];
+    // ---- MFMA phase: wave w owns TH/4 consecutive residual rows ------------------------------------------------
+    // independent accumulators (channel x chunk x tap blocks): the three split terms of one product never follow
+    // each other on the same accumulator
+    constexpr int NX = C::TW / 32;
+    constexpr int AX = NB == 1 ? NX : 1;   // accumulator sets along the chunk axis (registers: NB = 2 has 12 blocks already)
+    f4 acc[3][AX][NB][NB];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int X = 0; X < C::TW / 32; ++X) acc[c][X] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int X = 0; X < AX; ++X)
+#pragma unroll
+        for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb) acc[c][X][ia][jb] = (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 2
     for (int yy = 0; yy < C::TH / C::NW; ++yy) {
       const int y = wave * (C::TH / C::NW) + yy;
-      // A: U row (y + 15 - a) of the staged block for lane a, columns 32X + 8g .. +7
-      const unsigned char* arow = lds + C::UOFF + (y + C::NT - 1 - li) * C::ROWB + 16 * lg;
-      // B: E row y, this lane's 8 halves start at half `bo` of the 48-half segment that starts at column 32X
-      const unsigned char* erow = lds + C::EOFF + y * C::ROWB + 4 * (bo >> 1);
-      h8 Ah[3][C::TW / 32], Al[3][C::TW / 32], Bh[3][C::TW / 32], Bl[3][C::TW / 32];
+      // A: U row (y + NT - 1 - a) of the staged block for tap a = 16 ia + lane row, columns 32X + 8g .. +7
+      const unsigned char* arow = lds + C::UOFF + (y + C::NT - 1 - li) * C::UROWB + 16 * lg;
+      // B: E row y, this lane's 8 halves start at half `bo` of the segment that starts at column 32X
+      const unsigned char* erow = lds + C::EOFF + y * C::EROWB;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < 3; ++c) {
+        h8 Ah[NX][NB], Al[NX][NB], Bh[NX][NB], Bl[NX][NB];
 #pragma unroll
-        for (int X = 0; X < C::TW / 32; ++X) {
-          Ah[c][X] = *reinterpret_cast<const h8*>(arow + (2 * c) * C::UPLANE + 64 * X);
-          Al[c][X] = *reinterpret_cast<const h8*>(arow + (2 * c + 1) * C::UPLANE + 64 * X);
+        for (int X = 0; X < NX; ++X) {
 #pragma unroll
-          for (int sp = 0; sp < 2; ++sp) {
-            // 8 halves from half `bo` of the segment: five dwords from dword bo >> 1, funnel-shifted by the parity
-            const uint32_t* ep = reinterpret_cast<const uint32_t*>(erow + (2 * c + sp) * C::EPLANE + 64 * X);
-            const uint32_t d0 = ep[0], d1 = ep[1], d2 = ep[2], d3 = ep[3], d4 = ep[4];
-            u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh), __builtin_amdgcn_alignbit(d2, d1, bsh),
-                    __builtin_amdgcn_alignbit(d3, d2, bsh), __builtin_amdgcn_alignbit(d4, d3, bsh)};
-            (sp ? Bl[c][X] : Bh[c][X]) = __builtin_bit_cast(h8, w);
+          for (int ia = 0; ia < NB; ++ia) {
+            Ah[X][ia] = *reinterpret_cast<const h8*>(arow - 16 * ia * C::UROWB + (2 * c) * C::UPLANE + 64 * X);
+            Al[X][ia] = *reinterpret_cast<const h8*>(arow - 16 * ia * C::UROWB + (2 * c + 1) * C::UPLANE + 64 * X);
           }
+#pragma unroll
+          for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+              // 8 halves from half `bo` of the segment: five dwords from dword bo >> 1, funnel-shifted by the parity
+              const uint32_t* ep = reinterpret_cast<const uint32_t*>(erow + boff[jb] + (2 * c + sp) * C::EPLANE + 64 * X);
+              const uint32_t d0 = ep[0], d1 = ep[1], d2 = ep[2], d3 = ep[3], d4 = ep[4];
+              u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh[jb]), __builtin_amdgcn_alignbit(d2, d1, bsh[jb]),
+                      __builtin_amdgcn_alignbit(d3, d2, bsh[jb]), __builtin_amdgcn_alignbit(d4, d3, bsh[jb])};
+              (sp ? Bl[X][jb] : Bh[X][jb]) = __builtin_bit_cast(h8, w);
+            }
         }
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+          for (int X = 0; X < NX; ++X)
 #pragma unroll
-          for (int X = 0; X < C::TW / 32; ++X)
-            acc[c][X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al[c][X] : Ah[c][X], term == 1 ? Bl[c][X] : Bh[c][X], acc[c][X], 0, 0, 0);
+            for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+              for (int jb = 0; jb < NB; ++jb)
+                acc[c][X % AX][ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al[X][ia] : Ah[X][ia], term == 1 ? Bl[X][jb] : Bh[X][jb],
+                                                                                acc[c][X % AX][ia][jb], 0, 0, 0);
+      }
     }
     const float sc = inv_u * inv_e;   // powers of two
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tot[c][r] += (acc[c][0][r] + acc[c][1][r]) * sc;
+      for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+        for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int X = 0; X < AX; ++X) v += acc[c][X][ia][jb][r];
+            tot[c][ia][jb][r] += v * sc;
+          }
   }
 
   // ---- cross-wave reduction (fixed order) and partial write, one channel per pass ----------------------------
-  float* red = reinterpret_cast<float*>(lds);   // [wave][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]
+  float* red = reinterpret_cast<float*>(lds);   // [wave][ia][jb][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]
+  constexpr int PER = NB * NB * 256;
   float* dst = a.partial + (size_t)blockIdx.x * (3 * C::NT * C::NT);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + r * 64 + lane] = tot[c][r];
+    for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NB + ia) * NB + jb) * 256 + r * 64 + lane] = tot[c][ia][jb][r];
     __syncthreads();
-    {
-      const int v = tid;   // 256 threads, 256 outputs
+    for (int v = tid; v < PER; v += C::NTH) {
       float s = red[v];
 #pragma unroll
-      for (int w = 1; w < C::NW; ++w) s += red[w * 256 + v];   // fixed order -> deterministic
-      const int l = v & 63, r = v >> 6;
-      const int ta = 4 * (l >> 4) + r, tb = l & 15;
+      for (int w = 1; w < C::NW; ++w) s += red[w * PER + v];   // fixed order -> deterministic
+      const int l = v & 63, r = (v >> 6) & 3, blk = v >> 8;
+      const int jb = blk % NB, ia = blk / NB;
+      const int ta = 16 * ia + 4 * (l >> 4) + r, tb = 16 * jb + (l & 15);
       dst[(c * C::NT + ta) * C::NT + tb] = s;
     }
   }
 }
 
-}  // namespace
-
-bool ics_gradk_mfma_supported(int K) { return K >= 3 && K <= 15 && (K & 1); }
-
-hipError_t ics_launch_gradk_mfma(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+template <int NB>
+hipError_t launch_nb(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+  using C = GCfg<NB>;
   static bool configured[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  auto kern = k_gradk_mfma<NB>;
   if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gradk_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCfg::LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }
     configured[dev] = true;
   }
-  hipLaunchKernelGGL(k_gradk_mfma, dim3(nblocks), dim3(GCfg::NTH), GCfg::LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
+}
+
+}  // namespace
+
+bool ics_gradk_mfma_supported(int K) { return K >= 3 && K <= 31 && (K & 1); }
+
+hipError_t ics_launch_gradk_mfma(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+  return a.geo.K <= 15 ? launch_nb<1>(a, nblocks, s) : launch_nb<2>(a, nblocks, s);
 }

@@ -514,9 +514,9 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     }
     a.wcorr[i] = v1; a.wconv[i] = v2;
   }
-  // Compact Toeplitz weight tables of the matrix-core convolution (ics_conv_mfma.hip): every weight scaled by a
-  // power of two (max -> [2^14, 2^15)) and split into fp16 hi + lo.  Entry (c*K + a)*2 + s holds the kernel
-  // row zero-padded to Wp[idx] = W[a][idx - 15][c] twice: 48 halves from idx 0 and 48 halves from idx 1.
+  // Weight tables of the matrix-core convolution (ics_conv_mfma.hip; = its LDS image): every weight scaled by a power
+  // of two (max -> [2^14, 2^15)) and split into fp16 hi + lo.  Row (c*K + a)*2 + s holds halves 8 .. of the zero-padded
+  // kernel row Wp[idx] = W[a][idx - 15][c], i.e. the taps at local halves 7 .. K+6 and zeros around them.
   if (a.bt_conv && a.bt_corr) {
     uint32_t km = 0u;
     for (int i = tid; i < n; i += 256) { const uint32_t k1 = key_of(__builtin_fabsf(p[i])); km = km > k1 ? km : k1; }
@@ -530,11 +530,12 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     const float s_w = __uint_as_float(sb << 23), inv_w = __uint_as_float((254u - sb) << 23);
     _Float16* tc = reinterpret_cast<_Float16*>(a.bt_conv);
     _Float16* tr = reinterpret_cast<_Float16*>(a.bt_corr);
-    const int nhalf = 3 * K * 2 * 96;
+    const int rh = ((2 * (K + 17) + 3) & ~3) / 2;      // halves per row (MCfg::WROWB / 2)
+    const int nhalf = 3 * K * 2 * rh;
     for (int i = tid; i < nhalf; i += 256) {
-      const int ent = i / 96, hh = i - ent * 96;
+      const int ent = i / rh, hh = i - ent * rh;
       const int sp = ent & 1, ca = ent >> 1, c = ca / K, ra = ca - c * K;
-      const int b = (hh % 48) + (hh / 48) - 15;
+      const int b = hh - 7;
       float w1 = 0.f, w2 = 0.f;
       if (b >= 0 && b < K) {
         w1 = p[(ra * K + b) * 3 + c] * s_w;
@@ -573,7 +574,7 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
 int ics_gradk_blocks(const IcsGeom& g, int cus) {
   const int nb = (g.K + 15) / 16;
   const int tiles = g.tiles_x * g.tiles_y * 2;
-  int blocks = cus * (nb == 1 ? 2 : 1);
+  int blocks = cus * (nb <= 2 ? 2 : 1);   // two persistent workgroups per CU where the matrix-core kernel exists
   return blocks < tiles ? blocks : tiles;
 }
 

@@ -20,11 +20,12 @@ int main(int argc, char** argv) {
   hipMemset(out, 0, nf * 4);
   const size_t tf = ics_conv_mfma_table_floats(K);
   std::vector<_Float16> tab(tf * 2, (_Float16)0.f);
-  for (int c = 0; c < 3; ++c) for (int a = 0; a < K; ++a) for (int s = 0; s < 2; ++s) for (int hh = 0; hh < 96; ++hh) {
-    const int b = (hh % 48) + (hh / 48) - 15;
+  const int rh = ((2 * (K + 17) + 3) & ~3) / 2;   // halves per weight row (MCfg::WROWB / 2)
+  for (int c = 0; c < 3; ++c) for (int a = 0; a < K; ++a) for (int s = 0; s < 2; ++s) for (int hh = 0; hh < rh; ++hh) {
+    const int b = hh - 7;
     const float w = (b >= 0 && b < K) ? 16384.f / (K * K) * (1.f + 0.01f * a + 0.02f * b) : 0.f;
     const _Float16 hi = (_Float16)w;
-    tab[(((size_t)c * K + a) * 2 + s) * 96 + hh] = s ? (_Float16)(w - (float)hi) : hi;
+    tab[(((size_t)c * K + a) * 2 + s) * rh + hh] = s ? (_Float16)(w - (float)hi) : hi;
   }
   reinterpret_cast<float*>(tab.data())[tf - 4] = 1.f / 16384.f;
   hipMalloc(&bt, tf * 4); hipMemcpy(bt, tab.data(), tf * 4, hipMemcpyHostToDevice);

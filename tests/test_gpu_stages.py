@@ -29,13 +29,13 @@ def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
 
 
 CONV_CASES = [(MK, 1) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 39, 45, 55, 63)] + \
-             [(MK, 2) for MK in (3, 5, 7, 9, 11, 13, 15)]
+             [(MK, 2) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37)]
 
 
 @pytest.mark.parametrize("MK,conv", CONV_CASES)
 def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
     """conv = 1: packed-fp32 vector kernels (ics_conv.hip); conv = 2: matrix-core kernels with fp16-split
-    operands (ics_conv_mfma.hip, MK <= 15).  Same tolerance for both against float64 direct sums."""
+    operands (ics_conv_mfma.hip, MK <= 37).  Same tolerance for both against float64 direct sums."""
     from lib import _native as nv
     M, N = 70 + MK, 131
     job, case, psf = make_job(M, N, MK, seed=MK)
@@ -59,8 +59,12 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
     job.close()
 
 
-@pytest.mark.parametrize("M,N,MK,blind", [(64, 64, 15, False), (65, 191, 15, False), (130, 67, 9, True), (257, 300, 15, True), (40, 50, 31, False), (100, 90, 45, True), (80, 120, 63, True), (70, 70, 21, True)])
-def test_one_inner_iteration_stage_by_stage(M, N, MK, blind):
+# conv: 0 = ICS_CONV_AUTO, 1 = fp32 products (vector convolutions, fp32-MFMA gradient), 2 = matrix-core kernels
+@pytest.mark.parametrize("M,N,MK,blind,conv", [(64, 64, 15, False, 0), (65, 191, 15, False, 0), (130, 67, 9, True, 0), (257, 300, 15, True, 0),
+                                               (40, 50, 31, False, 0), (100, 90, 45, True, 0), (80, 120, 63, True, 0), (70, 70, 21, True, 0),
+                                               (257, 300, 15, True, 1), (130, 67, 9, True, 1), (70, 70, 21, True, 2), (90, 100, 31, True, 2),
+                                               (66, 70, 17, True, 2), (97, 133, 27, True, 0)])
+def test_one_inner_iteration_stage_by_stage(M, N, MK, blind, conv):
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=M + N, blind=blind)
     pad = MK // 2
@@ -71,7 +75,7 @@ def test_one_inner_iteration_stage_by_stage(M, N, MK, blind):
     job.write(nv.BUF_U, u)
     job.write(nv.BUF_UT, ut)
     win = orc.default_window(M, N, MK)
-    p = job.params(*win, 1e9, 1, step, lambd, blind=blind)
+    p = job.params(*win, 1e9, 1, step, lambd, blind=blind, conv=conv)
     job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
     e = job.read(nv.BUF_ERROR)
     job.stage(nv.STAGE_BACKPROJECT, p)
