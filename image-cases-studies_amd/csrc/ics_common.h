@@ -113,9 +113,9 @@ struct IcsConvArgs {
 hipError_t ics_launch_conv(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_supported(int K);
 // Matrix-core variant (ics_conv_mfma.hip): modes 0 and 1, odd K <= 37, operands split into two fp16 terms.
-// Weight table (built by k_psf, = the kernel's LDS image): row (c*K + a)*2 + s (s = 0 hi, 1 lo) of
-// WROWB = round4(2*(K+17)) bytes holds halves 8.. of the scaled zero-padded kernel row Wp[idx] = s_w * W[a][idx - 15][c]
-// (taps at local halves 7 .. K+6); one float 1/s_w behind the last row.
+// Weight table (built by k_psf, = the kernel's LDS image): row c*K + a of 2*WROWB bytes, WROWB = round4(2*(K+17)), holds
+// halves 8.. of the scaled zero-padded kernel row Wp[idx] = s_w * W[a][idx - 15][c] (taps at local halves 7 .. K+6) as its
+// two fp16 split terms interleaved dword by dword (hi dword d at 2d, lo dword d at 2d + 1); one float 1/s_w behind the last row.
 hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_mfma_supported(int K);
 bool ics_conv_mfma_preferred(int K);   // what ICS_CONV_AUTO picks

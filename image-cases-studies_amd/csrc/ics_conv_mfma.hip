@@ -42,6 +42,21 @@
 //     same epilogue arithmetic as the VALU kernel (residual / back-projection + step-size reductions).
 #include "ics_common.h"
 
+#ifndef ICS_EPI_DIRECT
+#define ICS_EPI_DIRECT 1   /* 0 = the former epilogue through an LDS transpose (kept for A/B timing in tools/) */
+#endif
+#ifndef ICS_SKEW
+#define ICS_SKEW 0
+#endif
+#ifndef ICS_EPI_EARLY
+#define ICS_EPI_EARLY(mode) 0   /* 1 = epilogue operand requested before the matrix phase (measured: no gain) */
+#endif
+#ifndef ICS_MFMA_INTERLEAVE
+#define ICS_MFMA_INTERLEAVE 1
+#endif
+#ifndef ICS_EPI_TB
+#define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
+#endif
 #ifndef ICS_MFMA_ABLATE
 #define ICS_MFMA_ABLATE 0  /* tools/bench_conv_mfma.hip: 1 = no MFMA loop, 2 = no conversion, 4 = no epilogue */
 #endif
@@ -52,6 +67,14 @@ __device__ unsigned long long ics_mfma_ticks[11];
 #define ICS_TICK_INIT unsigned long long tk_prev = __builtin_readcyclecounter(), tk_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define ICS_TICK(i) do { const unsigned long long tk_now = __builtin_readcyclecounter(); tk_acc[i] += tk_now - tk_prev; tk_prev = tk_now; } while (0)
 #define ICS_TICK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 10; ++i) atomicAdd(&ics_mfma_ticks[i], tk_acc[i]); atomicAdd(&ics_mfma_ticks[10], 1ull); } } while (0)
+#elif defined(ICS_MFMA_TRACE)
+// phase timeline (tools/bench_conv_mfma.hip -DICS_MFMA_TRACE): lane 0 of every wave records (100 MHz wall clock << 8 | mark)
+// at each mark; entry 0 = HW_ID | XCC_ID << 32.  1024 entries per wave.
+__device__ unsigned long long* ics_trace_buf;
+#define ICS_TICK_INIT unsigned long long* tr_ = ics_trace_buf + ((size_t)blockIdx.x * 4 + wv) * 1024; int tri_ = 0; \
+  if (lane == 0) { tr_[tri_++] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); tr_[tri_++] = (wall_clock64() << 8) | 15; }
+#define ICS_TICK(i) do { if (lane == 0 && tri_ < 1023) tr_[tri_++] = (wall_clock64() << 8) | (i); } while (0)
+#define ICS_TICK_FLUSH do { if (lane == 0) tr_[tri_] = 0; } while (0)
 #else
 #define ICS_TICK_INIT
 #define ICS_TICK(i)
@@ -65,6 +88,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u3 __attribute__((ext_vector_type(3)));
 
 template <int K>
 struct MCfg {
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     const int bo = 32 * h + 8 * lg - li + 15;
     const bool bzero = bo < 8 || bo > K + 14;                       // window entirely in the zero padding
     bsh[h] = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
-    wa0[h] = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 4u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+    wa0[h] = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
     asm volatile("" : "+v"(wa0[h]));
   }
   const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
@@ -201,12 +225,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   // epilogue operands and output through buffer addressing as well (frame origins; offsets are >= 0 there)
   const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
+  const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.out);
   f32x4u raw[C::NIT][3];
   {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + txi * C::TW - C::PAD)), tid, pitch);
   }
 
+#if ICS_SKEW
+  // start-up skew: the second workgroup of a CU (dispatch order: workgroup b -> XCD b % 8, CU (b / 8) % 32) begins
+  // late, so that its matrix phases fall into the memory phases of the first one
+  if (blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < ICS_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
   ICS_TICK_INIT;
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -271,6 +302,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
       load_raw<C>(raw, rs_in, 4 * ((a.g.ay + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + nxi * C::TW - C::PAD)), opaque(tid), pitch);
     }
+#if ICS_EPI_DIRECT
+    // ---- ...and the epilogue operand of THIS tile (mode 0: the image; one 12-byte pixel per accumulator row), so that
+    // after the matrix phase the wave only subtracts and stores
+    constexpr bool EARLY = ICS_EPI_EARLY(MODE);
+    u3 eop_early[4][4];
+    if (EARLY) {
+      const int tide = opaque(tid);
+      const int voff = 4 * (16 * ((tide >> 4) & 3) * pitch + 3 * (tide & 15));
+      const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) eop_early[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 
     ICS_TICK(7);
@@ -293,22 +339,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         h8 Bh[K][C::NCH], Bl[K][C::NCH];
         // software pipeline: the operands of step q + 1 (A fragments from the planes, B fragments from the weight
         // rows) are requested before the MFMAs of step q
-        auto gatherB = [&](int ka) {
+        // B fragments in two halves: the raw dwords of kernel row q + 1 are requested before the MFMAs of step q and
+        // funnel-shifted behind them.  The reads are volatile: as plain loads they were sunk to the shifts, and the wave
+        // waited out the LDS latency in front of every step's MFMAs (466 cycles per step for 192 cycles of MFMA,
+        // tools/bench_conv_mfma.hip -DICS_MFMA_TRACE).
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+        u2 rawB[C::NCH][5];   // (hi, lo) dword pairs: the table interleaves the two split terms dword by dword
+        auto issueB = [&](int ka) {
 #pragma unroll
-          for (int h = 0; h < C::NCH; ++h)
+          for (int h = 0; h < C::NCH; ++h) {
+            const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb[h] + (uint32_t)((ch * K + ka) * 2 * C::WROWB));
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-              const lds_u32p r = reinterpret_cast<lds_u32p>(wb[h] + (uint32_t)(((ch * K + ka) * 2 + sp) * C::WROWB));
-              const uint32_t d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3], d4 = r[4];
-              u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh[h]), __builtin_amdgcn_alignbit(d2, d1, bsh[h]),
-                      __builtin_amdgcn_alignbit(d3, d2, bsh[h]), __builtin_amdgcn_alignbit(d4, d3, bsh[h])};
-              (sp ? Bl[ka][h] : Bh[ka][h]) = __builtin_bit_cast(h8, w);
-            }
+            for (int d = 0; d < 5; ++d) rawB[h][d] = (ICS_MFMA_ABLATE & 32) ? (u2){0x3c003c00u + ka + d, 0x3c003c00u + d} : r[d];
+          }
         };
-        gatherB(0);
+        auto finishB = [&](int ka) {
+#pragma unroll
+          for (int h = 0; h < C::NCH; ++h) {
+            const u2* d = rawB[h];
+            u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, bsh[h]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, bsh[h]),
+                     __builtin_amdgcn_alignbit(d[3].x, d[2].x, bsh[h]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, bsh[h])};
+            u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, bsh[h]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, bsh[h]),
+                     __builtin_amdgcn_alignbit(d[3].y, d[2].y, bsh[h]), __builtin_amdgcn_alignbit(d[4].y, d[3].y, bsh[h])};
+            Bh[ka][h] = __builtin_bit_cast(h8, wh);
+            Bl[ka][h] = __builtin_bit_cast(h8, wl);
+          }
+        };
+        issueB(0);
         h8 Ah[C::NCH], Al[C::NCH];
 #pragma unroll
         for (int h = 0; h < C::NCH; ++h) { Ah[h] = *reinterpret_cast<const h8*>(ph + 64 * h); Al[h] = *reinterpret_cast<const h8*>(pl + 64 * h); }
+        finishB(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < C::NQ; ++q) {
           h8 Nh[C::NCH], Nl[C::NCH];
@@ -324,8 +387,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               }
             }
           }
-          if (q + 1 < K) gatherB(q + 1);
-          __builtin_amdgcn_sched_barrier(0);   // ...and all of them are in flight before the step's MFMAs start
+          if (q + 1 < K) issueB(q + 1);
+#if !ICS_MFMA_INTERLEAVE
+          __builtin_amdgcn_sched_barrier(0);   // ...all requested before the step's MFMAs start
+#endif
           // three split terms x windows; the (up to) 4 accumulators of a pass are independent
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
@@ -341,13 +406,117 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               }
             }
           }
+#if !ICS_MFMA_INTERLEAVE
+          __builtin_amdgcn_sched_barrier(0);   // ...and consumed behind them
+#endif
+          if (q + 1 < K) finishB(q + 1);
 #pragma unroll
           for (int h = 0; h < C::NCH; ++h) { Ah[h] = Nh[h]; Al[h] = Nl[h]; }
+#if ICS_MFMA_INTERLEAVE
+          // issue order inside the step: the LDS reads go into the shadows of the first MFMAs (an MFMA holds the matrix
+          // pipe for 16 cycles, the wave can issue an independent instruction meanwhile), the funnel shifts into the
+          // shadows of the last ones; as three blocks (reads | MFMAs | shifts) a step cost their sum
+          {
+            int nt = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
+            const int nm = 3 * C::NCH * nt;                                             // MFMAs of this step
+            const int nr = ((q + 1 < C::NQ) ? 2 * C::NCH : 0) + ((q + 1 < K) ? 5 * C::NCH : 0);   // LDS reads
+            const int nv = (q + 1 < K) ? 8 * C::NCH : 0;                                // funnel shifts
+            const int tail = nv ? (nm > 4 ? 4 : nm) : 0;                                // MFMAs that cover the shifts
+            const int head = nm - tail;
+#pragma unroll
+            for (int i = 0; i < (head > nr ? head : nr); ++i) {
+              if (i < head) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < tail; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+              for (int j = 0; j < (nv / 2 + tail - 1) / tail; ++j) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+          }
+#endif
           __builtin_amdgcn_sched_barrier(0);   // keep each step's prefetches in that step (register pressure)
         }
       }
     }
     ICS_TICK(1);
+#if ICS_EPI_DIRECT
+    // ---- epilogue straight from the accumulators: lane (li, lg) holds, for each channel, the 16 rows
+    // t + 16*lg + 4*r of pixel column 16*wv + li, i.e. one 12-byte HWC pixel per (t, r): operands arrive and
+    // results leave as dwordx3 (16 lanes = 192 contiguous bytes of a row), no LDS transpose and no workgroup
+    // barrier between the matrix phase and the stores -- the four waves drift apart and overlap their phases.
+    if (x0 + 16 * wv < a.g.uN && !(ICS_MFMA_ABLATE & 4)) {
+      const float sc = inv_w * inv_x;   // powers of two
+      const int tide = opaque(tid);
+      const int eli = tide & 15, elg = (tide >> 4) & 3;
+      const int colx = x0 + 16 * wv + eli;
+      const int voff = 4 * (16 * elg * pitch + 3 * eli);          // lane part of the byte offset
+      const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));      // wave-uniform part (tile origin + column block)
+      constexpr int EOPS = (MODE == 0) ? 1 : 2;
+      constexpr int TB = ICS_EPI_TB(MODE);   // accumulator sets per batch: the operands of a batch are requested together
+#pragma unroll
+      for (int t0 = 0; t0 < 4; t0 += TB) {
+      u3 eop[EOPS][4][4];
+#pragma unroll
+      for (int t = t0; t < t0 + TB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int so = sb + 4 * (t + 4 * r) * pitch;
+          if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
+          eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, 0);
+          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, 0);
+        }
+      if (t0 == 0) ICS_TICK(3);
+#pragma unroll
+      for (int t = t0; t < t0 + TB; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = y0 + t + 16 * elg + 4 * r;
+          const int so = sb + 4 * (t + 4 * r) * pitch;
+          float av[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) av[c] = acc[c][t][r] * sc;
+          if (MODE == 0) {
+            // error = synth - image on the M x N interior (pyx:488); the border ring of the frame stays 0
+            if (y >= C::PAD && y < C::PAD + a.g.M && colx >= C::PAD && colx < C::PAD + a.g.N && (!(ICS_MFMA_ABLATE & 8) || av[0] + av[1] + av[2] == 12345.678f)) {
+              u3 e;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) e[c] = __float_as_uint(__fsub_rn(av[c], __uint_as_float(eop[0][t][r][c])));
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, 0);
+            }
+          } else {
+            // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
+            if (y < a.g.uM && colx < a.g.uN && (!(ICS_MFMA_ABLATE & 8) || av[0] + av[1] + av[2] == 12345.678f)) {
+              const float lambd = a.lambd;
+              const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * colx;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float uv = __uint_as_float(eop[0][t][r][c]), tv = __uint_as_float(eop[EOPS - 1][t][r][c]);
+                float g;
+                if (a.tv_kind >= 2)
+                  g = (float)((double)a.tv[o + c] + (double)__fmul_rn(lambd, av[c]));
+                else if (a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && colx >= 1 && colx <= a.g.uN - 2)
+                  g = (float)(((double)a.tv[o + c] + (double)__fmul_rn(lambd, av[c])) + (double)__fsub_rn(uv, tv) / 4.0);
+                else
+                  g = __fadd_rn(__fmul_rn(lambd, av[c]), __fmul_rn(__fsub_rn(uv, tv), 0.5f));
+                mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
+                mu[c] = __builtin_fmaxf(mu[c], uv);
+                rflags |= ((g != g) ? (1u << c) : 0u) | ((uv != uv) ? (8u << c) : 0u) | 64u;
+              }
+              u3 e = {__float_as_uint(av[0]), __float_as_uint(av[1]), __float_as_uint(av[2])};
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, 0);
+            }
+          }
+        }
+      }
+    }
+    ICS_TICK(5);
+    // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
+    //  before the next conversion overwrites the planes)
+#else
     __syncthreads();  // every wave is done with the planes
     ICS_TICK(2);
 
@@ -482,6 +651,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     ICS_TICK(5);
     __syncthreads();  // the transpose buffer is consumed before the next tile's planes overwrite it
     ICS_TICK(6);
+#endif
   }
 
   ICS_TICK_FLUSH;
@@ -530,6 +700,9 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   }
   const int ntiles = a.g.tiles_x * a.g.tiles_y;
   int grid = C::WGS * cus[dev];              // persistent workgroups: as many as fit the LDS of a CU
+#ifdef ICS_GRID_WGS
+  grid = ICS_GRID_WGS * cus[dev];
+#endif
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();
@@ -548,7 +721,7 @@ bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   /
 // are useful and the 126 KB of planes leave room for one workgroup per CU; the packed-fp32 kernels win at K = 19, 21.
 bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K) && K != 19 && K != 21; }
 
-// weight table: [c][a][hi/lo] rows of WROWB bytes (the LDS image), then one float 1/s_w (ics_common.h)
+// weight table: [c][a] rows of 2 * WROWB bytes, hi/lo dword-interleaved (the LDS image), then one float 1/s_w (ics_common.h)
 size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * (((2 * (K + 17) + 3) & ~3) / 4) + 4; }
 
 hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {

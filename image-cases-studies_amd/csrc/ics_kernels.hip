@@ -542,8 +542,11 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
         w2 = p[((K - 1 - ra) * K + (K - 1 - b)) * 3 + c] * s_w;
       }
       const _Float16 h1 = (_Float16)w1, h2 = (_Float16)w2;
-      tr[i] = sp ? (_Float16)(w1 - (float)h1) : h1;
-      tc[i] = sp ? (_Float16)(w2 - (float)h2) : h2;
+      // the two split terms of a row are interleaved dword by dword (hi dword d at 2d, lo at 2d + 1): one 8-byte LDS read
+      // fetches both
+      const int o = ca * 2 * rh + 4 * (hh >> 1) + 2 * sp + (hh & 1);
+      tr[o] = sp ? (_Float16)(w1 - (float)h1) : h1;
+      tc[o] = sp ? (_Float16)(w2 - (float)h2) : h2;
     }
     if (tid == 0) {
       *reinterpret_cast<float*>(tc + nhalf) = inv_w;

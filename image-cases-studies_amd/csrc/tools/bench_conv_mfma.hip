@@ -7,8 +7,8 @@
 #include <vector>
 
 int main(int argc, char** argv) {
-  const int M = argc > 1 ? atoi(argv[1]) : 4096, K = argc > 2 ? atoi(argv[2]) : 15;
-  IcsGeom g = ics_make_geom(M, M, K);
+  const int M = argc > 1 ? atoi(argv[1]) : 4096, K = argc > 2 ? atoi(argv[2]) : 15, N = argc > 3 ? atoi(argv[3]) : M;
+  IcsGeom g = ics_make_geom(M, N, K);
   const size_t nf = ics_frame_floats(g), org = ics_origin_offset(g);
   std::vector<float> h(nf);
   srand(1);
@@ -25,20 +25,52 @@ int main(int argc, char** argv) {
     const int b = hh - 7;
     const float w = (b >= 0 && b < K) ? 16384.f / (K * K) * (1.f + 0.01f * a + 0.02f * b) : 0.f;
     const _Float16 hi = (_Float16)w;
-    tab[(((size_t)c * K + a) * 2 + s) * rh + hh] = s ? (_Float16)(w - (float)hi) : hi;
+    tab[((size_t)c * K + a) * 2 * rh + 4 * (hh >> 1) + 2 * s + (hh & 1)] = s ? (_Float16)(w - (float)hi) : hi;
   }
   reinterpret_cast<float*>(tab.data())[tf - 4] = 1.f / 16384.f;
   hipMalloc(&bt, tf * 4); hipMemcpy(bt, tab.data(), tf * 4, hipMemcpyHostToDevice);
   IcsConvArgs a = {};
   a.in = in + org; a.out = out + org; a.f = f + org; a.u = u + org; a.ut = ut + org; a.red = red; a.lambd = 1.f; a.bt = bt; a.g = g;
+  {
+    int nb0 = -1, nb1 = -1;
+    if (K == 15) {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_conv_mfma<15, 0>, 256, MCfg<15>::LDS_BYTES);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_conv_mfma<15, 1>, 256, MCfg<15>::LDS_BYTES);
+      printf("occupancy (workgroups per CU) K=15: mode 0 %d, mode 1 %d, LDS %zu B\n", nb0, nb1, (size_t)MCfg<15>::LDS_BYTES);
+    }
+  }
+#ifdef ICS_MFMA_TRACE
+  unsigned long long* trace; const size_t trace_n = (size_t)1024 * 4 * 1024;   // up to 1024 workgroups
+  hipMalloc(&trace, trace_n * 8); hipMemset(trace, 0, trace_n * 8);
+  hipMemcpyToSymbol(HIP_SYMBOL(ics_trace_buf), &trace, sizeof trace);
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int mode = 0; mode < 2; ++mode) {
     for (int i = 0; i < 3; ++i) if (ics_launch_conv_mfma(mode, a, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) ics_launch_conv_mfma(mode, a, 0);
+    const int reps = getenv("ICS_BENCH_REPS") ? atoi(getenv("ICS_BENCH_REPS")) : 20;   // long runs: sample clocks / power beside it
+    for (int i = 0; i < reps; ++i) ics_launch_conv_mfma(mode, a, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    printf("ablate=%d mode %d: %.4f ms\n", ICS_MFMA_ABLATE, mode, ms / 20);
+    printf("ablate=%d mode %d: %.4f ms\n", ICS_MFMA_ABLATE, mode, ms / reps);
+#ifdef ICS_MFMA_TRACE
+    {  // one more launch, traced
+      hipMemset(trace, 0, trace_n * 8);
+      ics_launch_conv_mfma(mode, a, 0); hipDeviceSynchronize();
+      std::vector<unsigned long long> ht(trace_n);
+      hipMemcpy(ht.data(), trace, trace_n * 8, hipMemcpyDeviceToHost);
+      char nm[256]; snprintf(nm, sizeof nm, "%s/trace_mode%d.bin", getenv("ICS_TRACE_DIR") ? getenv("ICS_TRACE_DIR") : ".", mode);
+      FILE* fp = fopen(nm, "wb");
+      if (fp) {  // compact: per wave only the used entries
+        for (size_t w = 0; w < trace_n / 1024; ++w) {
+          const unsigned long long* t = ht.data() + w * 1024; int n = 0; while (n < 1024 && t[n]) ++n;
+          if (!n) continue;
+          unsigned long long hdr[2] = {w, (unsigned long long)n}; fwrite(hdr, 8, 2, fp); fwrite(t, 8, n, fp);
+        }
+        fclose(fp);
+      }
+    }
+#endif
 #ifdef ICS_MFMA_TIMING
     {
       unsigned long long h[11]; hipMemcpyFromSymbol(h, HIP_SYMBOL(ics_mfma_ticks), sizeof h);
