@@ -18,6 +18,7 @@
 // (A ds_bpermute gather from a row image measured ~5 LDS cycles per bpermute: the kernel was LDS-bound at 63 %.)
 // Workgroups are persistent and write one partial block each, reduced in double by k_gradk_reduce (deterministic).
 #include "ics_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -38,7 +39,10 @@ struct GCfg {
   static constexpr int EROWB = 2 * ECOLS;
   static constexpr int UPLANE = UROWS * UROWB, EPLANE = TH * EROWB;
   static constexpr int UOFF = 0, EOFF = 6 * UPLANE;
-  static constexpr int DATA = 6 * UPLANE + 6 * EPLANE + 64;   // + slack: the five-dword B read may overshoot a row
+  // (the E planes of a channel are interleaved dword by dword -- hi dword d at 2d, lo dword d at 2d + 1 -- so that one
+  //  8-byte LDS read fetches both split terms of the sliding window: 10 ds_read_b64 instead of 20 ds_read_b32 per
+  //  row and channel; the kernel is bound by LDS-array cycles)
+  static constexpr int DATA = 6 * UPLANE + 6 * EPLANE + 128;   // + slack: the five-dword B read may overshoot a row
   static constexpr size_t RED_BYTES = (size_t)NW * NB * NB * 256 * 4;   // cross-wave reduction, one channel at a time
   static constexpr size_t LDS_BYTES = (DATA > (int)RED_BYTES ? DATA : (int)RED_BYTES) + 256;
   static constexpr int SCR = (int)LDS_BYTES - 256;
@@ -90,6 +94,27 @@ __device__ __forceinline__ void split_store(const f32x4u (&v)[3], float s, unsig
     }
     *reinterpret_cast<h4*>(dst + (2 * c) * plane_bytes) = hi;
     *reinterpret_cast<h4*>(dst + (2 * c + 1) * plane_bytes) = lo;
+  }
+}
+
+// 4 pixels (12 floats, HWC) -> one 16-byte group {hi d0, lo d0, hi d1, lo d1} per channel of the interleaved E planes
+__device__ __forceinline__ void split_store_interleaved(const f32x4u (&v)[3], float s, unsigned char* dst, int chan_bytes) {
+  float f[12];
+#pragma unroll
+  for (int h = 0; h < 3; ++h)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[4 * h + e] = v[h][e] * s;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    _Float16 hi[4], lo[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float x = f[3 * p + c];
+      hi[p] = (_Float16)x;
+      lo[p] = (_Float16)(x - (float)hi[p]);
+    }
+    const h8 w = {hi[0], hi[1], lo[0], lo[1], hi[2], hi[3], lo[2], lo[3]};
+    *reinterpret_cast<h8*>(dst + c * chan_bytes) = w;
   }
 }
 
@@ -146,7 +171,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int jb = 0; jb < NB; ++jb) {
     const int tap = 16 * jb + li < G.K ? 16 * jb + li : G.K - 1;
     const int bo = 8 * lg + tap + 8 * NB - pad;
-    boff[jb] = 4u * (uint32_t)(bo >> 1);
+    boff[jb] = 8u * (uint32_t)(bo >> 1);   // interleaved planes: 8 bytes per dword index
     bsh[jb] = (uint32_t)(bo & 1) * 16u;
   }
 
@@ -195,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int v = tid + k * C::NTH;
       if (v < C::ETASK) {
         const int row = v / C::EXG, xg = v - row * C::EXG;
-        split_store(pe[k], s_e, lds + C::EOFF + row * C::EROWB + 8 * xg, C::EPLANE);
+        split_store_interleaved(pe[k], s_e, lds + C::EOFF + row * (2 * C::EROWB) + 16 * xg, 2 * C::EPLANE);
       }
     }
     __syncthreads();
@@ -218,45 +243,88 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ia = 0; ia < NB; ++ia)
 #pragma unroll
           for (int jb = 0; jb < NB; ++jb) acc[c][X][ia][jb] = (f4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int yy = 0; yy < C::TH / C::NW; ++yy) {
-      const int y = wave * (C::TH / C::NW) + yy;
+    // Software pipeline over the steps (residual row, channel), two steps deep (NB = 1): the LDS operands of step i + 2
+    // are requested, and the funnel shifts of step i + 1 done, in the shadows of the MFMAs of step i.  The reads are
+    // volatile: plain loads were sunk to their first use, and the wave then waited out the LDS latency in front of every
+    // group of MFMAs.
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    constexpr bool PIPE = NB == 1;   // NB = 2 sits at 256 registers already: operands requested and used in the same step
+    typedef typename std::conditional<PIPE, const volatile __attribute__((address_space(3))) u2*, const __attribute__((address_space(3))) u2*>::type lds_u2p;
+    typedef typename std::conditional<PIPE, const volatile __attribute__((address_space(3))) u4*, const __attribute__((address_space(3))) u4*>::type lds_u4p;
+    constexpr int NSTEP = 3 * (C::TH / C::NW);
+    constexpr int RD = PIPE ? 3 : 1, BD = PIPE ? 2 : 1;   // buffers of raw operands / of finished B fragments
+    u4 rAh[RD][NX][NB], rAl[RD][NX][NB];
+    u2 rB[RD][NX][NB][5];
+    h8 Bh[BD][NX][NB], Bl[BD][NX][NB];
+    auto issue = [&](int i) {
+      const int y = wave * (C::TH / C::NW) + i / 3, c = i % 3, pb = i % RD;
       // A: U row (y + NT - 1 - a) of the staged block for tap a = 16 ia + lane row, columns 32X + 8g .. +7
-      const unsigned char* arow = lds + C::UOFF + (y + C::NT - 1 - li) * C::UROWB + 16 * lg;
+      const uint32_t arow = (uint32_t)(uintptr_t)(lds_u4p)(lds + C::UOFF) + (uint32_t)((y + C::NT - 1 - li) * C::UROWB + 16 * lg);
       // B: E row y, this lane's 8 halves start at half `bo` of the segment that starts at column 32X
-      const unsigned char* erow = lds + C::EOFF + y * C::EROWB;
+      const uint32_t erow = (uint32_t)(uintptr_t)(lds_u2p)(lds + C::EOFF) + (uint32_t)(y * (2 * C::EROWB) + c * (2 * C::EPLANE));
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        h8 Ah[NX][NB], Al[NX][NB], Bh[NX][NB], Bl[NX][NB];
+      for (int X = 0; X < NX; ++X) {
 #pragma unroll
-        for (int X = 0; X < NX; ++X) {
-#pragma unroll
-          for (int ia = 0; ia < NB; ++ia) {
-            Ah[X][ia] = *reinterpret_cast<const h8*>(arow - 16 * ia * C::UROWB + (2 * c) * C::UPLANE + 64 * X);
-            Al[X][ia] = *reinterpret_cast<const h8*>(arow - 16 * ia * C::UROWB + (2 * c + 1) * C::UPLANE + 64 * X);
-          }
-#pragma unroll
-          for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-              // 8 halves from half `bo` of the segment: five dwords from dword bo >> 1, funnel-shifted by the parity
-              const uint32_t* ep = reinterpret_cast<const uint32_t*>(erow + boff[jb] + (2 * c + sp) * C::EPLANE + 64 * X);
-              const uint32_t d0 = ep[0], d1 = ep[1], d2 = ep[2], d3 = ep[3], d4 = ep[4];
-              u4 w = {__builtin_amdgcn_alignbit(d1, d0, bsh[jb]), __builtin_amdgcn_alignbit(d2, d1, bsh[jb]),
-                      __builtin_amdgcn_alignbit(d3, d2, bsh[jb]), __builtin_amdgcn_alignbit(d4, d3, bsh[jb])};
-              (sp ? Bl[X][jb] : Bh[X][jb]) = __builtin_bit_cast(h8, w);
-            }
+        for (int ia = 0; ia < NB; ++ia) {
+          rAh[pb][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c) * C::UPLANE + 64 * X));
+          rAl[pb][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c + 1) * C::UPLANE + 64 * X));
         }
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int jb = 0; jb < NB; ++jb) {
+          const lds_u2p ep = reinterpret_cast<lds_u2p>(erow + boff[jb] + (uint32_t)(128 * X));
 #pragma unroll
-          for (int X = 0; X < NX; ++X)
+          for (int d = 0; d < 5; ++d) rB[pb][X][jb][d] = ep[d];
+        }
+      }
+    };
+    // 8 halves from half `bo` of the segment: five (hi, lo) dword pairs from dword bo >> 1, funnel-shifted by the parity
+    auto finish = [&](int i) {
 #pragma unroll
-            for (int ia = 0; ia < NB; ++ia)
+      for (int X = 0; X < NX; ++X)
 #pragma unroll
-              for (int jb = 0; jb < NB; ++jb)
-                acc[c][X % AX][ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al[X][ia] : Ah[X][ia], term == 1 ? Bl[X][jb] : Bh[X][jb],
-                                                                                acc[c][X % AX][ia][jb], 0, 0, 0);
+        for (int jb = 0; jb < NB; ++jb) {
+          const u2* d = rB[i % RD][X][jb];
+          const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, bsh[jb]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, bsh[jb]),
+                         __builtin_amdgcn_alignbit(d[3].x, d[2].x, bsh[jb]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, bsh[jb])};
+          const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, bsh[jb]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, bsh[jb]),
+                         __builtin_amdgcn_alignbit(d[3].y, d[2].y, bsh[jb]), __builtin_amdgcn_alignbit(d[4].y, d[3].y, bsh[jb])};
+          Bh[i % BD][X][jb] = __builtin_bit_cast(h8, wh);
+          Bl[i % BD][X][jb] = __builtin_bit_cast(h8, wl);
+        }
+    };
+    if (PIPE) { issue(0); issue(1); finish(0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int i = 0; i < NSTEP; ++i) {
+      const int c = i % 3;
+      if (!PIPE) { issue(i); finish(i); }
+      if (PIPE && i + 1 < NSTEP) finish(i + 1);   // requested a step ago
+      if (PIPE && i + 2 < NSTEP) issue(i + 2);
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int X = 0; X < NX; ++X)
+#pragma unroll
+          for (int ia = 0; ia < NB; ++ia)
+#pragma unroll
+            for (int jb = 0; jb < NB; ++jb) {
+              const h8 av = __builtin_bit_cast(h8, term == 2 ? rAl[i % RD][X][ia] : rAh[i % RD][X][ia]);
+              acc[c][X % AX][ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, term == 1 ? Bl[i % BD][X][jb] : Bh[i % BD][X][jb], acc[c][X % AX][ia][jb], 0, 0, 0);
+            }
+      if (PIPE) {
+        // issue order of a step: per MFMA (6) two or three of the 14 reads of step i + 2 and three of the 16 shifts of step i + 1
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i + 2 < NSTEP) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (k < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (i + 1 < NSTEP) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            if (k < 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     const float sc = inv_u * inv_e;   // powers of two

@@ -46,9 +46,11 @@ int main(int argc, char** argv) {
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int mode = 0; mode < 2; ++mode) {
-    for (int i = 0; i < 3; ++i) if (ics_launch_conv_mfma(mode, a, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
+    // long runs: the first milliseconds after idle are timed at ramping clocks, and a sustained loop of this kernel sits at
+    // the board power cap (1.39 kW, sclk ~2.1 GHz) -- a 20-launch timing ranked the variants differently
+    for (int i = 0; i < 200; ++i) if (ics_launch_conv_mfma(mode, a, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
     hipEventRecord(e0);
-    const int reps = getenv("ICS_BENCH_REPS") ? atoi(getenv("ICS_BENCH_REPS")) : 20;   // long runs: sample clocks / power beside it
+    const int reps = getenv("ICS_BENCH_REPS") ? atoi(getenv("ICS_BENCH_REPS")) : 2000;   // long runs: sample clocks / power beside it
     for (int i = 0; i < reps; ++i) ics_launch_conv_mfma(mode, a, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
