@@ -54,6 +54,18 @@
 #ifndef ICS_MFMA_INTERLEAVE
 #define ICS_MFMA_INTERLEAVE 1
 #endif
+#ifndef ICS_EPI_LOAD_AUX
+#define ICS_EPI_LOAD_AUX 0    /* cache policy of the epilogue operand loads (2 = nt measured slower: the update pass that follows finds less of u / ut in the memory-side cache) */
+#endif
+#ifndef ICS_EPI_LOAD_AUX0
+#define ICS_EPI_LOAD_AUX0 ICS_EPI_LOAD_AUX   /* the same for mode 0 (image operand) */
+#endif
+#ifndef ICS_RAW_AUX
+#define ICS_RAW_AUX 0         /* cache policy of the tile loads */
+#endif
+#ifndef ICS_EPI_STORE_AUX
+#define ICS_EPI_STORE_AUX 0
+#endif
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
 #endif
@@ -162,7 +174,7 @@ __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer
     const int row = t / C::XG, xg = t - row * C::XG;
     const int toff = 4 * (row * pitch + 12 * xg);
 #pragma unroll
-    for (int h = 0; h < 3; ++h) v[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16 * h, soff, 0));
+    for (int h = 0; h < 3; ++h) v[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16 * h, soff, ICS_RAW_AUX));
   }
 }
 
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) eop_early[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, 0);
+        for (int r = 0; r < 4; ++r) eop_early[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -466,8 +478,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         for (int r = 0; r < 4; ++r) {
           const int so = sb + 4 * (t + 4 * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
-          eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, 0);
-          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, 0);
+          eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
+          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
         }
       if (t0 == 0) ICS_TICK(3);
 #pragma unroll
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               u3 e;
 #pragma unroll
               for (int c = 0; c < 3; ++c) e[c] = __float_as_uint(__fsub_rn(av[c], __uint_as_float(eop[0][t][r][c])));
-              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, ICS_EPI_STORE_AUX);
             }
           } else {
             // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
                 rflags |= ((g != g) ? (1u << c) : 0u) | ((uv != uv) ? (8u << c) : 0u) | 64u;
               }
               u3 e = {__float_as_uint(av[0]), __float_as_uint(av[1]), __float_as_uint(av[2])};
-              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, ICS_EPI_STORE_AUX);
             }
           }
         }

@@ -20,6 +20,13 @@
 #include "ics_kernels.h"
 #include <type_traits>
 
+#ifndef ICS_GRADK_U_AUX
+#define ICS_GRADK_U_AUX 0   /* cache policy of the tile loads (2 = nt) */
+#endif
+#ifndef ICS_GRADK_E_AUX
+#define ICS_GRADK_E_AUX 0
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -132,7 +139,7 @@ __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg<NB>::UIT][3], f32x4u
     const int row = v / C::UXG, xg = v - row * C::UXG;
 #pragma unroll
     for (int h = 0; h < 3; ++h)
-      pu[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_u, 4 * (row * pitch + 12 * xg) + 16 * h, su, 0));
+      pu[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_u, 4 * (row * pitch + 12 * xg) + 16 * h, su, ICS_GRADK_U_AUX));
   }
   const int se = 4 * ((G.ay + y0) * pitch + 3 * (G.ax + x0 - 8 * NB));
 #pragma unroll
@@ -141,7 +148,7 @@ __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg<NB>::UIT][3], f32x4u
     const int row = v / C::EXG, xg = v - row * C::EXG;
 #pragma unroll
     for (int h = 0; h < 3; ++h)
-      pe[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_e, 4 * (row * pitch + 12 * xg) + 16 * h, se, 0));
+      pe[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_e, 4 * (row * pitch + 12 * xg) + 16 * h, se, ICS_GRADK_E_AUX));
   }
 }
 

@@ -4,6 +4,9 @@
 #include "ics_kernels.h"
 #include "ics_tv.h"
 
+#ifndef ICS_UPDATE_NT
+#define ICS_UPDATE_NT 15  /* streaming (nt) loads in k_update_rows: bit 0 u, 1 ut, 2 g, 3 f */
+#endif
 #ifndef ICS_GRADK_WAVES
 #define ICS_GRADK_WAVES 4   /* waves per k_gradk workgroup (4 or 8: measured equal, 0.28 ms at 4096^2) */
 #endif
@@ -555,6 +558,98 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
   }
 }
 
+
+// The same pass for the shipped mode (no T frame), lane-contiguous: a wave owns 256 consecutive floats of a row
+// (1 KiB per frame and instruction instead of 64 x 16 B at a 48-byte stride, a third of the cache-line requests); three
+// such segments per iteration keep 12 loads in flight per lane.  A float's channel is (flat index) mod 3: with
+// r = (first flat index of the lane) mod 3 the lane's element e has channel (r + e) mod 3 and pixel q + (r + e >= 3).
+// Same arithmetic, bit-identical to k_update.
+__global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
+  const IcsGeom& G = a.geo;
+  float dt[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float maxu = ics_key2f(a.red[ICS_RED_MAXU + c]);
+    const float maxg = ics_key2f(a.red[ICS_RED_MAXG + c]);
+    dt[c] = __fdiv_rn(__fmul_rn(a.step, maxu), __fadd_rn(maxg, 1e-15f));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      a.scal[ICS_SC_DT + c] = dt[c]; a.scal[ICS_SC_MAXU + c] = maxu; a.scal[ICS_SC_MAXG + c] = maxg;
+    }
+  }
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, knan = 0u;
+  const float lambd = a.lambd;
+  const int lane = threadIdx.x & 63;
+  const int rowf = 3 * G.uN;                       // floats per row
+  const int nwc = (rowf + 255) / 256;              // wave segments per row
+  const long nitems = (long)G.uM * nwc;
+  const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
+  constexpr int U = 3;
+  for (long it0 = gw * U; it0 < nitems; it0 += nw * U) {
+    f32x4 uq[U], tq[U], gq[U], fq[U];
+    int ys[U], f0s[U];
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      long it = it0 + s; it = it < nitems ? it : nitems - 1;
+      const int y = (int)(it / nwc), wc = (int)(it - (long)y * nwc);
+      ys[s] = __builtin_amdgcn_readfirstlane(y);
+      f0s[s] = 256 * __builtin_amdgcn_readfirstlane(wc) + 4 * lane;
+      const ptrdiff_t o = (ptrdiff_t)ys[s] * G.pitch + f0s[s];
+      const f32x4* pu = reinterpret_cast<const f32x4*>(a.u + o); const f32x4* pt = reinterpret_cast<const f32x4*>(a.ut + o);
+      const f32x4* pg = reinterpret_cast<const f32x4*>(a.g + o); const f32x4* pf = reinterpret_cast<const f32x4*>(a.f + o);
+      uq[s] = (ICS_UPDATE_NT & 1) ? __builtin_nontemporal_load(pu) : *pu;
+      tq[s] = (ICS_UPDATE_NT & 2) ? __builtin_nontemporal_load(pt) : *pt;
+      gq[s] = (ICS_UPDATE_NT & 4) ? __builtin_nontemporal_load(pg) : *pg;
+      fq[s] = (ICS_UPDATE_NT & 8) ? __builtin_nontemporal_load(pf) : *pf;
+    }
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      if (it0 + s >= nitems) break;                // wave-uniform
+      const int y = ys[s], f0 = f0s[s];
+      if (f0 >= rowf) continue;
+      const int q = f0 / 3, r = f0 - 3 * q;
+      const float dtr[3] = {r == 0 ? dt[0] : (r == 1 ? dt[1] : dt[2]), r == 0 ? dt[1] : (r == 1 ? dt[2] : dt[0]), r == 0 ? dt[2] : (r == 1 ? dt[0] : dt[1])};
+      const bool yin = (y >= G.pad) && (y < G.pad + G.M);
+      float un4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = q + ((r + e) >= 3 ? 1 : 0);
+        const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
+        const float uv = uq[s][e], tv = tq[s][e], gv = gq[s][e], fv = fq[s][e];
+        const float g = __fadd_rn(__fmul_rn(lambd, gv), __fmul_rn(__fsub_rn(uv, tv), 0.5f));
+        float un = __fsub_rn(uv, __fmul_rn(dtr[e % 3], g));
+        if (inside) {
+          const float d = __fdiv_rn(__fsub_rn(gv, fv), __fadd_rn(gv, fv));
+          float D = __fmul_rn(d, d);
+          if (!a.blind) D = __fdiv_rn(D, lambd);
+          un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fv));
+          if (a.want_dof) {
+            if (D != D) knan = 1u;
+            else { const uint32_t k = ics_f2key(D); kmin = kmin < k ? kmin : k; kmax = kmax > k ? kmax : k; }
+          }
+        }
+        un4[e] = un;
+      }
+      const ptrdiff_t o = (ptrdiff_t)y * G.pitch + f0;
+      if (f0 + 3 < rowf) {
+        const f32x4 w = {un4[0], un4[1], un4[2], un4[3]};
+        if (ICS_UPDATE_NT & 16) __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(a.u_out + o));
+        else *reinterpret_cast<f32x4*>(a.u_out + o) = w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (f0 + e < rowf) a.u_out[o + e] = un4[e];
+      }
+    }
+  }
+  if (a.want_dof) {
+    kmin = wave_min_u32(kmin); kmax = wave_max_u32(kmax); knan = wave_max_u32(knan);
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(a.dofkeys + 0, kmin); atomicMax(a.dofkeys + 1, kmax);
+      if (knan) atomicOr(a.dofkeys + 2, 1u);
+    }
+  }
+}
+
 }  // namespace
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
@@ -570,7 +665,9 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   static const int per_cu = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 2;
   const long cap = 256L * (per_cu > 0 ? per_cu : 2);
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_update, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  static const int rows_kernel = getenv("ICS_UPDATE_KERNEL") ? atoi(getenv("ICS_UPDATE_KERNEL")) : 1;   // 0: the pixel-group kernel everywhere
+  if (rows_kernel && !a.tv && a.tv_kind == 0) hipLaunchKernelGGL(k_update_rows, dim3((unsigned)cap), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_update, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
