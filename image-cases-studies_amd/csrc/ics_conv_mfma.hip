@@ -31,20 +31,23 @@
 //     gfx950, MI355X_MICROARCH.md LDS).  Two workgroups per CU: one's memory phases (conversion, epilogue)
 //     overlap the other's matrix phase.
 //   * wave w owns the 16-column block w of the tile for all three channels (12 accumulators).
-//   * Toeplitz fragments are never stored: the weights sit in LDS as zero-padded rows (64 B per (c, a, hi/lo),
-//     5.6 KB at K = 15); a lane's 8 consecutive halves start at half 8g - j + 15 of the row: it reads the five
-//     dwords that contain them and funnel-shifts by the parity.  (Full 1-KiB fragments from global memory made
-//     the kernel L1-bound; a ds_bpermute gather from a row image cost ~5 LDS cycles per bpermute.)
+//   * Toeplitz fragments are never stored: the weights sit in LDS as zero-padded rows (2 x 64 B per (c, a): the hi and lo
+//     split terms interleaved dword by dword, 5.6 KB at K = 15); a lane's 8 consecutive halves start at half 8g - j + 15 of
+//     the row: it reads the five (hi, lo) dword pairs that contain them (ds_read_b64) and funnel-shifts by the parity.
+//     (Full 1-KiB fragments from global memory made the kernel L1-bound; a ds_bpermute gather from a row image cost ~5 LDS
+//     cycles per bpermute; separate hi and lo rows cost 12 LDS instructions per step instead of 7.)
+//   * issue order inside a step (12 MFMAs): the LDS reads of the next step go into the shadows of the first MFMAs, the funnel
+//     shifts into the shadows of the last ones (sched_group_barrier); the reads are volatile so that they stay where they are
+//     requested -- as plain loads they were sunk to the shifts and every step waited out the LDS latency.
 //   * the fp32 HWC rows of the NEXT tile are requested into registers (2 waves per SIMD -> 256 VGPRs) before
 //     the MFMA loop, which itself issues no vector-memory load (they return in order): HBM latency is covered
 //     by the matrix phase; conversion to the fp16 planes happens after the epilogue of the current tile.
-//   * the accumulators are transposed back to HWC through LDS (aliasing the planes) and leave through the
-//     same epilogue arithmetic as the VALU kernel (residual / back-projection + step-size reductions).
+//   * epilogue straight from the accumulators: a lane holds one 12-byte HWC pixel per accumulator row, operands arrive and
+//     results leave as dwordx3 (16 lanes = 192 contiguous bytes), same arithmetic as the VALU kernel (residual /
+//     back-projection + step-size reductions).  Two barriers per tile (scale, planes written).
 #include "ics_common.h"
+#include <type_traits>
 
-#ifndef ICS_EPI_DIRECT
-#define ICS_EPI_DIRECT 1   /* 0 = the former epilogue through an LDS transpose (kept for A/B timing in tools/) */
-#endif
 #ifndef ICS_SKEW
 #define ICS_SKEW 0
 #endif
@@ -65,6 +68,9 @@
 #endif
 #ifndef ICS_EPI_STORE_AUX
 #define ICS_EPI_STORE_AUX 0
+#endif
+#ifndef ICS_EPI_ONEOP
+#define ICS_EPI_ONEOP 0   /* 1 = mode 1 with a single-operand epilogue when the majoriser frame is the u frame (measured: no gain) */
 #endif
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
@@ -117,8 +123,7 @@ struct MCfg {
   static constexpr int ROWB = 2 * LCOLS;             // 160 / 224 bytes per LDS row: conflict-free for the fragment reads
   static constexpr int PLANE = LROWS * ROWB;     // bytes per (channel, hi/lo) plane
   static constexpr int DATA = 6 * PLANE;
-  static constexpr int OUTB = TH * TW * 3 * 4;   // fp32 HWC transpose buffer (aliases the planes)
-  static constexpr int SCRATCH = DATA > OUTB ? DATA : OUTB;
+  static constexpr int SCRATCH = DATA;
   // weight rows in LDS: halves 8 .. K+24 of the zero-padded row Wp[idx] = W[idx - 15] (the taps sit at local
   // halves 7 .. K+6, at least ten zeros follow): every 8-half window that meets a tap lies inside, and the
   // all-zero windows are redirected to the zero tail
@@ -314,7 +319,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
       load_raw<C>(raw, rs_in, 4 * ((a.g.ay + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + nxi * C::TW - C::PAD)), opaque(tid), pitch);
     }
-#if ICS_EPI_DIRECT
     // ---- ...and the epilogue operand of THIS tile (mode 0: the image; one 12-byte pixel per accumulator row), so that
     // after the matrix phase the wave only subtracts and stores
     constexpr bool EARLY = ICS_EPI_EARLY(MODE);
@@ -328,7 +332,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 #pragma unroll
         for (int r = 0; r < 4; ++r) eop_early[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 
     ICS_TICK(7);
@@ -455,7 +458,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       }
     }
     ICS_TICK(1);
-#if ICS_EPI_DIRECT
     // ---- epilogue straight from the accumulators: lane (li, lg) holds, for each channel, the 16 rows
     // t + 16*lg + 4*r of pixel column 16*wv + li, i.e. one 12-byte HWC pixel per (t, r): operands arrive and
     // results leave as dwordx3 (16 lanes = 192 contiguous bytes of a row), no LDS transpose and no workgroup
@@ -468,7 +470,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int voff = 4 * (16 * elg * pitch + 3 * eli);          // lane part of the byte offset
       const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));      // wave-uniform part (tile origin + column block)
       constexpr int EOPS = (MODE == 0) ? 1 : 2;
-      constexpr int TB = ICS_EPI_TB(MODE);   // accumulator sets per batch: the operands of a batch are requested together
+      // TBc = accumulator sets per batch (the operands of a batch are requested together); ONE = the majoriser frame IS the u
+      // frame (first inner iteration of an outer one, pyx:462): one operand, and registers for a single batch
+      auto run_epi = [&](auto tbc, auto onec) {
+      constexpr int TB = decltype(tbc)::value;
+      constexpr bool ONE = decltype(onec)::value;
 #pragma unroll
       for (int t0 = 0; t0 < 4; t0 += TB) {
       u3 eop[EOPS][4][4];
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
           const int so = sb + 4 * (t + 4 * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
-          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
+          if (MODE == 1 && !ONE) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
         }
       if (t0 == 0) ICS_TICK(3);
 #pragma unroll
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * colx;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                const float uv = __uint_as_float(eop[0][t][r][c]), tv = __uint_as_float(eop[EOPS - 1][t][r][c]);
+                const float uv = __uint_as_float(eop[0][t][r][c]), tv = ONE ? uv : __uint_as_float(eop[EOPS - 1][t][r][c]);
                 float g;
                 if (a.tv_kind >= 2)
                   g = (float)((double)a.tv[o + c] + (double)__fmul_rn(lambd, av[c]));
@@ -524,146 +530,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
           }
         }
       }
+      };
+      if (ICS_EPI_ONEOP && MODE == 1 && a.u == a.ut) run_epi(std::integral_constant<int, 4>{}, std::true_type{});
+      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
     //  before the next conversion overwrites the planes)
-#else
-    __syncthreads();  // every wave is done with the planes
-    ICS_TICK(2);
-
-    // ---- accumulators -> fp32 HWC tile in LDS (row t + 16*lg + 4*r, column 16*wv + li) -------------------
-    {
-      float* o = reinterpret_cast<float*>(lds);
-      const float sc = inv_w * inv_x;   // powers of two
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int y = t + 16 * lg + 4 * r, x = 16 * wv + li;
-            o[(y * C::TW + x) * 3 + ch] = acc[ch][t][r] * sc;
-          }
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the accumulators are dead before the epilogue operands are requested
-    ICS_TICK(8);
-    // ---- epilogue (same arithmetic as ics_conv.hip): a task = one row x 4 pixels, processed in batches of EB
-    // tasks; the global operands of a batch are requested first (the first batch before the barrier, so that
-    // their latency overlaps the transposes).  Mode 1 carries two operand frames: smaller batches.
-    constexpr int EOPS = (MODE == 0) ? 1 : 2;
-    constexpr int EB = (MODE == 0) ? 2 : 1;
-    static_assert(C::EIT % EB == 0, "epilogue batches");
-    const float* ot = reinterpret_cast<const float*>(lds);
-    const int tide = opaque(tid);
-#pragma unroll
-    for (int eb = 0; eb < C::EIT; eb += EB) {
-      float4 eop[EB][EOPS][3];
-      bool evalid[EB];
-  #pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        const int task = tide + (eb + k) * C::NT;
-        const int ty = task / (C::TW / 4), tx = task - ty * (C::TW / 4);
-        const int y = y0 + ty, xp = x0 + 4 * tx;
-        bool ok = task < ((ICS_MFMA_ABLATE & 4) ? 16 : C::ETASK);
-        if (MODE == 0) ok = ok && y >= C::PAD && y < C::PAD + a.g.M && xp + 3 >= C::PAD && xp < C::PAD + a.g.N;
-        else ok = ok && y < a.g.uM && xp < a.g.uN;
-        evalid[k] = ok;
-        if (ok) {
-          const int ob = 4 * (ty * pitch + 12 * tx);      // byte offset inside the tile; the tile origin is uniform
-          const int sb = 4 * (y0 * pitch + 3 * x0);
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            eop[k][0][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_f, ob + 16 * j, sb, 0));
-            if (MODE == 1) eop[k][EOPS - 1][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_t, ob + 16 * j, sb, 0));
-          }
-        }
-      }
-      if (eb == 0) {
-        ICS_TICK(3);
-        __syncthreads();
-        ICS_TICK(4);
-      }
-
-      // ---- epilogue (same arithmetic as ics_conv.hip): a task = one row x 4 pixels --------------------------
-  #pragma unroll
-      for (int k = 0; k < EB; ++k) {
-        if (!evalid[k]) continue;
-        const int task = tide + (eb + k) * C::NT;
-        const int ty = task / (C::TW / 4), tx = task - ty * (C::TW / 4);
-        const int y = y0 + ty, xp = x0 + 4 * tx;
-        float av[12];
-        {
-          const float4* lp = reinterpret_cast<const float4*>(ot + ty * (C::TW * 3) + 12 * tx);
-  #pragma unroll
-          for (int j = 0; j < 3; ++j) { const float4 t4 = lp[j]; av[4*j] = t4.x; av[4*j+1] = t4.y; av[4*j+2] = t4.z; av[4*j+3] = t4.w; }
-        }
-        const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * xp;
-        if (MODE == 0) {
-          // error = synth - image on the M x N interior (pyx:488); the border ring of the frame stays 0
-          const int lo_x = C::PAD, hi_x = C::PAD + a.g.N;
-          float fv[12];
-  #pragma unroll
-          for (int j = 0; j < 3; ++j) { const float4 t4 = eop[k][0][j]; fv[4*j] = t4.x; fv[4*j+1] = t4.y; fv[4*j+2] = t4.z; fv[4*j+3] = t4.w; }
-          float e[12];
-  #pragma unroll
-          for (int f = 0; f < 12; ++f) e[f] = __fsub_rn(av[f], fv[f]);
-          if (xp >= lo_x && xp + 3 < hi_x) {
-            float4* op = reinterpret_cast<float4*>(a.out + o);
-  #pragma unroll
-            for (int j = 0; j < 3; ++j) op[j] = make_float4(e[4*j], e[4*j+1], e[4*j+2], e[4*j+3]);
-          } else {
-  #pragma unroll
-            for (int p = 0; p < 4; ++p)
-              if (xp + p >= lo_x && xp + p < hi_x) {
-                a.out[o + 3*p] = e[3*p]; a.out[o + 3*p + 1] = e[3*p+1]; a.out[o + 3*p + 2] = e[3*p+2];
-              }
-          }
-        } else {
-          // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
-          const float lambd = a.lambd;
-          float uv[12], tv[12];
-  #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float4 t4 = eop[k][0][j]; uv[4*j] = t4.x; uv[4*j+1] = t4.y; uv[4*j+2] = t4.z; uv[4*j+3] = t4.w;
-            const float4 s4 = eop[k][EOPS - 1][j]; tv[4*j] = s4.x; tv[4*j+1] = s4.y; tv[4*j+2] = s4.z; tv[4*j+3] = s4.w;
-          }
-  #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (xp + p < a.g.uN) {
-  #pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                float g;
-                if (a.tv_kind >= 2)
-                  g = (float)((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, av[3*p+c]));
-                else if (a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && xp + p >= 1 && xp + p <= a.g.uN - 2)
-                  g = (float)(((double)a.tv[o + 3*p+c] + (double)__fmul_rn(lambd, av[3*p+c])) + (double)__fsub_rn(uv[3*p+c], tv[3*p+c]) / 4.0);
-                else
-                  g = __fadd_rn(__fmul_rn(lambd, av[3*p+c]), __fmul_rn(__fsub_rn(uv[3*p+c], tv[3*p+c]), 0.5f));
-                mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
-                mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
-                rflags |= ((g != g) ? (1u << c) : 0u) | ((uv[3*p+c] != uv[3*p+c]) ? (8u << c) : 0u) | 64u;
-              }
-            }
-          }
-          if (xp + 3 < a.g.uN) {
-            float4* op = reinterpret_cast<float4*>(a.out + o);
-  #pragma unroll
-            for (int j = 0; j < 3; ++j) op[j] = make_float4(av[4*j], av[4*j+1], av[4*j+2], av[4*j+3]);
-          } else {
-  #pragma unroll
-            for (int p = 0; p < 4; ++p)
-              if (xp + p < a.g.uN) {
-                a.out[o + 3*p] = av[3*p]; a.out[o + 3*p + 1] = av[3*p+1]; a.out[o + 3*p + 2] = av[3*p+2];
-              }
-          }
-        }
-      }
-    }
-    ICS_TICK(5);
-    __syncthreads();  // the transpose buffer is consumed before the next tile's planes overwrite it
-    ICS_TICK(6);
-#endif
   }
 
   ICS_TICK_FLUSH;
