@@ -751,3 +751,43 @@ extern "C" int ics_bilateral(ics_ctx* c, const double* src, int H, int W, int ra
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "bilateral: %s", hipGetErrorString(e));
   return ICS_OK;
 }
+
+// deconvolve.py:245-249 -- skimage.transform.resize(order=3, mode="edge") restated on scipy.ndimage semantics (oracle/resize_oracle.py)
+extern "C" int ics_resize_bicubic(ics_ctx* c, const double* src, int H, int W, int C, double* out, int OH, int OW) {
+  if (!c || !src || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (H < 2 || W < 2 || C < 1 || OH < 1 || OW < 1) return fail(ICS_EINVAL, "bad sizes");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)H * W * C, no = (size_t)OH * OW * C;
+  // Gaussian anti-aliasing weights (host, float64 like scipy.ndimage.gaussian_filter1d)
+  auto weights = [](double sigma, std::vector<double>& w) {
+    const int r = (int)(4.0 * sigma + 0.5);
+    w.resize(2 * r + 1);
+    double sum = 0.0;
+    for (int k = -r; k <= r; ++k) { w[k + r] = exp(-0.5 / (sigma * sigma) * (double)k * (double)k); sum += w[k + r]; }
+    for (double& v : w) v /= sum;
+    return r;
+  };
+  const double sy = fmax(0.0, ((double)H / OH - 1.0) / 2.0), sx = fmax(0.0, ((double)W / OW - 1.0) / 2.0);
+  const bool smooth = (sy > 0.0 || sx > 0.0) && !(H == OH && W == OW);
+  std::vector<double> hwy, hwx;
+  int ry = 0, rx = 0;
+  if (smooth && sy > 1e-15) ry = weights(sy, hwy);
+  if (smooth && sx > 1e-15) rx = weights(sx, hwx);
+  double *ds = nullptr, *scr = nullptr, *dout = nullptr, *dw = nullptr;
+  hipError_t e = hipMalloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&scr, ics_resize_scratch_doubles(H, W, C) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, no * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && !hwy.empty()) e = hipMemcpyAsync(dw, hwy.data(), hwy.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    if (H == OH && W == OW) e = hipMemcpyAsync(dout, ds, n * 8, hipMemcpyDeviceToDevice, c->stream);
+    else e = ics_launch_resize(ds, H, W, C, hwy.empty() ? nullptr : dw, ry, hwx.empty() ? nullptr : dw + hwy.size(), rx, scr, dout, OH, OW, c->stream);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, no * 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (also keeps hwy / hwx alive until the copies are done)
+  hipFree(ds); hipFree(scr); hipFree(dout); hipFree(dw);
+  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "resize: %s", hipGetErrorString(e));
+  return ICS_OK;
+}

@@ -92,3 +92,8 @@ hipError_t ics_launch_tv(const float* u, int M, int N, float eps, int order, int
 hipError_t ics_launch_conv2d_symm(const double* src, int H, int W, const double* kern, int KH, int KW, double* out,
                                   int usm, double amount, hipStream_t s);
 hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, double std_s, double* out, hipStream_t s);
+
+// ---- bicubic resize between pyramid levels (ics_resize.hip; reference deconvolve.py:245-249) -------------
+size_t ics_resize_scratch_doubles(int H, int W, int C);
+hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
+                             double* out, int OH, int OW, hipStream_t s);

@@ -9,9 +9,10 @@ pyramid schedule, the mask-window arithmetic (:209-230) and the three call shape
 
 What differs, and why:
   * `skimage.transform.resize(order=3, mode="edge")` (:245-249) is an un-vendored dependency that is
-    not installed in this image; `resize_bicubic` below (scipy.ndimage cubic spline + the Gaussian
-    anti-aliasing skimage applies when shrinking) stands in for it.  PARITY UNPINNED for the pyramid
-    levels below 1.0; with `pyramid=False` (one level, scale 1) no resize is involved.
+    not installed in this image; `resize_bicubic` below runs its documented algorithm (Gaussian anti-aliasing
+    when shrinking + cubic B-spline interpolation) on the GPU (csrc/ics_resize.hip), checked against
+    scipy.ndimage in oracle/resize_oracle.py.  PARITY with skimage itself is UNPINNED for the pyramid levels
+    below 1.0; with `pyramid=False` (one level, scale 1) no resize is involved.
   * matplotlib pop-ups (:331-336) only when `display=True` and matplotlib is importable.
   * the 16-bit TIFF is written by `lib.utils.save` (own minimal writer instead of the vendored tifffile).
 """
@@ -45,24 +46,13 @@ def build_pyramid(psf_size, lambd):
 
 
 def resize_bicubic(img, shape):
-    """Stand-in for skimage.transform.resize(img, shape, order=3, mode="edge", preserve_range=True)."""
-    from scipy import ndimage
+    """skimage.transform.resize(img, shape, order=3, mode="edge", preserve_range=True) (deconvolve.py:245-249) on the GPU:
+    Gaussian anti-aliasing when shrinking + cubic B-spline interpolation, `ics_resize_bicubic` (csrc/ics_resize.hip)."""
     img = np.asarray(img, dtype=np.float64)
-    out_h, out_w = int(shape[0]), int(shape[1])
-    in_h, in_w = img.shape[0], img.shape[1]
-    if (in_h, in_w) == (out_h, out_w):
+    if img.shape[:2] == (int(shape[0]), int(shape[1])):   # scale 1: the interpolating spline reproduces the samples
         return img.copy()
-    fy, fx = in_h / out_h, in_w / out_w
-    sy, sx = max(0.0, (fy - 1) / 2), max(0.0, (fx - 1) / 2)       # skimage's anti-aliasing sigma
-    if sy > 0 or sx > 0:
-        img = ndimage.gaussian_filter(img, (sy, sx, 0), mode="nearest")
-    ys = (np.arange(out_h) + 0.5) * fy - 0.5
-    xs = (np.arange(out_w) + 0.5) * fx - 0.5
-    yy, xx = np.meshgrid(ys, xs, indexing="ij")
-    out = np.empty((out_h, out_w, img.shape[2]))
-    for c in range(img.shape[2]):
-        out[..., c] = ndimage.map_coordinates(img[..., c], [yy, xx], order=3, mode="nearest")
-    return out
+    from lib import _native
+    return _native.Context.get().resize_bicubic(img, shape)
 
 
 def mask_window(i, top, bottom, left, right):

@@ -90,9 +90,10 @@ def load():
     lib.ics_conv2d_symm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
     lib.ics_usm.argtypes = [vp, vp, ci, ci, vp, ci, ci, cd, vp]
     lib.ics_bilateral.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp]
+    lib.ics_resize_bicubic.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
                  "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_normalize_kernel",
-                 "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral"):
+                 "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic"):
         getattr(lib, name).restype = ci
     if lib.ics_abi_version() != 1:
         raise ImportError("libics_hip.so ABI version %d, expected 1" % lib.ics_abi_version())
@@ -174,6 +175,17 @@ class Context:
         src = np.ascontiguousarray(src, dtype=np.float64)
         out = np.empty_like(src)
         _check(load().ics_bilateral(self._h, _ptr(src), src.shape[0], src.shape[1], int(radius), float(std_i), float(std_s), _ptr(out)))
+        return out
+
+
+    def resize_bicubic(self, img, shape):
+        """deconvolve.py:245-249 (skimage.transform.resize order=3, mode="edge") on the device; H x W x C float64 in and out."""
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        if img.ndim == 2:
+            return self.resize_bicubic(img[..., None], shape)[..., 0]
+        oh, ow = int(shape[0]), int(shape[1])
+        out = np.empty((oh, ow, img.shape[2]), np.float64)
+        _check(load().ics_resize_bicubic(self._h, _ptr(img), img.shape[0], img.shape[1], img.shape[2], _ptr(out), oh, ow))
         return out
 
 
