@@ -462,11 +462,20 @@ static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   return ICS_OK;
 }
 
+// The PSF gradient has its own choice: the matrix-core kernel wins at every size it is built for (K <= 31; at K = 19, 21,
+// where AUTO keeps the packed-fp32 convolutions, 0.35 vs 0.97 ms at 4096^2)
+static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
+  if (!ics_gradk_mfma_supported(j->g.K) || p->conv == ICS_CONV_VECTOR) return false;
+  if (p->conv == ICS_CONV_MATRIX) return true;
+  static const int env = [] { const char* e = getenv("ICS_CONV_PATH"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+  return env != 1;
+}
+
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   IcsGradkArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
   RC(pr.begin(ICS_K_PSF_GRADIENT));
-  if (use_matrix_conv(j, p) && ics_gradk_mfma_supported(j->g.K)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
+  if (use_matrix_gradk(j, p)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
   else HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
   HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
   RC(pr.end());

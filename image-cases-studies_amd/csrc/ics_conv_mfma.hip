@@ -336,6 +336,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 
     ICS_TICK(7);
     // ---- Toeplitz MFMA loop ----------------------------------------------------------------------------
+    // (with two MFMA windows per column block, K >= 19, the interleaved order measured 5x slower -- 3.3 vs 0.58 ms at
+    //  4096^2 / 31x31 -- than the three blocks: kept for the single-window kernels only)
+    constexpr bool INTERLEAVE = ICS_MFMA_INTERLEAVE && C::NCH == 1;
     f4 acc[3][4];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
@@ -403,9 +406,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
             }
           }
           if (q + 1 < K) issueB(q + 1);
-#if !ICS_MFMA_INTERLEAVE
-          __builtin_amdgcn_sched_barrier(0);   // ...all requested before the step's MFMAs start
-#endif
+          if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);   // ...all requested before the step's MFMAs start
           // three split terms x windows; the (up to) 4 accumulators of a pass are independent
 #pragma unroll
           for (int term = 0; term < 3; ++term) {
@@ -421,17 +422,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               }
             }
           }
-#if !ICS_MFMA_INTERLEAVE
-          __builtin_amdgcn_sched_barrier(0);   // ...and consumed behind them
-#endif
+          if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);   // ...and consumed behind them
           if (q + 1 < K) finishB(q + 1);
 #pragma unroll
           for (int h = 0; h < C::NCH; ++h) { Ah[h] = Nh[h]; Al[h] = Nl[h]; }
-#if ICS_MFMA_INTERLEAVE
           // issue order inside the step: the LDS reads go into the shadows of the first MFMAs (an MFMA holds the matrix
           // pipe for 16 cycles, the wave can issue an independent instruction meanwhile), the funnel shifts into the
           // shadows of the last ones; as three blocks (reads | MFMAs | shifts) a step cost their sum
-          {
+          if (INTERLEAVE) {
             int nt = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
@@ -452,7 +450,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               for (int j = 0; j < (nv / 2 + tail - 1) / tail; ++j) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             }
           }
-#endif
           __builtin_amdgcn_sched_barrier(0);   // keep each step's prefetches in that step (register pressure)
         }
       }

@@ -90,11 +90,11 @@ typedef struct ics_rl_params {
   int reserved[1];
 } ics_rl_params;
 
-#define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built and faster (MK <= 17 and 23..37; the PSF
-                             gradient for MK <= 15), vector kernels otherwise; env ICS_CONV_PATH=vector|matrix
+#define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built and faster (convolutions: MK <= 17 and 23..37;
+                             PSF gradient: MK <= 31), vector kernels otherwise; env ICS_CONV_PATH=vector|matrix
                              overrides the choice of AUTO                                                 */
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip) + fp32-MFMA PSF gradient: fp32 products */
-#define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 37, ics_gradk_mfma.hip MK <= 15): operands split
+#define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 37, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
 
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
