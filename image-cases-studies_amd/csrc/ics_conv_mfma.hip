@@ -336,9 +336,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 
     ICS_TICK(7);
     // ---- Toeplitz MFMA loop ----------------------------------------------------------------------------
-    // (with two MFMA windows per column block, K >= 19, the interleaved order measured 5x slower -- 3.3 vs 0.58 ms at
-    //  4096^2 / 31x31 -- than the three blocks: kept for the single-window kernels only)
-    constexpr bool INTERLEAVE = ICS_MFMA_INTERLEAVE && C::NCH == 1;
+    // (The two-window kernels, K >= 19, need the whole q loop unrolled for this -- the Makefile raises the pragma-unroll
+    //  threshold for this file; with the default threshold the loop stayed rolled, the B fragments went to scratch and
+    //  the kernel was 5x slower: 3.3 vs 0.51 ms at 4096^2 / 31x31.)
+    constexpr bool INTERLEAVE = ICS_MFMA_INTERLEAVE != 0;
     f4 acc[3][4];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
@@ -597,10 +598,49 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// Translation units: the 36 kernel instances take minutes to compile, so libics_hip.so builds them in three parts
+// (ICS_MFMA_PART = 0: K <= 17 + the public entry points, 1: K = 19..27, 2: K = 29..37; ics_conv_mfma_p1/_p2.hip include this
+// file).  Without ICS_MFMA_PART (tools/) everything is in one unit.
+#ifndef ICS_MFMA_PART
+#define ICS_MFMA_ALL 1
+#define ICS_MFMA_PART 0
+#else
+#define ICS_MFMA_ALL 0
+#endif
+
+hipError_t ics_launch_conv_mfma_part1(int mode, const IcsConvArgs& a, hipStream_t s);
+hipError_t ics_launch_conv_mfma_part2(int mode, const IcsConvArgs& a, hipStream_t s);
+
+#if ICS_MFMA_ALL || ICS_MFMA_PART == 1
+hipError_t ics_launch_conv_mfma_part1(int mode, const IcsConvArgs& a, hipStream_t s) {
+  switch (a.g.K) {
+    case 19: return launch_k<19>(mode, a, s);
+    case 21: return launch_k<21>(mode, a, s);
+    case 23: return launch_k<23>(mode, a, s);
+    case 25: return launch_k<25>(mode, a, s);
+    case 27: return launch_k<27>(mode, a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
+#if ICS_MFMA_ALL || ICS_MFMA_PART == 2
+hipError_t ics_launch_conv_mfma_part2(int mode, const IcsConvArgs& a, hipStream_t s) {
+  switch (a.g.K) {
+    case 29: return launch_k<29>(mode, a, s);
+    case 31: return launch_k<31>(mode, a, s);
+    case 33: return launch_k<33>(mode, a, s);
+    case 35: return launch_k<35>(mode, a, s);
+    case 37: return launch_k<37>(mode, a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
+
+#if ICS_MFMA_PART == 0
 bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   // K = 39: planes + weights exceed 160 KB
 
 // Measured on MI355X at 4096^2: with two 32-wide windows per column block (K >= 19) only K/64 of the MACs
-// are useful and the 126 KB of planes leave room for one workgroup per CU; the packed-fp32 kernels win at K = 19, 21.
+// are useful and the 126 KB of planes leave room for one workgroup per CU; the packed-fp32 kernels are level at K = 19, 21.
 bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K) && K != 19 && K != 21; }
 
 // weight table: [c][a] rows of 2 * WROWB bytes, hi/lo dword-interleaved (the LDS image), then one float 1/s_w (ics_common.h)
@@ -617,16 +657,7 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 13: return launch_k<13>(mode, a, s);
     case 15: return launch_k<15>(mode, a, s);
     case 17: return launch_k<17>(mode, a, s);
-    case 19: return launch_k<19>(mode, a, s);
-    case 21: return launch_k<21>(mode, a, s);
-    case 23: return launch_k<23>(mode, a, s);
-    case 25: return launch_k<25>(mode, a, s);
-    case 27: return launch_k<27>(mode, a, s);
-    case 29: return launch_k<29>(mode, a, s);
-    case 31: return launch_k<31>(mode, a, s);
-    case 33: return launch_k<33>(mode, a, s);
-    case 35: return launch_k<35>(mode, a, s);
-    case 37: return launch_k<37>(mode, a, s);
-    default: return hipErrorInvalidValue;
+    default: return a.g.K <= 27 ? ics_launch_conv_mfma_part1(mode, a, s) : ics_launch_conv_mfma_part2(mode, a, s);
   }
 }
+#endif
