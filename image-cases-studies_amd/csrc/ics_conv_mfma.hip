@@ -470,12 +470,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       constexpr int EOPS = (MODE == 0) ? 1 : 2;
       // TBc = accumulator sets per batch (the operands of a batch are requested together); ONE = the majoriser frame IS the u
       // frame (first inner iteration of an outer one, pyx:462): one operand, and registers for a single batch
-      auto run_epi = [&](auto tbc, auto onec) {
+      // TVOP (extended modes): the T frame is a third operand, requested like the others (as per-element scalar loads it
+      // cost the back-projection +40 %)
+      const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
+      auto run_epi = [&](auto tbc, auto onec, auto tvc) {
       constexpr int TB = decltype(tbc)::value;
       constexpr bool ONE = decltype(onec)::value;
+      constexpr bool TVOP = decltype(tvc)::value;
 #pragma unroll
       for (int t0 = 0; t0 < 4; t0 += TB) {
-      u3 eop[EOPS][4][4];
+      u3 eop[EOPS][4][4], eopT[4][4];
 #pragma unroll
       for (int t = t0; t < t0 + TB; ++t)
 #pragma unroll
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
           if (MODE == 1 && !ONE) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
+          if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
       if (t0 == 0) ICS_TICK(3);
 #pragma unroll
@@ -507,15 +512,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
             // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
             if (y < a.g.uM && colx < a.g.uN && (!(ICS_MFMA_ABLATE & 8) || av[0] + av[1] + av[2] == 12345.678f)) {
               const float lambd = a.lambd;
-              const ptrdiff_t o = (ptrdiff_t)y * pitch + 3 * colx;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
                 const float uv = __uint_as_float(eop[0][t][r][c]), tv = ONE ? uv : __uint_as_float(eop[EOPS - 1][t][r][c]);
                 float g;
-                if (a.tv_kind >= 2)
-                  g = (float)((double)a.tv[o + c] + (double)__fmul_rn(lambd, av[c]));
-                else if (a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && colx >= 1 && colx <= a.g.uN - 2)
-                  g = (float)(((double)a.tv[o + c] + (double)__fmul_rn(lambd, av[c])) + (double)__fsub_rn(uv, tv) / 4.0);
+                const float Tv = TVOP ? __uint_as_float(eopT[t][r][c]) : 0.f;
+                if (TVOP && a.tv_kind >= 2)
+                  g = (float)((double)Tv + (double)__fmul_rn(lambd, av[c]));
+                else if (TVOP && a.tv_kind == 1 && y >= 1 && y <= a.g.uM - 2 && colx >= 1 && colx <= a.g.uN - 2)
+                  g = (float)(((double)Tv + (double)__fmul_rn(lambd, av[c])) + (double)__fsub_rn(uv, tv) / 4.0);
                 else
                   g = __fadd_rn(__fmul_rn(lambd, av[c]), __fmul_rn(__fsub_rn(uv, tv), 0.5f));
                 mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
@@ -529,8 +534,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         }
       }
       };
-      if (ICS_EPI_ONEOP && MODE == 1 && a.u == a.ut) run_epi(std::integral_constant<int, 4>{}, std::true_type{});
-      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{});
+      if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+      else if (ICS_EPI_ONEOP && MODE == 1 && a.u == a.ut) run_epi(std::integral_constant<int, 4>{}, std::true_type{}, std::false_type{});
+      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{}, std::false_type{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads

@@ -186,30 +186,40 @@ __device__ __forceinline__ float pam_term(const float (&n)[3][20], int i, int c,
 // for the image step of pyx:548.  One lane = 4 pixels; the 3x6-px neighbourhoods of u and ut come as 3 rows of
 // 5 unaligned dwordx4 loads each (served by L1/L2).
 // =================================================================================================
+// One thread = 4 pixels x TVSEG rows, walking down with a three-row window in registers (each row of u / ut is loaded
+// once per thread instead of three times; KIND is a template parameter so that the PAM kinds do not load ut at all).
+// (KIND 1 evaluates four stencils with IEEE divisions and square roots per value: bound by VALU latency, it ran slower with
+//  the 164 registers of the walking window -- 0.50 vs 0.44 ms -- and keeps one row per thread.)
+template <int KIND>
 __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
+  constexpr int TVSEG = KIND == 1 ? 1 : 16;
   const IcsGeom& G = a.geo;
   const int ngx = G.tiles_x * 16;
-  const long total = (long)G.uM * ngx;
+  const int nseg = (G.uM + TVSEG - 1) / TVSEG;
+  const long total = (long)nseg * ngx;
   typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   float mt[3] = {0.f, 0.f, 0.f}, mf[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   bool nan_t[3] = {false, false, false}, nan_f[3] = {false, false, false}, any_f = false;
   const float eps = a.epsilon;
-  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
-    const int y = (int)(gid / ngx);
-    const int xp = 4 * (int)(gid - (long)y * ngx);
-    if (xp >= G.uN) continue;
-    float nu[3][20], nt[3][20];
+  auto load_row = [&](const float* base, int y, int xp, float (&row)[20]) {
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * (xp - 1);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const ptrdiff_t o = (ptrdiff_t)(y - 1 + r) * G.pitch + 3 * (xp - 1);
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        const f32x4u p = *reinterpret_cast<const f32x4u*>(a.u + o + 4 * j);
-        const f32x4u q = *reinterpret_cast<const f32x4u*>(a.ut + o + 4 * j);
-        nu[r][4*j] = p.x; nu[r][4*j+1] = p.y; nu[r][4*j+2] = p.z; nu[r][4*j+3] = p.w;
-        nt[r][4*j] = q.x; nt[r][4*j+1] = q.y; nt[r][4*j+2] = q.z; nt[r][4*j+3] = q.w;
-      }
+    for (int j = 0; j < 5; ++j) {
+      const f32x4u p = *reinterpret_cast<const f32x4u*>(base + o + 4 * j);
+      row[4*j] = p.x; row[4*j+1] = p.y; row[4*j+2] = p.z; row[4*j+3] = p.w;
     }
+  };
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int seg = (int)(gid / ngx);
+    const int xp = 4 * (int)(gid - (long)seg * ngx);
+    if (xp >= G.uN) continue;
+    const int ybeg = seg * TVSEG, yend = ybeg + TVSEG < G.uM ? ybeg + TVSEG : G.uM;
+    float nu[3][20], nt[3][20];
+    load_row(a.u, ybeg - 1, xp, nu[0]); load_row(a.u, ybeg, xp, nu[1]);
+    if (KIND == 1) { load_row(a.ut, ybeg - 1, xp, nt[0]); load_row(a.ut, ybeg, xp, nt[1]); }
+    for (int y = ybeg; y < yend; ++y) {
+    load_row(a.u, y + 1, xp, nu[2]);
+    if (KIND == 1) load_row(a.ut, y + 1, xp, nt[2]);
     const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
     float T[12];
     const bool yact = (y >= 1) && (y <= G.uM - 2);
@@ -221,8 +231,8 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
       for (int c = 0; c < 3; ++c) {
         const int i = 3 * (p + 1) + c;
         float t = 0.f;
-        if (a.kind >= 2) {
-          if (yact && x >= 1 && x <= G.uN - 2) t = pam_term(nu, i, c, eps, a.kind == 3);
+        if (KIND >= 2) {
+          if (yact && x >= 1 && x <= G.uN - 2) t = pam_term(nu, i, c, eps, KIND == 3);
         } else if (yact && x >= 1 && x <= G.uN - 2) {
           const IcsTvOut u1 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 1);
           const IcsTvOut u2 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 2);
@@ -255,6 +265,12 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
         if (xp + p < G.uN) { a.tv[o + 3*p] = T[3*p]; a.tv[o + 3*p + 1] = T[3*p+1]; a.tv[o + 3*p + 2] = T[3*p+2]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+      nu[0][k] = nu[1][k]; nu[1][k] = nu[2][k];
+      if (KIND == 1) { nt[0][k] = nt[1][k]; nt[1][k] = nt[2][k]; }
+    }
     }
   }
 #pragma unroll
@@ -559,19 +575,23 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
 }
 
 
-// The same pass for the shipped mode (no T frame), lane-contiguous: a wave owns 256 consecutive floats of a row
-// (1 KiB per frame and instruction instead of 64 x 16 B at a 48-byte stride, a third of the cache-line requests); three
-// such segments per iteration keep 12 loads in flight per lane.  A float's channel is (flat index) mod 3: with
-// r = (first flat index of the lane) mod 3 the lane's element e has channel (r + e) mod 3 and pixel q + (r + e >= 3).
-// Same arithmetic, bit-identical to k_update.
+// The same pass, lane-contiguous: a wave owns 256 consecutive floats of a row (1 KiB per frame and instruction instead
+// of 64 x 16 B at a 48-byte stride, a third of the cache-line requests); three such segments per iteration keep 12+ loads
+// in flight per lane.  A float's channel is (flat index) mod 3: with r = (first flat index of the lane) mod 3 the lane's
+// element e has channel (r + e) mod 3 and pixel q + (r + e >= 3).  Loads are streaming (nt): nothing read here is read
+// again before ~1 GB of other traffic, and default loads evicted what the next kernel re-reads (0.197 -> 0.173 ms).
+// Same arithmetic, bit-identical to k_update.  TVK: 0 shipped mode, 1 active MM-TV, 2 PAM (kinds 2 and 3).
+template <int TVK>
 __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
   const IcsGeom& G = a.geo;
-  float dt[3];
+  float dt[3], dt2[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float maxu = ics_key2f(a.red[ICS_RED_MAXU + c]);
     const float maxg = ics_key2f(a.red[ICS_RED_MAXG + c]);
     dt[c] = __fdiv_rn(__fmul_rn(a.step, maxu), __fadd_rn(maxg, 1e-15f));
+    if (TVK == 1)   // pyx:548: dt = step*(max image_k + 0)/(max|gradu_k| + 1e-15) with gradu = T
+      dt2[c] = __fdiv_rn(__fmul_rn(a.step, ics_key2f(a.red[ICS_RED_MAXF + c])), __fadd_rn(ics_key2f(a.red[ICS_RED_MAXT + c]), 1e-15f));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       a.scal[ICS_SC_DT + c] = dt[c]; a.scal[ICS_SC_MAXU + c] = maxu; a.scal[ICS_SC_MAXG + c] = maxg;
     }
@@ -583,9 +603,9 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
   const int nwc = (rowf + 255) / 256;              // wave segments per row
   const long nitems = (long)G.uM * nwc;
   const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
-  constexpr int U = 3;
+  constexpr int U = TVK == 0 ? 3 : 2;
   for (long it0 = gw * U; it0 < nitems; it0 += nw * U) {
-    f32x4 uq[U], tq[U], gq[U], fq[U];
+    f32x4 uq[U], tq[U], gq[U], fq[U], Tq[U];
     int ys[U], f0s[U];
 #pragma unroll
     for (int s = 0; s < U; ++s) {
@@ -597,9 +617,10 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
       const f32x4* pu = reinterpret_cast<const f32x4*>(a.u + o); const f32x4* pt = reinterpret_cast<const f32x4*>(a.ut + o);
       const f32x4* pg = reinterpret_cast<const f32x4*>(a.g + o); const f32x4* pf = reinterpret_cast<const f32x4*>(a.f + o);
       uq[s] = (ICS_UPDATE_NT & 1) ? __builtin_nontemporal_load(pu) : *pu;
-      tq[s] = (ICS_UPDATE_NT & 2) ? __builtin_nontemporal_load(pt) : *pt;
+      if (TVK != 2) tq[s] = (ICS_UPDATE_NT & 2) ? __builtin_nontemporal_load(pt) : *pt;
       gq[s] = (ICS_UPDATE_NT & 4) ? __builtin_nontemporal_load(pg) : *pg;
-      fq[s] = (ICS_UPDATE_NT & 8) ? __builtin_nontemporal_load(pf) : *pf;
+      if (TVK != 2) fq[s] = (ICS_UPDATE_NT & 8) ? __builtin_nontemporal_load(pf) : *pf;
+      if (TVK != 0) Tq[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.tv + o));
     }
 #pragma unroll
     for (int s = 0; s < U; ++s) {
@@ -608,19 +629,32 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
       if (f0 >= rowf) continue;
       const int q = f0 / 3, r = f0 - 3 * q;
       const float dtr[3] = {r == 0 ? dt[0] : (r == 1 ? dt[1] : dt[2]), r == 0 ? dt[1] : (r == 1 ? dt[2] : dt[0]), r == 0 ? dt[2] : (r == 1 ? dt[0] : dt[1])};
+      const float dt2r[3] = {r == 0 ? dt2[0] : (r == 1 ? dt2[1] : dt2[2]), r == 0 ? dt2[1] : (r == 1 ? dt2[2] : dt2[0]), r == 0 ? dt2[2] : (r == 1 ? dt2[0] : dt2[1])};
       const bool yin = (y >= G.pad) && (y < G.pad + G.M);
+      const ptrdiff_t o = (ptrdiff_t)y * G.pitch + f0;
       float un4[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int x = q + ((r + e) >= 3 ? 1 : 0);
         const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
-        const float uv = uq[s][e], tv = tq[s][e], gv = gq[s][e], fv = fq[s][e];
-        const float g = __fadd_rn(__fmul_rn(lambd, gv), __fmul_rn(__fsub_rn(uv, tv), 0.5f));
+        const float uv = uq[s][e], gv = gq[s][e];
+        float g;
+        if (TVK == 2)                                                            // PAM: G = T + lambd*gradu, no majoriser term
+          g = (float)((double)Tq[s][e] + (double)__fmul_rn(lambd, gv));
+        else if (TVK == 1 && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
+          g = (float)(((double)Tq[s][e] + (double)__fmul_rn(lambd, gv)) + (double)__fsub_rn(uv, tq[s][e]) / 4.0);
+        else
+          g = __fadd_rn(__fmul_rn(lambd, gv), __fmul_rn(__fsub_rn(uv, tq[s][e]), 0.5f));
         float un = __fsub_rn(uv, __fmul_rn(dtr[e % 3], g));
-        if (inside) {
+        if (inside && TVK != 2) {   // (PAM has no DoF blend)
+          float fv = fq[s][e];
           const float d = __fdiv_rn(__fsub_rn(gv, fv), __fadd_rn(gv, fv));
           float D = __fmul_rn(d, d);
           if (!a.blind) D = __fdiv_rn(D, lambd);
+          if (TVK == 1) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
+            fv = __fsub_rn(fv, __fdiv_rn(__fmul_rn(dt2r[e % 3], Tq[s][e]), lambd));
+            a.f_rw[o + e] = fv;
+          }
           un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fv));
           if (a.want_dof) {
             if (D != D) knan = 1u;
@@ -629,7 +663,6 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
         }
         un4[e] = un;
       }
-      const ptrdiff_t o = (ptrdiff_t)y * G.pitch + f0;
       if (f0 + 3 < rowf) {
         const f32x4 w = {un4[0], un4[1], un4[2], un4[3]};
         if (ICS_UPDATE_NT & 16) __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(a.u_out + o));
@@ -653,7 +686,9 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
 }  // namespace
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_tvterm, dim3(1024), dim3(256), 0, s, a);
+  if (a.kind == 1) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a);
+  else if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -666,7 +701,10 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   const long cap = 256L * (per_cu > 0 ? per_cu : 2);
   if (blocks > cap) blocks = cap;
   static const int rows_kernel = getenv("ICS_UPDATE_KERNEL") ? atoi(getenv("ICS_UPDATE_KERNEL")) : 1;   // 0: the pixel-group kernel everywhere
-  if (rows_kernel && !a.tv && a.tv_kind == 0) hipLaunchKernelGGL(k_update_rows, dim3((unsigned)cap), dim3(256), 0, s, a);
+  const int tvk = (a.tv && a.tv_kind) ? (a.tv_kind >= 2 ? 2 : 1) : 0;
+  if (rows_kernel && tvk == 0) hipLaunchKernelGGL(k_update_rows<0>, dim3((unsigned)cap), dim3(256), 0, s, a);
+  else if (rows_kernel && tvk == 1) hipLaunchKernelGGL(k_update_rows<1>, dim3((unsigned)cap), dim3(256), 0, s, a);
+  else if (rows_kernel && tvk == 2) hipLaunchKernelGGL(k_update_rows<2>, dim3((unsigned)cap), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_update, dim3((unsigned)blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
