@@ -14,4 +14,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -- python3 $R/bench.py --s
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -- python3 $R/bench.py --steps 5 --warmup 0 --no-cpu-baseline --no-profile --no-other-mode > /dev/null 2>&1
 for d in kt fetch write; do f=$(find $O/$d -name "*.db" | head -1); python3 $R/scripts/rocprof_summary.py $f > $O/$d.txt 2>&1; done
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete
-tail -1 $O/bench_blind.json | cut -c1-400; head -12 $O/kt.txt; grep -A1 "k_conv_mfma\|k_update\|k_gradk<" $O/fetch.txt | head -20; grep -A1 "k_conv_mfma\|k_update\|k_gradk<" $O/write.txt | head -20
+tail -1 $O/bench_blind.json | cut -c1-400; head -12 $O/kt.txt; grep -A1 "k_conv_mfma\|k_update\|k_gradk" $O/fetch.txt | head -20; grep -A1 "k_conv_mfma\|k_update\|k_gradk" $O/write.txt | head -20
