@@ -1,5 +1,5 @@
 T=image-cases-studies_amd/csrc/tools
-for v in v3 a1 a10; do
+for v in 0 a1; do   # `make -C image-cases-studies_amd/csrc tools` builds them
   echo "=== $v"
   ICS_BENCH_REPS=20000 $T/bench_conv_mfma_$v > gpurun_out/smi_$v.log 2>&1 &
   PID=$!
