@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "../../include/ics_hip.h"
@@ -798,5 +799,161 @@ extern "C" int ics_resize_bicubic(ics_ctx* c, const double* src, int H, int W, i
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (also keeps hwy / hwx alive until the copies are done)
   hipFree(ds); hipFree(scr); hipFree(dout); hipFree(dw);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "resize: %s", hipGetErrorString(e));
+  return ICS_OK;
+}
+
+// ================================================================================================
+// Device-resident images: the frames deconvolve.py keeps between two richardson_lucy_MM calls (pyramid levels, blind ->
+// non-blind phase) stay in HBM; every operation is queued on the context's stream, only ics_img_download synchronises.
+// ================================================================================================
+struct ics_img {
+  ics_ctx* ctx;
+  int H, W;
+  float* d;
+};
+
+static int img_new(ics_ctx* c, int H, int W, ics_img** out) {
+  if (!c || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (H < 1 || W < 1) return fail(ICS_EINVAL, "bad image size %d x %d", H, W);
+  HIPCHK(hipSetDevice(c->device));
+  ics_img* m = new (std::nothrow) ics_img{c, H, W, nullptr};
+  if (!m) return fail(ICS_ENOMEM, "host allocation failed");
+  hipError_t e = hipMalloc((void**)&m->d, (size_t)H * W * 3 * 4);
+  if (e != hipSuccess) { delete m; (void)hipGetLastError(); return fail(ICS_ENOMEM, "hipMalloc of a %d x %d image: %s", H, W, hipGetErrorString(e)); }
+  *out = m;
+  return ICS_OK;
+}
+
+extern "C" int ics_img_create(ics_ctx* c, int H, int W, ics_img** out) { return img_new(c, H, W, out); }
+extern "C" void ics_img_destroy(ics_img* m) {
+  if (!m) return;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  hipFree(m->d);
+  delete m;
+}
+extern "C" int ics_img_shape(const ics_img* m, int* H, int* W) {
+  if (!m) return fail(ICS_EINVAL, "image is NULL");
+  if (H) *H = m->H;
+  if (W) *W = m->W;
+  return ICS_OK;
+}
+extern "C" int ics_img_upload(ics_img* m, const float* host) {
+  if (!m || !host) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  HIPCHK(hipMemcpyAsync(m->d, host, (size_t)m->H * m->W * 12, hipMemcpyHostToDevice, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));   // the host buffer may be released by the caller
+  return ICS_OK;
+}
+extern "C" int ics_img_download(const ics_img* m, float* host) {
+  if (!m || !host) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  HIPCHK(hipMemcpyAsync(host, m->d, (size_t)m->H * m->W * 12, hipMemcpyDeviceToHost, m->ctx->stream));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  return ICS_OK;
+}
+extern "C" int ics_img_pad_edge(const ics_img* src, int top, int bottom, int left, int right, ics_img** out) {
+  if (!src || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (top < 0 || bottom < 0 || left < 0 || right < 0) return fail(ICS_EINVAL, "negative padding");
+  RC(img_new(src->ctx, src->H + top + bottom, src->W + left + right, out));
+  HIPCHK(ics_launch_img_pad_edge(src->d, src->H, src->W, (*out)->d, top, bottom, left, right, src->ctx->stream));
+  return ICS_OK;
+}
+static int rect_ok(const ics_img* m, int y0, int x0, int H, int W) { return y0 >= 0 && x0 >= 0 && H >= 1 && W >= 1 && y0 + H <= m->H && x0 + W <= m->W; }
+extern "C" int ics_img_crop(const ics_img* src, int y0, int x0, int H, int W, ics_img** out) {
+  if (!src || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (!rect_ok(src, y0, x0, H, W)) return fail(ICS_EINVAL, "crop [%d:%d, %d:%d] outside a %d x %d image", y0, y0 + H, x0, x0 + W, src->H, src->W);
+  RC(img_new(src->ctx, H, W, out));
+  HIPCHK(hipMemcpy2DAsync((*out)->d, (size_t)W * 12, src->d + ((size_t)y0 * src->W + x0) * 3, (size_t)src->W * 12, (size_t)W * 12, H,
+                          hipMemcpyDeviceToDevice, src->ctx->stream));
+  return ICS_OK;
+}
+extern "C" int ics_img_paste(ics_img* dst, int y0, int x0, const ics_img* src) {
+  if (!src || !dst) return fail(ICS_EINVAL, "NULL argument");
+  if (src->ctx != dst->ctx) return fail(ICS_EINVAL, "images of different contexts");
+  if (!rect_ok(dst, y0, x0, src->H, src->W)) return fail(ICS_EINVAL, "paste of %d x %d at (%d, %d) outside a %d x %d image", src->H, src->W, y0, x0, dst->H, dst->W);
+  HIPCHK(hipSetDevice(dst->ctx->device));
+  HIPCHK(hipMemcpy2DAsync(dst->d + ((size_t)y0 * dst->W + x0) * 3, (size_t)dst->W * 12, src->d, (size_t)src->W * 12, (size_t)src->W * 12, src->H,
+                          hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return ICS_OK;
+}
+extern "C" int ics_img_gamma(ics_img* m, float div, float exponent, float mul, int clip01) {
+  if (!m) return fail(ICS_EINVAL, "image is NULL");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  HIPCHK(ics_launch_img_gamma(m->d, (long)m->H * m->W * 3, div, exponent, mul, clip01, m->ctx->stream));
+  return ICS_OK;
+}
+// deconvolve.py:245-249 on a device image: float64 inside (as skimage / scipy compute), rounded to float32 like the
+// reference's `.astype(np.float32)`
+extern "C" int ics_img_resize(const ics_img* src, int OH, int OW, ics_img** out) {
+  if (!src || !out) return fail(ICS_EINVAL, "NULL argument");
+  if (OH < 1 || OW < 1 || src->H < 2 || src->W < 2) return fail(ICS_EINVAL, "bad sizes");
+  ics_ctx* c = src->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const int H = src->H, W = src->W;
+  if (H == OH && W == OW) return ics_img_crop(src, 0, 0, H, W, out);
+  RC(img_new(c, OH, OW, out));
+  const size_t n = (size_t)H * W * 3, no = (size_t)OH * OW * 3;
+  auto weights = [](double sigma, std::vector<double>& w) {
+    const int r = (int)(4.0 * sigma + 0.5);
+    w.resize(2 * r + 1);
+    double sum = 0.0;
+    for (int k = -r; k <= r; ++k) { w[k + r] = exp(-0.5 / (sigma * sigma) * (double)k * (double)k); sum += w[k + r]; }
+    for (double& v : w) v /= sum;
+    return r;
+  };
+  const double sy = fmax(0.0, ((double)H / OH - 1.0) / 2.0), sx = fmax(0.0, ((double)W / OW - 1.0) / 2.0);
+  std::vector<double> hwy, hwx;
+  int ry = 0, rx = 0;
+  if (sy > 1e-15) ry = weights(sy, hwy);
+  if (sx > 1e-15) rx = weights(sx, hwx);
+  double *ds = nullptr, *scr = nullptr, *dout = nullptr, *dw = nullptr;
+  hipError_t e = hipMalloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&scr, ics_resize_scratch_doubles(H, W, 3) * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, no * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
+  if (e == hipSuccess && !hwy.empty()) e = hipMemcpyAsync(dw, hwy.data(), hwy.size() * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = ics_launch_f32_to_f64(src->d, ds, (long)n, s);
+  if (e == hipSuccess) e = ics_launch_resize(ds, H, W, 3, hwy.empty() ? nullptr : dw, ry, hwx.empty() ? nullptr : dw + hwy.size(), rx, scr, dout, OH, OW, s);
+  if (e == hipSuccess) e = ics_launch_f64_to_f32(dout, (*out)->d, (long)no, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);   // scratch and the host weight vectors are released below
+  hipFree(ds); hipFree(scr); hipFree(dout); hipFree(dw);
+  if (e != hipSuccess) { ics_img_destroy(*out); *out = nullptr; return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "img_resize: %s", hipGetErrorString(e)); }
+  return ICS_OK;
+}
+
+// richardson_lucy_MM(image[iy:iy+M, ix:ix+N], u[uy:uy+uM, ux:ux+uN], psf, ...) with both arrays on the device
+// (deconvolve.py:277-313 passes such window views)
+extern "C" int ics_rl_upload_img(ics_rl* j, const ics_img* image, int iy, int ix, const ics_img* u, int uy, int ux, const float* psf) {
+  if (!j || !image || !u || !psf) return fail(ICS_EINVAL, "NULL argument");
+  const IcsGeom& g = j->g;
+  if (image->ctx != j->ctx || u->ctx != j->ctx) return fail(ICS_EINVAL, "images of another context");
+  if (!rect_ok(image, iy, ix, g.M, g.N)) return fail(ICS_EINVAL, "image window [%d:%d, %d:%d] outside a %d x %d image", iy, iy + g.M, ix, ix + g.N, image->H, image->W);
+  if (!rect_ok(u, uy, ux, g.uM, g.uN)) return fail(ICS_EINVAL, "u window [%d:%d, %d:%d] outside a %d x %d image", uy, uy + g.uM, ux, ux + g.uN, u->H, u->W);
+  HIPCHK(hipSetDevice(j->ctx->device));
+  hipStream_t s = j->ctx->stream;
+  float* df = org(j, j->f) + (ptrdiff_t)g.pad * g.pitch + 3 * g.pad;
+  HIPCHK(hipMemcpy2DAsync(df, (size_t)g.pitch * 4, image->d + ((size_t)iy * image->W + ix) * 3, (size_t)image->W * 12, (size_t)g.N * 12, g.M, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemcpy2DAsync(org(j, j->u), (size_t)g.pitch * 4, u->d + ((size_t)uy * u->W + ux) * 3, (size_t)u->W * 12, (size_t)g.uN * 12, g.uM, hipMemcpyDeviceToDevice, s));
+  const size_t n = (size_t)3 * g.K * g.K * 4;
+  HIPCHK(hipMemcpyAsync(j->psf, psf, n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(j->psf_caller, psf, n, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemsetAsync(j->flags, 0, 4 * sizeof(int), s));
+  RC(pack_weights(j, 0, 0.f, 0, s));
+  HIPCHK(hipStreamSynchronize(s));   // psf is a host buffer
+  j->uploaded = true;
+  return ICS_OK;
+}
+// the whole u frame (the reference updates the caller's `u` view in place, border ring included) -> dst[y:y+uM, x:x+uN]
+extern "C" int ics_rl_download_img(ics_rl* j, ics_img* dst, int y, int x) {
+  if (!j || !dst) return fail(ICS_EINVAL, "NULL argument");
+  const IcsGeom& g = j->g;
+  if (dst->ctx != j->ctx) return fail(ICS_EINVAL, "image of another context");
+  if (!rect_ok(dst, y, x, g.uM, g.uN)) return fail(ICS_EINVAL, "u window [%d:%d, %d:%d] outside a %d x %d image", y, y + g.uM, x, x + g.uN, dst->H, dst->W);
+  HIPCHK(hipSetDevice(j->ctx->device));
+  HIPCHK(hipMemcpy2DAsync(dst->d + ((size_t)y * dst->W + x) * 3, (size_t)dst->W * 12, org(j, j->u), (size_t)g.pitch * 4, (size_t)g.uN * 12, g.uM,
+                          hipMemcpyDeviceToDevice, j->ctx->stream));
   return ICS_OK;
 }

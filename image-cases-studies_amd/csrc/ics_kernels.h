@@ -97,3 +97,9 @@ hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, dou
 size_t ics_resize_scratch_doubles(int H, int W, int C);
 hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
                              double* out, int OH, int OW, hipStream_t s);
+
+// ---- device-resident images (ics_img.hip; deconvolve.py:24-37, :100-103, :346-352) ----------------------
+hipError_t ics_launch_img_pad_edge(const float* in, int H, int W, float* out, int top, int bottom, int left, int right, hipStream_t s);
+hipError_t ics_launch_img_gamma(float* a, long n, float div, float exponent, float mul, int clip01, hipStream_t s);
+hipError_t ics_launch_f32_to_f64(const float* in, double* out, long n, hipStream_t s);
+hipError_t ics_launch_f64_to_f32(const double* in, float* out, long n, hipStream_t s);

@@ -80,10 +80,16 @@ def mask_window(i, top, bottom, left, right):
 @utils.timeit
 def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance=1, quality="normal", bits=8,
                   mask=None, display=True, blur="static", preview=False, p=1, order=2, norm=1, priority=0, mask_size=255,
-                  iterations=200, refocus=False, pyramid=True, solver=None, save=True):
+                  iterations=200, refocus=False, pyramid=True, solver=None, save=True, device_resident=False):
     """deconvolve.py:65-368.  Extra keyword arguments (not in the reference): `pyramid=False` runs the
     single scale-1 level only, `solver` replaces `dc.richardson_lucy_MM` (tests record the calls),
-    `save=False` returns the float image instead of writing the TIFF."""
+    `save=False` returns the float image instead of writing the TIFF, `device_resident=True` keeps every frame in HBM
+    from the first upload to the final download (`_deblur_device`; same arithmetic, same calls into the solver)."""
+    if device_resident:
+        if solver is not None:
+            raise ValueError("device_resident=True runs the GPU solver; `solver` cannot be replaced")
+        return _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, quality, bits, mask, display, blur, preview, p,
+                              order, norm, priority, mask_size, iterations, refocus, pyramid, save)
     rl = solver if solver is not None else dc.richardson_lucy_MM
     pic = np.ascontiguousarray(pic, dtype=np.float32)
     pic = pad_image(pic, (1, 1)).astype(np.float32)                       # :94
@@ -200,6 +206,130 @@ def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance
     if save:
         utils.save(deblured_image, filename, dest_path)
     return deblured_image, psf
+
+
+def _level_shape(i, M, N):
+    """deconvolve.py:232-243 -- odd size of pyramid level `i`"""
+    temp_width, temp_height = int(np.floor(i * N)), int(np.floor(i * M))
+    if temp_width % 2 == 0:
+        temp_width += 1
+    if temp_height % 2 == 0:
+        temp_height += 1
+    return temp_height, temp_width
+
+
+def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, quality, bits, mask, display, blur, preview, p, order, norm,
+                   priority, mask_size, iterations, refocus, pyramid, save):
+    """`deblur_module` (deconvolve.py:65-368) with every frame resident in HBM: one upload of the picture,
+    one download of the result; pad_image, gamma, the window views, the resize between pyramid levels and the solver all
+    work on `lib._native.DeviceImage`s.  Line references as in `deblur_module` above."""
+    from lib._native import DeviceImage
+    if blur_width < 3:
+        raise ValueError("The blur width should be at least 3 pixels.")
+    elif blur_width % 2 == 0:
+        raise ValueError("The blur width should be odd. You can use %i." % (blur_width + 1))
+    raw = DeviceImage.from_host(np.ascontiguousarray(pic, dtype=np.float32))
+    pic_d = raw.pad_edge(1, 1, 1, 1)                                        # :94
+    raw.close()
+    pic_d.gamma(2 ** bits - 1, 1 / 2.2)                                     # :97-103
+    step = {"normal": 1e-3, "high": 5e-4, "veryhigh": 1e-4, "low": 5e-3}[quality]
+    M, N, _ = pic_d.shape
+    if mask is None:
+        mask = [M // 2, N // 2]
+    top, bottom = mask[0] - mask_size // 2, mask[0] + mask_size // 2
+    left, right = mask[1] - mask_size // 2, mask[1] + mask_size // 2
+    print("Mask size :", (bottom - top + 1), "×", (right - left + 1))
+    if not (top > 0 and bottom < M and left > 0 and right < N):
+        raise ValueError("The mask is outside the picture boundaries. Move its center inside or reduce the blur size.")
+    correlation = {"static": False, "motion": True}[blur]
+    tolerance /= 100.
+    odd_vert = odd_hor = False
+    if M % 2 == 0:                                                          # :167-175
+        pic_d, old = pic_d.pad_edge(1, 0, 0, 0), pic_d
+        old.close()
+        odd_vert = True
+        print("Padded vertically")
+    if N % 2 == 0:
+        pic_d, old = pic_d.pad_edge(0, 0, 1, 0), pic_d
+        old.close()
+        odd_hor = True
+        print("Padded horizontally")
+    M, N, _ = pic_d.shape
+    psf = utils.uniform_kernel(blur_width)
+    psf = np.dstack((psf, psf, psf))
+    images, kernels = build_pyramid(blur_width, confidence)
+    if not pyramid:
+        images, kernels = images[:1], kernels[:1]
+    deb = pic_d.copy()
+    try:
+        for case in ["blind", "non-blind"]:
+            print("\n===== %s DECONVOLUTION =====" % case)
+            deb.close()
+            deb = pic_d.copy()
+            lambd = confidence * 1000
+            for i, k in zip(reversed(images), reversed(kernels)):
+                print("======== Pyramid step %1.3f ========" % i)
+                tt, tb, tl, tr = mask_window(i, top, bottom, left, right)
+                th, tw = _level_shape(i, M, N)
+                blurry = pic_d.resize(th, tw)                                # :245
+                deb, old = deb.resize(th, tw), deb                           # :246
+                old.close()
+                if case == "blind":
+                    psf_copy = np.ascontiguousarray(resize_bicubic(psf, (k, k, 3)).astype(np.float32))   # :249
+                    dc.normalize_kernel(psf_copy, k)
+                else:
+                    psf_copy = np.ascontiguousarray(psf, dtype=np.float32).copy()
+                    k = kernels[0]
+                blurry, old = blurry.pad_edge(1, 1, 1, 1), blurry            # :256-257
+                old.close()
+                deb, old = deb.pad_edge(1, 1, 1, 1), deb
+                old.close()
+                pad = int(np.floor(k / 2))
+                print("Image size", blurry.shape)
+                print("u size", deb.shape)
+                print("Mask size", (tb - tt), (tr - tl))
+                print("PSF size", psf_copy.shape)
+                tolerance_temp = tolerance if i == 1. else 0
+                win = (pad + 1, tb - tt - pad - 1, pad + 1, tb - tt - pad - 1)
+                if case == "blind" or preview:                               # :277-300: windows of both frames
+                    dc.richardson_lucy_MM_device(
+                        blurry, (tt - 1, tl - 1), deb, (tt - pad - 1, tl - pad - 1), psf_copy, *win,
+                        0 if case == "blind" else tolerance_temp, tb - tt + 2, tr - tl + 2, 3, k, iterations, step, lambd,
+                        blind=(case == "blind"), p=p, correlation=(correlation if case == "blind" else False), order=order, norm=2,
+                        priority=(0 if case == "blind" else priority), refocus=refocus)
+                    if case == "blind":
+                        psf = psf_copy.copy()
+                else:                                                        # :301-316: the whole frame
+                    big = deb.pad_edge(pad, pad, pad, pad)
+                    dc.richardson_lucy_MM_device(blurry, (0, 0), big, (0, 0), psf_copy, *win, tolerance_temp, th + 2, tw + 2, 3, k,
+                                                 iterations, step, lambd, blind=False, p=p, order=order, norm=2, priority=priority,
+                                                 refocus=refocus)
+                    deb.close()
+                    H2, W2, _ = big.shape
+                    deb = big.crop(pad, H2 - pad, pad, W2 - pad)
+                    big.close()
+                blurry.close()
+                H1, W1, _ = deb.shape
+                deb, old = deb.crop(1, H1 - 1, 1, W1 - 1), deb               # :322-323
+                old.close()
+    except KeyboardInterrupt:
+        pass
+    deb.gamma(1.0, 2.2, 2 ** 16 - 1, clip01=True)                           # :346-352
+    out = deb.to_host()
+    deb.close()
+    pic_d.close()
+    if preview:
+        filename = filename + "-preview"
+        out = out[top:bottom, left:right, ...]
+    else:
+        if odd_hor:
+            out = out[:, 1:, ...]
+        if odd_vert:
+            out = out[1:, :, ...]
+        out = out[1:-1, 1:-1, ...]
+    if save:
+        utils.save(out, filename, dest_path)
+    return out, psf
 
 
 if __name__ == '__main__':

@@ -91,9 +91,23 @@ def load():
     lib.ics_usm.argtypes = [vp, vp, ci, ci, vp, ci, ci, cd, vp]
     lib.ics_bilateral.argtypes = [vp, vp, ci, ci, ci, cd, cd, vp]
     lib.ics_resize_bicubic.argtypes = [vp, vp, ci, ci, ci, vp, ci, ci]
+    lib.ics_img_create.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.ics_img_destroy.argtypes = [vp]; lib.ics_img_destroy.restype = None
+    lib.ics_img_shape.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    lib.ics_img_upload.argtypes = [vp, vp]
+    lib.ics_img_download.argtypes = [vp, vp]
+    lib.ics_img_pad_edge.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.ics_img_crop.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
+    lib.ics_img_paste.argtypes = [vp, ci, ci, vp]
+    lib.ics_img_gamma.argtypes = [vp, cf, cf, cf, ci]
+    lib.ics_img_resize.argtypes = [vp, ci, ci, C.POINTER(vp)]
+    lib.ics_rl_upload_img.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
+    lib.ics_rl_download_img.argtypes = [vp, vp, ci, ci]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
                  "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_normalize_kernel",
-                 "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic"):
+                 "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
+                 "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
+                 "ics_rl_upload_img", "ics_rl_download_img"):
         getattr(lib, name).restype = ci
     if lib.ics_abi_version() != 1:
         raise ImportError("libics_hip.so ABI version %d, expected 1" % lib.ics_abi_version())
@@ -189,6 +203,73 @@ class Context:
         return out
 
 
+class DeviceImage:
+    """ics_img: an H x W x 3 float32 image that lives in HBM (the frames `deconvolve.deblur_module` carries between two
+    richardson_lucy_MM calls).  Methods that return an image create a new one; `gamma` and `paste` work in place."""
+
+    def __init__(self, handle, ctx):
+        self._h, self.ctx = handle, ctx
+
+    @classmethod
+    def from_host(cls, arr, ctx=None):
+        ctx = ctx or Context.get()
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if arr.ndim != 3 or arr.shape[2] != 3:
+            raise ValueError("DeviceImage needs an H x W x 3 array")
+        h = C.c_void_p()
+        _check(load().ics_img_create(ctx._h, arr.shape[0], arr.shape[1], C.byref(h)))
+        img = cls(h, ctx)
+        _check(load().ics_img_upload(img._h, _ptr(arr)))
+        return img
+
+    @property
+    def shape(self):
+        H, W = C.c_int(), C.c_int()
+        _check(load().ics_img_shape(self._h, C.byref(H), C.byref(W)))
+        return (H.value, W.value, 3)
+
+    def to_host(self):
+        out = np.empty(self.shape, np.float32)
+        _check(load().ics_img_download(self._h, _ptr(out)))
+        return out
+
+    def _new(self, fn, *args):
+        h = C.c_void_p()
+        _check(fn(self._h, *args, C.byref(h)))
+        return DeviceImage(h, self.ctx)
+
+    def pad_edge(self, top, bottom, left, right):
+        return self._new(load().ics_img_pad_edge, int(top), int(bottom), int(left), int(right))
+
+    def crop(self, y0, y1, x0, x1):
+        """self[y0:y1, x0:x1]"""
+        return self._new(load().ics_img_crop, int(y0), int(x0), int(y1 - y0), int(x1 - x0))
+
+    def copy(self):
+        H, W, _ = self.shape
+        return self.crop(0, H, 0, W)
+
+    def resize(self, oh, ow):
+        return self._new(load().ics_img_resize, int(oh), int(ow))
+
+    def paste(self, y0, x0, src):
+        _check(load().ics_img_paste(self._h, int(y0), int(x0), src._h))
+
+    def gamma(self, div, exponent, mul=1.0, clip01=False):
+        _check(load().ics_img_gamma(self._h, float(div), float(exponent), float(mul), int(bool(clip01))))
+
+    def close(self):
+        if self._h:
+            load().ics_img_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RLJob:
     """ics_rl: device-resident frames of one richardson_lucy_MM problem (M x N x 3, MK x MK x 3)."""
 
@@ -228,6 +309,20 @@ class RLJob:
         assert image.shape == (self.M, self.N, 3) and u.shape == (self.uM, self.uN, 3) and psf.shape == (self.MK, self.MK, 3), \
             (image.shape, u.shape, psf.shape)
         _check(load().ics_rl_upload(self._h, _ptr(image), _ptr(u), _ptr(psf)))
+
+    def upload_img(self, image, image_origin, u, u_origin, psf):
+        """frames from windows of device images (ics_rl_upload_img)"""
+        psf = np.ascontiguousarray(psf, dtype=np.float32)
+        assert psf.shape == (self.MK, self.MK, 3), psf.shape
+        _check(load().ics_rl_upload_img(self._h, image._h, int(image_origin[0]), int(image_origin[1]), u._h, int(u_origin[0]), int(u_origin[1]), _ptr(psf)))
+
+    def download_img(self, u, u_origin):
+        _check(load().ics_rl_download_img(self._h, u._h, int(u_origin[0]), int(u_origin[1])))
+
+    def download_psf_caller(self):
+        psf_caller = np.empty((self.MK, self.MK, 3), np.float32)
+        _check(load().ics_rl_download(self._h, None, None, _ptr(psf_caller)))
+        return psf_caller
 
     def download(self):
         u = np.empty((self.uM, self.uN, 3), np.float32)

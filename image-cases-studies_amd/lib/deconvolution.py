@@ -66,6 +66,48 @@ def normalize_kernel(kern, MK):
     kern[:MK, :MK, :3] = work
 
 
+def _report(st, top, bottom, left, right, lambd):
+    """the reference's stdout (pyx:593,648,658-672), printed after the device run from the returned trace"""
+    for it in range(st.trace_len):
+        print("DoF : min = %f | max = %f" % (st.trace_dof_min[it], st.trace_dof_max[it]))
+        if st.stopped and it == st.iterations_done - 1:
+            print("white autocorellation condition met")
+        if (it + 1) % 50 == 0:
+            print("%i iterations completed" % (it + 1))
+    if st.stopped:
+        print("Convergence after %i iterations." % st.iterations_done)
+    else:
+        print("Did not converge after %i iterations. Don't use the result." % st.iterations_done)
+    print("Stats : autocovariance = %.6f | lamdba = %.0f | residual = %.6f | variance/noise = %.6f" % (
+        1000 * st.M_r / ((bottom - top) * (right - left) * 3), np.float32(lambd), st.Hu, st.varu))
+    if st.has_nan:
+        print("has NaN after DoF correction")
+
+
+def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom, left, right, tau, M, N, C, MK, iterations,
+                              step_factor, lambd, blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *,
+                              tv_mode=0, conv=0):
+    """`richardson_lucy_MM` on device-resident frames (not in the reference): `image` and `u` are
+    `_native.DeviceImage`s, the solver works on the windows image[iy:iy+M, ix:ix+N] and u[uy:uy+uM, ux:ux+uN]
+    (`image_origin = (iy, ix)`, `u_origin = (uy, ux)`) -- the views deconvolve.py:277-313 passes -- and the whole `u`
+    window is updated in place like the reference's `u` argument.  `psf` stays a host array, updated in place when
+    `blind`.  Nothing crosses PCIe but the PSF and the statistics."""
+    _check_buffer("psf", psf)
+    M, N, MK = int(M), int(N), int(MK)
+    if tv_mode == 1:
+        raise ValueError("tv_mode 1 modifies `image`; use richardson_lucy_MM for it")
+    job = _get_job(M, N, MK)
+    job.upload_img(image, image_origin, u, u_origin, psf)
+    params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
+                        tv_mode=tv_mode, conv=conv)
+    st = job.run(params)
+    job.download_img(u, u_origin)
+    if blind:
+        psf[...] = job.download_psf_caller()
+    _report(st, top, bottom, left, right, lambd)
+    richardson_lucy_MM.last = st
+
+
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
                        blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0, conv=0):
     """Richardson-Lucy blind / non-blind deconvolution by majorisation-minimisation
@@ -98,21 +140,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
         psf[...] = psf_caller
     if tv_mode:
         image[...] = job.read(_native.BUF_IMAGE)                               # pyx:549 (live in this mode)
-    # the reference's stdout (pyx:593,648,658-672)
-    for it in range(st.trace_len):
-        print("DoF : min = %f | max = %f" % (st.trace_dof_min[it], st.trace_dof_max[it]))
-        if st.stopped and it == st.iterations_done - 1:
-            print("white autocorellation condition met")
-        if (it + 1) % 50 == 0:
-            print("%i iterations completed" % (it + 1))
-    if st.stopped:
-        print("Convergence after %i iterations." % st.iterations_done)
-    else:
-        print("Did not converge after %i iterations. Don't use the result." % st.iterations_done)
-    print("Stats : autocovariance = %.6f | lamdba = %.0f | residual = %.6f | variance/noise = %.6f" % (
-        1000 * st.M_r / ((bottom - top) * (right - left) * 3), np.float32(lambd), st.Hu, st.varu))
-    if st.has_nan:
-        print("has NaN after DoF correction")
+    _report(st, top, bottom, left, right, lambd)
     richardson_lucy_MM.last = st
     return u[pad:pad + M, pad:pad + N, ...]                                    # pyx:675 (view)
 

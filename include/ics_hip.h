@@ -17,6 +17,10 @@
  *                                                          (scipy.signal.convolve2d same/symm)
  *   ics_usm                lib/utils.py:267-277            USM
  *   ics_bilateral          lib/utils.py:173-234            bilateral_filter
+ *   ics_img_*              deconvolve.py:24-37,:94-103,:245-257,:303,:322-323,:346-352
+ *                                                          the frames the driver keeps between two
+ *                                                          richardson_lucy_MM calls (pad_image, gamma, window
+ *                                                          views, resize), device-resident
  *   ics_resize_bicubic     deconvolve.py:245-249           skimage.transform.resize(order=3, mode="edge")
  *                                                          between pyramid levels (un-vendored dependency of
  *                                                          the reference: restated on scipy.ndimage semantics)
@@ -194,6 +198,34 @@ int ics_bilateral(ics_ctx *ctx, const double *src, int H, int W, int radius, dou
  * sigma = (scale - 1) / 2 per axis when shrinking, cubic B-spline interpolation at the pixel-centre grid, edge mode
  * "nearest"; the algorithm is written out in oracle/resize_oracle.py and pinned there against scipy.ndimage. */
 int ics_resize_bicubic(ics_ctx *ctx, const double *src, int H, int W, int C, double *out, int OH, int OW);
+
+/* ---- device-resident images -----------------------------------------------
+ * H x W x 3 float32 HWC images in HBM, so that deblur_module (deconvolve.py:65-368) keeps its frames on the
+ * device across pyramid levels and between the blind and the non-blind phase.  Operations are queued on the
+ * context's stream; upload / download synchronise.  Functions with an `out` argument create a new image. */
+typedef struct ics_img ics_img;
+int ics_img_create(ics_ctx *ctx, int H, int W, ics_img **out);
+void ics_img_destroy(ics_img *img);
+int ics_img_shape(const ics_img *img, int *H, int *W);
+int ics_img_upload(ics_img *img, const float *host);        /* H*W*3 floats */
+int ics_img_download(const ics_img *img, float *host);
+/* deconvolve.py:24-37 pad_image (np.pad mode="edge" on the two spatial axes) */
+int ics_img_pad_edge(const ics_img *src, int top, int bottom, int left, int right, ics_img **out);
+/* src[y0:y0+H, x0:x0+W] (the slices of deconvolve.py:322-323, :360-366) */
+int ics_img_crop(const ics_img *src, int y0, int x0, int H, int W, ics_img **out);
+/* dst[y0:y0+h, x0:x0+w] = src */
+int ics_img_paste(ics_img *dst, int y0, int x0, const ics_img *src);
+/* in place: x = powf(clip01 ? clip(x / div, 0, 1) : x / div, exponent) * mul
+ * (deconvolve.py:100-103: div = 2^bits - 1, exponent = 1/2.2; :346-352: clip, exponent = 2.2, mul = 65535) */
+int ics_img_gamma(ics_img *img, float div, float exponent, float mul, int clip01);
+/* deconvolve.py:245-249 on a device image (ics_resize_bicubic semantics, result rounded to float32) */
+int ics_img_resize(const ics_img *src, int OH, int OW, ics_img **out);
+/* richardson_lucy_MM(image[iy:iy+M, ix:ix+N], u[uy:uy+uM, ux:ux+uN], psf, ...) with both windows taken from device
+ * images (deconvolve.py:277-313 passes such views); psf is a host MK*MK*3 array as in ics_rl_upload. */
+int ics_rl_upload_img(ics_rl *job, const ics_img *image, int iy, int ix, const ics_img *u, int uy, int ux, const float *psf);
+/* The reference updates the caller's `u` view in place, border ring included (pyx:527-531): the whole u frame goes
+ * back to dst[y:y+uM, x:x+uN]. */
+int ics_rl_download_img(ics_rl *job, ics_img *dst, int y, int x);
 
 #ifdef __cplusplus
 }

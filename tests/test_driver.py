@@ -84,3 +84,49 @@ def test_deblur_module_end_to_end_on_gpu(tmp_path):
                                 pyramid=True)
     assert out.shape == (120, 140, 3) and np.isfinite(out).all() and (tmp_path / "gpu.tif").exists()
     assert np.all(psf >= 0) and np.allclose(psf.sum(axis=(0, 1)), 1, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pyramid", [False, True])
+def test_device_resident_driver_equals_the_host_driver(pyramid, capsys):
+    """the same picture through `deblur_module` with the frames on the host (numpy pads, slices and gamma,
+    one upload / download per solver call) and with the frames resident in HBM.  The two paths run the same solver on
+    the same windows; they differ by float32 `powf` (device vs numpy) in the two gamma steps only."""
+    import deconvolve as dv
+    import rl_mm_oracle as orc
+    case = orc.synth_case(118, 141, 5, seed=2)
+    pic = np.clip(case["image"] ** 2.2 * 255, 0, 255).astype(np.uint8)
+    kw = dict(mask=[60, 70], mask_size=61, display=False, iterations=3, pyramid=pyramid, save=False)
+    out_h, psf_h = dv.deblur_module(pic, "h", ".", 5, **kw)
+    log_h = capsys.readouterr().out
+    out_d, psf_d = dv.deblur_module(pic, "d", ".", 5, device_resident=True, **kw)
+    log_d = capsys.readouterr().out
+    assert out_d.shape == out_h.shape == (118, 141, 3)
+    assert np.abs(psf_d - psf_h).max() < 1e-5
+    assert np.abs(out_d - out_h).max() / 65535 < 2e-5, np.abs(out_d - out_h).max()
+    strip = lambda t: [l for l in t.splitlines() if not l.startswith("'deblur_module'") and "sec" not in l]
+    assert [l.split("=")[0] for l in strip(log_h)] == [l.split("=")[0] for l in strip(log_d)]   # same progress lines
+
+
+@pytest.mark.gpu
+def test_device_image_operations_match_numpy():
+    from lib import _native
+    import resize_oracle as ro
+    rng = np.random.default_rng(5)
+    a = rng.random((37, 45, 3), dtype=np.float32)
+    d = _native.DeviceImage.from_host(a)
+    assert d.shape == (37, 45, 3) and np.array_equal(d.to_host(), a)
+    assert np.array_equal(d.pad_edge(2, 0, 1, 3).to_host(), np.pad(a, ((2, 0), (1, 3), (0, 0)), mode="edge"))
+    assert np.array_equal(d.crop(3, 30, 5, 44).to_host(), a[3:30, 5:44])
+    e = d.copy()
+    e.paste(4, 6, d.crop(0, 10, 0, 12))
+    ref = a.copy(); ref[4:14, 6:18] = a[0:10, 0:12]
+    assert np.array_equal(e.to_host(), ref)
+    g = d.copy(); g.gamma(2.0, 1 / 2.2)
+    assert np.abs(g.to_host() - (a / np.float32(2.0)) ** np.float32(1 / 2.2)).max() < 3e-7
+    g = d.copy(); g.gamma(0.5, 2.2, 65535, clip01=True)
+    assert np.abs(g.to_host() - np.clip(a / np.float32(0.5), 0, 1) ** np.float32(2.2) * np.float32(65535)).max() < 0.02
+    r = d.resize(27, 31).to_host()
+    assert np.abs(r - ro.resize_scipy(a, (27, 31)).astype(np.float32)).max() < 1e-6
+    with pytest.raises(_native.NativeError):
+        d.crop(0, 38, 0, 45)
