@@ -99,8 +99,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--conv", choices=["auto", "vector", "matrix"], default="auto",
                     help="convolution kernels: auto = matrix-core (fp16-split MFMA) where built and faster (PSF <= 17, 23..37), else packed-fp32 vector")
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--mode", choices=["blind", "nonblind"], default="blind")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--psf", type=int, default=15)
