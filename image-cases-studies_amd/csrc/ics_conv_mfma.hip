@@ -48,12 +48,6 @@
 #include "ics_common.h"
 #include <type_traits>
 
-#ifndef ICS_SKEW
-#define ICS_SKEW 0
-#endif
-#ifndef ICS_EPI_EARLY
-#define ICS_EPI_EARLY(mode) 0   /* 1 = epilogue operand requested before the matrix phase (measured: no gain) */
-#endif
 #ifndef ICS_MFMA_INTERLEAVE
 #define ICS_MFMA_INTERLEAVE 1
 #endif
@@ -68,9 +62,6 @@
 #endif
 #ifndef ICS_EPI_STORE_AUX
 #define ICS_EPI_STORE_AUX 0
-#endif
-#ifndef ICS_EPI_ONEOP
-#define ICS_EPI_ONEOP 0   /* 1 = mode 1 with a single-operand epilogue when the majoriser frame is the u frame (measured: no gain) */
 #endif
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
@@ -249,12 +240,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + txi * C::TW - C::PAD)), tid, pitch);
   }
 
-#if ICS_SKEW
-  // start-up skew: the second workgroup of a CU (dispatch order: workgroup b -> XCD b % 8, CU (b / 8) % 32) begins
-  // late, so that its matrix phases fall into the memory phases of the first one
-  if (blockIdx.x >= gridDim.x / 2)
-    for (int i = 0; i < ICS_SKEW; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
   ICS_TICK_INIT;
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -318,19 +303,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int nt = tile + nx;
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
       load_raw<C>(raw, rs_in, 4 * ((a.g.ay + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + nxi * C::TW - C::PAD)), opaque(tid), pitch);
-    }
-    // ---- ...and the epilogue operand of THIS tile (mode 0: the image; one 12-byte pixel per accumulator row), so that
-    // after the matrix phase the wave only subtracts and stores
-    constexpr bool EARLY = ICS_EPI_EARLY(MODE);
-    u3 eop_early[4][4];
-    if (EARLY) {
-      const int tide = opaque(tid);
-      const int voff = 4 * (16 * ((tide >> 4) & 3) * pitch + 3 * (tide & 15));
-      const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) eop_early[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -468,14 +440,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int voff = 4 * (16 * elg * pitch + 3 * eli);          // lane part of the byte offset
       const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));      // wave-uniform part (tile origin + column block)
       constexpr int EOPS = (MODE == 0) ? 1 : 2;
-      // TBc = accumulator sets per batch (the operands of a batch are requested together); ONE = the majoriser frame IS the u
-      // frame (first inner iteration of an outer one, pyx:462): one operand, and registers for a single batch
+      // TB = accumulator sets per batch: the operands of a batch are requested together.  (Measured without gain, and removed:
+      // requesting the operands before the matrix phase -- the kernel follows its memory traffic, not the epilogue's latency --
+      // and a single-operand variant for the launches where the majoriser frame is the u frame.)
       // TVOP (extended modes): the T frame is a third operand, requested like the others (as per-element scalar loads it
       // cost the back-projection +40 %)
       const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
-      auto run_epi = [&](auto tbc, auto onec, auto tvc) {
+      auto run_epi = [&](auto tbc, auto tvc) {
       constexpr int TB = decltype(tbc)::value;
-      constexpr bool ONE = decltype(onec)::value;
       constexpr bool TVOP = decltype(tvc)::value;
 #pragma unroll
       for (int t0 = 0; t0 < 4; t0 += TB) {
@@ -486,8 +458,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         for (int r = 0; r < 4; ++r) {
           const int so = sb + 4 * (t + 4 * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
-          eop[0][t][r] = EARLY ? eop_early[t][r] : __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
-          if (MODE == 1 && !ONE) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
+          eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
+          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
       if (t0 == 0) ICS_TICK(3);
@@ -514,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
               const float lambd = a.lambd;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                const float uv = __uint_as_float(eop[0][t][r][c]), tv = ONE ? uv : __uint_as_float(eop[EOPS - 1][t][r][c]);
+                const float uv = __uint_as_float(eop[0][t][r][c]), tv = __uint_as_float(eop[EOPS - 1][t][r][c]);
                 float g;
                 const float Tv = TVOP ? __uint_as_float(eopT[t][r][c]) : 0.f;
                 if (TVOP && a.tv_kind >= 2)
@@ -534,9 +506,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         }
       }
       };
-      if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
-      else if (ICS_EPI_ONEOP && MODE == 1 && a.u == a.ut) run_epi(std::integral_constant<int, 4>{}, std::true_type{}, std::false_type{});
-      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{}, std::false_type{});
+      if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::true_type{});
+      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
