@@ -174,6 +174,12 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   j->g = ics_make_geom(M, N, MK);
   j->frame_floats = ics_frame_floats(j->g);
   j->origin = ics_origin_offset(j->g);
+  // the matrix-core kernels address a frame through a raw buffer descriptor with 32-bit byte offsets
+  if (j->frame_floats * 4 >= ((size_t)1 << 31)) {
+    delete j;
+    return fail(ICS_ENOSUP, "a %d x %d frame with a %d x %d PSF takes %.2f GB; frames are limited to 2 GiB (about 13000 x 13000 px)", M, N, MK, MK,
+                (double)ics_frame_floats(ics_make_geom(M, N, MK)) * 4e-9);
+  }
   const size_t n = (size_t)3 * MK * MK;
   const int nt = 16 * ((MK + 15) / 16);
   j->gradk_blocks = ics_gradk_blocks(j->g, c->cus);

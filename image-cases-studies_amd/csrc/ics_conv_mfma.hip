@@ -463,6 +463,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
       if (t0 == 0) ICS_TICK(3);
+      if (MODE == 1 && t0 == 0) {
+        // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
+        // shadow of their latency (u and ut only feed the step-size reductions)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int y = y0 + t + 16 * elg + 4 * r;
+            if (y < a.g.uM && colx < a.g.uN && !(ICS_MFMA_ABLATE & 8)) {
+              const u3 e = {__float_as_uint(acc[0][t][r] * sc), __float_as_uint(acc[1][t][r] * sc), __float_as_uint(acc[2][t][r] * sc)};
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, sb + 4 * (t + 4 * r) * pitch, ICS_EPI_STORE_AUX);
+            }
+          }
+      }
 #pragma unroll
       for (int t = t0; t < t0 + TB; ++t)
 #pragma unroll
@@ -499,8 +513,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
                 mu[c] = __builtin_fmaxf(mu[c], uv);
                 rflags |= ((g != g) ? (1u << c) : 0u) | ((uv != uv) ? (8u << c) : 0u) | 64u;
               }
-              u3 e = {__float_as_uint(av[0]), __float_as_uint(av[1]), __float_as_uint(av[2])};
-              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, so, ICS_EPI_STORE_AUX);
             }
           }
         }

@@ -93,3 +93,11 @@ def test_unsupported_sizes_fail_loudly():
         job.run(job.params(0, 40, 0, 10, 0, 1, 1e-3, 1e4, False))
     assert ei.value.code == nv.ICS_EINVAL
     job.close()
+
+
+def test_frames_beyond_the_32_bit_offset_range_are_refused_not_corrupted():
+    """the matrix-core kernels use 32-bit byte offsets into a frame: 2 GiB per frame is the documented limit"""
+    from lib import _native
+    with pytest.raises(_native.NativeError) as ei:
+        _native.RLJob(14000, 14000, 15)
+    assert ei.value.code == _native.ICS_ENOSUP
