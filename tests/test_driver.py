@@ -87,8 +87,8 @@ def test_deblur_module_end_to_end_on_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pyramid", [False, True])
-def test_device_resident_driver_equals_the_host_driver(pyramid, capsys):
+@pytest.mark.parametrize("pyramid,preview,blur", [(False, False, "static"), (True, False, "static"), (True, True, "static"), (False, False, "motion")])
+def test_device_resident_driver_equals_the_host_driver(pyramid, preview, blur, capsys):
     """the same picture through `deblur_module` with the frames on the host (numpy pads, slices and gamma,
     one upload / download per solver call) and with the frames resident in HBM.  The two paths run the same solver on
     the same windows; they differ by float32 `powf` (device vs numpy) in the two gamma steps only."""
@@ -96,12 +96,12 @@ def test_device_resident_driver_equals_the_host_driver(pyramid, capsys):
     import rl_mm_oracle as orc
     case = orc.synth_case(118, 141, 5, seed=2)
     pic = np.clip(case["image"] ** 2.2 * 255, 0, 255).astype(np.uint8)
-    kw = dict(mask=[60, 70], mask_size=61, display=False, iterations=3, pyramid=pyramid, save=False)
+    kw = dict(mask=[60, 70], mask_size=61, display=False, iterations=3, pyramid=pyramid, save=False, preview=preview, blur=blur)
     out_h, psf_h = dv.deblur_module(pic, "h", ".", 5, **kw)
     log_h = capsys.readouterr().out
     out_d, psf_d = dv.deblur_module(pic, "d", ".", 5, device_resident=True, **kw)
     log_d = capsys.readouterr().out
-    assert out_d.shape == out_h.shape == (118, 141, 3)
+    assert out_d.shape == out_h.shape == ((61 - 1, 61 - 1, 3) if preview else (118, 141, 3))
     assert np.abs(psf_d - psf_h).max() < 1e-5
     assert np.abs(out_d - out_h).max() / 65535 < 2e-5, np.abs(out_d - out_h).max()
     strip = lambda t: [l for l in t.splitlines() if not l.startswith("'deblur_module'") and "sec" not in l]
