@@ -64,3 +64,26 @@ def test_driver_resize_goes_through_the_device(monkeypatch):
     out = dv.resize_bicubic(img, (33, 43, 3))
     assert np.abs(out - ro.resize_scipy(img, (33, 43))).max() < 1e-12
     assert np.array_equal(dv.resize_bicubic(img, img.shape), img.astype(np.float64))
+
+
+@pytest.mark.gpu
+def test_gpu_resize_extreme_ratios_and_many_calls():
+    """large up- and down-scaling factors (wide anti-aliasing kernels), 2 x 2 sources, and a create / resize / destroy
+    loop on device images (same result every time, nothing left behind)"""
+    from lib import _native
+    ctx = _native.Context.get()
+    rng = np.random.default_rng(7)
+    for src, dst in [((2, 2), (9, 7)), ((120, 90), (13, 11)), ((13, 11), (120, 90)), ((64, 3), (31, 5)), ((300, 300), (7, 299))]:
+        img = rng.random((*src, 3))
+        got = ctx.resize_bicubic(img, dst)
+        assert np.abs(got - ro.resize_scipy(img, dst)).max() < 1e-11, (src, dst)
+    a = rng.random((256, 256, 3), dtype=np.float32)
+    first = None
+    for i in range(60):
+        d = _native.DeviceImage.from_host(a)
+        r = d.resize(181, 181).pad_edge(1, 1, 1, 1)
+        out = r.to_host()
+        if first is None:
+            first = out
+        assert np.array_equal(out, first)
+        d.close(); r.close()
