@@ -118,7 +118,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     unpinned), in which `image` is also updated in place as pyx:549 intends.
 
     `conv` (keyword-only, not in the reference): include/ics_hip.h ICS_CONV_*: 0 = auto (matrix-core kernels with
-    fp16-split operands for MK <= 15), 1 = fp32 products everywhere, 2 = force the matrix-core kernels."""
+    fp16-split operands where they are built and faster: convolutions MK <= 17 and 23..37, PSF gradient MK <= 31), 1 = fp32 products everywhere, 2 = force the matrix-core kernels."""
     _check_buffer("image", image)
     _check_buffer("u", u)
     _check_buffer("psf", psf)
