@@ -191,8 +191,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 
   // persistent tile walk: workgroup b runs on XCD b % 8 (observed dispatch); every XCD owns one contiguous
   // band of tiles so that the halos shared by neighbouring tiles hit in that XCD's L2
-  const int tpr = a.g.tiles_x;   // tiles per row
-  const int ntiles = tpr * a.g.tiles_y;
+  // Tile grid.  Mode 1 writes the whole u-frame: tiles start at its origin.  Mode 0 writes the M x N interior only: its
+  // tiles start at (PAD, PAD), so that a 4096^2 image is 64 x 64 tiles -- 8 per persistent workgroup -- instead of the 65 x 65
+  // (8.25 per workgroup = 9 rounds, the last column and row nearly empty) of the u-frame grid.
+  constexpr int TORG = MODE == 0 ? C::PAD : 0;
+  const int tpr = MODE == 0 ? (a.g.N + C::TW - 1) / C::TW : a.g.tiles_x;   // tiles per row
+  const int ntiles = tpr * (MODE == 0 ? (a.g.M + C::TH - 1) / C::TH : a.g.tiles_y);
+  const int xend = MODE == 0 ? C::PAD + a.g.N : a.g.uN;                    // first column without output
   const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;         // bands (= XCDs when the grid covers them all)
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
   const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;            // workgroups walking this band
@@ -237,14 +242,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   f32x4u raw[C::NIT][3];
   {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
-    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + txi * C::TW - C::PAD)), tid, pitch);
+    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
 
   ICS_TICK_INIT;
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
-    const int x0 = txi * C::TW, y0 = tyi * C::TH;
+    const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
 
     // ---- raw fp32 HWC rows (registers) -> six fp16 planes, scaled by a per-tile power of two ----------
     float inv_x;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     if (tile + nx < band1) {
       const int nt = tile + nx;
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
-      load_raw<C>(raw, rs_in, 4 * ((a.g.ay + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + nxi * C::TW - C::PAD)), opaque(tid), pitch);
+      load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + nxi * C::TW - C::PAD)), opaque(tid), pitch);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[ch][t] = (f4){0.f, 0.f, 0.f, 0.f};
-    if (x0 + 16 * wv < a.g.uN) {   // wave-uniform: a column block right of the frame carries no output
+    if (x0 + 16 * wv < xend) {   // wave-uniform: a column block right of the output carries none
 #pragma unroll
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
         // (re-hidden per tile and channel: the weight reads are tile-invariant and would otherwise be hoisted out
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     // t + 16*lg + 4*r of pixel column 16*wv + li, i.e. one 12-byte HWC pixel per (t, r): operands arrive and
     // results leave as dwordx3 (16 lanes = 192 contiguous bytes of a row), no LDS transpose and no workgroup
     // barrier between the matrix phase and the stores -- the four waves drift apart and overlap their phases.
-    if (x0 + 16 * wv < a.g.uN && !(ICS_MFMA_ABLATE & 4)) {
+    if (x0 + 16 * wv < xend && !(ICS_MFMA_ABLATE & 4)) {
       const float sc = inv_w * inv_x;   // powers of two
       const int tide = opaque(tid);
       const int eli = tide & 15, elg = (tide >> 4) & 3;
@@ -570,7 +575,7 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
     cus[dev] = n;
   }
-  const int ntiles = a.g.tiles_x * a.g.tiles_y;
+  const int ntiles = MODE == 0 ? ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH) : a.g.tiles_x * a.g.tiles_y;
   int grid = C::WGS * cus[dev];              // persistent workgroups: as many as fit the LDS of a CU
 #ifdef ICS_GRID_WGS
   grid = ICS_GRID_WGS * cus[dev];
