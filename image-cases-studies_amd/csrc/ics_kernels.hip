@@ -4,6 +4,9 @@
 #include "ics_kernels.h"
 #include "ics_tv.h"
 
+#ifndef ICS_UPDATE_U
+#define ICS_UPDATE_U 4   /* wave segments (1 KiB per frame each) per loop iteration of k_update_rows */
+#endif
 #ifndef ICS_UPDATE_NT
 #define ICS_UPDATE_NT 15  /* streaming (nt) loads in k_update_rows: bit 0 u, 1 ut, 2 g, 3 f */
 #endif
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
   const int nwc = (rowf + 255) / 256;              // wave segments per row
   const long nitems = (long)G.uM * nwc;
   const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
-  constexpr int U = TVK == 0 ? 3 : 2;
+  constexpr int U = TVK == 0 ? ICS_UPDATE_U : 2;
   for (long it0 = gw * U; it0 < nitems; it0 += nw * U) {
     f32x4 uq[U], tq[U], gq[U], fq[U], Tq[U];
     int ys[U], f0s[U];
@@ -695,10 +698,10 @@ hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
 hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   const long total = (long)a.geo.uM * a.geo.tiles_x * 16;
   long blocks = (total + 255) / 256;
-  // Few long-lived workgroups stream best here: measured at 4096^2 (4 reads + 1 write, 1.0 GB):
-  // 2 per CU 0.202 ms, 8 per CU 0.215, 16 per CU 0.244, one per 256 px-groups (16.5k) 0.458 ms.
-  static const int per_cu = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 2;
-  const long cap = 256L * (per_cu > 0 ? per_cu : 2);
+  // Few long-lived workgroups stream best here.  k_update_rows at 4096^2 (4 reads + 1 write, 1.0 GB), segments per loop
+  // iteration x workgroups per CU: 3x2 0.173 ms, 4x2 0.167, 4x3 0.164, 4x4 0.170, 6x2 0.164, 6x4 0.180 (scripts/sweep_update.sh).
+  static const int per_cu = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 3;
+  const long cap = 256L * (per_cu > 0 ? per_cu : 3);
   if (blocks > cap) blocks = cap;
   static const int rows_kernel = getenv("ICS_UPDATE_KERNEL") ? atoi(getenv("ICS_UPDATE_KERNEL")) : 1;   // 0: the pixel-group kernel everywhere
   const int tvk = (a.tv && a.tv_kind) ? (a.tv_kind >= 2 ? 2 : 1) : 0;
