@@ -6,7 +6,7 @@
 // The reference evaluates the autocorrelation with scipy's FFT convolution (pyx:632).  Here the
 // window (<= 1024 px) is zero-padded to a power of two P >= 2*max(H,W)-1 and autocorrelated by
 // Wiener-Khinchin with a radix-2 Stockham FFT that runs entirely in LDS (one line per workgroup):
-// rows, columns, |Z|^2, inverse columns, inverse rows.  3*P*P complex64 = 6 MB for a 255^2 window,
+// rows of the window, columns, |Z|^2 + inverse columns, inverse rows of the lags that are read.  3*P*P complex64 = 6 MB for a 255^2 window,
 // a few tens of microseconds per outer iteration, so the stop test never leaves the GPU.
 #include "ics_kernels.h"
 
@@ -98,42 +98,60 @@ __global__ __launch_bounds__(256) void k_mom3(IcsStatsArgs a) {
   if (threadIdx.x == 0) atomicMax(a.ukey, (mx != mx) ? 0xFFC00000u : ics_f2key(mx));
 }
 
-// z[c][i][j] = ((e - mean)/std)/max|t| inside the window, 0 elsewhere (zero padding to P x P)
-__global__ __launch_bounds__(256) void k_win_fill(IcsStatsArgs a) {
-  const IcsGeom& G = a.geo;
-  const Win w = make_win(a);
-  const int H = w.H, W = w.W, P = a.P, pad = G.pad;
-  const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne), mx = ics_key2f(a.ukey[0]);
-  const long total = 3L * P * P;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int j = (int)(i % P), r = (int)((i / P) % P), c = (int)(i / ((long)P * P));
-    float v = 0.f;
-    if (r < H && j < W) {
-      const float e = a.e[(ptrdiff_t)(a.top + pad + r) * G.pitch + 3 * (a.left + pad + j) + c];
-      v = __fdiv_rn(__fdiv_rn(__fsub_rn(e, mean_e), std_e), mx);
-    }
-    a.z[i] = make_float2(v, 0.f);
-  }
-}
-
-// One P-point complex FFT per workgroup (P/2 threads), radix-2 Stockham autosort in LDS.
-// element j of line `b` lives at data[b_off + j*stride]; forward: exp(-i...), inverse: conjugate, unscaled.
-__global__ void k_fft(float2* data, int P, int logP, long stride_elem, long line_stride, int lines_per_plane,
-                      long plane_stride, int inverse, const float2* __restrict__ tw) {
+// One P-point complex FFT per workgroup (P/2 threads), radix-2 Stockham autosort in LDS; element j of a line lives at
+// base + j * stride_elem; forward: exp(-i...), inverse: conjugate, unscaled.  The element-wise passes around the four
+// transforms are folded into the loads, and only the lines that matter are transformed:
+//   LOAD 1: row transform of the normalised window z = ((e - mean)/std)/max|t| straight from the residual frame, zero
+//           padded to P columns; rows >= H of the padded P x P array are zero and are neither written nor transformed
+//   LOAD 2: forward column transform; rows >= H are read as zero
+//   LOAD 3: inverse column transform of |Z|^2 (Wiener-Khinchin)
+//   LOAD 0: inverse row transform of the rows k_mr reads (|row offset| <= H/2, through the line remap)
+// line l of a plane is row/column  l < n0 ? l : l + skip.  (As separate kernels -- window fill, four full transforms,
+// |Z|^2 -- the same arithmetic took six launches and 0.075 ms.)
+struct FftX {
+  float2* data; int P, logP; long stride_elem, line_stride; int lines_per_plane; long plane_stride; int inverse; const float2* tw;
+  int n0, skip, nvalid;
+};
+template <int LOAD>
+__global__ void k_fftx(FftX f, IcsStatsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float2 sm[];
   float2* x = sm;
-  float2* y = sm + P;
-  const int t = P >> 1, tid = threadIdx.x;
-  const int line = blockIdx.x;
-  float2* base = data + (long)(line / lines_per_plane) * plane_stride + (long)(line % lines_per_plane) * line_stride;
-  x[tid] = base[(long)tid * stride_elem];
-  x[tid + t] = base[(long)(tid + t) * stride_elem];
+  float2* y = sm + f.P;
+  const int P = f.P, t = P >> 1, tid = threadIdx.x;
+  const int plane = blockIdx.x / f.lines_per_plane;
+  int line = blockIdx.x - plane * f.lines_per_plane;
+  line = line < f.n0 ? line : line + f.skip;
+  float2* base = f.data + (long)plane * f.plane_stride + (long)line * f.line_stride;
+  if (LOAD == 1) {
+    const IcsGeom& G = a.geo;
+    const Win w = make_win(a);
+    const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne), mx = ics_key2f(a.ukey[0]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = tid + h * t;
+      float v = 0.f;
+      if (line < w.H && j < w.W) {
+        const float e = a.e[(ptrdiff_t)(a.top + G.pad + line) * G.pitch + 3 * (a.left + G.pad + j) + plane];
+        v = __fdiv_rn(__fdiv_rn(__fsub_rn(e, mean_e), std_e), mx);
+      }
+      x[j] = make_float2(v, 0.f);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = tid + h * t;
+      float2 v = make_float2(0.f, 0.f);
+      if (LOAD != 2 || j < f.nvalid) v = base[(long)j * f.stride_elem];
+      if (LOAD == 3) v = make_float2(v.x * v.x + v.y * v.y, 0.f);
+      x[j] = v;
+    }
+  }
   __syncthreads();
-  for (int s = 0, p = 1; s < logP; ++s, p <<= 1) {
+  for (int s = 0, p = 1; s < f.logP; ++s, p <<= 1) {
     const int k = tid & (p - 1);
     const int j = ((tid - k) << 1) + k;
-    float2 w = tw[k * (t / p)];
-    if (inverse) w.y = -w.y;
+    float2 w = f.tw[k * (t / p)];
+    if (f.inverse) w.y = -w.y;
     const float2 u0 = x[tid], v = x[tid + t];
     const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
     y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
@@ -141,15 +159,8 @@ __global__ void k_fft(float2* data, int P, int logP, long stride_elem, long line
     __syncthreads();
     float2* tmp = x; x = y; y = tmp;
   }
-  base[(long)tid * stride_elem] = x[tid];
-  base[(long)(tid + t) * stride_elem] = x[tid + t];
-}
-
-__global__ __launch_bounds__(256) void k_abs2(float2* z, long total) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const float2 v = z[i];
-    z[i] = make_float2(v.x * v.x + v.y * v.y, 0.f);
-  }
+  base[(long)tid * f.stride_elem] = x[tid];
+  base[(long)(tid + t) * f.stride_elem] = x[tid + t];
 }
 
 // sum over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
@@ -210,17 +221,19 @@ hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
   if (a.do_mr) {
     hipLaunchKernelGGL(k_mom3, dim3(gb), dim3(256), 0, s, a);
     const int P = a.P;
-    const long total = 3L * P * P;
-    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_win_fill, dim3((unsigned)blocks), dim3(256), 0, s, a);
     const size_t lds = 2 * (size_t)P * sizeof(float2);
     const long plane = (long)P * P;
+    const int H = a.bottom - a.top;
     // rows: line = row, elements contiguous; columns: line = column, element stride P
-    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, 1L, (long)P, P, plane, 0, a.tw);
-    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, (long)P, 1L, P, plane, 0, a.tw);
-    hipLaunchKernelGGL(k_abs2, dim3((unsigned)blocks), dim3(256), 0, s, a.z, total);
-    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, (long)P, 1L, P, plane, 1, a.tw);
-    hipLaunchKernelGGL(k_fft, dim3(3 * P), dim3(P / 2), lds, s, a.z, P, a.logP, 1L, (long)P, P, plane, 1, a.tw);
+    FftX f = {a.z, P, a.logP, 1L, (long)P, H, plane, 0, a.tw, H, 0, H};
+    hipLaunchKernelGGL(k_fftx<1>, dim3(3 * H), dim3(P / 2), lds, s, f, a);                     // rows of the window
+    f.stride_elem = P; f.line_stride = 1; f.lines_per_plane = P; f.n0 = P;
+    hipLaunchKernelGGL(k_fftx<2>, dim3(3 * P), dim3(P / 2), lds, s, f, a);                     // columns (rows >= H are zero)
+    f.inverse = 1;
+    hipLaunchKernelGGL(k_fftx<3>, dim3(3 * P), dim3(P / 2), lds, s, f, a);                     // |Z|^2, inverse columns
+    // inverse rows: k_mr reads rows (r - H/2) mod P, r < H:  0 .. H - H/2 - 1  and  P - H/2 .. P - 1
+    f.stride_elem = 1; f.line_stride = P; f.lines_per_plane = H; f.n0 = H - H / 2; f.skip = P - H;
+    hipLaunchKernelGGL(k_fftx<0>, dim3(3 * H), dim3(P / 2), lds, s, f, a);
     hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);
   }
   hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);
