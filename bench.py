@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "image-cases-studies_amd"))
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic bytes per pixel and launch (one fp32 x 3 frame transit T = 12 B/px)
-BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "psf_gradient": 24.0,
+BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "psf_gradient": 24.0, "synth_gradk": 60.0,
                 "update_synth": 72.0}  # fused update + convolution: 4 reads + 2 writes
 ITER_BYTES_PER_PX = {"nonblind": 144.0, "blind": 204.0}
 
@@ -175,7 +175,7 @@ def main():
         ms_per_step = elapsed * 1e3 / steps
         value = grp.size * M * N * steps / elapsed / 1e6
         names = _native.KERNEL_NAMES
-        kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(8) if st.launches[k]}
+        kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
         traffic = None
         try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/)

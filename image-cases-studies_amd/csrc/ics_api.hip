@@ -28,6 +28,11 @@ static int fail(int code, const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
   return code;
 }
+// the same for the other translation units (ics_group.hip)
+int ics_set_error(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
 #define HIPCHK(x)                                                                                \
   do {                                                                                           \
     hipError_t e_ = (x);                                                                         \
@@ -489,6 +494,26 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   return ICS_OK;
 }
 
+// A11 + A13 in one kernel where it exists (matrix-core path, MK <= 15): ics_synth_gradk_mfma.hip
+static bool use_fused_gradk(const ics_rl* j, const ics_rl_params* p) {
+  if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return false;
+  if (p->flags & ICS_FLAG_NO_FUSED_GRADK) return false;
+  static const int env = [] { const char* e = getenv("ICS_FUSED_GRADK"); return (e && e[0] == '0') ? 0 : 1; }();
+  return env && use_matrix_conv(j, p) && use_matrix_gradk(j, p);
+}
+
+static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof& pr) {
+  IcsFusedArgs a;
+  a.u = org(j, j->u); a.f = org(j, j->f); a.e_out = org(j, j->e); a.bt = j->bt_conv; a.partial = j->partial; a.g = j->g;
+  a.wy0 = p->top + j->g.pad; a.wy1 = p->bottom + j->g.pad; a.wx0 = p->left + j->g.pad; a.wx1 = p->right + j->g.pad;
+  a.store_all = store_all;
+  RC(pr.begin(ICS_K_SYNTH_GRADK));
+  HIPCHK(ics_launch_synth_gradk(a, j->gradk_blocks, j->ctx->stream));
+  HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
 static int do_psf(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   RC(pr.begin(ICS_K_PSF_UPDATE));
   RC(pack_weights(j, 1, p->step_factor, p->correlation, j->ctx->stream));
@@ -565,6 +590,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
     RC(reset_dofkeys(j));
     const bool fuse = p->fuse != 0;
+    const bool fused_gk = p->blind && !fuse && use_fused_gradk(j, p);
     bool have_e = false;  // error already produced by a fused update+synth kernel
     for (int itt = 0; itt < INNER; ++itt) {                   // pyx:473
       const int last = itt == INNER - 1;
@@ -577,8 +603,12 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       RC(do_conv(j, 1, p, itt, 0, pr));                       // A3 (+A7)
       if (p->blind) {                                         // pyx:555
         if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
-        else { RC(do_update(j, p, itt, last, pr)); RC(do_conv(j, 0, p, itt, 0, pr)); }
-        RC(do_gradk(j, p, pr));                               // A12+A13
+        else {
+          RC(do_update(j, p, itt, last, pr));
+          if (fused_gk) RC(do_synth_gradk(j, p, 0, pr));      // A11 + A12 + A13, e' stays on chip
+          else RC(do_conv(j, 0, p, itt, 0, pr));
+        }
+        if (fuse || !fused_gk) RC(do_gradk(j, p, pr));        // A12+A13
         RC(do_psf(j, p, pr));                                 // A14-A17
       } else if (fuse && !last) {
         RC(do_conv(j, 2, p, itt, 0, pr));                     // A5-A10 fused with A1+A2 of itt+1
@@ -656,6 +686,11 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       RC(do_conv(j, 2, p, 0, 1, pr));
       break;
     case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, p, pr)); break;
+    case ICS_STAGE_SYNTH_GRADK:
+      if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_GRADK is built for PSF sizes <= 15");
+      RC(pack_weights(j, 0, 0.f, 0, s));
+      RC(do_synth_gradk(j, p, 1, pr));
+      break;
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
     case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;
     case ICS_STAGE_STATS:

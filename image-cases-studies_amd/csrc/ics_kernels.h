@@ -47,6 +47,19 @@ hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s);
 // matrix-core variant for PSF sizes <= 15 (ics_gradk_mfma.hip): fp16-split operands, same partial layout
 bool ics_gradk_mfma_supported(int K);
 hipError_t ics_launch_gradk_mfma(const IcsGradkArgs& a, int nblocks, hipStream_t s);
+// ---- A11 + A13 fused (ics_synth_gradk_mfma.hip, PSF sizes <= 15): e' = conv(u, psf) - image never leaves the CU ---------
+struct IcsFusedArgs {
+  const float* u;     // u frame origin
+  const float* f;     // image frame origin
+  float* e_out;       // residual frame origin: e' is stored only where tiles meet the window below (or everywhere: store_all)
+  const void* bt;     // weight table of the matrix-core convolution, conv orientation (ics_common.h)
+  float* partial;     // [nblocks][3][16][16] per-workgroup partial sums (layout of k_gradk_mfma, reduced by k_gradk_reduce)
+  int wy0, wy1, wx0, wx1;   // stats window (pyx:600-601,627) in u-frame coordinates
+  int store_all;
+  IcsGeom g;
+};
+bool ics_synth_gradk_supported(int K);
+hipError_t ics_launch_synth_gradk(const IcsFusedArgs& a, int nblocks, hipStream_t s);
 // gradk[a][b][c] = sum over workgroups (double accumulation, fixed order)
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s);
 

@@ -1,0 +1,535 @@
+// ics_synth_gradk_mfma.hip -- A11 + A12 + A13 of the blind inner iteration in ONE pass over u (PSF sizes 3..15):
+//
+//   e'    = convolve(u, psf, "valid") - image                      lib/deconvolution.pyx:555-565   (A11)
+//   gradk = convolve(rot180(u), e', "valid")                       lib/deconvolution.pyx:567-571   (A12 + A13)
+//         = sum_{y,x} e'[y, x, c] * u[y + pad - a, x + pad - b, c]                (u-frame coordinates)
+//
+// Why fuse: as two kernels the residual e' makes a round trip through HBM (written by k_conv_mfma<K,0>, re-read with a
+// 16-column halo by k_gradk_mfma) and u is staged and split into fp16 planes twice; the PSF gradient alone moved 1.63x its
+// algorithmic bytes (profiles/r01_hbm_traffic.json).  The u planes a convolution tile holds in LDS are exactly the A operand
+// of the gradient restricted to that tile's residual pixels, so the tile sums need nothing from neighbouring tiles.  Here e'
+// never leaves the CU (it is written to HBM only where the stop-test statistics read it, A18/A19 pyx:593-638), u is read
+// once: 2 frame transits (u, image) instead of 5.3.
+//
+// Shape.  Persistent 4-wave workgroups, two per CU, 64x64-pixel tiles of the M x N interior, same walk, same fp16-split
+// arithmetic and the same Toeplitz convolution loop as ics_conv_mfma.hip (see there), but ONE CHANNEL AT A TIME through LDS so
+// that two workgroups still fit a CU:
+//   * the fp32 HWC rows of the tile stay in registers (84 VGPRs) until the third channel is converted; the next tile's rows
+//     are requested right after that and are in flight during the last two matrix phases;
+//   * LDS (77 KB): two buffers of (hi, lo) u planes for one channel (rows grouped by y mod 4 as in ics_conv_mfma.hip), the e'
+//     planes of one channel (64 rows x 80 halves, hi/lo interleaved dword by dword, zero columns left and right so that the
+//     sliding windows of the tile's border need no neighbour), the convolution weights;
+//   * per channel c:  conv(c) -> e'(c) in registers -> [barrier: tile maximum of |e'|] -> e'(c) planes, u planes of c+1 ->
+//     [barrier] -> gradk(c), conv(c+1) ...: two barriers per channel, and a wave runs gradk(c) and conv(c+1) back to back so
+//     the four waves drift apart and overlap their LDS-heavy (gradient) and matrix-heavy (convolution) phases;
+//   * gradient step = one residual row y, one channel, three 32-column chunks of the 80 staged u columns:
+//         D[a][b] += sum_k A[a][k] B[k][b],   A[a][k] = u[y + 2 pad - a][32 X + k],   B[k][b] = e'[y][32 X + k - 2 pad + b]
+//     A = 16 lane rows of the u planes (ds_read_b128), B = sliding window of the e' row (five dword pairs + v_alignbit, as in
+//     ics_gradk_mfma.hip), three MFMAs (hi*hi, hi*lo, lo*hi) per chunk; wave w owns rows 16w..16w+15.
+//   * accumulators are folded into fp32 totals per tile and channel with the exact inverse scales; one partial block per
+//     workgroup, reduced in double by k_gradk_reduce (ics_kernels.hip), deterministic.
+#include "ics_kernels.h"
+#include <type_traits>
+
+#ifndef ICS_FUSED_INTERLEAVE
+#define ICS_FUSED_INTERLEAVE 1
+#endif
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// row classes of the u planes (rows c, c+4, ... contiguous): sizes and padded byte offsets.  The bases are padded so that the
+// gradient's A fragments (16 consecutive rows = 4 rows of each class) spread over the banks (brute-force search over the
+// offsets modulo 256, ds_read_b128 lane groups of gfx950: 7 LDS cycles on average instead of 12 unpadded; 4 = conflict-free)
+template <int K>
+struct FRows {
+  static constexpr int LROWS = 64 + K - 1, ROWB = 160;
+  static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
+  static constexpr int want(int c) { return c == 0 ? 0 : (c == 1 ? 32 : (c == 2 ? 96 : 224)); }
+  static constexpr int cls_off(int c) {
+    if (c == 0) return 0;
+    int off = cls_off(c - 1) + cls_rows(c - 1) * ROWB;
+    while (off % 256 != want(c)) off += 16;
+    return off;
+  }
+};
+
+template <int K>
+struct FCfg {
+  static constexpr int PAD = K / 2;
+  static constexpr int TH = 64, TW = 64;
+  static constexpr int NW = 4, NT = 64 * NW;
+  static constexpr int LROWS = TH + K - 1;           // staged u rows
+  static constexpr int LCOLS = TW + 16;              // staged u columns [x0 - PAD, x0 - PAD + 80)
+  static constexpr int ROWB = 2 * LCOLS;             // 160 bytes per plane row
+  static constexpr int OFF0 = 0, OFF1 = FRows<K>::cls_off(1), OFF2 = FRows<K>::cls_off(2), OFF3 = FRows<K>::cls_off(3);
+  static constexpr int cls_off(int c) { return c == 0 ? OFF0 : (c == 1 ? OFF1 : (c == 2 ? OFF2 : OFF3)); }
+  static constexpr int PLANE = ((OFF3 + FRows<K>::cls_rows(3) * ROWB + 32 + 15) / 16) * 16;   // + 32: the third chunk over-reads a row
+  static constexpr int UOFF = 0;                       // [buffer][hi/lo] planes
+  static constexpr int EROWB = 4 * LCOLS;              // 320 bytes: (hi, lo) dword pairs of 80 halves, x = -8 .. 71
+  static constexpr int EOFF = 4 * PLANE;
+  static constexpr int EBYTES = TH * EROWB + 64;       // + slack: the five-pair read of the last row
+  static constexpr int SCR = EOFF + EBYTES;            // 256 bytes of floats
+  static constexpr int WROWB = (2 * (K + 17) + 3) & ~3;
+  static constexpr int WZERO = (K + 7) / 2;
+  static constexpr int WLDS = 3 * K * 2 * WROWB;
+  static constexpr int WOFF = SCR + 256;
+  static constexpr size_t LDS_BYTES = WOFF + WLDS;
+  static constexpr int NQ = K + 3;
+  static constexpr int XG = LCOLS / 4;
+  static constexpr int NTASK = LROWS * XG;
+  static constexpr int NIT = (NTASK + NT - 1) / NT;
+  static_assert(K >= 3 && K <= 15 && (K & 1), "one 32-wide MFMA window per column block, one 16-tap block");
+  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+};
+
+#define ICS_BUF_WORD3 0x00020000  /* gfx9 raw buffer: DATA_FORMAT = 32 */
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, ICS_BUF_WORD3);
+}
+
+// power-of-two scale that brings a maximum magnitude m into [2^14, 2^15); 1 for m = 0 / Inf / NaN.  `inv` is the exact inverse.
+__device__ __forceinline__ void pow2_scale(float m, float& s, float& inv) {
+  const uint32_t e = (__float_as_uint(m) >> 23) & 0xFFu;
+  uint32_t sb = 127u;
+  if (m > 0.f && e != 255u) { sb = 268u - e; sb = sb > 240u ? 240u : sb; }
+  s = __uint_as_float(sb << 23);
+  inv = __uint_as_float((254u - sb) << 23);
+}
+
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+template <typename C>
+__device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer_rsrc_t rs, int soff, int tid, int pitch) {
+#pragma unroll
+  for (int k = 0; k < C::NIT; ++k) {
+    int t = tid + k * C::NT;
+    t = t < C::NTASK ? t : C::NTASK - 1;
+    const int row = t / C::XG, xg = t - row * C::XG;
+    const int toff = 4 * (row * pitch + 12 * xg);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) v[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16 * h, soff, 0));
+  }
+}
+
+// one channel of the staged rows -> (hi, lo) fp16 planes, rows grouped by y mod 4
+template <typename C, int CH>
+__device__ __forceinline__ void convert_channel(const f32x4u (&raw)[C::NIT][3], float s_x, unsigned char* plane, int tid) {
+#pragma unroll
+  for (int k = 0; k < C::NIT; ++k) {
+    const int t = tid + k * C::NT;
+    if (t < C::NTASK) {
+      const int row = t / C::XG, xg = t - row * C::XG;
+      const int rc = row & 3;
+      const int coff = C::cls_off(rc) + (row >> 2) * C::ROWB;
+      unsigned char* dst = plane + coff + 8 * xg;
+      h4 hi, lo;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int idx = 3 * p + CH;
+        const float x = raw[k][idx >> 2][idx & 3] * s_x;
+        const _Float16 xh = (_Float16)x;
+        hi[p] = xh;
+        lo[p] = (_Float16)(x - (float)xh);
+      }
+      *reinterpret_cast<h4*>(dst) = hi;
+      *reinterpret_cast<h4*>(dst + C::PLANE) = lo;
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_synth_gradk(IcsFusedArgs a) {
+  using C = FCfg<K>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* fscr = reinterpret_cast<float*>(lds + C::SCR);
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int pitch = a.g.pitch;
+
+  // persistent tile walk over the M x N interior (tiles start at (PAD, PAD)), one contiguous band of tiles per XCD
+  constexpr int TORG = C::PAD;
+  const int tpr = (a.g.N + C::TW - 1) / C::TW;
+  const int ntiles = tpr * ((a.g.M + C::TH - 1) / C::TH);
+  const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
+  const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;
+  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  int tile = band0 + kx;
+
+  f4 tot[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tot[c] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  // LDS: everything zero once (class padding, over-read slack and the zero columns of the e' rows are never written again),
+  // then the weight rows (the global table is the LDS image)
+  {
+    u4* z = reinterpret_cast<u4*>(lds);
+    for (int i = tid; i < C::WOFF / 16; i += C::NT) z[i] = (u4){0u, 0u, 0u, 0u};
+    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
+    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+  }
+  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
+
+  // ---- lane constants --------------------------------------------------------------------------------------------
+  typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)(lds);
+  // convolution, B operand (weight rows): see ics_conv_mfma.hip
+  uint32_t wa0, wsh;
+  {
+    const int bo = 8 * lg - li + 15;
+    const bool bzero = bo < 8 || bo > K + 14;
+    wsh = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
+    wa0 = lds0 + (uint32_t)C::WOFF + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+    asm volatile("" : "+v"(wa0));
+  }
+  // convolution, A operand: lane row li of column block wv, 8 halves at 16 wv + 8 lg
+  const uint32_t conv_a = lds0 + (uint32_t)(C::UOFF + li * C::ROWB + (16 * wv + 8 * lg) * 2);
+  // gradient, A operand: lane row li <-> tap a (rows of D), u row (16 wv + i) + 2 pad - a of the staged block, 8 halves at 8 lg
+  // of each 32-column chunk.  For i mod 4 = j the class and the row inside the class are lane constants; i -> i + 4 is one row
+  // further inside the class.
+  uint32_t ga[4];
+  {
+    const int ta = li < K ? li : K - 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = j + 2 * C::PAD - ta;                        // >= 0
+      const int rc = r & 3;
+      const int coff = C::cls_off(rc) + ((r >> 2) + 4 * wv) * C::ROWB;
+      ga[j] = lds0 + (uint32_t)(C::UOFF + coff + 16 * lg);
+    }
+  }
+  // gradient, B operand: lane column li <-> tap b; in chunk X its 8 halves start at e' column s = 32 X + 8 lg + b - 2 pad.
+  // Windows entirely left / right of the tile's 64 columns are moved onto the zero columns of the row.
+  uint32_t gb[3], gsh[3];
+  {
+    const int tb = li < K ? li : K - 1;
+#pragma unroll
+    for (int X = 0; X < 3; ++X) {
+      int s = 32 * X + 8 * lg + tb - 2 * C::PAD;
+      s = s <= -8 ? -8 : (s >= 64 ? 64 : s);
+      gsh[X] = (uint32_t)(s & 1) * 16u;
+      gb[X] = lds0 + (uint32_t)(C::EOFF + 16 * wv * C::EROWB + 8 * ((s + 8) >> 1));
+    }
+  }
+  // e' planes, store side: value (row t + 16 lg + 4 r, column 16 wv + li); lanes li, li ^ 1 share a dword pair
+  const uint32_t ew = lds0 + (uint32_t)(C::EOFF + 16 * lg * C::EROWB + 8 * ((16 * wv + li + 8) >> 1) + 4 * (li & 1));
+
+  const ptrdiff_t orgoff = (ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax;
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.u - orgoff);
+  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(a.f);
+  const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.e_out);
+
+  f32x4u raw[C::NIT][3];
+  if (tile < band1) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
+  }
+  __syncthreads();   // LDS initialised
+
+#pragma unroll 1
+  for (; tile < band1; tile += nx) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
+    const bool store_e = a.store_all || (y0 < a.wy1 && y0 + C::TH > a.wy0 && x0 < a.wx1 && x0 + C::TW > a.wx0);   // wave-uniform
+
+    // ---- per-tile power-of-two scale of u (all three channels) ---------------------------------------------------
+    float s_x, inv_x;
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::NIT; ++k)
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(raw[k][h][e]));
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      if (lane == 0) fscr[wv] = m;
+      __syncthreads();   // S0: also orders the previous tile's last gradient phase before the planes are rewritten
+#pragma unroll
+      for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
+      pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
+    }
+    const float sc = inv_w * inv_x;
+
+    // lane part of the epilogue addresses (image operand, optional e' store): pixel column 16 wv + li, rows 16 lg + ...
+    const int tide = opaque(tid);
+    const int eli = tide & 15, elg = (tide >> 4) & 3;
+    const int colx = x0 + 16 * wv + eli;
+    const int voff = 4 * (16 * elg * pitch + 3 * eli);
+    const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
+
+    uint32_t fop[4][4];   // image operand of the channel being convolved
+    auto load_f = [&](int ch) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          fop[t][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff + 4 * ch, sb + 4 * (t + 4 * r) * pitch, 0);
+    };
+
+    f4 acc[4];
+    // ---- Toeplitz convolution of one channel from plane buffer (ch & 1): ics_conv_mfma.hip, one channel -------------
+    auto conv_phase = [&](auto chc) {
+      constexpr int ch = decltype(chc)::value;
+      constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+      typedef const __attribute__((address_space(3))) h8* lds_h8p;
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+      uint32_t wb = wa0; asm volatile("" : "+v"(wb));
+      uint32_t ca = conv_a; asm volatile("" : "+v"(ca));
+      h8 Bh[K], Bl[K];
+      u2 rawB[5];
+      auto issueB = [&](int ka) {
+        const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb + (uint32_t)((ch * K + ka) * 2 * C::WROWB));
+#pragma unroll
+        for (int d = 0; d < 5; ++d) rawB[d] = r[d];
+      };
+      auto finishB = [&](int ka) {
+        const u2* d = rawB;
+        const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, wsh), __builtin_amdgcn_alignbit(d[2].x, d[1].x, wsh),
+                       __builtin_amdgcn_alignbit(d[3].x, d[2].x, wsh), __builtin_amdgcn_alignbit(d[4].x, d[3].x, wsh)};
+        const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, wsh), __builtin_amdgcn_alignbit(d[2].y, d[1].y, wsh),
+                       __builtin_amdgcn_alignbit(d[3].y, d[2].y, wsh), __builtin_amdgcn_alignbit(d[4].y, d[3].y, wsh)};
+        Bh[ka] = __builtin_bit_cast(h8, wh);
+        Bl[ka] = __builtin_bit_cast(h8, wl);
+      };
+      issueB(0);
+      h8 Ah = *reinterpret_cast<lds_h8p>(ca + PB), Al = *reinterpret_cast<lds_h8p>(ca + PB + C::PLANE);
+      finishB(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < C::NQ; ++q) {
+        h8 Nh = Ah, Nl = Al;
+        if (q + 1 < C::NQ) {
+            const uint32_t off = (uint32_t)(C::cls_off((q + 1) & 3) + ((q + 1) >> 2) * C::ROWB);
+          Nh = *reinterpret_cast<lds_h8p>(ca + PB + off);
+          Nl = *reinterpret_cast<lds_h8p>(ca + PB + C::PLANE + off);
+        }
+        if (q + 1 < K) issueB(q + 1);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int ka = q - t;
+            if (ka < 0 || ka >= K) continue;
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al : Ah, term == 1 ? Bl[ka] : Bh[ka], acc[t], 0, 0, 0);
+          }
+        if (q + 1 < K) finishB(q + 1);
+        Ah = Nh; Al = Nl;
+        if (ICS_FUSED_INTERLEAVE) {
+          int nt = 0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
+          const int nm = 3 * nt;
+          const int nr = ((q + 1 < C::NQ) ? 2 : 0) + ((q + 1 < K) ? 5 : 0);
+          const int nv = (q + 1 < K) ? 8 : 0;
+          const int tail = nv ? (nm > 4 ? 4 : nm) : 0;
+          const int head = nm - tail;
+#pragma unroll
+          for (int i = 0; i < (head > nr ? head : nr); ++i) {
+            if (i < head) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < tail; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+            for (int j = 0; j < (nv / 2 + tail - 1) / tail; ++j) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // ---- e'(ch) = conv - image (0 outside the M x N interior), kept in `acc`; returns the lane's max |e'| ---------------
+    auto residual = [&](int ch) -> float {
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = y0 + t + 16 * elg + 4 * r;
+          const bool in = y < C::PAD + a.g.M && colx < C::PAD + a.g.N;   // (tiles start at (PAD, PAD))
+          const float e = in ? __fsub_rn(acc[t][r] * sc, __uint_as_float(fop[t][r])) : 0.f;
+          acc[t][r] = e;
+          m = __builtin_fmaxf(m, __builtin_fabsf(e));
+          if (store_e && in) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rs_o, voff + 4 * ch, sb + 4 * (t + 4 * r) * pitch, 0);
+        }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      return m;
+    };
+
+    // ---- e' -> fp16 (hi, lo) planes: a lane packs (hi | lo << 16), swaps with its column neighbour and stores one dword --
+    auto write_e = [&](float s_e) {
+      typedef __attribute__((address_space(3))) uint32_t* lds_wp;
+      const bool odd = (li & 1) != 0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = acc[t][r] * s_e;
+          const _Float16 xh = (_Float16)x;
+          const _Float16 xl = (_Float16)(x - (float)xh);
+          const uint32_t P = (uint32_t)__builtin_bit_cast(unsigned short, xh) | ((uint32_t)__builtin_bit_cast(unsigned short, xl) << 16);
+          const uint32_t Q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+          // even column: hi dword = (own hi, neighbour hi); odd column: lo dword = (neighbour lo, own lo)
+          const uint32_t w = odd ? ((Q >> 16) | (P & 0xFFFF0000u)) : ((P & 0xFFFFu) | (Q << 16));
+          *reinterpret_cast<lds_wp>(ew + (uint32_t)((t + 4 * r) * C::EROWB)) = w;
+        }
+    };
+
+    // ---- PSF gradient of one channel: 16 residual rows of this wave x 3 chunks x 3 split terms ----------------------------
+    auto gradk_phase = [&](auto chc, float scale) {
+      constexpr int ch = decltype(chc)::value;
+      constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
+      typedef const __attribute__((address_space(3))) h8* lds_h8p;
+      typedef const __attribute__((address_space(3))) u2* lds_u2p;
+      f4 g[3];
+#pragma unroll
+      for (int X = 0; X < 3; ++X) g[X] = (f4){0.f, 0.f, 0.f, 0.f};
+      uint32_t gav[4], gbv[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
+#pragma unroll
+      for (int X = 0; X < 3; ++X) { gbv[X] = gb[X]; asm volatile("" : "+v"(gbv[X])); }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        h8 Ah[3], Al[3], Bh[3], Bl[3];
+#pragma unroll
+        for (int X = 0; X < 3; ++X) {
+          const uint32_t ar = gav[i & 3] + PB + (uint32_t)((i >> 2) * C::ROWB + 64 * X);
+          Ah[X] = *reinterpret_cast<lds_h8p>(ar);
+          Al[X] = *reinterpret_cast<lds_h8p>(ar + C::PLANE);
+          const lds_u2p ep = reinterpret_cast<lds_u2p>(gbv[X] + (uint32_t)(i * C::EROWB));
+          u2 d[5];
+#pragma unroll
+          for (int k = 0; k < 5; ++k) d[k] = ep[k];
+          const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, gsh[X]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, gsh[X]),
+                         __builtin_amdgcn_alignbit(d[3].x, d[2].x, gsh[X]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, gsh[X])};
+          const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, gsh[X]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, gsh[X]),
+                         __builtin_amdgcn_alignbit(d[3].y, d[2].y, gsh[X]), __builtin_amdgcn_alignbit(d[4].y, d[3].y, gsh[X])};
+          Bh[X] = __builtin_bit_cast(h8, wh);
+          Bl[X] = __builtin_bit_cast(h8, wl);
+        }
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int X = 0; X < 3; ++X)
+            g[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al[X] : Ah[X], term == 1 ? Bl[X] : Bh[X], g[X], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[ch][r] += ((g[0][r] + g[1][r]) + g[2][r]) * scale;
+    };
+
+    // ================================ the tile ======================================================================
+    unsigned char* const up = lds + C::UOFF;
+    convert_channel<C, 0>(raw, s_x, up, opaque(tid));
+    load_f(0);
+    __syncthreads();                                                   // planes of channel 0 visible
+    conv_phase(std::integral_constant<int, 0>{});
+    float s_e, inv_e, me;
+
+#define ICS_FUSED_CHANNEL(CH)                                                                                           \
+    me = residual(CH);                                                                                                  \
+    if (lane == 0) fscr[8 + 4 * (CH) + wv] = me;                                                                        \
+    if ((CH) < 2) load_f((CH) + 1);                                                                                     \
+    __syncthreads();   /* tile maximum; every wave is past the previous gradient phase: e' planes and u buffer free */  \
+    me = __builtin_fmaxf(__builtin_fmaxf(fscr[8 + 4 * (CH)], fscr[9 + 4 * (CH)]), __builtin_fmaxf(fscr[10 + 4 * (CH)], fscr[11 + 4 * (CH)])); \
+    pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me))), s_e, inv_e);      \
+    write_e(s_e);
+
+    ICS_FUSED_CHANNEL(0)
+    convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
+    __syncthreads();                                                   // e'(0) and planes(1) visible
+    gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
+    conv_phase(std::integral_constant<int, 1>{});
+
+    ICS_FUSED_CHANNEL(1)
+    convert_channel<C, 2>(raw, s_x, up, opaque(tid));
+    // the rows of the next tile: in flight during gradk(1), conv(2) (no vector-memory loads in there; the image operand of
+    // channel 2 was requested before them and returns first)
+    if (tile + nx < band1) {
+      const int nt = tile + nx;
+      const int nyi = nt / tpr, nxi = nt - nyi * tpr;
+      load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + nxi * C::TW - C::PAD)), opaque(tid), pitch);
+    }
+    __syncthreads();                                                   // e'(1) and planes(2) visible
+    gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
+    conv_phase(std::integral_constant<int, 2>{});
+
+    ICS_FUSED_CHANNEL(2)
+    __syncthreads();                                                   // e'(2) visible
+    gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
+#undef ICS_FUSED_CHANNEL
+  }
+
+  // ---- cross-wave reduction (fixed order) and partial write, one channel per pass ------------------------------------
+  float* red = reinterpret_cast<float*>(lds);   // [wave][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]
+  float* dst = a.partial + (size_t)blockIdx.x * (3 * 16 * 16);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv * 256 + r * 64 + lane] = tot[c][r];
+    __syncthreads();
+    {
+      const int v = tid;
+      float s = red[v];
+#pragma unroll
+      for (int w = 1; w < C::NW; ++w) s += red[w * 256 + v];   // fixed order -> deterministic
+      const int l = v & 63, r = (v >> 6) & 3;
+      const int ta = 4 * (l >> 4) + r, tb = l & 15;
+      dst[(c * 16 + ta) * 16 + tb] = s;
+    }
+  }
+}
+
+template <int K>
+hipError_t launch_k(const IcsFusedArgs& a, int nblocks, hipStream_t s) {
+  using C = FCfg<K>;
+  static bool configured[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  auto kern = k_synth_gradk<K>;
+  if (!configured[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
+    configured[dev] = true;
+  }
+  const int ntiles = ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH);
+  // every workgroup of the grid writes its partial block (the reduction reads `nblocks` of them): workgroups without a tile
+  // write zeros
+  (void)ntiles;
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NT), C::LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+bool ics_synth_gradk_supported(int K) { return K >= 3 && K <= 15 && (K & 1); }
+
+hipError_t ics_launch_synth_gradk(const IcsFusedArgs& a, int nblocks, hipStream_t s) {
+  if (!a.bt) return hipErrorInvalidValue;
+  switch (a.g.K) {
+    case 3: return launch_k<3>(a, nblocks, s);
+    case 5: return launch_k<5>(a, nblocks, s);
+    case 7: return launch_k<7>(a, nblocks, s);
+    case 9: return launch_k<9>(a, nblocks, s);
+    case 11: return launch_k<11>(a, nblocks, s);
+    case 13: return launch_k<13>(a, nblocks, s);
+    case 15: return launch_k<15>(a, nblocks, s);
+    default: return hipErrorInvalidValue;
+  }
+}

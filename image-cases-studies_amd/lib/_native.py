@@ -15,14 +15,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libics_hip.so"))
 
 ICS_MAX_TRACE = 1024
-ICS_KERNEL_COUNT = 8
-KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth")
+ICS_KERNEL_COUNT = 12
+KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth",
+                "synth_gradk", "_9", "_10", "_11")
 
 # error codes (include/ics_hip.h)
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
 
 # stages / buffers
-STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM = range(1, 10)
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK = range(1, 11)
+FLAG_NO_FUSED_GRADK = 1   # ics_rl_params.flags (include/ics_hip.h ICS_FLAG_*)
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV = range(9)
 CONV_AUTO, CONV_VECTOR, CONV_MATRIX = range(3)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
@@ -33,7 +35,7 @@ class RLParams(C.Structure):
     _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
                 ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
                 ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
-                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("reserved", C.c_int * 1)]
+                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("flags", C.c_int)]
 
 
 class RLStats(C.Structure):
@@ -103,14 +105,21 @@ def load():
     lib.ics_img_resize.argtypes = [vp, ci, ci, C.POINTER(vp)]
     lib.ics_rl_upload_img.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
     lib.ics_rl_download_img.argtypes = [vp, vp, ci, ci]
+    lib.ics_group_create.argtypes = [ci, ci, ci, C.c_char_p, ci, C.POINTER(vp)]
+    lib.ics_group_destroy.argtypes = [vp]; lib.ics_group_destroy.restype = None
+    lib.ics_group_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    lib.ics_group_barrier.argtypes = [vp]
+    lib.ics_group_allreduce_max.argtypes = [vp, vp, ci]
+    lib.ics_group_allgather.argtypes = [vp, vp, ci, vp]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
                  "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_normalize_kernel",
                  "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
                  "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
-                 "ics_rl_upload_img", "ics_rl_download_img"):
+                 "ics_rl_upload_img", "ics_rl_download_img", "ics_group_create", "ics_group_info", "ics_group_barrier",
+                 "ics_group_allreduce_max", "ics_group_allgather"):
         getattr(lib, name).restype = ci
-    if lib.ics_abi_version() != 1:
-        raise ImportError("libics_hip.so ABI version %d, expected 1" % lib.ics_abi_version())
+    if lib.ics_abi_version() != 2:
+        raise ImportError("libics_hip.so ABI version %d, expected 2" % lib.ics_abi_version())
     _lib = lib
     return lib
 
@@ -346,12 +355,12 @@ class RLJob:
 
     @staticmethod
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
-               stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0):
+               stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0, flags=0):
         p = RLParams()
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
         p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), int(tv_mode)
-        p.stop_test, p.profile, p.fuse, p.conv = int(stop_test), int(profile), int(fuse), int(conv)
+        p.stop_test, p.profile, p.fuse, p.conv, p.flags = int(stop_test), int(profile), int(fuse), int(conv), int(flags)
         return p
 
     def run(self, params):

@@ -21,6 +21,7 @@
  *                                                          the frames the driver keeps between two
  *                                                          richardson_lucy_MM calls (pad_image, gamma, window
  *                                                          views, resize), device-resident
+ *   ics_group_*            (none: the reference is single-process; SURVEY.md 8e defines image-per-GPU sharding)
  *   ics_resize_bicubic     deconvolve.py:245-249           skimage.transform.resize(order=3, mode="edge")
  *                                                          between pyramid levels (un-vendored dependency of
  *                                                          the reference: restated on scipy.ndimage semantics)
@@ -37,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ICS_ABI_VERSION 1
+#define ICS_ABI_VERSION 2
 
 /* error codes */
 #define ICS_OK 0
@@ -91,8 +92,14 @@ typedef struct ics_rl_params {
                                    the 1.8x halo recompute with two IEEE divisions per element outweighs
                                    the saved frame pass                            */
   int conv;                     /* ICS_CONV_*: which kernels run the convolutions A1/A3 and the PSF gradient A13    */
-  int reserved[1];
+  int flags;                    /* ICS_FLAG_* bits, 0 = defaults                                                     */
 } ics_rl_params;
+
+#define ICS_FLAG_NO_FUSED_GRADK 1 /* blind, matrix-core path, MK <= 15: run A11 and A13 as two kernels (k_conv_mfma<K,0> +
+                                     k_gradk_mfma) instead of the fused k_synth_gradk (ics_synth_gradk_mfma.hip); env
+                                     ICS_FUSED_GRADK=0 does the same for an unmodified caller.  With the fused kernel the
+                                     residual frame (ICS_BUF_ERROR) holds e' of pyx:555-565 only on the 64x64 tiles that
+                                     meet the stats window -- the only place the loop reads it (pyx:600-601,627)         */
 
 #define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built and faster (convolutions: MK <= 17 and 23..37;
                              PSF gradient: MK <= 31), vector kernels otherwise; env ICS_CONV_PATH=vector|matrix
@@ -129,8 +136,8 @@ typedef struct ics_rl_stats {
   float ms_total;      /* whole run (first launch -> last kernel), device time             */
   int inner_iterations;/* inner iterations executed                                       */
   /* params.profile = 1: average milliseconds per launch and launch count per kernel class */
-  float ms_kernel[8];
-  int launches[8];
+  float ms_kernel[12];  /* ICS_KERNEL_COUNT */
+  int launches[12];
 } ics_rl_stats;
 
 /* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 63):
@@ -156,6 +163,7 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 #define ICS_STAGE_STATS 7          /* A18+A19 on device -> stats scalars           (pyx:593-638)   */
 #define ICS_STAGE_UPDATE_SYNTH 8   /* ICS_STAGE_UPDATE fused with ICS_STAGE_SYNTH_RESIDUAL (one kernel) */
 #define ICS_STAGE_TVTERM 9         /* tv_mode 1: TV term T of u against ut (+ max|T_k|, max image_k)     */
+#define ICS_STAGE_SYNTH_GRADK 10   /* A11 + A13 in one kernel (MK <= 15): gradk, and the residual e' over the whole frame */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -180,7 +188,8 @@ int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
 #define ICS_K_MAJORIZE 5     /* ut = u copy                     */
 #define ICS_K_STATS 6        /* A18/A19 window statistics + FFT */
 #define ICS_K_UPDATE_SYNTH 7 /* fused A5-A10 + A1/A2 (or A11) kernel */
-#define ICS_KERNEL_COUNT 8
+#define ICS_K_SYNTH_GRADK 8  /* fused A11 + A13 kernel (+ reduction)  */
+#define ICS_KERNEL_COUNT 12  /* (9..11 reserved) */
 
 /* ---- small standalone operators ---------------------------------------------------------- */
 /* lib/deconvolution.pyx:73-75 -- in place on a host MK*MK*3 float32 array, computed on device. */
@@ -226,6 +235,21 @@ int ics_rl_upload_img(ics_rl *job, const ics_img *image, int iy, int ix, const i
 /* The reference updates the caller's `u` view in place, border ring included (pyx:527-531): the whole u frame goes
  * back to dst[y:y+uM, x:x+uN]. */
 int ics_rl_download_img(ics_rl *job, ics_img *dst, int y, int x);
+
+/* ---- one image per GPU (BASELINE.json configs[4]) ------------------------------------------------
+ * The reference has no multi-device code: every richardson_lucy_MM call (lib/deconvolution.pyx:341) is an independent
+ * job, so N GPUs run N jobs, one process per GPU, and nothing is exchanged during the iterations.  The only collective
+ * is the gather of a small per-rank record at the end -- RCCL over xGMI, called directly from this library (librccl.so
+ * is dlopen'ed by ics_group_create when world > 1).  `rendezvous` is a file path shared by the ranks of the node: rank
+ * 0 publishes the RCCL unique id there, the others wait up to `timeout_s` seconds for it.  With world == 1 every call
+ * is a local no-op / copy and no device is touched.  count <= 64 doubles per call. */
+typedef struct ics_group ics_group;
+int ics_group_create(int device, int rank, int world, const char *rendezvous, int timeout_s, ics_group **out);
+void ics_group_destroy(ics_group *g);
+int ics_group_info(const ics_group *g, int *rank, int *world);
+int ics_group_barrier(ics_group *g);
+int ics_group_allreduce_max(ics_group *g, double *inout, int count);
+int ics_group_allgather(ics_group *g, const double *send, int count, double *recv /* world * count */);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "libics_hip.so does not export %s" % n
-    assert lib.ics_abi_version() == 1
+    assert lib.ics_abi_version() == 2
 
 
 def test_struct_layout_matches_the_header(tmp_path):

@@ -23,7 +23,7 @@ def kernel_ms(MK, conv, size=1536):
         job.run(job.params(*win, 1e9, 2, 1e-3, 10000.0, True, stop_test=0, conv=conv))          # warm-up
         st = job.run(job.params(*win, 1e9, 4, 1e-3, 10000.0, True, stop_test=0, profile=1, conv=conv))
         names = _native.KERNEL_NAMES
-        return {names[k]: st.ms_kernel[k] for k in range(8) if st.launches[k]}
+        return {names[k]: st.ms_kernel[k] for k in range(len(names)) if st.launches[k]}
     finally:
         job.close()
 

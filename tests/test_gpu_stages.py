@@ -179,3 +179,52 @@ def test_fused_update_synth_equals_separate_kernels(M, N, MK, blind):
     assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
     assert np.array_equal(res[0][1], res[1][1], equal_nan=True)
     assert res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("M,N,MK", [(64, 64, 15), (257, 300, 15), (130, 67, 9), (200, 333, 3), (97, 133, 5), (191, 129, 7), (150, 150, 11),
+                                    (300, 260, 13), (640, 700, 15)])
+def test_fused_synth_gradk_stage(M, N, MK):
+    """ICS_STAGE_SYNTH_GRADK (ics_synth_gradk_mfma.hip: A11 + A13 in one kernel, e' on chip) against float64 direct sums, and
+    against the two-kernel path it replaces: the residual it stores (whole frame in the stage call) within the convolution
+    gate, gradk within the PSF-gradient gate of the separate kernels (1e-5 of max|gradk|)."""
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=M + 2 * N + MK, blind=True)
+    rng = np.random.default_rng(5)
+    u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=True)
+    job.stage(nv.STAGE_SYNTH_GRADK, p)
+    e = job.read(nv.BUF_ERROR)
+    gk = job.read(nv.BUF_GRADK)
+    synth = conv_valid64(u, psf)
+    e_ref = synth - case["image"]
+    assert np.max(np.abs(e - e_ref)) / np.max(np.abs(synth)) < CONV_TOL
+    gk_ref = gradk64(u.astype(np.float64), e.astype(np.float64))      # teacher-forced on the device's own residual
+    assert rel_err(gk, gk_ref) < 1e-5
+    # the two-kernel path on the same inputs
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e2 = job.read(nv.BUF_ERROR)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk2 = job.read(nv.BUF_GRADK)
+    assert np.max(np.abs(e - e2)) / np.max(np.abs(synth)) < 1e-6
+    assert rel_err(gk, gk2) < 1e-5
+    job.close()
+
+
+def test_fused_synth_gradk_in_the_loop_matches_two_kernel_path():
+    """Whole blind runs with and without the fused kernel (ICS_FLAG_NO_FUSED_GRADK): same u / psf within 1e-5, same
+    statistics (the fused kernel stores e' only on the tiles of the stats window)."""
+    from lib import _native as nv
+    M, N, MK = 300, 333, 15
+    out = []
+    for flags in (0, nv.FLAG_NO_FUSED_GRADK):
+        job, case, psf = make_job(M, N, MK, seed=21, blind=True)
+        p = job.params(40, 295, 50, 305, 1e9, 3, 1e-3, 10000.0, blind=True, flags=flags, stop_test=2, profile=1)
+        st = job.run(p)
+        u, psf_l, _ = job.download()
+        out.append((u, psf_l, st.M_r, st.Hu, st.varu, st.launches[8]))
+        job.close()
+    assert out[0][5] == 15 and out[1][5] == 0          # the fused kernel ran (or not) as requested
+    assert rel_err(out[0][0], out[1][0]) < 1e-5 and rel_err(out[0][1], out[1][1]) < 1e-5
+    for k in (2, 3, 4):
+        assert abs(out[0][k] - out[1][k]) <= 2e-4 * abs(out[1][k])
