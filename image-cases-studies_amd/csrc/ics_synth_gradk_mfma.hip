@@ -35,6 +35,21 @@
 #define ICS_FUSED_INTERLEAVE 1
 #endif
 
+// phase timing probe (tools/bench_synth_gradk.hip -DICS_FUSED_TIMING): per-wave cycle totals between the marks
+#ifdef ICS_FUSED_TIMING
+__device__ unsigned long long ics_fused_ticks[17];
+#define FTICK_INIT unsigned long long tk_prev = __builtin_readcyclecounter(), tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define FTICK(i) do { const unsigned long long tk_now = __builtin_readcyclecounter(); tk_acc[i] += tk_now - tk_prev; tk_prev = tk_now; } while (0)
+#define FTICK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 16; ++i) atomicAdd(&ics_fused_ticks[i], tk_acc[i]); atomicAdd(&ics_fused_ticks[16], 1ull); } } while (0)
+#else
+#define FTICK_INIT
+#define FTICK(i)
+#define FTICK_FLUSH
+#endif
+#ifndef ICS_FUSED_ABLATE
+#define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand */
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -104,6 +119,10 @@ __device__ __forceinline__ void pow2_scale(float m, float& s, float& inv) {
 }
 
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (vmcnt(0)):
+// with the image operand or the next tile's rows in flight it stalled the whole workgroup for an HBM round trip.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename C>
 __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer_rsrc_t rs, int soff, int tid, int pitch) {
@@ -234,6 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
   __syncthreads();   // LDS initialised
+  FTICK_INIT;
 
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -254,11 +274,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
       if (lane == 0) fscr[wv] = m;
-      __syncthreads();   // S0: also orders the previous tile's last gradient phase before the planes are rewritten
+      lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
       pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
     }
+    FTICK(0);
     const float sc = inv_w * inv_x;
 
     // lane part of the epilogue addresses (image operand, optional e' store): pixel column 16 wv + li, rows 16 lg + ...
@@ -270,6 +291,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     uint32_t fop[4][4];   // image operand of the channel being convolved
     auto load_f = [&](int ch) {
+      if (ICS_FUSED_ABLATE & 16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fop[t][r] = 0u;
+        return;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -284,6 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (ICS_FUSED_ABLATE & 2) return;
       typedef const __attribute__((address_space(3))) h8* lds_h8p;
       typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
       uint32_t wb = wa0; asm volatile("" : "+v"(wb));
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- e' -> fp16 (hi, lo) planes: a lane packs (hi | lo << 16), swaps with its column neighbour and stores one dword --
     auto write_e = [&](float s_e) {
       typedef __attribute__((address_space(3))) uint32_t* lds_wp;
+      if (ICS_FUSED_ABLATE & 4) return;
       const bool odd = (li & 1) != 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -391,31 +421,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     // ---- PSF gradient of one channel: 16 residual rows of this wave x 3 chunks x 3 split terms ----------------------------
+    // Software pipeline, one row deep: the LDS operands of row i + 1 are requested in the shadows of the first MFMAs of row i
+    // (the e' windows first: they still need their funnel shifts, which go behind the later MFMAs of the same row).  The reads
+    // are volatile: plain loads were merged into ds_read2_b64 (8 LDS cycles for two 8-byte reads instead of 2 + 2) and sunk to
+    // their first use.
     auto gradk_phase = [&](auto chc, float scale) {
       constexpr int ch = decltype(chc)::value;
       constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
-      typedef const __attribute__((address_space(3))) h8* lds_h8p;
-      typedef const __attribute__((address_space(3))) u2* lds_u2p;
+      typedef const volatile __attribute__((address_space(3))) u4* lds_vu4p;
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
       f4 g[3];
 #pragma unroll
       for (int X = 0; X < 3; ++X) g[X] = (f4){0.f, 0.f, 0.f, 0.f};
+      if (ICS_FUSED_ABLATE & 1) { tot[ch][0] += scale; return; }
       uint32_t gav[4], gbv[3];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
 #pragma unroll
       for (int X = 0; X < 3; ++X) { gbv[X] = gb[X]; asm volatile("" : "+v"(gbv[X])); }
+      u4 Ah[3], Al[3], nAh[3], nAl[3];
+      u2 rB[3][5];
+      h8 Bh[3], Bl[3];
+      auto issue = [&](int i) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        h8 Ah[3], Al[3], Bh[3], Bl[3];
+        for (int X = 0; X < 3; ++X) {
+          const lds_vu2p ep = reinterpret_cast<lds_vu2p>(gbv[X] + (uint32_t)(i * C::EROWB));
+#pragma unroll
+          for (int k = 0; k < 5; ++k) rB[X][k] = ep[k];
+        }
 #pragma unroll
         for (int X = 0; X < 3; ++X) {
           const uint32_t ar = gav[i & 3] + PB + (uint32_t)((i >> 2) * C::ROWB + 64 * X);
-          Ah[X] = *reinterpret_cast<lds_h8p>(ar);
-          Al[X] = *reinterpret_cast<lds_h8p>(ar + C::PLANE);
-          const lds_u2p ep = reinterpret_cast<lds_u2p>(gbv[X] + (uint32_t)(i * C::EROWB));
-          u2 d[5];
+          nAh[X] = *reinterpret_cast<lds_vu4p>(ar);
+          nAl[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE);
+        }
+      };
+      auto finish = [&]() {
 #pragma unroll
-          for (int k = 0; k < 5; ++k) d[k] = ep[k];
+        for (int X = 0; X < 3; ++X) {
+          const u2* d = rB[X];
           const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, gsh[X]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, gsh[X]),
                          __builtin_amdgcn_alignbit(d[3].x, d[2].x, gsh[X]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, gsh[X])};
           const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, gsh[X]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, gsh[X]),
@@ -423,11 +467,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           Bh[X] = __builtin_bit_cast(h8, wh);
           Bl[X] = __builtin_bit_cast(h8, wl);
         }
+      };
+      issue(0);
+      finish();
+#pragma unroll
+      for (int X = 0; X < 3; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        h8 cBh[3], cBl[3];
+#pragma unroll
+        for (int X = 0; X < 3; ++X) { cBh[X] = Bh[X]; cBl[X] = Bl[X]; }
+        if (i + 1 < 16) issue(i + 1);
 #pragma unroll
         for (int term = 0; term < 3; ++term)
 #pragma unroll
           for (int X = 0; X < 3; ++X)
-            g[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al[X] : Ah[X], term == 1 ? Bl[X] : Bh[X], g[X], 0, 0, 0);
+            g[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[X], 0, 0, 0);
+        if (i + 1 < 16) {
+          finish();
+#pragma unroll
+          for (int X = 0; X < 3; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+        }
+        if (ICS_FUSED_INTERLEAVE && i + 1 < 16) {
+          // 9 MFMAs, 21 LDS reads (15 e' dword pairs, then 6 u fragments), 24 funnel shifts
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (k < 7) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if (k >= 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) tot[ch][r] += ((g[0][r] + g[1][r]) + g[2][r]) * scale;
@@ -436,45 +507,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ================================ the tile ======================================================================
     unsigned char* const up = lds + C::UOFF;
     convert_channel<C, 0>(raw, s_x, up, opaque(tid));
+    lds_barrier();                                                     // planes of channel 0 visible
+    FTICK(1);
     load_f(0);
-    __syncthreads();                                                   // planes of channel 0 visible
     conv_phase(std::integral_constant<int, 0>{});
+    FTICK(2);
     float s_e, inv_e, me;
 
 #define ICS_FUSED_CHANNEL(CH)                                                                                           \
     me = residual(CH);                                                                                                  \
     if (lane == 0) fscr[8 + 4 * (CH) + wv] = me;                                                                        \
-    if ((CH) < 2) load_f((CH) + 1);                                                                                     \
-    __syncthreads();   /* tile maximum; every wave is past the previous gradient phase: e' planes and u buffer free */  \
+    FTICK(3);                                                                                                           \
+    lds_barrier();     /* tile maximum; every wave is past the previous gradient phase: e' planes and u buffer free */  \
+    FTICK(4);                                                                                                           \
     me = __builtin_fmaxf(__builtin_fmaxf(fscr[8 + 4 * (CH)], fscr[9 + 4 * (CH)]), __builtin_fmaxf(fscr[10 + 4 * (CH)], fscr[11 + 4 * (CH)])); \
     pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me))), s_e, inv_e);      \
     write_e(s_e);
 
     ICS_FUSED_CHANNEL(0)
-    convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
-    __syncthreads();                                                   // e'(0) and planes(1) visible
+    if (!(ICS_FUSED_ABLATE & 8)) convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
+    FTICK(5);
+    lds_barrier();                                                     // e'(0) and planes(1) visible
+    FTICK(6);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
+    FTICK(7);
+    load_f(1);
     conv_phase(std::integral_constant<int, 1>{});
+    FTICK(2);
 
     ICS_FUSED_CHANNEL(1)
-    convert_channel<C, 2>(raw, s_x, up, opaque(tid));
-    // the rows of the next tile: in flight during gradk(1), conv(2) (no vector-memory loads in there; the image operand of
-    // channel 2 was requested before them and returns first)
+    if (!(ICS_FUSED_ABLATE & 8)) convert_channel<C, 2>(raw, s_x, up, opaque(tid));
+    FTICK(5);
+    lds_barrier();                                                     // e'(1) and planes(2) visible
+    FTICK(6);
+    gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
+    FTICK(7);
+    load_f(2);
+    // the rows of the next tile: in flight during conv(2), gradk(2) (no vector-memory loads in there; the image operand of
+    // channel 2 was requested before them and returns first).  (Spreading the 21 requests of a lane over the steps of conv(2)
+    // instead of one burst measured slower: 0.315 vs 0.285 ms.)
     if (tile + nx < band1) {
       const int nt = tile + nx;
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
       load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + nxi * C::TW - C::PAD)), opaque(tid), pitch);
     }
-    __syncthreads();                                                   // e'(1) and planes(2) visible
-    gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
+    __builtin_amdgcn_sched_barrier(0);
+    FTICK(8);
     conv_phase(std::integral_constant<int, 2>{});
+    FTICK(2);
 
     ICS_FUSED_CHANNEL(2)
-    __syncthreads();                                                   // e'(2) visible
+    FTICK(5);
+    lds_barrier();                                                     // e'(2) visible
+    FTICK(6);
     gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
+    FTICK(7);
 #undef ICS_FUSED_CHANNEL
   }
 
+  FTICK_FLUSH;
   // ---- cross-wave reduction (fixed order) and partial write, one channel per pass ------------------------------------
   float* red = reinterpret_cast<float*>(lds);   // [wave][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]
   float* dst = a.partial + (size_t)blockIdx.x * (3 * 16 * 16);
