@@ -46,6 +46,12 @@ __device__ unsigned long long ics_fused_ticks[17];
 #define FTICK(i)
 #define FTICK_FLUSH
 #endif
+#ifndef ICS_FUSED_GK_INTERLEAVE
+#define ICS_FUSED_GK_INTERLEAVE 1
+#endif
+#ifndef ICS_FUSED_PRIO
+#define ICS_FUSED_PRIO 0
+#endif
 #ifndef ICS_FUSED_ABLATE
 #define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand */
 #endif
@@ -228,12 +234,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // gradient, B operand: lane column li <-> tap b; in chunk X its 8 halves start at e' column s = 32 X + 8 lg + b - 2 pad.
   // Windows entirely left / right of the tile's 64 columns are moved onto the zero columns of the row.
+  // The third chunk (columns 64 .. 79) is 16 wide: 4 halves per lane, u columns 64 + 4 lg .., e' window at 64 + 4 lg + b - 2 pad.
   uint32_t gb[3], gsh[3];
+  const uint32_t ga2 = (uint32_t)(8 * lg);
   {
     const int tb = li < K ? li : K - 1;
 #pragma unroll
     for (int X = 0; X < 3; ++X) {
-      int s = 32 * X + 8 * lg + tb - 2 * C::PAD;
+      int s = X < 2 ? 32 * X + 8 * lg + tb - 2 * C::PAD : 64 + 4 * lg + tb - 2 * C::PAD;
       s = s <= -8 ? -8 : (s >= 64 ? 64 : s);
       gsh[X] = (uint32_t)(s & 1) * 16u;
       gb[X] = lds0 + (uint32_t)(C::EOFF + 16 * wv * C::EROWB + 8 * ((s + 8) >> 1));
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       h8 Ah = *reinterpret_cast<lds_h8p>(ca + PB), Al = *reinterpret_cast<lds_h8p>(ca + PB + C::PLANE);
       finishB(0);
       __builtin_amdgcn_sched_barrier(0);
+      if (ICS_FUSED_PRIO & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int q = 0; q < C::NQ; ++q) {
         h8 Nh = Ah, Nl = Al;
@@ -420,7 +429,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // ---- PSF gradient of one channel: 16 residual rows of this wave x 3 chunks x 3 split terms ----------------------------
+    // ---- PSF gradient of one channel: 16 residual rows of this wave x (2 chunks of 32 + 1 chunk of 16 columns) x 3 split terms
+    // The 80 staged u columns are two 32-column chunks (v_mfma_f32_16x16x32_f16) and one 16-column chunk (the K = 16 form,
+    // v_mfma_f32_16x16x16_f16: 8-byte A fragments, a 4-half e' window from three dword pairs).  Same matrix-pipe time as a
+    // third 32-column chunk (measured: both forms issue at the same rate), but 10 instead of 24 LDS cycles, and this phase is
+    // LDS-bound.
     // Software pipeline, one row deep: the LDS operands of row i + 1 are requested in the shadows of the first MFMAs of row i
     // (the e' windows first: they still need their funnel shifts, which go behind the later MFMAs of the same row).  The reads
     // are volatile: plain loads were merged into ds_read2_b64 (8 LDS cycles for two 8-byte reads instead of 2 + 2) and sunk to
@@ -439,26 +452,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int j = 0; j < 4; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
 #pragma unroll
       for (int X = 0; X < 3; ++X) { gbv[X] = gb[X]; asm volatile("" : "+v"(gbv[X])); }
-      u4 Ah[3], Al[3], nAh[3], nAl[3];
-      u2 rB[3][5];
-      h8 Bh[3], Bl[3];
+      u4 Ah[2], Al[2], nAh[2], nAl[2];
+      u2 A2h, A2l, nA2h, nA2l;           // third chunk: 4 halves per lane
+      u2 rB[2][5], rB2[3];
+      h8 Bh[2], Bl[2];
+      h4 B2h, B2l;
       auto issue = [&](int i) {
 #pragma unroll
-        for (int X = 0; X < 3; ++X) {
+        for (int X = 0; X < 2; ++X) {
           const lds_vu2p ep = reinterpret_cast<lds_vu2p>(gbv[X] + (uint32_t)(i * C::EROWB));
 #pragma unroll
           for (int k = 0; k < 5; ++k) rB[X][k] = ep[k];
         }
+        {
+          const lds_vu2p ep = reinterpret_cast<lds_vu2p>(gbv[2] + (uint32_t)(i * C::EROWB));
 #pragma unroll
-        for (int X = 0; X < 3; ++X) {
-          const uint32_t ar = gav[i & 3] + PB + (uint32_t)((i >> 2) * C::ROWB + 64 * X);
-          nAh[X] = *reinterpret_cast<lds_vu4p>(ar);
-          nAl[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE);
+          for (int k = 0; k < 3; ++k) rB2[k] = ep[k];
         }
+        const uint32_t ar = gav[i & 3] + PB + (uint32_t)((i >> 2) * C::ROWB);
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+          nAh[X] = *reinterpret_cast<lds_vu4p>(ar + 64 * X);
+          nAl[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE + 64 * X);
+        }
+        // third chunk: columns 64 + 4 lg .. + 3 (the lane address carries 16 lg: back by 8 lg)
+        nA2h = *reinterpret_cast<lds_vu2p>(ar + 128 - ga2);
+        nA2l = *reinterpret_cast<lds_vu2p>(ar + C::PLANE + 128 - ga2);
       };
       auto finish = [&]() {
 #pragma unroll
-        for (int X = 0; X < 3; ++X) {
+        for (int X = 0; X < 2; ++X) {
           const u2* d = rB[X];
           const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, gsh[X]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, gsh[X]),
                          __builtin_amdgcn_alignbit(d[3].x, d[2].x, gsh[X]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, gsh[X])};
@@ -467,39 +490,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           Bh[X] = __builtin_bit_cast(h8, wh);
           Bl[X] = __builtin_bit_cast(h8, wl);
         }
+        const u2 wh2 = {__builtin_amdgcn_alignbit(rB2[1].x, rB2[0].x, gsh[2]), __builtin_amdgcn_alignbit(rB2[2].x, rB2[1].x, gsh[2])};
+        const u2 wl2 = {__builtin_amdgcn_alignbit(rB2[1].y, rB2[0].y, gsh[2]), __builtin_amdgcn_alignbit(rB2[2].y, rB2[1].y, gsh[2])};
+        B2h = __builtin_bit_cast(h4, wh2);
+        B2l = __builtin_bit_cast(h4, wl2);
       };
       issue(0);
       finish();
 #pragma unroll
-      for (int X = 0; X < 3; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+      for (int X = 0; X < 2; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+      A2h = nA2h; A2l = nA2l;
       __builtin_amdgcn_sched_barrier(0);
+      if (ICS_FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        h8 cBh[3], cBl[3];
+        h8 cBh[2], cBl[2];
 #pragma unroll
-        for (int X = 0; X < 3; ++X) { cBh[X] = Bh[X]; cBl[X] = Bl[X]; }
+        for (int X = 0; X < 2; ++X) { cBh[X] = Bh[X]; cBl[X] = Bl[X]; }
+        const h4 cB2h = B2h, cB2l = B2l;
         if (i + 1 < 16) issue(i + 1);
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
+        for (int term = 0; term < 3; ++term) {
 #pragma unroll
-          for (int X = 0; X < 3; ++X)
+          for (int X = 0; X < 2; ++X)
             g[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[X], 0, 0, 0);
+          g[2] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, term == 2 ? A2l : A2h), term == 1 ? cB2l : cB2h, g[2], 0, 0, 0);
+        }
         if (i + 1 < 16) {
           finish();
 #pragma unroll
-          for (int X = 0; X < 3; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+          for (int X = 0; X < 2; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+          A2h = nA2h; A2l = nA2l;
         }
-        if (ICS_FUSED_INTERLEAVE && i + 1 < 16) {
-          // 9 MFMAs, 21 LDS reads (15 e' dword pairs, then 6 u fragments), 24 funnel shifts
+        if (ICS_FUSED_GK_INTERLEAVE && i + 1 < 16) {
+          // 9 MFMAs, 19 LDS reads (13 e' dword pairs, then 4 + 2 u fragments), 20 funnel shifts
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 7) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if (k >= 3) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if (k == 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (k >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (ICS_FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) tot[ch][r] += ((g[0][r] + g[1][r]) + g[2][r]) * scale;
     };
