@@ -46,6 +46,7 @@
 //     results leave as dwordx3 (16 lanes = 192 contiguous bytes), same arithmetic as the VALU kernel (residual /
 //     back-projection + step-size reductions).  Two barriers per tile (scale, planes written).
 #include "ics_common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 #ifndef ICS_MFMA_INTERLEAVE
@@ -581,6 +582,9 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   grid = ICS_GRID_WGS * cus[dev];
 #endif
   if (grid > ntiles) grid = ntiles;
+  // test hook: fewer persistent workgroups, so that small frames make every workgroup walk several tiles (next-tile
+  // prefetch, band split) -- tests/test_gpu_rl.py::test_blind_golden_576x520_multi_tile_walk
+  if (const char* e = getenv("ICS_TEST_MAX_WGS")) { const int m = atoi(e); if (m > 0 && grid > m) grid = m; }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }

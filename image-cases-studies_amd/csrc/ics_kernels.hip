@@ -716,6 +716,7 @@ int ics_gradk_blocks(const IcsGeom& g, int cus) {
   const int nb = (g.K + 15) / 16;
   const int tiles = g.tiles_x * g.tiles_y * 2;
   int blocks = cus * (nb <= 2 ? 2 : 1);   // two persistent workgroups per CU where the matrix-core kernel exists
+  if (const char* e = getenv("ICS_TEST_MAX_WGS")) { const int m = atoi(e); if (m > 0 && blocks > m) blocks = m; }   // test hook (ics_conv_mfma.hip)
   return blocks < tiles ? blocks : tiles;
 }
 

@@ -44,17 +44,27 @@ def _check_buffer(name, arr):
         raise ValueError("Buffer dtype mismatch, expected 'DTYPE_t' but got '%s'" % cname)
 
 
+_JOB_CACHE_MAX = 4   # deblur_module alternates between the pyramid levels' window and full-frame sizes
+
+
 def _get_job(M, N, MK):
-    """Keep the frames of the last problem size alive: deblur_module calls the solver repeatedly."""
+    """Keep the device frames of the most recent problem sizes alive (least recently used out): deblur_module calls the
+    solver once or twice per pyramid level, and the reference's per-call allocation of 13 scratch frames (pyx:378-390) is
+    what this replaces."""
     key = (int(M), int(N), int(MK), _native.default_device())
-    job = _job_cache.get(key)
+    job = _job_cache.pop(key, None)
     if job is None:
-        for old in list(_job_cache.values()):
-            old.close()
-        _job_cache.clear()
+        while len(_job_cache) >= _JOB_CACHE_MAX:
+            _job_cache.pop(next(iter(_job_cache))).close()
         job = _native.RLJob(M, N, MK)
-        _job_cache[key] = job
+    _job_cache[key] = job            # (re)inserted last = most recently used
     return job
+
+
+def _drop_jobs():
+    """Release every cached job (device frames)."""
+    while _job_cache:
+        _job_cache.pop(next(iter(_job_cache))).close()
 
 
 def normalize_kernel(kern, MK):
@@ -86,7 +96,7 @@ def _report(st, top, bottom, left, right, lambd):
 
 def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom, left, right, tau, M, N, C, MK, iterations,
                               step_factor, lambd, blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *,
-                              tv_mode=0, conv=0):
+                              tv_mode=0, conv=0, flags=0):
     """`richardson_lucy_MM` on device-resident frames (not in the reference): `image` and `u` are
     `_native.DeviceImage`s, the solver works on the windows image[iy:iy+M, ix:ix+N] and u[uy:uy+uM, ux:ux+uN]
     (`image_origin = (iy, ix)`, `u_origin = (uy, ux)`) -- the views deconvolve.py:277-313 passes -- and the whole `u`
@@ -99,7 +109,7 @@ def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom
     job = _get_job(M, N, MK)
     job.upload_img(image, image_origin, u, u_origin, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
-                        tv_mode=tv_mode, conv=conv)
+                        tv_mode=tv_mode, conv=conv, flags=flags)
     st = job.run(params)
     job.download_img(u, u_origin)
     if blind:
@@ -109,7 +119,7 @@ def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom
 
 
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
-                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0, conv=0):
+                       blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, tv_mode=0, conv=0, flags=0):
     """Richardson-Lucy blind / non-blind deconvolution by majorisation-minimisation
     (lib/deconvolution.pyx:341-675), executed on the GPU.  See the module docstring.
 
@@ -118,7 +128,10 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     unpinned), in which `image` is also updated in place as pyx:549 intends.
 
     `conv` (keyword-only, not in the reference): include/ics_hip.h ICS_CONV_*: 0 = auto (matrix-core kernels with
-    fp16-split operands where they are built and faster: convolutions MK <= 17 and 23..37, PSF gradient MK <= 31), 1 = fp32 products everywhere, 2 = force the matrix-core kernels."""
+    fp16-split operands where they are built and faster: convolutions MK <= 17 and 23..37, PSF gradient MK <= 31), 1 = fp32 products everywhere, 2 = force the matrix-core kernels.
+
+    `flags` (keyword-only, not in the reference): include/ics_hip.h ICS_FLAG_* bits (1 = run A11 and A13 as two kernels
+    instead of the fused one)."""
     _check_buffer("image", image)
     _check_buffer("u", u)
     _check_buffer("psf", psf)
@@ -132,7 +145,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     job = _get_job(M, N, MK)
     job.upload(image, u, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
-                        tv_mode=tv_mode, conv=conv)
+                        tv_mode=tv_mode, conv=conv, flags=flags)
     st = job.run(params)
     u_new, _psf_local, psf_caller = job.download()
     u[...] = u_new                                                             # in place, any strides

@@ -134,3 +134,71 @@ def test_update_formula_on_crops_at_4096():
     assert [sc["dt0"], sc["dt1"], sc["dt2"]] == [float(x) for x in dt]
     assert np.array_equal(u_dev, u_ref, equal_nan=True)
     job.close()
+
+
+# ---- whole frames against float64 FFT convolutions (scipy.signal.fftconvolve) --------------------------------------------
+def _fft_valid64(u, psf):
+    from scipy.signal import fftconvolve
+    return np.stack([fftconvolve(u[..., c].astype(np.float64), psf[..., c].astype(np.float64), mode="valid") for c in range(3)], -1)
+
+
+def _fft_full_corr64(e, psf):
+    from scipy.signal import fftconvolve
+    rot = psf[::-1, ::-1]
+    return np.stack([fftconvolve(e[..., c].astype(np.float64), rot[..., c].astype(np.float64), mode="full") for c in range(3)], -1)
+
+
+def _fft_gradk64(u, e):
+    """gradk = convolve(rot180(u), e, "valid") (pyx:567-571) in float64."""
+    from scipy.signal import fftconvolve
+    return np.stack([fftconvolve(u[::-1, ::-1, c].astype(np.float64), e[..., c].astype(np.float64), mode="valid") for c in range(3)], -1)
+
+
+@pytest.mark.parametrize("S,MK,conv", [(2048, 15, 2), (2048, 15, 1), (4096, 15, 2), (4096, 15, 1), (6144, 31, 2)])
+def test_whole_frame_stage_pass_against_float64_fft(S, MK, conv):
+    """BASELINE.json configs[1..3] sizes: the ENTIRE residual, back-projection and PSF gradient of one stage pass against
+    float64 convolutions (every tile of the persistent walk, the band split, the next-tile prefetch and the interior-origin
+    grid are covered, not crops).  Gates: 5e-6 of the frame maximum (7e-6 scaled by (MK/31)^2 above 31), and the number of
+    pixels beyond 1e-6 of the maximum is reported.  conv = 2: matrix-core kernels (fp16-split), 1: fp32 products."""
+    from lib import _native as nv
+    import bench
+    pad = MK // 2
+    image, u0, psf_true, _ = bench.synth_frame(S, S, MK, seed=S + MK)
+    psf = rand_psf(MK, 7)
+    rng = np.random.default_rng(2)
+    u = (u0 + np.float32(0.02) * rng.standard_normal(u0.shape, dtype=np.float32)).astype(np.float32)
+    job = nv.RLJob(S, S, MK)
+    job.upload(image, u, psf)
+    job.write(nv.BUF_UT, u0)
+    p = job.params(pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1, 1e9, 1, 1e-3, 10000.0, blind=True, conv=conv)
+    # A1 + A2
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    synth = _fft_valid64(u, psf)
+    d = np.abs(e - (synth - image)) / np.max(np.abs(synth))
+    print("%d^2 k%d conv=%d residual: max %.2e, fraction > 1e-6: %.2e" % (S, MK, conv, d.max(), np.mean(d > 1e-6)))
+    assert d.max() < 5e-6
+    del synth, d
+    # A3 on the device's own residual
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    g_ref = _fft_full_corr64(e, psf)
+    d = np.abs(g - g_ref) / np.max(np.abs(g_ref))
+    print("   back-projection: max %.2e, fraction > 1e-6: %.2e" % (d.max(), np.mean(d > 1e-6)))
+    assert g.shape == g_ref.shape and d.max() < 5e-6
+    del g, g_ref, d
+    # A13 (two-kernel path) and, where it exists, the fused A11 + A13 kernel
+    gk_ref = _fft_gradk64(u, e)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    err = np.max(np.abs(gk - gk_ref)) / np.max(np.abs(gk_ref))
+    print("   PSF gradient: %.2e of max|gradk|" % err)
+    assert err < 1e-5
+    if MK <= 15 and conv == 2:
+        job.stage(nv.STAGE_SYNTH_GRADK, p)
+        e2, gk2 = job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK)
+        assert np.max(np.abs(e2 - e)) / np.max(np.abs(u)) < 1e-6
+        err2 = np.max(np.abs(gk2 - _fft_gradk64(u, e2))) / np.max(np.abs(gk_ref))
+        print("   fused A11 + A13: PSF gradient %.2e of max|gradk|" % err2)
+        assert err2 < 1e-5
+    job.close()

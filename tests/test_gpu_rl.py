@@ -65,9 +65,19 @@ def fragile_decisions(z, blind, tau):
     return out
 
 
+def _ref_iterations(ref_log):
+    """(iterations done, stopped) from the reference's last progress line (pyx:661-667)."""
+    line = [l for l in ref_log.splitlines() if "iterations" in l and ("Convergence" in l or "converge" in l)][-1]
+    return int([w for w in line.replace(".", " ").split() if w.isdigit()][0]), line.startswith("Convergence"), line
+
+
 @pytest.mark.parametrize("conv", [0, 1], ids=["auto", "fp32"])   # 0: matrix-core kernels (MK <= 15), 1: fp32 products
 @pytest.mark.parametrize("name", CASES)
 def test_trajectory_matches_reference_golden(golden_dir, name, conv):
+    """Every snapshot: same stop decision, u / psf within the gate, and the per-outer-iteration scalars of the run equal to
+    the reference's trace.  A different stop decision is accepted ONLY when the first differing decision (outer iteration
+    d = min(done_gpu, done_ref) - 1, pyx:643-654) is one whose margin in the reference itself is below fp32-FFT rounding
+    of M_r (`fragile`); snapshots that end before the first fragile decision must match unconditionally."""
     z, meta = load_golden(golden_dir, name)
     fragile = fragile_decisions(z, meta["blind"], meta["tau"])
     for n in meta["snaps"]:
@@ -75,24 +85,27 @@ def test_trajectory_matches_reference_golden(golden_dir, name, conv):
         eu = rel_err(u, z["u_%d" % n])
         ep = rel_err(psf, z["psf_%d" % n])
         (tu, lim_u), (tp, lim_p) = gate(meta, n, 0), gate(meta, n, 1)
-        ref_log = meta["logs"][str(n)]
-        ref_done = [l for l in ref_log.splitlines() if "iterations" in l and ("Convergence" in l or "converge" in l)][-1]
-        same_stop = ref_done in log
-        print("%s it=%d: rel err u=%.2e (gate %.1e%s) psf=%.2e done=%d stopped=%d same_stop=%s" % (
-            name, n, eu, tu, " noise-floor-limited" if lim_u else "", ep, st.iterations_done, st.stopped, same_stop))
+        ref_done, ref_stopped, ref_line = _ref_iterations(meta["logs"][str(n)])
+        same_stop = (st.iterations_done == ref_done) and (bool(st.stopped) == ref_stopped)
+        assert same_stop == (ref_line in log)          # the printed line is the reference's line
+        print("%s it=%d: rel err u=%.2e (gate %.1e%s) psf=%.2e done=%d/%d stopped=%d same_stop=%s" % (
+            name, n, eu, tu, " noise-floor-limited" if lim_u else "", ep, st.iterations_done, ref_done, st.stopped, same_stop))
         if not same_stop:
-            # only acceptable when the reference's own decision sits inside fp32 rounding of M_r
-            assert fragile, (name, n, ref_done, log)
-            continue
-        assert eu < tu, (name, n, eu)
-        assert ep < tp, (name, n, ep)
-    if same_stop and not gate(meta, meta["snaps"][-1], 0)[1]:  # per-outer scalars of the longest run (pinned oracle)
-        k = st.trace_len
-        assert k == len(z["M_r"])
-        np.testing.assert_allclose(np.array(st.trace_M_r[:k]), z["M_r"], rtol=5e-3)
-        np.testing.assert_allclose(np.array(st.trace_Hu[:k]), z["Hu"], rtol=5e-3)
-        np.testing.assert_allclose(np.array(st.trace_varu[:k]), z["varu"], rtol=1e-3)
-        np.testing.assert_allclose(np.array(st.trace_dof_max[:k]), z["dof_max"], rtol=5e-3, atol=1e-12)
+            d = min(st.iterations_done, ref_done) - 1   # the decision that came out differently
+            assert d in fragile, (name, n, "stop decision differs at outer iteration %d, fragile = %s" % (d, fragile), ref_line, log)
+            assert n > min(fragile)
+            print("   (the reference's own decision at outer iteration %d has a margin < 1e-4: arrays not compared)" % d)
+            k = d                                        # scalars up to (not including) the fragile decision are still comparable
+        else:
+            assert eu < tu, (name, n, eu)
+            assert ep < tp, (name, n, ep)
+            k = st.trace_len
+            assert k == min(ref_done, len(z["M_r"]))
+        if not gate(meta, n, 0)[1]:   # per-outer scalars (pinned oracle trace; a shorter run is a prefix of the longest)
+            np.testing.assert_allclose(np.array(st.trace_M_r[:k]), z["M_r"][:k], rtol=5e-3)
+            np.testing.assert_allclose(np.array(st.trace_Hu[:k]), z["Hu"][:k], rtol=5e-3)
+            np.testing.assert_allclose(np.array(st.trace_varu[:k]), z["varu"][:k], rtol=1e-3)
+            np.testing.assert_allclose(np.array(st.trace_dof_max[:k]), z["dof_max"][:k], rtol=5e-3, atol=1e-12)
 
 
 def test_blind_chain_of_calls_100_inner_iterations(golden_dir):
@@ -138,7 +151,14 @@ def test_correlation_caller_psf_quirk(golden_dir):
     u, psf, _, st = run_gpu(z, meta, 3)
     # the caller's array holds the un-normalised first step (pyx:585 rebinding)
     assert rel_err(psf, z["psf_3"]) < TRAJ_TOL
-    assert abs(float(psf[..., 0].sum()) - 1.0) > 1e-9 or True
+    # ... which is NOT normalised (the reference's caller array sums to 1 -/+ 5e-5 per channel, float32 eps is 6e-8)
+    for c in range(3):
+        assert abs(float(z["psf_3"][..., c].astype(np.float64).sum()) - 1.0) > 1e-5
+        assert abs(float(psf[..., c].astype(np.float64).sum()) - 1.0) > 1e-5
+    # while the solver's local psf stays on the simplex
+    from lib import deconvolution as dc
+    _, psf_local, _ = list(dc._job_cache.values())[-1].download()
+    assert np.allclose(psf_local.astype(np.float64).sum(axis=(0, 1)), 1.0, atol=1e-6)
 
 
 def test_config1_512_k9_20_outer(golden_dir):
@@ -158,6 +178,53 @@ def test_config1_512_k9_20_outer(golden_dir):
     assert rel_err(u[::64], z["u_rows"]) < TRAJ_TOL
     uf = u.astype(np.float64)
     assert abs(uf.sum() - z["moments"][0]) / abs(z["moments"][0]) < 1e-5
+
+
+@pytest.mark.parametrize("max_wgs,conv,flags", [(8, 0, 0), (8, 0, 1), (3, 0, 0), (0, 0, 0), (8, 1, 0)],
+                         ids=["8wg-fused", "8wg-two-kernel", "3wg-fused", "full-grid", "8wg-fp32"])
+def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, conv, flags):
+    """Blind reference golden on a 9 x 9-tile frame (oracle/make_golden_large.py).  With ICS_TEST_MAX_WGS = 8 (3) every
+    persistent workgroup of the matrix-core convolutions, of the PSF-gradient kernel and of the fused A11 + A13 kernel
+    walks 8-11 (24-27) tiles: next-tile register prefetch, band split and the interior-origin grid run under a reference
+    trajectory, which the 129^2 goldens (<= 3 x 3 tiles, one tile per workgroup) cannot do."""
+    import json
+    import os
+    from lib import deconvolution as dc
+    z = np.load(os.path.join(golden_dir, "rl_bl_576x520_k15.npz"))
+    meta = json.loads(str(z["meta"]))
+    M, N, MK = meta["M"], meta["N"], meta["MK"]
+    case = orc.synth_case(M, N, MK, seed=meta["seed"], blind=True)
+    if max_wgs:
+        monkeypatch.setenv("ICS_TEST_MAX_WGS", str(max_wgs))
+    dc._drop_jobs()                # the workgroup count of the gradient kernels is fixed when the job is created
+    for n in (1, 2):
+        u, psf = case["u0"].copy(), case["psf0"].copy()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            dc.richardson_lucy_MM(case["image"].copy(), u, psf, *meta["window"], meta["tau"], M, N, 3, MK, n, meta["step"], meta["lambd"],
+                                  blind=True, conv=conv, flags=flags)
+        st = dc.richardson_lucy_MM.last
+        # same progress lines; the printed DoF extrema (%f, six decimals) may differ in the last digit
+        got, ref = buf.getvalue().splitlines(), meta["logs"][str(n)].splitlines()
+        assert st.iterations_done == n and len(got) == len(ref)
+        for lg, lr in zip(got, ref):
+            if lg != lr:
+                vg = [float(w) for w in lg.replace("|", " ").split() if w.replace(".", "").replace("-", "").isdigit()]
+                vr = [float(w) for w in lr.replace("|", " ").split() if w.replace(".", "").replace("-", "").isdigit()]
+                assert len(vg) == len(vr) and np.allclose(vg, vr, rtol=1e-4, atol=2e-6), (lg, lr)
+        c = meta["crop"]
+        errs = [rel_err(u[c[0]:c[1], c[2]:c[3]], z["u_crop_%d" % n]), rel_err(u[::meta["row_step"]], z["u_rows_%d" % n]),
+                rel_err(u[-meta["corner"]:, -meta["corner"]:], z["u_corner_%d" % n]), rel_err(psf, z["psf_%d" % n])]
+        uf = u.astype(np.float64)
+        mom = np.array([uf.sum(), (uf ** 2).sum(), uf.min(), uf.max()])
+        print("576x520 blind, %d outer, max_wgs=%s conv=%d flags=%d: crop %.2e rows %.2e corner %.2e psf %.2e" % (n, max_wgs, conv, flags, *errs))
+        assert max(errs) < 1e-5          # (the float64-direct oracle is 2e-7 / 3e-7 from the reference here)
+        assert np.all(np.abs(mom - z["moments_%d" % n]) <= 1e-6 * np.abs(z["moments_%d" % n]))
+    k = st.trace_len
+    np.testing.assert_allclose(np.array(st.trace_M_r[:k]), z["M_r"][:k], rtol=5e-3)
+    np.testing.assert_allclose(np.array(st.trace_Hu[:k]), z["Hu"][:k], rtol=5e-3)
+    np.testing.assert_allclose(np.array(st.trace_varu[:k]), z["varu"][:k], rtol=1e-3)
+    dc._drop_jobs()
 
 
 def test_wrong_dtype_and_ndim_raise_like_the_reference():
