@@ -70,8 +70,12 @@ def synth_frame(M, N, MK, seed):
     return image, u0, psf_true, psf_uniform
 
 
-def cpu_baseline(mode, MK, budget_s=20.0):
-    """The oracle (numpy/scipy port of lib/deconvolution.pyx, same FFT call pattern) on the host cores."""
+def cpu_baseline(mode, MK, M_full, budget_s=20.0):
+    """The oracle (numpy/scipy port of lib/deconvolution.pyx, same FFT call pattern as the reference: scipy.signal.convolve ->
+    pocketfft, which runs on ONE thread whatever the host has) on the host cores, on a bounded sample: 2048 x 2048 frames,
+    as many whole outer iterations as fit the budget.  MPix/s/iter of this loop falls slowly with the frame size
+    (0.86 at 1024^2, 0.68 at 2048^2 for the compiled reference), so the 2048^2 figure is an upper
+    bound for the 4096^2 workload; one blind outer iteration at 4096^2 takes ~25 s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import rl_mm_oracle as orc  # cpu_baseline leg only
     S = 2048
@@ -90,8 +94,95 @@ def cpu_baseline(mode, MK, budget_s=20.0):
     inner = 5 * outer
     return {"value": round(S * S * inner / dt / 1e6, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port",
             "host_cores_available": os.cpu_count(),
+            "threads": "1 (scipy.signal.convolve -> scipy.fft pocketfft with workers=None = single thread, numpy elementwise single thread; "
+                       "OMP_NUM_THREADS=%s)" % os.environ.get("OMP_NUM_THREADS", "unset"),
             "sample": "%s, %dx%dx3, %dx%d PSF, %d outer (=%d inner) iterations of oracle/rl_mm_oracle.py "
-                      "(numpy + scipy.signal.convolve FFT, single thread), %.1f s" % (mode, S, S, MK, MK, outer, inner, dt)}
+                      "(numpy + scipy.signal.convolve FFT, single thread), %.1f s" % (mode, S, S, MK, MK, outer, inner, dt),
+            "extrapolation": "measured at 2048^2, NOT at the %d^2 of `value`: per-pixel cost of the FFT loop grows slowly with size, so this is an upper bound for %d^2" % (M_full, M_full),
+            "reference_compiled_survey_container": {"value": 0.68 if mode == "blind" else 1.80, "unit": "MPixels/s/iter", "cores": 8, "kind": "reference",
+                                                     "sample": "lib/deconvolution.pyx compiled (Cython, -O3 -fopenmp, 8 OpenMP threads, scipy FFT 1 thread), %s 2048^2 15x15, 2 outer iterations, "
+                                                               "in the survey container (8 vCPU Xeon 2.1 GHz), BASELINE.md section 2 -- not measured on this box: the reference cannot travel" % mode}}
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes (one per GPU, RCCL rendezvous through
+    a file) BEFORE this process touches HIP, relay rank 0's JSON line, fail loudly when the box has fewer than N GPUs."""
+    import socket
+    import subprocess
+    pkg = os.path.join(ROOT, "image-cases-studies_amd")
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from lib import _native; print(_native.device_count())" % pkg],
+                           capture_output=True, text=True)
+    try:
+        ndev = int(probe.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        ndev = 0
+    if ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but %d gfx950 device(s) are visible on this box; one GPU per rank is required "
+                         "(no fallback to fewer GPUs)\n" % (args.gpus, ndev))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdzv = "/tmp/ics_rccl_%d_%d_%d" % (port, os.getpid(), int(time.time()))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   ICS_RDZV=rdzv, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        rc = rc or pr.wait()
+    sys.stdout.write(out0)
+    if rc:
+        sys.stderr.write("bench.py: a rank failed (exit code %d)\n" % rc)
+    return rc
+
+
+def conv_rel_err(ctx, MK):
+    """max |residual - float64| / max |synth| of one A1 + A2 pass at 1024^2 for both convolution paths (float64 FFT convolution on
+    the host): the number the fp16-split matrix-core path is judged by, measured in this run."""
+    from scipy.signal import fftconvolve
+    from lib import _native
+    S = 1024
+    image, u0, psf_true, _ = synth_frame(S, S, MK, seed=11)
+    rng = np.random.default_rng(12)
+    u = (u0 + np.float32(0.02) * rng.standard_normal(u0.shape, dtype=np.float32)).astype(np.float32)
+    job = _native.RLJob(S, S, MK, ctx)
+    job.upload(image, u, psf_true)
+    synth = np.stack([fftconvolve(u[..., c].astype(np.float64), psf_true[..., c].astype(np.float64), mode="valid") for c in range(3)], -1)
+    out = {}
+    for name, conv in (("matrix", 2), ("vector", 1)):
+        try:
+            job.stage(_native.STAGE_SYNTH_RESIDUAL, job.params(1, 200, 1, 200, 1e9, 1, 1e-3, 10000.0, False, conv=conv))
+            out[name] = float(np.max(np.abs(job.read(_native.BUF_ERROR) - (synth - image))) / np.max(np.abs(synth)))
+        except _native.NativeError:
+            out[name] = None
+    job.close()
+    return out
+
+
+def timed_run(ctx, M, MK, blind, tv_mode, conv, steps, warm, seed=0):
+    """ms per inner iteration of one configuration on a fresh job (secondary lines of the JSON)."""
+    from lib import _native
+    image, u0, psf_true, psf_uniform = synth_frame(M, M, MK, seed=seed)
+    job = _native.RLJob(M, M, MK, ctx)
+    job.upload(image, u0, psf_uniform if blind else psf_true)
+    pad = MK // 2
+    win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)
+    job.run(job.params(*win, 1e9, max(1, warm // 5), 1e-3, 10000.0, blind, 0, 3, stop_test=2, tv_mode=tv_mode, conv=conv))
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    st = job.run(job.params(*win, 1e9, steps // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=4, tv_mode=tv_mode, conv=conv))
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    names = _native.KERNEL_NAMES
+    kern = {names[k]: round(st.ms_kernel[k], 5) for k in range(len(names)) if st.launches[k]}
+    job.close()
+    mode = "blind" if blind else "nonblind"
+    gb = ITER_BYTES_PER_PX[mode] * M * M / (el / steps) / 1e9
+    return {"ms_per_step": round(el * 1e3 / steps, 4), "MPixels_per_s_per_iter": round(M * M * steps / el / 1e6, 1),
+            "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[mode], "frac_of_8TBps": round(gb / HBM_PEAK_GBPS, 4), "kernels_ms": kern, "steps": steps}
 
 
 def main():
@@ -106,16 +197,20 @@ def main():
     ap.add_argument("--psf", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the secondary (untimed for `value`) run of the other mode")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary lines for BASELINE.json configs[1], configs[3] and the TV variants")
     ap.add_argument("--tv-mode", type=int, default=0, help="0 = shipped loop (TV term dead, the parity-pinned path); 1 = build-defined active MM-TV")
     ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))   # (no HIP / torch call has happened in this process)
+
     import multi_gpu
     from lib import _native
     grp = multi_gpu.Group()
-    if grp.size != args.gpus and grp.size > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, grp.size))
+    if grp.size != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, grp.size))
     M = N = args.size
     MK = args.psf
     steps = ((args.steps + 4) // 5) * 5
@@ -127,8 +222,11 @@ def main():
     # which convolution kernels the run resolves to (include/ics_hip.h ICS_CONV_*, csrc ics_conv_mfma_preferred)
     matrix = (conv == 2 and MK <= 37) or (conv == 0 and (MK <= 17 or 23 <= MK <= 37))
 
-    ndev = max(1, _native.device_count())
-    ctx = _native.Context.get(grp.local_rank % ndev)  # (% ndev only matters when ranks share a GPU in tests)
+    ndev = _native.device_count()
+    dev = int(os.environ.get("ICS_DEVICE", grp.local_rank))
+    if dev >= ndev:
+        raise SystemExit("bench.py: rank %d wants device %d but only %d device(s) are visible" % (grp.rank, dev, ndev))
+    ctx = _native.Context.get(dev)
     image, u0, psf_true, psf_uniform = synth_frame(M, N, MK, seed=grp.rank)
     job = _native.RLJob(M, N, MK, ctx)
     job.upload(image, u0, psf_uniform if blind else psf_true)
@@ -171,15 +269,16 @@ def main():
                  "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[omode], "frac_of_8TBps": round(ogb / HBM_PEAK_GBPS, 4)}
 
     per_rank = grp.gather([st.ms_total, float(st.iterations_done), float(st.M_r), float(st.has_nan)])
+    job.close()
     if grp.rank == 0:
         ms_per_step = elapsed * 1e3 / steps
         value = grp.size * M * N * steps / elapsed / 1e6
         names = _native.KERNEL_NAMES
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
-        traffic = None
-        try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+        traffic, traffic_file = None, "profiles/r02_hbm_traffic.json"
+        try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
+            tj = json.load(open(os.path.join(ROOT, traffic_file)))
             if tj["workload"] == {"size": M, "psf": MK}:
                 traffic = tj["kernels_matrix" if matrix and not args.fuse else "kernels_vector"]
         except (OSError, ValueError, KeyError):
@@ -191,19 +290,25 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": (traffic[dom]["hbm_bytes"] if traffic and dom in traffic else None),
-                    "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kern[dom]["ms"]}
+                    "traffic_source": "%s (static: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of an earlier run of this command, not measured live)" % traffic_file,
+                    "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kern[dom]["ms"],
+                    "per_kernel": {k: {"algorithmic_GBps": round(BYTES_PER_PX[k] * M * N / (kern[k]["ms"] * 1e-3) / 1e9, 1),
+                                       "frac": round(BYTES_PER_PX[k] * M * N / (kern[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                       "traffic": (traffic[k]["hbm_bytes"] if traffic and k in traffic else None)} for k in kern if k in BYTES_PER_PX}}
         it_gbps = ITER_BYTES_PER_PX[args.mode] * M * N / (ms_per_step * 1e-3) / 1e9
         out = {
             "metric": "MPixels/sec/iter RL-TV deconv @%d^2x3 fp32, %dx%d PSF" % (M, MK, MK),
             "value": round(value, 1), "unit": "MPixels/s/iter", "n_gpus": grp.size, "steps": steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "dtype_note": ("frames, sums and every elementwise step in fp32; the two PSF convolutions run on the matrix cores with each "
-                           "fp32 operand split into two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation"
+            "dtype": ("f32 (fp16x2-split MFMA convolutions, fp32 accumulate)" if matrix and not args.fuse else "f32"), "data": "synthetic",
+            "dtype_note": ("frames, sums and every elementwise step in fp32; the two PSF convolutions and the PSF gradient run on the matrix cores with each "
+                           "fp32 operand split into two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation; "
+                           "`--conv vector` runs fp32 products throughout"
                            if matrix and not args.fuse else "fp32 throughout (packed-fp32 vector convolutions)"),
-            "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
-                                   "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", M, N, MK, MK),
-                       "mode": args.mode, "tv_mode": args.tv_mode, "conv": "matrix" if matrix and not args.fuse else "vector", "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size},
+            "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop as shipped: the TV term is arithmetically dead in the reference, tv_mode %d), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
+                                   "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", args.tv_mode, M, N, MK, MK),
+                       "mode": args.mode, "tv_mode": args.tv_mode, "conv": "matrix" if matrix and not args.fuse else "vector", "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size,
+                       "collective": "none in the iterations; %s barrier / max / all-gather of a 4-double record per rank" % (grp.backend if grp.size > 1 else "no")},
             "hbm_roofline_iteration": {"algorithmic_bytes_per_px": ITER_BYTES_PER_PX[args.mode], "achieved_GBps": round(it_gbps, 1),
                                        "frac_of_8TBps": round(it_gbps / HBM_PEAK_GBPS, 4)},
             "kernels_ms": kern, "device_ms_total_rank0": round(st.ms_total, 3),
@@ -211,10 +316,20 @@ def main():
             "roofline": roof,
             "other_mode_same_frame": other,
         }
+        if grp.size == 1 and not args.no_other_configs and args.size == 4096 and args.psf == 15 and args.tv_mode == 0 and not args.fuse:
+            # secondary lines (never `value`): the other BASELINE.json configurations and the build-defined TV variants they name
+            out["conv_rel_err_vs_f64"] = conv_rel_err(ctx, MK)
+            oc = {}
+            oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)
+            oc["configs[1] non-blind 2048^2 15x15 + active MM-TV (tv_mode 1, build-defined)"] = timed_run(ctx, 2048, 15, False, 1, conv, 50, 5)
+            oc["configs[2] blind 4096^2 15x15 PAM isotropic TV (tv_mode 2, build-defined)"] = timed_run(ctx, 4096, 15, True, 2, conv, 50, 5)
+            oc["configs[2] blind 4096^2 15x15 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 4096, 15, True, 3, conv, 50, 5)
+            oc["configs[3] blind 6144^2 31x31 (shipped loop)"] = timed_run(ctx, 6144, 31, True, 0, conv, 25, 5)
+            oc["configs[3] blind 6144^2 31x31 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 6144, 31, True, 3, conv, 25, 5)
+            out["other_configs"] = oc
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.mode, MK)
+            out["cpu_baseline"] = cpu_baseline(args.mode, MK, M)
         print(json.dumps(out))
-    job.close()
     grp.close()
 
 

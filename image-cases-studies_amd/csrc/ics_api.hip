@@ -67,6 +67,7 @@ struct ics_rl {
   // stop-test scratch (allocated for the window of the last run)
   float2* z; float2* tw; float* weights;
   int P, logP, wt, wb, wl, wr;
+  bool win_empty;
   float* h_scal;                        // pinned host mirror of scal (+ flags)
   bool uploaded;
   bool ut_is_u;                         // majoriser aliased to u (first inner iteration of an outer one, no copy made yet)
@@ -330,13 +331,16 @@ extern "C" int ics_rl_write(ics_rl* j, int which, const float* host, size_t coun
 static int ensure_window(ics_rl* j, const ics_rl_params* p) {
   if (j->z && j->wt == p->top && j->wb == p->bottom && j->wl == p->left && j->wr == p->right) return ICS_OK;
   const int H = p->bottom - p->top, W = p->right - p->left;
-  if (H < 1 || W < 1) return fail(ICS_EINVAL, "empty stats window [%d:%d, %d:%d]", p->top, p->bottom, p->left, p->right);
+  // an empty window: the reference slices error[top:bottom, left:right] into an empty array and every statistic is NaN
+  // (numpy warns, pyx:600-601,627-638 do not raise); the stop test then never fires
+  j->win_empty = (H < 1 || W < 1);
+  if (j->win_empty) return ICS_OK;
   if (p->top < 0 || p->left < 0 || p->bottom > j->g.M || p->right > j->g.N)
     return fail(ICS_EINVAL, "stats window [%d:%d, %d:%d] outside the %dx%d image", p->top, p->bottom, p->left, p->right, j->g.M, j->g.N);
   const int need = 2 * (H > W ? H : W) - 1;
   int P = 2, logP = 1;
   while (P < need) { P <<= 1; ++logP; }
-  if (P > 2048) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 2048)", H, W, P);
+  if (P > 2048) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 2048, i.e. windows up to 1024 px; deblur_module: mask_size <= 1025)", H, W, P);
   if (j->z) { hipFree(j->z); j->z = nullptr; }
   if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
   if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
@@ -530,6 +534,11 @@ static int do_majorize(ics_rl* j, Prof& pr) {
 }
 
 static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  if (j->win_empty) {
+    static const float nan3[3] = {nanf(""), nanf(""), nanf("")};   // M_r, Hu, varu
+    HIPCHK(hipMemcpyAsync(j->scal + ICS_SC_MR, nan3, sizeof nan3, hipMemcpyHostToDevice, j->ctx->stream));
+    return ICS_OK;
+  }
   IcsStatsArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.dacc = j->dacc; a.ukey = j->ukey;
   a.z = j->z; a.tw = j->tw; a.weights = j->weights;
@@ -897,7 +906,8 @@ extern "C" int ics_img_pad_edge(const ics_img* src, int top, int bottom, int lef
   if (!src || !out) return fail(ICS_EINVAL, "NULL argument");
   if (top < 0 || bottom < 0 || left < 0 || right < 0) return fail(ICS_EINVAL, "negative padding");
   RC(img_new(src->ctx, src->H + top + bottom, src->W + left + right, out));
-  HIPCHK(ics_launch_img_pad_edge(src->d, src->H, src->W, (*out)->d, top, bottom, left, right, src->ctx->stream));
+  hipError_t e = ics_launch_img_pad_edge(src->d, src->H, src->W, (*out)->d, top, bottom, left, right, src->ctx->stream);
+  if (e != hipSuccess) { ics_img_destroy(*out); *out = nullptr; return fail(ICS_EHIP, "img_pad_edge: %s", hipGetErrorString(e)); }
   return ICS_OK;
 }
 static int rect_ok(const ics_img* m, int y0, int x0, int H, int W) { return y0 >= 0 && x0 >= 0 && H >= 1 && W >= 1 && y0 + H <= m->H && x0 + W <= m->W; }
@@ -905,8 +915,9 @@ extern "C" int ics_img_crop(const ics_img* src, int y0, int x0, int H, int W, ic
   if (!src || !out) return fail(ICS_EINVAL, "NULL argument");
   if (!rect_ok(src, y0, x0, H, W)) return fail(ICS_EINVAL, "crop [%d:%d, %d:%d] outside a %d x %d image", y0, y0 + H, x0, x0 + W, src->H, src->W);
   RC(img_new(src->ctx, H, W, out));
-  HIPCHK(hipMemcpy2DAsync((*out)->d, (size_t)W * 12, src->d + ((size_t)y0 * src->W + x0) * 3, (size_t)src->W * 12, (size_t)W * 12, H,
-                          hipMemcpyDeviceToDevice, src->ctx->stream));
+  hipError_t e = hipMemcpy2DAsync((*out)->d, (size_t)W * 12, src->d + ((size_t)y0 * src->W + x0) * 3, (size_t)src->W * 12, (size_t)W * 12, H,
+                                  hipMemcpyDeviceToDevice, src->ctx->stream);
+  if (e != hipSuccess) { ics_img_destroy(*out); *out = nullptr; return fail(ICS_EHIP, "img_crop: %s", hipGetErrorString(e)); }
   return ICS_OK;
 }
 extern "C" int ics_img_paste(ics_img* dst, int y0, int x0, const ics_img* src) {

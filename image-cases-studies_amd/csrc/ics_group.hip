@@ -35,6 +35,7 @@ int ics_set_error(int code, const char* fmt, ...);   // ics_api.hip
 
 struct ics_group {
   int rank, world, device;
+  bool local;        // world == 1: no communicator (ICS_GROUP_FORCE_RCCL=1 builds one anyway -- plumbing test on a 1-GPU box)
   rcclComm_t comm;
   hipStream_t stream;
   double* dbuf;      // device staging: (world + 1) * ICS_GROUP_MAX_COUNT doubles
@@ -72,7 +73,9 @@ extern "C" int ics_group_create(int device, int rank, int world, const char* ren
   if (world < 1 || rank < 0 || rank >= world) return ics_set_error(ICS_EINVAL, "rank %d of %d", rank, world);
   ics_group* g = new ics_group();
   g->rank = rank; g->world = world; g->device = device; g->comm = nullptr; g->stream = nullptr; g->dbuf = nullptr;
-  if (world == 1) { *out = g; return ICS_OK; }   // nothing to exchange: no RCCL, no device
+  const char* force = getenv("ICS_GROUP_FORCE_RCCL");
+  g->local = world == 1 && !(force && force[0] == '1');
+  if (g->local) { *out = g; return ICS_OK; }   // nothing to exchange: no RCCL, no device
   if (!rendezvous || !rendezvous[0]) { delete g; return ics_set_error(ICS_EINVAL, "a rendezvous file path is required for world > 1"); }
   int rc = load_rccl();
   if (rc != ICS_OK) { delete g; return rc; }
@@ -117,7 +120,7 @@ extern "C" int ics_group_create(int device, int rank, int world, const char* ren
 
 extern "C" void ics_group_destroy(ics_group* g) {
   if (!g) return;
-  if (g->world > 1) {
+  if (!g->local) {
     hipSetDevice(g->device);
     if (g->stream) hipStreamSynchronize(g->stream);
     if (g->comm) g_rccl.CommDestroy(g->comm);
@@ -138,7 +141,7 @@ extern "C" int ics_group_info(const ics_group* g, int* rank, int* world) {
 extern "C" int ics_group_allgather(ics_group* g, const double* send, int count, double* recv) {
   if (!g || !send || !recv) return ics_set_error(ICS_EINVAL, "NULL argument");
   if (count < 1 || count > ICS_GROUP_MAX_COUNT) return ics_set_error(ICS_EINVAL, "count %d (1..%d)", count, ICS_GROUP_MAX_COUNT);
-  if (g->world == 1) { memcpy(recv, send, (size_t)count * sizeof(double)); return ICS_OK; }
+  if (g->local) { memcpy(recv, send, (size_t)count * sizeof(double)); return ICS_OK; }
   GHIP(hipSetDevice(g->device));
   double* dsend = g->dbuf;
   double* drecv = g->dbuf + ICS_GROUP_MAX_COUNT;
@@ -152,7 +155,7 @@ extern "C" int ics_group_allgather(ics_group* g, const double* send, int count, 
 extern "C" int ics_group_allreduce_max(ics_group* g, double* inout, int count) {
   if (!g || !inout) return ics_set_error(ICS_EINVAL, "NULL argument");
   if (count < 1 || count > ICS_GROUP_MAX_COUNT) return ics_set_error(ICS_EINVAL, "count %d (1..%d)", count, ICS_GROUP_MAX_COUNT);
-  if (g->world == 1) return ICS_OK;
+  if (g->local) return ICS_OK;
   GHIP(hipSetDevice(g->device));
   GHIP(hipMemcpyAsync(g->dbuf, inout, (size_t)count * sizeof(double), hipMemcpyHostToDevice, g->stream));
   GRCCL(g_rccl.AllReduce(g->dbuf, g->dbuf, (size_t)count, RCCL_FLOAT64, RCCL_MAX, g->comm, g->stream));

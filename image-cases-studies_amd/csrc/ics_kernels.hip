@@ -701,7 +701,15 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   // Few long-lived workgroups stream best here.  k_update_rows at 4096^2 (4 reads + 1 write, 1.0 GB), segments per loop
   // iteration x workgroups per CU: 3x2 0.173 ms, 4x2 0.167, 4x3 0.164, 4x4 0.170, 6x2 0.164, 6x4 0.180 (scripts/sweep_update.sh).
   static const int per_cu = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 3;
-  const long cap = 256L * (per_cu > 0 ? per_cu : 3);
+  static int cus[64] = {};   // per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+  }
+  const long cap = (long)cus[dev] * (per_cu > 0 ? per_cu : 3);
   if (blocks > cap) blocks = cap;
   static const int rows_kernel = getenv("ICS_UPDATE_KERNEL") ? atoi(getenv("ICS_UPDATE_KERNEL")) : 1;   // 0: the pixel-group kernel everywhere
   const int tvk = (a.tv && a.tv_kind) ? (a.tv_kind >= 2 ? 2 : 1) : 0;

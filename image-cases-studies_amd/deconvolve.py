@@ -78,6 +78,14 @@ def mask_window(i, top, bottom, left, right):
 
 
 @utils.timeit
+def _check_mask_size(mask_size):
+    """The stop-test statistics of the GPU solver (residual autocorrelation, lib/deconvolution.pyx:623-638) run a P x P FFT with
+    P <= 2048: windows up to 1024 px.  The reference has no such limit (its examples use 255 and 811, deconvolve.py:67,416);
+    fail here with a clear message rather than from inside the first solver call."""
+    if 2 * (2 * (int(mask_size) // 2)) - 1 > 2048:
+        raise ValueError("mask_size = %d: the GPU path evaluates the stop test on windows of at most 1024 x 1024 px (mask_size <= 1025)" % mask_size)
+
+
 def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance=1, quality="normal", bits=8,
                   mask=None, display=True, blur="static", preview=False, p=1, order=2, norm=1, priority=0, mask_size=255,
                   iterations=200, refocus=False, pyramid=True, solver=None, save=True, device_resident=False):
@@ -104,6 +112,7 @@ def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance
     M, N = pic.shape[0], pic.shape[1]
     if mask is None:
         mask = [M // 2, N // 2]
+    _check_mask_size(mask_size)
     top, bottom = mask[0] - mask_size // 2, mask[0] + mask_size // 2       # :138-141
     left, right = mask[1] - mask_size // 2, mask[1] + mask_size // 2
     print("Mask size :", (bottom - top + 1), "×", (right - left + 1))
@@ -236,6 +245,7 @@ def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, 
     M, N, _ = pic_d.shape
     if mask is None:
         mask = [M // 2, N // 2]
+    _check_mask_size(mask_size)
     top, bottom = mask[0] - mask_size // 2, mask[0] + mask_size // 2
     left, right = mask[1] - mask_size // 2, mask[1] + mask_size // 2
     print("Mask size :", (bottom - top + 1), "×", (right - left + 1))

@@ -170,6 +170,21 @@ class Context:
     def synchronize(self):
         _check(load().ics_ctx_synchronize(self._h))
 
+    def close(self):
+        """Destroys the stream (ics_ctx_destroy).  Jobs and images of this context must be closed first."""
+        if getattr(self, "_h", None):
+            load().ics_ctx_destroy(self._h)
+            self._h = None
+            if Context._cache.get(self.device) is self:
+                del Context._cache[self.device]
+
+    def __del__(self):
+        try:
+            if Context._cache.get(self.device) is not self:    # cached contexts live as long as the process
+                self.close()
+        except Exception:
+            pass
+
     # ---- standalone operators ---------------------------------------------------------------
     def normalize_kernel(self, kern, MK):
         _check(load().ics_normalize_kernel(self._h, _ptr(kern), int(MK)))

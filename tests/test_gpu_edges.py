@@ -101,3 +101,24 @@ def test_frames_beyond_the_32_bit_offset_range_are_refused_not_corrupted():
     with pytest.raises(_native.NativeError) as ei:
         _native.RLJob(14000, 14000, 15)
     assert ei.value.code == _native.ICS_ENOSUP
+
+
+def test_empty_stats_window_gives_nan_statistics_like_the_reference():
+    """error[top:bottom, left:right] with bottom <= top is an empty array in the reference: M_r, Hu and varu are NaN
+    (numpy warns, lib/deconvolution.pyx:600-601,627-638 do not raise), the stop test never fires, and u does not depend
+    on the window at all."""
+    from lib import _native as nv
+    M, N, MK = 48, 56, 5
+    case = orc.synth_case(M, N, MK, seed=2)
+    res = []
+    for win in ((10, 10, 5, 30), orc.default_window(M, N, MK)):
+        job = nv.RLJob(M, N, MK)
+        job.upload(case["image"], case["u0"], case["psf0"])
+        st = job.run(job.params(*win, 0.0, 4, 1e-3, 1e4, False))
+        res.append((job.download()[0], st))
+        job.close()
+    (u_e, st_e), (u_w, st_w) = res
+    assert np.isnan(st_e.M_r) and np.isnan(st_e.Hu) and np.isnan(st_e.varu)
+    assert st_e.iterations_done == 4 and not st_e.stopped
+    if not st_w.stopped:
+        assert np.array_equal(u_e, u_w)

@@ -1,10 +1,17 @@
-"""One-image-per-GPU sharding: job assignment and the trivial gather, exercised with
-world_size 2 over gloo on CPU (the GPU path uses the same Group over RCCL)."""
+"""One-image-per-GPU sharding: job assignment, the launcher of bench.py, and the trivial gather.
+
+CPU (this container): world_size 2 over gloo with the oracle standing in for the GPU job; `bench.py --gpus N` must refuse
+to run on fewer than N GPUs; the native group entry points with world = 1.
+GPU (one MI355X): two ranks sharing device 0 drive the PRODUCT path (bench.py -> RLJob) with the gloo group (RCCL refuses
+two ranks on one device), and the RCCL plumbing of ics_group_* is exercised with a one-rank communicator."""
+import ctypes as C
 import json
 import os
 import subprocess
 import sys
 import textwrap
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,3 +62,83 @@ def test_two_ranks_gloo_barrier_max_gather(tmp_path):
     assert len(rec) == 2 and sorted(int(r[2]) for r in rec) == [0, 1]
     assert sorted(int(r[0]) for r in rec) == [2, 3]      # 5 jobs over 2 ranks
     assert res["dt"] > 0 and all(r[1] > 0 for r in rec)
+
+
+def _ndev():
+    sys.path.insert(0, os.path.join(ROOT, "image-cases-studies_amd"))
+    from lib import _native
+    return _native.device_count()
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` launches its own ranks; with fewer than N devices it must exit non-zero with a clear
+    message, never fall back to fewer GPUs (on the GPU-less container: 0 devices)."""
+    n = 9 if _ndev() >= 1 else 2
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "5", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert out.returncode != 0
+    assert "--gpus %d requested" % n in out.stderr and "no fallback" in out.stderr
+    assert out.stdout.strip() == ""
+
+
+def test_native_group_single_rank_needs_no_device_and_validates_arguments():
+    sys.path.insert(0, os.path.join(ROOT, "image-cases-studies_amd"))
+    from lib import _native
+    lib = _native.load()
+    h = C.c_void_p()
+    assert lib.ics_group_create(0, 0, 1, None, 1, C.byref(h)) == 0          # world = 1: nothing to exchange, no HIP call
+    send = (C.c_double * 3)(1.5, -2.0, 7.0)
+    recv = (C.c_double * 3)()
+    assert lib.ics_group_allgather(h, send, 3, recv) == 0 and list(recv) == [1.5, -2.0, 7.0]
+    x = (C.c_double * 1)(4.25)
+    assert lib.ics_group_allreduce_max(h, x, 1) == 0 and x[0] == 4.25
+    assert lib.ics_group_barrier(h) == 0
+    r, w = C.c_int(-1), C.c_int(-1)
+    assert lib.ics_group_info(h, C.byref(r), C.byref(w)) == 0 and (r.value, w.value) == (0, 1)
+    assert lib.ics_group_allgather(h, send, 65, recv) == _native.ICS_EINVAL
+    lib.ics_group_destroy(h)
+    assert lib.ics_group_create(0, 2, 2, b"/tmp/x", 1, C.byref(h)) == _native.ICS_EINVAL       # rank out of range
+    assert lib.ics_group_create(0, 1, 2, None, 1, C.byref(h)) == _native.ICS_EINVAL            # no rendezvous path
+    assert b"rendezvous" in lib.ics_last_error()
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_through_the_product_path():
+    """bench.py under torchrun with 2 ranks: both run the product RLJob on device 0 (ICS_DEVICE=0), group = gloo because
+    RCCL refuses two ranks on one device.  Checks the launch contract: n_gpus, per_rank, weak scaling, value = all pixels
+    of both ranks over the max-rank time."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ICS_DIST_BACKEND="gloo", ICS_DEVICE="0", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--size", "1024",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and len(d["per_rank"]) == 2 and d["scaling"] == "weak" and d["steps"] == 20
+    assert all(r["outer_done"] == 4 for r in d["per_rank"])
+    assert abs(d["value"] - 2 * 1024 * 1024 * 20 / (d["ms_per_step"] * 20 * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+@pytest.mark.gpu
+def test_rccl_plumbing_with_a_one_rank_communicator(tmp_path):
+    """ics_group_* over RCCL itself (dlopen, unique id through the rendezvous file, ncclCommInitRank, all-gather,
+    all-reduce) with a communicator of one rank -- all a single-GPU box allows.  Runs in a child process."""
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        from lib import _native
+        lib = _native.load()
+        h = C.c_void_p()
+        rc = lib.ics_group_create(0, 0, 1, %r.encode(), 30, C.byref(h))
+        assert rc == 0, lib.ics_last_error()
+        send = (C.c_double * 4)(1.0, 2.5, -3.0, 4e10); recv = (C.c_double * 4)()
+        assert lib.ics_group_allgather(h, send, 4, recv) == 0, lib.ics_last_error()
+        assert list(recv) == [1.0, 2.5, -3.0, 4e10]
+        x = (C.c_double * 2)(7.0, -1.0)
+        assert lib.ics_group_allreduce_max(h, x, 2) == 0 and list(x) == [7.0, -1.0]
+        assert lib.ics_group_barrier(h) == 0
+        lib.ics_group_destroy(h)
+        print("RCCL-OK")
+    """ % (os.path.join(ROOT, "image-cases-studies_amd"), str(tmp_path / "rdzv")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICS_GROUP_FORCE_RCCL="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-3000:]
+    assert not (tmp_path / "rdzv").exists()          # rank 0 removes the id file once the communicator exists
