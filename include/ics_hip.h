@@ -108,6 +108,19 @@ typedef struct ics_rl_params {
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 37, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
 
+/* Accuracy of the matrix-core path (tests/test_gpu_precision.py drives it with adversarial inputs).  Every fp32 operand x of a
+ * 78 x 80-pixel tile is scaled by a power of two s (tile maximum m -> [2^14, 2^15)) and split, x s = hi + lo + r, hi and lo
+ * fp16.  fp16 carries 11 significand bits down to 2^-14 and a fixed quantum of 2^-24 below, so
+ *        |r| / s  <=  max( 2^-22 |x| , 2^-39 m ):
+ * 22 bits for every element within 2^17 of the tile maximum, an ABSOLUTE error of 2^-39 of the tile maximum for smaller
+ * ones (the PSF taps likewise, against the largest tap).  Products drop the lo*lo term (< 2^-22 |x w|) and accumulate in fp32:
+ *        |err(sum w x)|  <=  8 * 2^-22 * sum |w||x|  +  2^-38 * ( m * sum |w|  +  w_max * sum |x| ).
+ * Measured: local relative error 0.6 - 1.4e-6 (the fp32 kernels: 0.7 - 2.5e-6) on ordinary frames, on 0..65535 frames and with
+ * pixels 10^4 above their tile; for residuals of 1e-7 next to an isolated 1.0 the absolute error is 5e-13 (1.6e-5 of the
+ * local values).  For comparison the reference's own convolution, scipy's FFT in complex64 (lib/deconvolution.pyx:478),
+ * has an absolute error of ~1e-7 of the FRAME maximum at every pixel.  There is therefore no data-dependent fall-back to
+ * the fp32 kernels in ICS_CONV_AUTO; ICS_CONV_VECTOR remains for callers who want fp32 products regardless. */
+
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
 #define ICS_TV_MM_ACTIVE 1 /* BUILD-DEFINED extension, parity unpinned: the if-branches :517/:543 made
                               reachable (TV_ut from the majoriser, image denoising step :547-549 live);
