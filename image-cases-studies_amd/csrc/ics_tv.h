@@ -1,6 +1,10 @@
 // ics_tv.h -- the 3x3 TV stencil of lib/deconvolution.pyx:137-239 as a device function, shared by the
 // standalone operator (k_tv, ics_filters.hip) and the active MM-TV mode (k_tvterm, ics_kernels.hip).
-// Separately rounded float32 operations in the reference's order (build with -ffp-contract=off).
+// Arithmetic as the COMPILED reference evaluates it, pinned by tests/golden/tv.npz (oracle/make_golden_tv.py): Cython writes the
+// literal of `-2 * u[i, j, k]` as the C double -2.0, so the second-order sums are double expressions rounded once
+// (lib/deconvolution.c:4176); the numerator of the diagonal terms is rounded to float before the float division by dxdy;
+// `adjust` is a double expression stored in a float (:4031); first-order differences stay float.  Everything else:
+// separately rounded float32 operations in the reference's order (build with -ffp-contract=off).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,15 +21,15 @@ __device__ __forceinline__ float ics_tv_norm(float x, float y, float eps, int no
 __device__ __forceinline__ IcsTvOut ics_tv_point(float c, float up, float dn, float lf, float rt, float ul, float dr, float ur,
                                                  float dl, float eps, int order, int norm) {
   const float dxdy = 1.41421354f;  // powf(2, 0.5) as a float (pyx:146)
-  const float adjust = (norm == 1) ? __fmul_rn(4.0f, __fadd_rn(1.0f, __fdiv_rn(1.0f, dxdy)))   // pyx:149-152
-                                   : __fmul_rn(2.0f, __fadd_rn(1.0f, dxdy));
+  const float adjust = (norm == 1) ? (float)(4.0 * (1.0 + 1.0 / (double)dxdy))   // pyx:149-152, evaluated in double
+                                   : (float)(2.0 * (1.0 + (double)dxdy));
   float d, r;
   if (order == 2) {  // pyx:156-189
-    const float m2c = __fmul_rn(-2.0f, c);
-    const float udx = __fadd_rn(__fadd_rn(m2c, up), dn);
-    const float udy = __fadd_rn(__fadd_rn(m2c, lf), rt);
-    const float udxdy = __fdiv_rn(__fadd_rn(__fadd_rn(m2c, ul), dr), dxdy);
-    const float udydx = __fdiv_rn(__fadd_rn(__fadd_rn(m2c, ur), dl), dxdy);
+    const double m2c = -2.0 * (double)c;   // exact
+    const float udx = (float)__dadd_rn(__dadd_rn(m2c, (double)up), (double)dn);
+    const float udy = (float)__dadd_rn(__dadd_rn(m2c, (double)lf), (double)rt);
+    const float udxdy = __fdiv_rn((float)__dadd_rn(__dadd_rn(m2c, (double)ul), (double)dr), dxdy);
+    const float udydx = __fdiv_rn((float)__dadd_rn(__dadd_rn(m2c, (double)ur), (double)dl), dxdy);
     d = __fsub_rn(__fsub_rn(__fsub_rn(-udx, udy), udxdy), udydx);
     r = __fadd_rn(ics_tv_norm(udx, udy, eps, norm), ics_tv_norm(udxdy, udydx, eps, norm));
   } else {           // pyx:191-237

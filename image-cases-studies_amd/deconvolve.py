@@ -77,7 +77,6 @@ def mask_window(i, top, bottom, left, right):
     return temp_top, temp_bottom, temp_left, temp_right
 
 
-@utils.timeit
 def _check_mask_size(mask_size):
     """The stop-test statistics of the GPU solver (residual autocorrelation, lib/deconvolution.pyx:623-638) run a P x P FFT with
     P <= 2048: windows up to 1024 px.  The reference has no such limit (its examples use 255 and 811, deconvolve.py:67,416);
@@ -86,6 +85,7 @@ def _check_mask_size(mask_size):
         raise ValueError("mask_size = %d: the GPU path evaluates the stop test on windows of at most 1024 x 1024 px (mask_size <= 1025)" % mask_size)
 
 
+@utils.timeit
 def deblur_module(pic, filename, dest_path, blur_width, confidence=10, tolerance=1, quality="normal", bits=8,
                   mask=None, display=True, blur="static", preview=False, p=1, order=2, norm=1, priority=0, mask_size=255,
                   iterations=200, refocus=False, pyramid=True, solver=None, save=True, device_resident=False):

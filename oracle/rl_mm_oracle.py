@@ -130,26 +130,52 @@ def _conv_direct(a, b, mode):
     raise ValueError(mode)
 
 
+_libm_powf = None
+
+
+def _powf(x, y):
+    """C `powf` of the host libm, element by element (the reference calls it for every square and square root, pyx:129-131;
+    glibc's powf is within 0.82 ulp, i.e. not always the correctly rounded value numpy's float32 power returns).  Arrays
+    beyond 2e5 elements fall back to the correctly rounded float64 evaluation (<= 1 ulp from libm)."""
+    global _libm_powf
+    x = np.asarray(x, dtype=np.float32)
+    if x.size > 200000:
+        return np.power(x.astype(np.float64), float(y)).astype(np.float32)
+    if _libm_powf is None:
+        import ctypes
+        import ctypes.util
+        lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        lib.powf.restype = ctypes.c_float
+        lib.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+        _libm_powf = np.frompyfunc(lambda a, b: lib.powf(a, b), 2, 1)
+    return np.asarray(_libm_powf(x, np.float32(y)), dtype=np.float32)
+
+
 def TV(u, M, N, epsilon, order, norm):
-    """pyx:137-239.  Returns (out, div); borders untouched (zero), as `:239` says."""
+    """pyx:137-239.  Returns (out, div); borders untouched (zero), as `:239` says.
+
+    Pinned against the compiled reference (oracle/make_golden_tv.py, tests/golden/tv.npz), which settled two points the
+    source does not show: Cython writes the integer literal of `-2 * u[i, j, k]` as the C double `-2.0`, so the
+    second-order stencil `-2*u + a + b` is evaluated in DOUBLE and rounded once (lib/deconvolution.c:4176); and
+    `adjust = 4. * (1 + 1/dxdy)` is likewise a double expression stored into a C float (:4031).  The first-order
+    differences `u - a`, `-u + b` involve no literal and stay float.  gcc folds `powf(x, 2)` into `x * x` (exactly rounded),
+    `powf(s, 0.5)` stays a libm call."""
     u = np.asarray(u, dtype=np.float32)
     out = np.zeros_like(u)
     div = np.zeros_like(u)
-    dxdy = F32(np.power(F32(2), F32(0.5)))
-    # pyx:149-152: `4. * (1 + 1/dxdy)`: 1/dxdy and 1 + ... are C float operations (dxdy is a float),
-    # the product with the double literal is exact (x4 / x2) and is stored into the C float `adjust`
+    dxdy = F32(_powf(np.array([2.0], np.float32), 0.5)[0])                       # powf(2.0, 0.5)
     if norm == 1:
-        adjust = F32(4.0) * F32(F32(1) + F32(F32(1) / dxdy))
+        adjust = F32(4.0 * (1.0 + 1.0 / np.float64(dxdy)))
     else:
-        adjust = F32(2.0) * F32(F32(1) + dxdy)
+        adjust = F32(2.0 * (1.0 + np.float64(dxdy)))
     eps = F32(epsilon)
     c = u[1:M - 1, 1:N - 1]
 
-    def n1(x, y):
+    def n1(x, y):                                                                 # fabsf(x) + fabsf(y) + epsilon
         return np.abs(x) + np.abs(y) + eps
 
-    def n2(x, y):
-        return np.power(np.power(x, F32(2)) + np.power(y, F32(2)) + np.power(eps, F32(2)), F32(0.5)).astype(np.float32)
+    def n2(x, y):                                                                 # powf(powf(x,2) + powf(y,2) + powf(eps,2), 0.5)
+        return _powf((x * x + y * y) + eps * eps, 0.5)
 
     nrm = n1 if norm == 1 else n2
     up, dn = u[0:M - 2, 1:N - 1], u[2:M, 1:N - 1]
@@ -157,10 +183,13 @@ def TV(u, M, N, epsilon, order, norm):
     ul, dr = u[0:M - 2, 0:N - 2], u[2:M, 2:N]
     ur, dl = u[0:M - 2, 2:N], u[2:M, 0:N - 2]
     if order == 2:
-        udx = F32(-2) * c + up + dn
-        udy = F32(-2) * c + lf + rt
-        udxdy = (F32(-2) * c + ul + dr) / dxdy
-        udydx = (F32(-2) * c + ur + dl) / dxdy
+        c64 = c.astype(np.float64)
+        udx = ((-2.0 * c64 + up) + dn).astype(np.float32)
+        udy = ((-2.0 * c64 + lf) + rt).astype(np.float32)
+        # (the numerator of the diagonal terms lands in a float temporary -- Cython's division-by-zero check -- before the
+        #  float division by dxdy: double sum, rounded, then divided in float)
+        udxdy = ((-2.0 * c64 + ul) + dr).astype(np.float32) / dxdy
+        udydx = ((-2.0 * c64 + ur) + dl).astype(np.float32) / dxdy
         d = (-udx - udy - udxdy - udydx) / adjust
         o = (nrm(udx, udy) + nrm(udxdy, udydx)) / adjust
     else:

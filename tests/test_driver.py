@@ -109,6 +109,36 @@ def test_device_resident_driver_equals_the_host_driver(pyramid, preview, blur, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pyramid,preview,blur", [(False, False, "static"), (True, False, "static"), (False, True, "static"), (False, False, "motion")])
+def test_device_resident_driver_against_the_oracle_solver(pyramid, preview, blur, capsys):
+    """SURVEY.md 8f N1 against an ORACLE run of the driver: `deblur_module(solver=<oracle richardson_lucy_MM>)` -- the host-frame
+    driver with the pinned numpy restatement of lib/deconvolution.pyx doing every solver call (blind on the mask window, then
+    the non-blind pass / preview; with `correlation` for motion blur) -- versus `deblur_module(device_resident=True)`, where
+    frames, pads, gamma, windows and the solver all run on the device.  (The bicubic resize between pyramid levels is the
+    device kernel in both runs: the reference's skimage dependency is absent from the image, parity unpinned.)"""
+    import deconvolve as dv
+    import rl_mm_oracle as orc
+    case = orc.synth_case(118, 141, 5, seed=2)
+    pic = np.clip(case["image"] ** 2.2 * 255, 0, 255).astype(np.uint8)
+    kw = dict(mask=[60, 70], mask_size=61, display=False, iterations=3, pyramid=pyramid, save=False, preview=preview, blur=blur)
+
+    def oracle_solver(image, u, psf, *args, **kwargs):
+        return orc.richardson_lucy_MM(image, u, psf, *args, **kwargs)      # prints the reference's lines itself
+
+    out_o, psf_o = dv.deblur_module(pic, "o", ".", 5, solver=oracle_solver, **kw)
+    log_o = capsys.readouterr().out
+    out_d, psf_d = dv.deblur_module(pic, "d", ".", 5, device_resident=True, **kw)
+    log_d = capsys.readouterr().out
+    assert out_d.shape == out_o.shape
+    ep = np.abs(psf_d - psf_o).max() / np.abs(psf_o).max()
+    eo = np.abs(out_d - out_o).max() / 65535
+    print("driver vs oracle-solver driver (pyramid=%s preview=%s blur=%s): psf %.2e, picture %.2e of full scale" % (pyramid, preview, blur, ep, eo))
+    assert ep < 1e-4 and eo < 1e-4
+    strip = lambda t: [l.split("=")[0] for l in t.splitlines() if not l.startswith("'deblur_module'") and "sec" not in l]
+    assert strip(log_o) == strip(log_d)                                    # same progress lines, same iteration counts
+
+
+@pytest.mark.gpu
 def test_device_image_operations_match_numpy():
     from lib import _native
     import resize_oracle as ro
