@@ -47,7 +47,24 @@ struct ics_ctx {
   int cus;
   char name[256];
   uint64_t hbm;
+  void* scratch;            // device scratch of the standalone operators: grown on demand, kept between calls
+  size_t scratch_bytes;
+  hipEvent_t ev0, ev1;      // device time of the last standalone operator (kernels only, no transfers)
+  float last_ms;
 };
+
+// at least `bytes` of device scratch that persists between calls (no hipMalloc / hipFree per filter call)
+static int ctx_scratch(ics_ctx* c, size_t bytes, void** p) {
+  if (c->scratch_bytes < bytes) {
+    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    const size_t want = bytes + bytes / 4;
+    hipError_t e = hipMalloc(&c->scratch, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); c->scratch = nullptr; return ICS_ENOMEM; }
+    c->scratch_bytes = want;
+  }
+  *p = c->scratch;
+  return ICS_OK;
+}
 
 struct ics_rl {
   ics_ctx* ctx;
@@ -111,6 +128,8 @@ extern "C" int ics_ctx_create(int device, ics_ctx** out) {
     return fail(ICS_ENODEV, "device %d is %s; this library only contains gfx950 (MI355X) code", device, prop.gcnArchName);
   ics_ctx* c = new ics_ctx();
   c->device = device;
+  c->scratch = nullptr; c->scratch_bytes = 0; c->last_ms = 0.f;
+  hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
   c->cus = prop.multiProcessorCount;
   c->hbm = prop.totalGlobalMem;
   snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
@@ -124,6 +143,8 @@ extern "C" void ics_ctx_destroy(ics_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->scratch) hipFree(c->scratch);
+  hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -132,6 +153,12 @@ extern "C" int ics_ctx_synchronize(ics_ctx* c) {
   if (!c) return fail(ICS_EINVAL, "ctx is NULL");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
+  return ICS_OK;
+}
+
+extern "C" int ics_ctx_last_kernel_ms(ics_ctx* c, float* ms) {
+  if (!c || !ms) return fail(ICS_EINVAL, "NULL argument");
+  *ms = c->last_ms;
   return ICS_OK;
 }
 
@@ -769,22 +796,53 @@ extern "C" int ics_tv(ics_ctx* c, const float* u, int M, int N, float eps, int o
   return ICS_OK;
 }
 
+// Rank-1 test: kern == outer(col, row)?  Every window of lib/utils.py (uniform, gaussian, kaiser, poisson) is an outer product
+// normalised by its sum; the two 1-D factors are taken through the largest element.
+static bool rank1_factors(const double* k, int KH, int KW, std::vector<double>& col, std::vector<double>& row) {
+  int r = 0, c = 0; double m = 0.0;
+  for (int i = 0; i < KH; ++i) for (int j = 0; j < KW; ++j) if (fabs(k[i * KW + j]) > m) { m = fabs(k[i * KW + j]); r = i; c = j; }
+  if (m == 0.0 || KH == 1 || KW == 1) return false;
+  const double piv = k[r * KW + c];
+  for (int i = 0; i < KH; ++i)
+    for (int j = 0; j < KW; ++j)
+      if (fabs(k[i * KW + j] * piv - k[i * KW + c] * k[r * KW + j]) > 4e-16 * m * m) return false;
+  col.resize(KH); row.resize(KW);
+  for (int i = 0; i < KH; ++i) col[i] = k[i * KW + c] / piv;
+  for (int j = 0; j < KW; ++j) row[j] = k[r * KW + j];
+  return true;
+}
+
 static int conv2d_common(ics_ctx* c, const double* src, int H, int W, const double* kern, int KH, int KW, int usm, double amount, double* out) {
   if (!c || !src || !kern || !out) return fail(ICS_EINVAL, "NULL argument");
   if (H < 1 || W < 1 || KH < 1 || KW < 1) return fail(ICS_EINVAL, "bad sizes");
+  if ((size_t)(32 + KH - 1) * (32 + KW - 1) * 8 > 160 * 1024) return fail(ICS_ENOSUP, "kernel %d x %d too large for the LDS tile (up to 111 x 111)", KH, KW);
   HIPCHK(hipSetDevice(c->device));
   const size_t n = (size_t)H * W, nk = (size_t)KH * KW;
-  double *ds = nullptr, *dk = nullptr, *dout = nullptr;
-  hipError_t e = hipMalloc((void**)&ds, n * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dk, nk * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 8);
-  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(dk, kern, nk * 8, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = ics_launch_conv2d_symm(ds, H, W, dk, KH, KW, dout, usm, amount, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(ds); hipFree(dk); hipFree(dout);
-  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "conv2d_symm: %s", hipGetErrorString(e));
+  std::vector<double> col, row;
+  const bool sep = rank1_factors(kern, KH, KW, col, row);
+  void* base = nullptr;
+  int rc = ctx_scratch(c, (3 * n + nk + KH + KW + 16) * 8, &base);
+  if (rc != ICS_OK) return fail(rc, "device scratch of %zu bytes", (3 * n + nk) * 8);
+  double *ds = (double*)base, *dout = ds + n, *dtmp = dout + n, *dk = dtmp + n;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, s));
+  if (sep) {
+    HIPCHK(hipMemcpyAsync(dk, row.data(), KW * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(dk + KW, col.data(), KH * 8, hipMemcpyHostToDevice, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(dk, kern, nk * 8, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(hipEventRecord(c->ev0, s));
+  if (sep) {   // rows (1 x KW), then columns (KH x 1) with the USM epilogue against the original channel
+    HIPCHK(ics_launch_conv2d_symm(ds, H, W, dk, 1, KW, dtmp, ds, 0, 0.0, s));
+    HIPCHK(ics_launch_conv2d_symm(dtmp, H, W, dk + KW, KH, 1, dout, ds, usm, amount, s));
+  } else {
+    HIPCHK(ics_launch_conv2d_symm(ds, H, W, dk, KH, KW, dout, ds, usm, amount, s));
+  }
+  HIPCHK(hipEventRecord(c->ev1, s));
+  HIPCHK(hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));   // (col / row are host vectors read by the async copies above)
+  HIPCHK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   return ICS_OK;
 }
 
@@ -798,17 +856,26 @@ extern "C" int ics_usm(ics_ctx* c, const double* src, int H, int W, const double
 extern "C" int ics_bilateral(ics_ctx* c, const double* src, int H, int W, int radius, double std_i, double std_s, double* out) {
   if (!c || !src || !out) return fail(ICS_EINVAL, "NULL argument");
   if (H < 1 || W < 1 || radius < 0) return fail(ICS_EINVAL, "bad sizes");
+  if ((size_t)(32 + 2 * radius) * (32 + 2 * radius) * 8 > 160 * 1024) return fail(ICS_ENOSUP, "radius %d too large for the LDS tile (up to 55)", radius);
   HIPCHK(hipSetDevice(c->device));
   const size_t n = (size_t)H * W;
-  double *ds = nullptr, *dout = nullptr;
-  hipError_t e = hipMalloc((void**)&ds, n * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 8);
-  if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = ics_launch_bilateral(ds, H, W, radius, std_i, std_s, dout, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(ds); hipFree(dout);
-  if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "bilateral: %s", hipGetErrorString(e));
+  const int D = 2 * radius + 1;
+  std::vector<double> ws((size_t)D * D);
+  for (int j = -radius; j <= radius; ++j)
+    for (int i = -radius; i <= radius; ++i) ws[(size_t)(j + radius) * D + (i + radius)] = exp((double)(i * i + j * j) * (-1.0 / (2.0 * std_s * std_s)));
+  void* base = nullptr;
+  int rc = ctx_scratch(c, (2 * n + ws.size() + 16) * 8, &base);
+  if (rc != ICS_OK) return fail(rc, "device scratch of %zu bytes", 2 * n * 8);
+  double *ds = (double*)base, *dout = ds + n, *dws = dout + n;
+  hipStream_t s = c->stream;
+  HIPCHK(hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(dws, ws.data(), ws.size() * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipEventRecord(c->ev0, s));
+  HIPCHK(ics_launch_bilateral(ds, H, W, radius, std_i, dws, dout, s));
+  HIPCHK(hipEventRecord(c->ev1, s));
+  HIPCHK(hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
   return ICS_OK;
 }
 

@@ -1,8 +1,7 @@
 // ics_filters.hip -- standalone operators next to the RL loop: the TV stencil of
 // lib/deconvolution.pyx:137-239 and the lib/utils.py filters (Gaussian/Bessel blur, USM, bilateral).
-// All of them are small 2-D stencils on contiguous host-shaped arrays: one output element per lane,
-// neighbours served by L1/L2 (3x3 .. (2r+1)^2 taps, rows are contiguous so a wave reads 64
-// consecutive elements per tap).
+// The TV stencil is 3 x 3 (one output per lane, neighbours from L1/L2); the blurs and the bilateral filter are LDS-tiled
+// (k_conv2d_tile, k_bilateral_tile below).
 #include "ics_kernels.h"
 #include "ics_tv.h"
 
@@ -37,39 +36,81 @@ __device__ __forceinline__ int symm(int i, int n) {  // ... x1 x0 | x0 x1 ... x(
   return i < n ? i : p - 1 - i;
 }
 
-__global__ __launch_bounds__(256) void k_conv2d_symm(const double* __restrict__ src, int H, int W, const double* __restrict__ kern,
-                                                    int KH, int KW, double* __restrict__ out, int usm, double amount) {
-  const long total = (long)H * W;
+// LDS-tiled: a 256-thread workgroup owns a 32 x 32 output tile; the tile plus its (KH-1) x (KW-1) halo is staged once in LDS
+// with the symmetric extension resolved at load time (coalesced row segments), every lane then produces 4 outputs (rows
+// ty, ty+8, ty+16, ty+24 of column tx) from LDS: KH*KW LDS reads per output instead of KH*KW global reads, and the weights
+// are wave-uniform (scalar loads).  float64 like SciPy.  Rank-1 kernels -- every lib/utils.py window is an outer product --
+// run as two passes of this kernel (1 x KW, then KH x 1): 2K instead of K^2 taps; the USM epilogue (lib/utils.py:275,
+// src + (src - blur) * amount) reads the ORIGINAL channel `src0`.
+#define CT 32
+__global__ __launch_bounds__(256) void k_conv2d_tile(const double* __restrict__ src, int H, int W, const double* __restrict__ kern,
+                                                    int KH, int KW, double* __restrict__ out, const double* __restrict__ src0, int usm, double amount) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];
   const int cy = (KH - 1) / 2, cx = (KW - 1) / 2;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int i = (int)(t / W), j = (int)(t - (long)i * W);
-    double s = 0.0;
-    for (int p = 0; p < KH; ++p) {
-      const int yy = symm(i + cy - p, H);
-      for (int q = 0; q < KW; ++q) s += kern[p * KW + q] * src[(long)yy * W + symm(j + cx - q, W)];
+  const int LW = CT + KW - 1, LH = CT + KH - 1;
+  const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+  // "same": out[i][j] = sum_{p,q} kern[p][q] * ext[i + cy - p][j + cx - q]  ->  staged rows y0 + cy - (KH-1) .. y0 + cy + CT - 1
+  const int ys = y0 + cy - (KH - 1), xs = x0 + cx - (KW - 1);
+  for (int t = threadIdx.x; t < LH * LW; t += 256) {
+    const int r = t / LW, c = t - r * LW;
+    tile[t] = src[(long)symm(ys + r, H) * W + symm(xs + c, W)];
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int p = 0; p < KH; ++p) {
+    for (int q = 0; q < KW; ++q) {
+      const double w = kern[p * KW + q];                       // uniform
+      // tile row of output row ty + 8m for tap p: (ty + 8m) + (KH-1) - p ; column tx + (KW-1) - q
+      const double* tp = tile + (ty + KH - 1 - p) * LW + (tx + KW - 1 - q);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] += w * tp[8 * m * LW];
     }
-    // USM (lib/utils.py:275): src + (src - blur) * amount
-    out[t] = usm ? src[t] + (src[t] - s) * amount : s;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int y = y0 + ty + 8 * m, x = x0 + tx;
+    if (y < H && x < W) {
+      const long o = (long)y * W + x;
+      out[o] = usm ? src0[o] + (src0[o] - acc[m]) * amount : acc[m];
+    }
   }
 }
 
 // ---- bilateral filter (lib/utils.py:173-234), gaussian(x, s) = exp(-x^2 / (2 s^2)) --------------
-__global__ __launch_bounds__(256) void k_bilateral(const double* __restrict__ src, int H, int W, int radius, double std_i, double std_s,
-                                                  double* __restrict__ out) {
-  const long total = (long)H * W;
-  const double ki = -1.0 / (2.0 * std_i * std_i), ks = -1.0 / (2.0 * std_s * std_s);
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int y = (int)(t / W), x = (int)(t - (long)y * W);
-    const double c = src[t];
-    double acc = 0.0, wsum = 0.0;
-    for (int j = -radius; j <= radius; ++j)       // lib/utils.py:209-213: j is the slow index of `combi`
-      for (int i = -radius; i <= radius; ++i) {
-        const double nb = src[(long)symm(y + i, H) * W + symm(x + j, W)];
-        const double dist2 = (double)(i * i + j * j);
-        const double w = exp((nb - c) * (nb - c) * ki) * exp(dist2 * ks);
-        acc += nb * w; wsum += w;
+// Same tiling: the 32 x 32 tile + radius halo (symmetric padding, lib/utils.py:204) in LDS; the spatial weights
+// exp(-(i^2 + j^2) / 2 std_s^2) of the (2r+1)^2 offsets are precomputed once per call (`ws`, wave-uniform reads), so each tap
+// costs one float64 exp (the range term) instead of two.  Accumulation order = the reference's offset order (j slow, i fast).
+__global__ __launch_bounds__(256) void k_bilateral_tile(const double* __restrict__ src, int H, int W, int radius, double std_i,
+                                                       const double* __restrict__ ws, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double tile[];
+  const int D = 2 * radius + 1, LW = CT + 2 * radius, LH = CT + 2 * radius;
+  const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+  for (int t = threadIdx.x; t < LH * LW; t += 256) {
+    const int r = t / LW, c = t - r * LW;
+    tile[t] = src[(long)symm(y0 - radius + r, H) * W + symm(x0 - radius + c, W)];
+  }
+  __syncthreads();
+  const double ki = -1.0 / (2.0 * std_i * std_i);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  double cen[4], acc[4] = {0.0, 0.0, 0.0, 0.0}, wsum[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int m = 0; m < 4; ++m) cen[m] = tile[(ty + 8 * m + radius) * LW + tx + radius];
+  for (int j = -radius; j <= radius; ++j)         // lib/utils.py:209-213: j (x offset) is the slow index of `combi`
+    for (int i = -radius; i <= radius; ++i) {
+      const double wsp = ws[(j + radius) * D + (i + radius)];
+      const double* tp = tile + (ty + radius + i) * LW + (tx + radius + j);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double nb = tp[8 * m * LW];
+        const double w = exp((nb - cen[m]) * (nb - cen[m]) * ki) * wsp;
+        acc[m] += nb * w; wsum[m] += w;
       }
-    out[t] = acc / wsum;
+    }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int y = y0 + ty + 8 * m, x = x0 + tx;
+    if (y < H && x < W) out[(long)y * W + x] = acc[m] / wsum[m];
   }
 }
 
@@ -83,17 +124,27 @@ hipError_t ics_launch_tv(const float* u, int M, int N, float eps, int order, int
   return hipGetLastError();
 }
 
+static hipError_t set_lds(const void* kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// one pass of the tiled convolution: out = conv2d_symm(src, kern) [USM epilogue against src0]
 hipError_t ics_launch_conv2d_symm(const double* src, int H, int W, const double* kern, int KH, int KW, double* out,
-                                  int usm, double amount, hipStream_t s) {
-  const long total = (long)H * W;
-  long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_conv2d_symm, dim3((unsigned)blocks), dim3(256), 0, s, src, H, W, kern, KH, KW, out, usm, amount);
+                                  const double* src0, int usm, double amount, hipStream_t s) {
+  const size_t lds = (size_t)(CT + KH - 1) * (CT + KW - 1) * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = set_lds(reinterpret_cast<const void*>(k_conv2d_tile), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_conv2d_tile, dim3((W + CT - 1) / CT, (H + CT - 1) / CT), dim3(256), lds, s, src, H, W, kern, KH, KW, out, src0, usm, amount);
   return hipGetLastError();
 }
 
-hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, double std_s, double* out, hipStream_t s) {
-  const long total = (long)H * W;
-  long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_bilateral, dim3((unsigned)blocks), dim3(256), 0, s, src, H, W, radius, std_i, std_s, out);
+hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, const double* ws, double* out, hipStream_t s) {
+  const size_t lds = (size_t)(CT + 2 * radius) * (CT + 2 * radius) * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = set_lds(reinterpret_cast<const void*>(k_bilateral_tile), lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_bilateral_tile, dim3((W + CT - 1) / CT, (H + CT - 1) / CT), dim3(256), lds, s, src, H, W, radius, std_i, ws, out);
   return hipGetLastError();
 }

@@ -102,9 +102,11 @@ hipError_t ics_launch_hasnan(const float* u, const IcsGeom& g, int* flag, hipStr
 
 // ---- standalone operators ----------------------------------------------------------------------
 hipError_t ics_launch_tv(const float* u, int M, int N, float eps, int order, int norm, float* out, float* div, hipStream_t s);
+// one LDS-tiled pass: out = conv2d_symm(src, kern); usm: out = src0 + (src0 - conv) * amount (lib/utils.py:275)
 hipError_t ics_launch_conv2d_symm(const double* src, int H, int W, const double* kern, int KH, int KW, double* out,
-                                  int usm, double amount, hipStream_t s);
-hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, double std_s, double* out, hipStream_t s);
+                                  const double* src0, int usm, double amount, hipStream_t s);
+// ws: (2 radius + 1)^2 spatial weights exp(-(i^2 + j^2) / (2 std_s^2)), j slow (the reference's offset order)
+hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, double std_i, const double* ws, double* out, hipStream_t s);
 
 // ---- bicubic resize between pyramid levels (ics_resize.hip; reference deconvolve.py:245-249) -------------
 size_t ics_resize_scratch_doubles(int H, int W, int C);

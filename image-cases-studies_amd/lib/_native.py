@@ -79,6 +79,7 @@ def load():
     lib.ics_ctx_destroy.argtypes = [vp]; lib.ics_ctx_destroy.restype = None
     lib.ics_ctx_synchronize.argtypes = [vp]
     lib.ics_ctx_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(ci), C.POINTER(C.c_uint64)]
+    lib.ics_ctx_last_kernel_ms.argtypes = [vp, C.POINTER(cf)]; lib.ics_ctx_last_kernel_ms.restype = ci
     lib.ics_rl_create.argtypes = [vp, ci, ci, ci, C.POINTER(vp)]
     lib.ics_rl_destroy.argtypes = [vp]; lib.ics_rl_destroy.restype = None
     lib.ics_rl_upload.argtypes = [vp, vp, vp, vp]
@@ -169,6 +170,12 @@ class Context:
 
     def synchronize(self):
         _check(load().ics_ctx_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        """device time of the kernels of the last blur / USM / bilateral call (transfers excluded)"""
+        ms = C.c_float(0)
+        _check(load().ics_ctx_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def close(self):
         """Destroys the stream (ics_ctx_destroy).  Jobs and images of this context must be closed first."""

@@ -61,6 +61,8 @@ int ics_device_count(int *count);
 int ics_ctx_create(int device, ics_ctx **out);
 void ics_ctx_destroy(ics_ctx *ctx);
 int ics_ctx_synchronize(ics_ctx *ctx);
+/* Device time in ms of the kernels of the last ics_conv2d_symm / ics_usm / ics_bilateral call (HIP events, transfers excluded). */
+int ics_ctx_last_kernel_ms(ics_ctx *ctx, float *ms);
 /* Device description: name (<=255 chars), compute units, HBM bytes. */
 int ics_ctx_info(ics_ctx *ctx, char *name, size_t name_len, int *compute_units, uint64_t *hbm_bytes);
 
@@ -209,7 +211,9 @@ int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
 int ics_normalize_kernel(ics_ctx *ctx, float *kern, int MK);
 /* lib/deconvolution.pyx:137-239 -- u: M*N*3 -> out, div (borders untouched = 0). */
 int ics_tv(ics_ctx *ctx, const float *u, int M, int N, float epsilon, int order, int norm, float *out, float *div);
-/* lib/utils.py:237-264 -- scipy.signal.convolve2d(src, kern, mode="same", boundary="symm"), float64. */
+/* lib/utils.py:237-264 -- scipy.signal.convolve2d(src, kern, mode="same", boundary="symm"), float64.  LDS-tiled; a rank-1
+ * kernel (every lib/utils.py window is one) runs as a row pass and a column pass.  The three filters keep their device
+ * scratch in the context between calls. */
 int ics_conv2d_symm(ics_ctx *ctx, const double *src, int H, int W, const double *kern, int KH, int KW, double *out);
 /* lib/utils.py:267-277 -- src + (src - conv2d_symm(src, kern)) * amount. */
 int ics_usm(ics_ctx *ctx, const double *src, int H, int W, const double *kern, int KH, int KW, double amount, double *out);
