@@ -106,6 +106,8 @@ struct IcsConvArgs {
   float step;
   int blind, want_dof;
   const void* bt;    // matrix-core path only: Toeplitz fragment table of this orientation (ics_conv_mfma.hip), else NULL
+  uint32_t* sched;   // matrix-core path: 9 zeroed words for the dynamic tile walk (8 per-band claim counters + 1 exit counter;
+                     // the last workgroup to leave zeroes them again), or NULL = static interleaved walk
   IcsGeom g;
 };
 // mode 0 = A1+A2 (valid convolution + residual), mode 1 = A3 (+A6/A7 reductions),

@@ -203,8 +203,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
   const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;            // workgroups walking this band
   const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  // Tile walk inside a band.  Static: workgroup kx takes tiles band0 + kx, + nx, ...  Dynamic (a.sched): the first tile is the
+  // static one, every further tile is claimed from the band's counter when the current one starts (early enough for the
+  // register prefetch) -- the back-projection's 65 x 65 tiles of a 4096^2 frame are 8.25 per workgroup and the edge tiles
+  // cost a quarter of an interior one: statically a quarter of the workgroups ran a ninth round while the rest idled.
   int tile = band0 + kx;
-  if (tile >= band1) return;
+  int* lds_next = reinterpret_cast<int*>(fscr + 8);   // two slots, by tile parity: a fast wave may claim for tile i + 1 before a slow one has read the claim of tile i
+  int parity = 0;
 
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
@@ -241,14 +246,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
   const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.out);
   f32x4u raw[C::NIT][3];
-  {
+  if (tile < band1) {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
 
   ICS_TICK_INIT;
+  int next_tile = 0;
 #pragma unroll 1
-  for (; tile < band1; tile += nx) {
+  for (; tile < band1; tile = next_tile) {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
     const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
 
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
       if (lane == 0) fscr[wv] = m;
+      if (a.sched && tid == 0) lds_next[parity] = band0 + nx + (int)atomicAdd(a.sched + xcd, 1u);   // visible behind the second barrier
       __syncthreads();
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
@@ -305,8 +312,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 
     // ---- request the next tile's rows: in flight during the whole matrix phase (the loop below issues no
     // vector-memory loads -- they return in order, a weight load behind this prefetch would wait for it) -----
-    if (tile + nx < band1) {
-      const int nt = tile + nx;
+    next_tile = a.sched ? __builtin_amdgcn_readfirstlane(lds_next[parity]) : tile + nx;
+    parity ^= 1;
+    if (next_tile < band1) {
+      const int nt = next_tile;
       const int nyi = nt / tpr, nxi = nt - nyi * tpr;
       load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + nxi * C::TW - C::PAD)), opaque(tid), pitch);
     }
@@ -533,6 +542,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   }
 
   ICS_TICK_FLUSH;
+  if (a.sched && tid == 0) {   // the last workgroup out re-arms the counters for the next launch
+    if (atomicAdd(a.sched + 8, 1u) == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) __hip_atomic_store(a.sched + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (MODE == 1) {
     // step-size reductions of all tiles of this workgroup: wave shuffle -> LDS -> one atomic per value
     uint32_t kg[3], ku[3];
