@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""HBM bytes per launch from the rocprofv3 PMC summaries (scripts/rocprof_summary.py output of a --pmc FETCH_SIZE run and of a
+--pmc WRITE_SIZE run of the same command): profiles/rNN_hbm_traffic.json, read by bench.py for `roofline.traffic`.
+Counters are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports half of a wide coalesced read -> x2
+(calibrated in round 1 on a 211.5 MB device copy: FETCH_SIZE 103 MB; WRITE_SIZE 206.5 MB -> x1)."""
+import json
+import re
+import sys
+
+KERNELS = {"k_conv_mfma<15, 0>": "synth_residual", "k_conv_mfma<15, 1>": "backproject", "k_update_rows<0>": "update",
+           "k_gradk_mfma<1>": "psf_gradient", "k_synth_gradk<15>": "synth_gradk"}
+ALGO = {"synth_residual": 36, "backproject": 48, "update": 60, "psf_gradient": 24, "synth_gradk": 60}   # bytes per pixel
+
+
+def counters(path, name):
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = next((v for k, v in KERNELS.items() if k in line), None) if "avg_us" not in line and len(line.split()) < 8 else None
+        elif cur and name in line:
+            m = re.search(r"mean ([0-9.e+]+)", line)
+            out[cur] = float(m.group(1))
+    return out
+
+
+def main():
+    fetch, write = counters(sys.argv[1], "FETCH_SIZE"), counters(sys.argv[2], "WRITE_SIZE")
+    px = 4096 * 4096
+    kern = {}
+    for k in fetch:
+        w = write.get(k, 0.0)
+        kern[k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": w, "hbm_bytes": int((2 * fetch[k] + w) * 1024), "algorithmic_bytes": ALGO[k] * px}
+        kern[k]["ratio"] = round(kern[k]["hbm_bytes"] / kern[k]["algorithmic_bytes"], 3)
+    out = {"_comment": __doc__.strip(), "workload": {"size": 4096, "psf": 15}, "kernels_matrix": kern}
+    if len(sys.argv) > 3:   # the two-kernel gradient path (ICS_FUSED_GRADK=0), fetch side only
+        f2 = counters(sys.argv[3], "FETCH_SIZE")
+        out["two_kernel_gradient_path_fetch_KiB"] = {k: f2[k] for k in ("synth_residual", "psf_gradient") if k in f2}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
