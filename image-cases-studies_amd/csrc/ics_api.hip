@@ -326,6 +326,10 @@ extern "C" int ics_rl_read(ics_rl* j, int which, float* host, size_t count) {
   } else if (which == ICS_BUF_SCALARS) {
     if (count != ICS_SC_COUNT) return fail(ICS_EINVAL, "scalars hold %d floats", ICS_SC_COUNT);
     HIPCHK(hipMemcpyAsync(host, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+  } else if (which == ICS_BUF_RED) {
+    if (count != ICS_RED_STRIDE) return fail(ICS_EINVAL, "the reduction slot holds %d words", ICS_RED_STRIDE);
+    HIPCHK(hipMemcpyAsync(host, j->red, 12 * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(host + 12, j->dofkeys, 4 * 4, hipMemcpyDeviceToHost, s));   // [12] min key, [13] max key, [14] NaN flag of the DoF mask
   } else {
     return fail(ICS_EINVAL, "unknown buffer %d", which);
   }
@@ -347,12 +351,30 @@ extern "C" int ics_rl_write(ics_rl* j, int which, const float* host, size_t coun
     if (count != n) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, n, count);
     HIPCHK(hipMemcpyAsync(which == ICS_BUF_PSF ? j->psf : j->gradk, host, n * 4, hipMemcpyHostToDevice, s));
     if (which == ICS_BUF_PSF) { int rc = pack_weights(j, 0, 0.f, 0, s); if (rc != ICS_OK) return rc; }
+  } else if (which == ICS_BUF_RED) {
+    if (count != ICS_RED_STRIDE) return fail(ICS_EINVAL, "the reduction slot holds %d words", ICS_RED_STRIDE);
+    HIPCHK(hipMemcpyAsync(j->red, host, ICS_RED_STRIDE * 4, hipMemcpyHostToDevice, s));
   } else {
     return fail(ICS_EINVAL, "buffer %d is not writable", which);
   }
   HIPCHK(hipStreamSynchronize(s));
   return ICS_OK;
 }
+
+static int rows_io(ics_rl* j, int which, int row0, int nrows, float* host, bool to_host) {
+  if (!j || !host) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  float* frame; int rows, cols, oy, ox;
+  if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) != 0) return fail(ICS_EINVAL, "buffer %d is not a frame", which);
+  if (row0 < 0 || nrows < 1 || row0 + nrows > rows) return fail(ICS_EINVAL, "rows [%d, %d) outside the %d rows of buffer %d", row0, row0 + nrows, rows, which);
+  float* dev = org(j, frame) + (ptrdiff_t)(oy + row0) * j->g.pitch + 3 * ox;
+  if (to_host) HIPCHK(hipMemcpy2DAsync(host, (size_t)cols * 12, dev, (size_t)j->g.pitch * 4, (size_t)cols * 12, nrows, hipMemcpyDeviceToHost, j->ctx->stream));
+  else HIPCHK(hipMemcpy2DAsync(dev, (size_t)j->g.pitch * 4, host, (size_t)cols * 12, (size_t)cols * 12, nrows, hipMemcpyHostToDevice, j->ctx->stream));
+  HIPCHK(hipStreamSynchronize(j->ctx->stream));
+  return ICS_OK;
+}
+extern "C" int ics_rl_read_rows(ics_rl* j, int which, int row0, int nrows, float* host) { return rows_io(j, which, row0, nrows, host, true); }
+extern "C" int ics_rl_write_rows(ics_rl* j, int which, int row0, int nrows, const float* host) { return rows_io(j, which, row0, nrows, const_cast<float*>(host), false); }
 
 // -------------------------------------------------------------------------------------------------
 // stop-test scratch: Gaussian window weights (pyx:393-404), twiddles, P x P x 3 complex buffer
@@ -729,6 +751,16 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       RC(do_conv(j, 2, p, 0, 1, pr));
       break;
     case ICS_STAGE_PSF_GRADIENT: RC(do_gradk(j, p, pr)); break;
+    case ICS_STAGE_BAND_REDUCE:
+      if (p->tv_mode != ICS_TV_SHIPPED) return fail(ICS_ENOSUP, "row bands are built for the shipped loop (tv_mode 0)");
+      if (p->band_row0 < 0 || p->band_row1 > j->g.uM || p->band_row0 >= p->band_row1) return fail(ICS_EINVAL, "band rows [%d, %d) outside the %d u rows", p->band_row0, p->band_row1, j->g.uM);
+      HIPCHK(hipMemsetAsync(j->red, 0, ICS_RED_STRIDE * sizeof(uint32_t), s));
+      HIPCHK(ics_launch_band_reduce(org(j, j->gr), org(j, j->u), org(j, ut_of(j)), j->g, p->lambd, p->band_row0, p->band_row1, j->red, s));
+      break;
+    case ICS_STAGE_BAND_MASK_E:
+      if (p->band_row0 < 0 || p->band_row1 > j->g.M || p->band_row0 > p->band_row1) return fail(ICS_EINVAL, "band rows [%d, %d) outside the %d image rows", p->band_row0, p->band_row1, j->g.M);
+      HIPCHK(ics_launch_band_mask_e(org(j, j->e), j->g, p->band_row0, p->band_row1, s));
+      break;
     case ICS_STAGE_SYNTH_GRADK:
       if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_GRADK is built for PSF sizes <= 15");
       RC(pack_weights(j, 0, 0.f, 0, s));

@@ -63,6 +63,10 @@ hipError_t ics_launch_synth_gradk(const IcsFusedArgs& a, int nblocks, hipStream_
 // gradk[a][b][c] = sum over workgroups (double accumulation, fixed order)
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s);
 
+// ---- row bands: see include/ics_hip.h ICS_STAGE_BAND_* ----------------------------------------------
+hipError_t ics_launch_band_reduce(const float* gr, const float* u, const float* ut, const IcsGeom& g, float lambd, int r0, int r1, uint32_t* red, hipStream_t s);
+hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hipStream_t s);
+
 // ---- A14-A17 (pyx:574-589) + weight packing ---------------------------------------------------
 struct IcsPsfArgs {
   float* psf;          // [K][K][3] local psf (pyx: the name `psf` inside the function)

@@ -686,7 +686,57 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
   }
 }
 
+// ---- row bands: the two global quantities of an inner iteration restricted to the rows a band owns -------
+// max |lambd*gradu + (u - ut)/2| and max u per channel (pyx:519,523-524, shipped regulariser) over u-frame rows [r0, r1)
+__global__ __launch_bounds__(256) void k_band_reduce(const float* __restrict__ gr, const float* __restrict__ u, const float* __restrict__ ut,
+                                                    IcsGeom G, float lambd, int r0, int r1, uint32_t* __restrict__ red) {
+  __shared__ uint32_t sh[4 * 8];
+  const int rowf = 3 * G.uN;
+  const long total = (long)(r1 - r0) * rowf;
+  uint32_t kg[3] = {0u, 0u, 0u}, ku[3] = {0u, 0u, 0u};
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int y = r0 + (int)(t / rowf), f = (int)(t - (long)(y - r0) * rowf), c = f % 3;
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + f;
+    const float uv = u[o];
+    const float g = __fadd_rn(__fmul_rn(lambd, gr[o]), __fmul_rn(__fsub_rn(uv, ut[o]), 0.5f));
+    const uint32_t k1 = key_of(__builtin_fabsf(g)), k2 = key_of(uv);
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) if (cc == c) { kg[cc] = kg[cc] > k1 ? kg[cc] : k1; ku[cc] = ku[cc] > k2 ? ku[cc] : k2; }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sh[wave * 8 + c] = kg[c]; sh[wave * 8 + 3 + c] = ku[c]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    uint32_t m = sh[threadIdx.x];
+    for (int w = 1; w < 4; ++w) m = m > sh[w * 8 + threadIdx.x] ? m : sh[w * 8 + threadIdx.x];
+    atomicMax(red + (threadIdx.x < 3 ? ICS_RED_MAXG + threadIdx.x : ICS_RED_MAXU + (threadIdx.x - 3)), m);
+  }
+}
+// residual rows outside image rows [i0, i1) := 0 (frame rows i + pad)
+__global__ __launch_bounds__(256) void k_band_mask_e(float* __restrict__ e, IcsGeom G, int i0, int i1) {
+  const int rowf = 3 * G.N;
+  const long total = (long)G.M * rowf;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int i = (int)(t / rowf), f = (int)(t - (long)i * rowf);
+    if (i < i0 || i >= i1) e[(ptrdiff_t)(i + G.pad) * G.pitch + 3 * G.pad + f] = 0.f;
+  }
+}
+
 }  // namespace
+
+hipError_t ics_launch_band_reduce(const float* gr, const float* u, const float* ut, const IcsGeom& g, float lambd, int r0, int r1, uint32_t* red, hipStream_t s) {
+  hipLaunchKernelGGL(k_band_reduce, dim3(1024), dim3(256), 0, s, gr, u, ut, g, lambd, r0, r1, red);
+  return hipGetLastError();
+}
+hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hipStream_t s) {
+  hipLaunchKernelGGL(k_band_mask_e, dim3(1024), dim3(256), 0, s, e, g, i0, i1);
+  return hipGetLastError();
+}
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
   if (a.kind == 1) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a);

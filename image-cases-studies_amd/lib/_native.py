@@ -23,9 +23,9 @@ KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
 
 # stages / buffers
-STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK = range(1, 11)
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK, STAGE_BAND_REDUCE, STAGE_BAND_MASK_E = range(1, 13)
 FLAG_NO_FUSED_GRADK = 1   # ics_rl_params.flags (include/ics_hip.h ICS_FLAG_*)
-BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV = range(9)
+BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV, BUF_RED = range(10)
 CONV_AUTO, CONV_VECTOR, CONV_MATRIX = range(3)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
                 "dof_min", "dof_max", "_")
@@ -35,7 +35,7 @@ class RLParams(C.Structure):
     _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
                 ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
                 ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
-                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("flags", C.c_int)]
+                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("flags", C.c_int), ("band_row0", C.c_int), ("band_row1", C.c_int)]
 
 
 class RLStats(C.Structure):
@@ -88,6 +88,8 @@ def load():
     lib.ics_rl_stage.argtypes = [vp, ci, C.POINTER(RLParams)]
     lib.ics_rl_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_write.argtypes = [vp, ci, vp, C.c_size_t]
+    lib.ics_rl_read_rows.argtypes = [vp, ci, ci, ci, vp]
+    lib.ics_rl_write_rows.argtypes = [vp, ci, ci, ci, vp]
     lib.ics_normalize_kernel.argtypes = [vp, vp, ci]
     lib.ics_tv.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp]
     lib.ics_conv2d_symm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
@@ -113,7 +115,7 @@ def load():
     lib.ics_group_allreduce_max.argtypes = [vp, vp, ci]
     lib.ics_group_allgather.argtypes = [vp, vp, ci, vp]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
-                 "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_normalize_kernel",
+                 "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_rl_read_rows", "ics_rl_write_rows", "ics_normalize_kernel",
                  "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
                  "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
                  "ics_rl_upload_img", "ics_rl_download_img", "ics_group_create", "ics_group_info", "ics_group_barrier",
@@ -331,7 +333,7 @@ class RLJob:
             return (self.M, self.N, 3)
         if which in (BUF_PSF, BUF_GRADK):
             return (self.MK, self.MK, 3)
-        return (16,)
+        return (16,)   # BUF_SCALARS, BUF_RED
 
     def upload(self, image, u, psf):
         image = np.ascontiguousarray(image, dtype=np.float32)
@@ -372,17 +374,37 @@ class RLJob:
         assert arr.shape == self._shape(which), (arr.shape, self._shape(which))
         _check(load().ics_rl_write(self._h, which, _ptr(arr), arr.size))
 
+    def read_rows(self, which, row0, nrows):
+        cols = self._shape(which)[1]
+        out = np.empty((int(nrows), cols, 3), np.float32)
+        _check(load().ics_rl_read_rows(self._h, which, int(row0), int(nrows), _ptr(out)))
+        return out
+
+    def write_rows(self, which, row0, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        assert arr.ndim == 3 and arr.shape[1:] == self._shape(which)[1:], (arr.shape, self._shape(which))
+        _check(load().ics_rl_write_rows(self._h, which, int(row0), arr.shape[0], _ptr(arr)))
+
+    def red_keys(self):
+        """reduction keys of the last stage call: [0..2] max|g_k|, [3..5] max u_k as order-preserving uint32 keys"""
+        return self.read(BUF_RED).view(np.uint32)
+
+    def set_red_keys(self, keys):
+        k = np.zeros(16, np.uint32); k[:len(keys)] = keys
+        _check(load().ics_rl_write(self._h, BUF_RED, _ptr(k.view(np.float32)), 16))
+
     def scalars(self):
         return dict(zip(SCALAR_NAMES, self.read(BUF_SCALARS).tolist()))
 
     @staticmethod
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
-               stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0, flags=0):
+               stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0, flags=0, band_rows=(0, 0)):
         p = RLParams()
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
         p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), int(tv_mode)
         p.stop_test, p.profile, p.fuse, p.conv, p.flags = int(stop_test), int(profile), int(fuse), int(conv), int(flags)
+        p.band_row0, p.band_row1 = int(band_rows[0]), int(band_rows[1])
         return p
 
     def run(self, params):

@@ -1,0 +1,189 @@
+"""One image over several GPUs: row-band sharding of `richardson_lucy_MM`.
+
+Not in the reference (a single-process Cython function, lib/deconvolution.pyx:341-675); this is the split SURVEY.md 8e
+describes for frames beyond one GPU's comfort.  The image rows [0, M) are cut into contiguous bands; band b lives in its
+own device job (its own GPU, or several bands on one GPU for testing) that holds its rows PLUS a halo of pad = MK // 2 image
+rows on either side, i.e. u rows [a, b + 2 pad) for extended image rows [a, b).  Every kernel of an inner iteration runs on
+the whole band job; only the rows the band OWNS come out exact, and three things cross bands per inner iteration:
+
+  1. step size (pyx:523-524): max |g_k| and max u_k over the owned rows only (ICS_STAGE_BAND_REDUCE), combined over the
+     bands as a max of 6 order-preserving keys and written back to every band before the update;
+  2. halo exchange: after the update (pyx:527-552) every band sends its first / last 2 pad owned u rows to its neighbours
+     (the back-projection of the next iteration reaches 2 pad rows beyond the owned ones);
+  3. blind: the PSF gradient (pyx:567-571) is summed over the owned rows only (ICS_STAGE_BAND_MASK_E zeroes the rest of the
+     residual first), the 3 MK^2 partial sums are added over the bands in float64, fixed order, and written back; the PSF
+     step (pyx:574-589) then runs identically on every band.
+
+The stop-test statistics (pyx:593-654) run on a small job of their own that receives the window's rows of the residual and of
+u from the bands that own them, once per outer iteration (the window may straddle bands).  Transfers go through the
+host (works across devices without peer access; a few hundred KB per inner iteration); band jobs run concurrently, one host
+thread per band (ctypes releases the GIL inside the C calls).  With the fp32 convolution kernels (`conv=1`) a non-blind
+banded run is bit-identical to the single-job run; the matrix-core kernels scale per tile, so results agree to ~1e-7.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import _native
+from .deconvolution import _check_buffer, _report
+
+INNER = 5   # pyx:375
+
+
+class _Band:
+    def __init__(self, index, y0, y1, M, pad, device):
+        self.index, self.y0, self.y1 = index, y0, y1                  # owned image rows [y0, y1)
+        self.a, self.b = max(0, y0 - pad), min(M, y1 + pad)           # extended image rows
+        self.first, self.last = y0 == 0, y1 == M
+        # owned u rows, global and job-local: image row i <-> u row i + pad; the first / last band also own the border ring
+        self.u0 = 0 if self.first else y0 + pad
+        self.u1 = M + 2 * pad if self.last else y1 + pad
+        self.lu0, self.lu1 = self.u0 - self.a, self.u1 - self.a
+        self.device = device
+        self.job = None
+
+
+def split_rows(M, bands, pad):
+    """[y0, y1) per band: contiguous, balanced; every band must be at least 2 pad rows high (halo exchange)."""
+    edges = [M * k // bands for k in range(bands + 1)]
+    out = [(edges[k], edges[k + 1]) for k in range(bands)]
+    if any(y1 - y0 < max(2 * pad, 1) for y0, y1 in out):
+        raise ValueError("%d rows over %d bands: a band must hold at least 2 * (MK // 2) = %d rows" % (M, bands, 2 * pad))
+    return out
+
+
+def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
+                              blind=True, correlation=False, p=1., norm=1, order=2, priority=0, refocus=0, *, bands=2, devices=None, conv=0):
+    """`richardson_lucy_MM` (same arguments, same in-place semantics, same printed lines) with the image split into `bands`
+    row bands; `devices` = one device index per band (default: band k on device k mod device_count)."""
+    _check_buffer("image", image); _check_buffer("u", u); _check_buffer("psf", psf)
+    M, N, MK = int(M), int(N), int(MK)
+    pad = MK // 2
+    if u.shape != (M + 2 * pad, N + 2 * pad, 3) or image.shape != (M, N, 3) or psf.shape != (MK, MK, 3):
+        raise ValueError("expected image (%d,%d,3), u (%d,%d,3), psf (%d,%d,3)" % (M, N, M + 2 * pad, N + 2 * pad, MK, MK))
+    ndev = max(1, _native.device_count())
+    devices = list(devices) if devices is not None else [k % ndev for k in range(bands)]
+    B = [_Band(k, y0, y1, M, pad, devices[k]) for k, (y0, y1) in enumerate(split_rows(M, bands, pad))]
+    if not (0 <= top < bottom <= M):
+        raise ValueError("stats window rows [%d, %d) outside the %d image rows" % (top, bottom, M))
+    image_c = np.ascontiguousarray(image, dtype=np.float32)
+    u_c = np.ascontiguousarray(u, dtype=np.float32)
+    psf_c = np.ascontiguousarray(psf, dtype=np.float32)
+    nv = _native
+    pool = ThreadPoolExecutor(max_workers=len(B))
+
+    def par(fn):
+        return list(pool.map(fn, B))
+
+    def setup(bd):
+        bd.job = nv.RLJob(bd.b - bd.a, N, MK, nv.Context.get(bd.device))
+        bd.job.upload(image_c[bd.a:bd.b], u_c[bd.a:bd.b + 2 * pad], psf_c)
+        bd.P = lambda **kw: bd.job.params(top - bd.a, bottom - bd.a, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C,
+                                          conv=conv, flags=nv.FLAG_NO_FUSED_GRADK, **kw)
+    par(setup)
+    # the statistics job: image rows [top, bottom) of the frame (u rows [top, bottom + 2 pad))
+    sj = nv.RLJob(bottom - top, N, MK, nv.Context.get(devices[0]))
+    sP = sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv)
+
+    def gather(which, g0, g1):
+        """global rows [g0, g1) of a frame buffer from the bands that own them (u-frame rows for BUF_U, image rows for BUF_ERROR)"""
+        parts = []
+        for bd in B:
+            o0, o1 = (bd.u0, bd.u1) if which == nv.BUF_U else (bd.y0, bd.y1)
+            lo, hi = max(g0, o0), min(g1, o1)
+            if lo < hi:
+                parts.append(bd.job.read_rows(which, lo - bd.a, hi - lo))
+        return np.concatenate(parts, axis=0)
+
+    def key2f(k):
+        k = np.uint32(k)
+        return (np.uint32(k & np.uint32(0x7FFFFFFF)) if k & np.uint32(0x80000000) else np.uint32(~k)).view(np.float32)
+
+    def statistics():
+        sj.write_rows(nv.BUF_ERROR, 0, gather(nv.BUF_ERROR, top, bottom))
+        sj.write_rows(nv.BUF_U, 0, gather(nv.BUF_U, top, bottom + 2 * pad))
+        sj.stage(nv.STAGE_STATS, sP)
+        out = sj.scalars()
+        # DoF extrema of the last update (printed diagnostics, pyx:593): over the rows of every band job, halos included
+        keys = np.stack(par(lambda bd: bd.job.red_keys()))
+        nan = bool(keys[:, 14].any())
+        out["dof_min"] = float("nan") if nan else float(key2f(keys[:, 12].min()))
+        out["dof_max"] = float("nan") if nan else float(key2f(keys[:, 13].max()))
+        return out
+
+    st = nv.RLStats()
+    sc = {"Hu": float("nan"), "varu": float("nan")}
+    it, stop = 0, 0
+    M_r = M_r_prev = 0.0
+    try:
+        while it < iterations and not stop:                                               # pyx:460
+            par(lambda bd: bd.job.stage(nv.STAGE_MAJORIZE, bd.P()))                       # pyx:462
+            for itt in range(INNER):                                                      # pyx:473
+                par(lambda bd: bd.job.stage(nv.STAGE_SYNTH_RESIDUAL, bd.P()))             # A1 + A2
+                par(lambda bd: bd.job.stage(nv.STAGE_BACKPROJECT, bd.P()))                # A3
+                par(lambda bd: bd.job.stage(nv.STAGE_BAND_REDUCE, bd.P(band_rows=(bd.lu0, bd.lu1))))
+                keys = np.max(np.stack(par(lambda bd: bd.job.red_keys())), axis=0)        # (1) max over the bands
+                par(lambda bd: bd.job.set_red_keys(keys))
+                par(lambda bd: bd.job.stage(nv.STAGE_UPDATE, bd.P()))                     # A5 - A10
+                # (2) halo exchange of the updated u: 2 pad owned rows each way
+                if len(B) > 1:
+                    up = par(lambda bd: None if bd.first else bd.job.read_rows(nv.BUF_U, bd.lu0, 2 * pad))
+                    dn = par(lambda bd: None if bd.last else bd.job.read_rows(nv.BUF_U, bd.lu1 - 2 * pad, 2 * pad))
+
+                    def put(bd):
+                        if not bd.first:
+                            bd.job.write_rows(nv.BUF_U, bd.lu0 - 2 * pad, dn[bd.index - 1])      # rows above my owned rows
+                        if not bd.last:
+                            bd.job.write_rows(nv.BUF_U, bd.lu1, up[bd.index + 1])                # rows below them
+                    par(put)
+                if blind:                                                                 # pyx:555
+                    par(lambda bd: bd.job.stage(nv.STAGE_SYNTH_RESIDUAL, bd.P()))         # A11
+                    if itt == INNER - 1:
+                        sc = statistics()                                                 # A18 + A19 need the unmasked residual
+                    par(lambda bd: bd.job.stage(nv.STAGE_BAND_MASK_E, bd.P(band_rows=(bd.y0 - bd.a, bd.y1 - bd.a))))
+                    par(lambda bd: bd.job.stage(nv.STAGE_PSF_GRADIENT, bd.P()))           # A12 + A13 over the owned rows
+                    gk = np.zeros((MK, MK, 3), np.float64)
+                    for g in par(lambda bd: bd.job.read(nv.BUF_GRADK)):                   # (3) fixed order
+                        gk += g
+                    gk32 = gk.astype(np.float32)
+                    par(lambda bd: bd.job.write(nv.BUF_GRADK, gk32))
+                    par(lambda bd: bd.job.stage(nv.STAGE_PSF_UPDATE, bd.P()))             # A14 - A17
+                elif itt == INNER - 1:
+                    sc = statistics()
+            if it > 0:
+                M_r_prev = M_r
+            M_r = sc["M_r"]
+            slot = min(it, nv.ICS_MAX_TRACE - 1)
+            st.trace_M_r[slot], st.trace_Hu[slot], st.trace_varu[slot] = sc["M_r"], sc["Hu"], sc["varu"]
+            st.trace_dof_min[slot], st.trace_dof_max[slot] = sc["dof_min"], sc["dof_max"]
+            st.trace_len = slot + 1
+            if it > 1:                                                                    # pyx:643-654
+                if blind:
+                    stop = int(M_r > M_r_prev)
+                else:
+                    stop = int((M_r - M_r_prev) / (M_r + M_r_prev) > tau)
+            it += 1
+        # gather: every band's owned rows -> the caller's u (in place, pyx:675), PSF of band 0
+        rows = par(lambda bd: bd.job.read_rows(nv.BUF_U, bd.lu0, bd.lu1 - bd.lu0))
+        for bd, r in zip(B, rows):
+            u[bd.u0:bd.u1] = r
+        if blind:
+            psf[...] = B[0].job.download_psf_caller()
+        st.iterations_done, st.stopped = it, stop
+        st.M_r, st.Hu, st.varu = M_r, sc["Hu"], sc["varu"]
+        st.has_nan = int(np.isnan(u).any())
+        st.inner_iterations = INNER * it
+    finally:
+        for bd in B:
+            if bd.job is not None:
+                bd.job.close()
+        sj.close()
+        pool.shutdown()
+    _report(st, top, bottom, left, right, lambd)
+    richardson_lucy_MM_banded.last = st
+    return u[pad:pad + M, pad:pad + N, ...]
+
+
+richardson_lucy_MM_banded.last = None

@@ -95,6 +95,9 @@ typedef struct ics_rl_params {
                                    the saved frame pass                            */
   int conv;                     /* ICS_CONV_*: which kernels run the convolutions A1/A3 and the PSF gradient A13    */
   int flags;                    /* ICS_FLAG_* bits, 0 = defaults                                                     */
+  int band_row0, band_row1;     /* ICS_STAGE_BAND_* only: the rows [row0, row1) this job OWNS when one image is split into
+                                   row bands over several jobs / GPUs; u-frame rows for BAND_REDUCE,
+                                   image rows for BAND_MASK_E.  Ignored everywhere else.                                */
 } ics_rl_params;
 
 #define ICS_FLAG_NO_FUSED_GRADK 1 /* blind, matrix-core path, MK <= 15: run A11 and A13 as two kernels (k_conv_mfma<K,0> +
@@ -179,6 +182,13 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 #define ICS_STAGE_UPDATE_SYNTH 8   /* ICS_STAGE_UPDATE fused with ICS_STAGE_SYNTH_RESIDUAL (one kernel) */
 #define ICS_STAGE_TVTERM 9         /* tv_mode 1: TV term T of u against ut (+ max|T_k|, max image_k)     */
 #define ICS_STAGE_SYNTH_GRADK 10   /* A11 + A13 in one kernel (MK <= 15): gradk, and the residual e' over the whole frame */
+/* One image over several jobs (row bands, lib/banded.py): a band job holds its rows plus a halo and computes everything on
+ * them; only its OWNED rows are exact.  These two stages restrict the two global quantities of an inner iteration to them: */
+#define ICS_STAGE_BAND_REDUCE 11   /* the step-size maxima of pyx:523-524 (max|g_k|, max u_k) over u-frame rows
+                                      [band_row0, band_row1) only, from the back-projection of ICS_STAGE_BACKPROJECT: replaces
+                                      the keys of ICS_BUF_RED; the caller combines them over the bands and writes them back */
+#define ICS_STAGE_BAND_MASK_E 12   /* residual rows outside image rows [band_row0, band_row1) := 0, so that the PSF gradient
+                                      of ICS_STAGE_PSF_GRADIENT sums the owned rows only (the caller adds the bands)       */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -191,8 +201,14 @@ int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 #define ICS_BUF_GRADK 6  /* MK x MK x 3  */
 #define ICS_BUF_TV 8      /* uM x uN x 3 : TV term T (tv_mode 1) */
 #define ICS_BUF_SCALARS 7 /* 16 floats: dt[3], maxu[3], maxg[3], dtpsf, M_r, Hu, varu, dof_min, dof_max, 0 */
+#define ICS_BUF_RED 9     /* 16 words (bit patterns in float slots): reduction keys of stage calls -- [0..2] max|g_k|,
+                             [3..5] max u_k as order-preserving uint32 keys (larger key = larger float; NaN = 0xFFC00000);
+                             read only: [12] min key, [13] max key, [14] NaN flag of the DoF mask of the last update (pyx:593) */
 int ics_rl_read(ics_rl *job, int which, float *host, size_t count);
 int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
+/* Rows [row0, row0 + nrows) of a frame buffer (ICS_BUF_U / UT / GRADU: uN*3 floats per row; IMAGE / ERROR: N*3). */
+int ics_rl_read_rows(ics_rl *job, int which, int row0, int nrows, float *host);
+int ics_rl_write_rows(ics_rl *job, int which, int row0, int nrows, const float *host);
 
 /* Kernel classes indexing ics_rl_stats.ms_kernel / launches. */
 #define ICS_K_SYNTH 0        /* A1+A2 convolution kernel        */
