@@ -52,6 +52,13 @@ __device__ unsigned long long ics_fused_ticks[17];
 #ifndef ICS_FUSED_PRIO
 #define ICS_FUSED_PRIO 0
 #endif
+#ifndef ICS_FUSED_F01
+#define ICS_FUSED_F01 1   /* image operand of channels 0 and 1 in one dwordx2 request (0: one dword request per channel) */
+#endif
+#ifndef ICS_FUSED_PERM
+#define ICS_FUSED_PERM 0   /* gradient: lane row -> tap permutation + matching class bases (stochastic bank search: 6 instead of 7 LDS cycles per
+                              A read): measured 0.2769 vs 0.2773 ms -- the bank conflicts of the A reads are not on the critical path; off */
+#endif
 #ifndef ICS_FUSED_ABLATE
 #define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand */
 #endif
@@ -72,7 +79,7 @@ template <int K>
 struct FRows {
   static constexpr int LROWS = 64 + K - 1, ROWB = 160;
   static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
-  static constexpr int want(int c) { return c == 0 ? 0 : (c == 1 ? 32 : (c == 2 ? 96 : 224)); }
+  static constexpr int want(int c) { return ICS_FUSED_PERM ? (c == 0 ? 0 : (c == 1 ? 128 : (c == 2 ? 96 : 224))) : (c == 0 ? 0 : (c == 1 ? 32 : (c == 2 ? 96 : 224))); }
   static constexpr int cls_off(int c) {
     if (c == 0) return 0;
     int off = cls_off(c - 1) + cls_rows(c - 1) * ROWB;
@@ -80,6 +87,14 @@ struct FRows {
     return off;
   }
 };
+
+// lane row (= row of the 16 x 16 result block) -> PSF tap row a.  Any permutation is valid -- the final write maps back; this one
+// came out of a stochastic search over permutations and class offsets (16 consecutive u rows = 4 rows of each y-mod-4 class):
+// 6 LDS cycles per ds_read_b128 on average over the four row phases (identity: 7; conflict-free would be 4)
+__host__ __device__ constexpr int ics_fused_tap(int lane_row) {
+  constexpr unsigned long long PERM = ICS_FUSED_PERM ? 0x4C51AF3E26B78D09ull : 0xFEDCBA9876543210ull;   // nibble i = tap of lane row i
+  return (int)((PERM >> (4 * lane_row)) & 15ull);
+}
 
 template <int K>
 struct FCfg {
@@ -223,7 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // further inside the class.
   uint32_t ga[4];
   {
-    const int ta = li < K ? li : K - 1;
+    const int tp = ics_fused_tap(li);
+    const int ta = tp < K ? tp : K - 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = j + 2 * C::PAD - ta;                        // >= 0
@@ -297,7 +313,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int voff = 4 * (16 * elg * pitch + 3 * eli);
     const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
 
-    uint32_t fop[4][4];   // image operand of the channel being convolved
+    // image operand: channels 0 and 1 arrive together (16 dwordx2 requests instead of 32 dword requests per lane: the TA
+    // processes a request per instruction, and 48 stride-12 dword requests per lane and tile cost 0.037 ms of the 0.29),
+    // channel 1 waits in 16 registers across gradk(0) and conv(1); channel 2 is requested on its own before conv(2)
+    uint32_t fop[4][4], fop1[4][4];
+    auto load_f01 = [&]() {
+      if (ICS_FUSED_ABLATE & 16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { fop[t][r] = 0u; fop1[t][r] = 0u; }
+        return;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_f, voff, sb + 4 * (t + 4 * r) * pitch, 0);
+          fop[t][r] = v.x; fop1[t][r] = v.y;
+        }
+    };
+    auto take_f1 = [&]() {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fop[t][r] = fop1[t][r];
+    };
     auto load_f = [&](int ch) {
       if (ICS_FUSED_ABLATE & 16) {
 #pragma unroll
@@ -544,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     convert_channel<C, 0>(raw, s_x, up, opaque(tid));
     lds_barrier();                                                     // planes of channel 0 visible
     FTICK(1);
-    load_f(0);
+    if (ICS_FUSED_F01) load_f01(); else load_f(0);
     conv_phase(std::integral_constant<int, 0>{});
     FTICK(2);
     float s_e, inv_e, me;
@@ -566,7 +607,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(6);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
     FTICK(7);
-    load_f(1);
+    if (ICS_FUSED_F01) take_f1(); else load_f(1);
     conv_phase(std::integral_constant<int, 1>{});
     FTICK(2);
 
@@ -616,7 +657,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int w = 1; w < C::NW; ++w) s += red[w * 256 + v];   // fixed order -> deterministic
       const int l = v & 63, r = (v >> 6) & 3;
-      const int ta = 4 * (l >> 4) + r, tb = l & 15;
+      const int ta = ics_fused_tap(4 * (l >> 4) + r), tb = l & 15;
       dst[(c * 16 + ta) * 16 + tb] = s;
     }
   }
