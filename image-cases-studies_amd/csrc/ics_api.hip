@@ -644,6 +644,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   float M_r = 0.f, M_r_prev = 0.f, Hu = 0.f, varu = 0.f, dmin = 0.f, dmax = 0.f;
   HIPCHK(hipMemsetAsync(j->flags, 0, 4 * sizeof(int), s));
   HIPCHK(hipMemsetAsync(j->sched, 0, 16 * sizeof(uint32_t), s));   // (the kernels re-arm them; an aborted launch must not leak a count)
+  HIPCHK(hipMemsetAsync(j->dacc, 0, 8 * sizeof(double), s));       // accumulators of the window statistics: likewise re-armed by their last kernel
+  HIPCHK(hipMemsetAsync(j->ukey, 0, 2 * sizeof(uint32_t), s));
   // the caller's psf array is the local psf when the call starts (pyx:341)
   HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf, (size_t)3 * j->g.K * j->g.K * 4, hipMemcpyDeviceToDevice, s));
   RC(pack_weights(j, 0, 0.f, 0, s));
@@ -769,6 +771,8 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
     case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;
     case ICS_STAGE_STATS:
+      HIPCHK(hipMemsetAsync(j->dacc, 0, 8 * sizeof(double), s));
+      HIPCHK(hipMemsetAsync(j->ukey, 0, 2 * sizeof(uint32_t), s));
       RC(ensure_window(j, p));
       RC(do_stats(j, p, pr));
       break;

@@ -73,31 +73,30 @@ __global__ __launch_bounds__(256) void k_mom1(IcsStatsArgs a) {
   s = block_sum(s, shd); s2 = block_sum(s2, shd); su = block_sum(su, shd);
   if (threadIdx.x == 0) { atomicAdd(a.dacc + 0, s); atomicAdd(a.dacc + 1, s2); atomicAdd(a.dacc + 2, su); }
 }
+// second pass: central moments, and max |e - mean| -- the maximum of |(e - mean) / std| the reference takes (pyx:628-629) is that
+// value divided by std (a division by a positive number is monotonic, so the arg-max element gives bit for bit the same quotient);
+// as a pass of its own behind this one it was one more 10-us launch per outer iteration
 __global__ __launch_bounds__(256) void k_mom2(IcsStatsArgs a) {
   __shared__ double shd[4];
+  __shared__ float shf[4];
   const Win w = make_win(a);
   const float mean_e = mean_of(a.dacc[0], w.ne), mean_u = w.nu ? mean_of(a.dacc[2], w.nu) : 0.f;
   double d2 = 0.0, du = 0.0;
-  const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-  for (int i = t0; i < w.ne; i += stride) { const float v = __fsub_rn(win_e(a, w, i), mean_e); d2 += (double)v * v; }
-  for (int i = t0; i < w.nu; i += stride) { const float v = __fsub_rn(win_u(a, w, i), mean_u); du += (double)v * v; }
-  d2 = block_sum(d2, shd); du = block_sum(du, shd);
-  if (threadIdx.x == 0) { atomicAdd(a.dacc + 3, d2); atomicAdd(a.dacc + 4, du); }
-}
-__global__ __launch_bounds__(256) void k_mom3(IcsStatsArgs a) {
-  __shared__ float shf[4];
-  const Win w = make_win(a);
-  const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
   float mx = 0.f;
   const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
   for (int i = t0; i < w.ne; i += stride) {
-    const float av = __builtin_fabsf(__fdiv_rn(__fsub_rn(win_e(a, w, i), mean_e), std_e));
+    const float v = __fsub_rn(win_e(a, w, i), mean_e); d2 += (double)v * v;
+    const float av = __builtin_fabsf(v);
     mx = (mx > av || mx != mx) ? mx : av;
   }
+  for (int i = t0; i < w.nu; i += stride) { const float v = __fsub_rn(win_u(a, w, i), mean_u); du += (double)v * v; }
+  d2 = block_sum(d2, shd); du = block_sum(du, shd);
   mx = block_maxf(mx, shf);
-  if (threadIdx.x == 0) atomicMax(a.ukey, (mx != mx) ? 0xFFC00000u : ics_f2key(mx));
+  if (threadIdx.x == 0) {
+    atomicAdd(a.dacc + 3, d2); atomicAdd(a.dacc + 4, du);
+    if (a.do_mr) atomicMax(a.ukey, (mx != mx) ? 0xFFC00000u : ics_f2key(mx));
+  }
 }
-
 // One P-point complex FFT per workgroup (P/2 threads), radix-2 Stockham autosort in LDS; element j of a line lives at
 // base + j * stride_elem; forward: exp(-i...), inverse: conjugate, unscaled.  The element-wise passes around the four
 // transforms are folded into the loads, and only the lines that matter are transformed:
@@ -125,7 +124,9 @@ __global__ void k_fftx(FftX f, IcsStatsArgs a) {
   if (LOAD == 1) {
     const IcsGeom& G = a.geo;
     const Win w = make_win(a);
-    const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne), mx = ics_key2f(a.ukey[0]);
+    const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
+    const float mxk = ics_key2f(a.ukey[0]);                       // max |e - mean| (k_mom2), NaN key kept
+    const float mx = (a.ukey[0] == 0xFFC00000u) ? mxk : __fdiv_rn(mxk, std_e);   // = max |(e - mean) / std|
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = tid + h * t;
@@ -163,6 +164,8 @@ __global__ void k_fftx(FftX f, IcsStatsArgs a) {
   base[(long)(tid + t) * f.stride_elem] = x[tid + t];
 }
 
+__device__ void stats_final(const IcsStatsArgs& a);
+
 // sum over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
 __global__ __launch_bounds__(256) void k_mr(IcsStatsArgs a) {
   __shared__ double shd[4];
@@ -177,21 +180,32 @@ __global__ __launch_bounds__(256) void k_mr(IcsStatsArgs a) {
     s += (double)__fmul_rn(__fmul_rn(ac, ac), a.weights[r * W + b]);
   }
   s = block_sum(s, shd);
-  if (threadIdx.x == 0) atomicAdd(a.dacc + 5, s);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.dacc + 5, s);
+    // the last workgroup out writes the scalars of the outer iteration (one launch less): its own sum is in, and so are all
+    // the others' -- every workgroup adds before it takes a ticket (device-scope atomics on the same L2-resident words)
+    __threadfence();
+    if (atomicAdd(a.ukey + 1, 1u) == gridDim.x - 1) { __threadfence(); stats_final(a); }
+  }
 }
 
-// scalars of the outer iteration (pyx:593-638) from the accumulators
-__global__ void k_stats_final(IcsStatsArgs a) {
+// scalars of the outer iteration (pyx:593-638) from the accumulators; re-arms the accumulators for the next call
+__device__ void stats_final(const IcsStatsArgs& a) {
   const Win w = make_win(a);
-  a.scal[ICS_SC_HU] = (float)(a.dacc[1] / ((double)w.H * w.W * 3));
+  volatile double* dacc = a.dacc;
+  a.scal[ICS_SC_HU] = (float)(dacc[1] / ((double)w.H * w.W * 3));
   float varu = __builtin_nanf("");
-  if (w.nu > 0) { const float sd = std_of(a.dacc[4], w.nu); varu = __fmul_rn(sd, sd); }
+  if (w.nu > 0) { const float sd = std_of(dacc[4], w.nu); varu = __fmul_rn(sd, sd); }
   a.scal[ICS_SC_VARU] = varu;
   const bool no_dof = a.dofkeys[0] == 0xFFFFFFFFu && a.dofkeys[1] == 0u;   // modes without a DoF blend (PAM)
   a.scal[ICS_SC_DOFMIN] = a.dofkeys[2] ? __builtin_nanf("") : (no_dof ? 0.f : ics_key2f(a.dofkeys[0]));
   a.scal[ICS_SC_DOFMAX] = a.dofkeys[2] ? __builtin_nanf("") : (no_dof ? 0.f : ics_key2f(a.dofkeys[1]));
-  if (a.do_mr) a.scal[ICS_SC_MR] = (float)(a.dacc[5] / w.ne);
+  if (a.do_mr) a.scal[ICS_SC_MR] = (float)(dacc[5] / w.ne);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dacc[i] = 0.0;
+  a.ukey[0] = 0u; a.ukey[1] = 0u;
 }
+__global__ void k_stats_final(IcsStatsArgs a) { stats_final(a); }
 
 __global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* flag) {
   const int ngx = G.tiles_x * 16;
@@ -210,16 +224,12 @@ __global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* 
 }  // namespace
 
 hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(a.dacc, 0, 8 * sizeof(double), s);
-  if (e != hipSuccess) return e;
-  e = hipMemsetAsync(a.ukey, 0, 2 * sizeof(uint32_t), s);
-  if (e != hipSuccess) return e;
+  // (dacc / ukey are zero: at job creation, and re-armed by the previous call's last kernel)
   const int ne = (a.bottom - a.top) * (a.right - a.left) * 3;
   int gb = (ne + 256 * 8 - 1) / (256 * 8); if (gb < 1) gb = 1; if (gb > 512) gb = 512;
   hipLaunchKernelGGL(k_mom1, dim3(gb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_mom2, dim3(gb), dim3(256), 0, s, a);
   if (a.do_mr) {
-    hipLaunchKernelGGL(k_mom3, dim3(gb), dim3(256), 0, s, a);
     const int P = a.P;
     const size_t lds = 2 * (size_t)P * sizeof(float2);
     const long plane = (long)P * P;
@@ -234,9 +244,10 @@ hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
     // inverse rows: k_mr reads rows (r - H/2) mod P, r < H:  0 .. H - H/2 - 1  and  P - H/2 .. P - 1
     f.stride_elem = 1; f.line_stride = P; f.lines_per_plane = H; f.n0 = H - H / 2; f.skip = P - H;
     hipLaunchKernelGGL(k_fftx<0>, dim3(3 * H), dim3(P / 2), lds, s, f, a);
-    hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);   // its last workgroup writes the scalars
+  } else {
+    hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);
   }
-  hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);
   return hipGetLastError();
 }
 
