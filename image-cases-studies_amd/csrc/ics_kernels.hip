@@ -750,7 +750,11 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   long blocks = (total + 255) / 256;
   // Few long-lived workgroups stream best here.  k_update_rows at 4096^2 (4 reads + 1 write, 1.0 GB), segments per loop
   // iteration x workgroups per CU: 3x2 0.173 ms, 4x2 0.167, 4x3 0.164, 4x4 0.170, 6x2 0.164, 6x4 0.180 (scripts/sweep_update.sh).
-  static const int per_cu = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 3;
+  // ... and at smaller frames fewer still: 2048^2 0.0568 / 0.0526 / 0.0565 ms and 3072^2 0.119 / 0.099 / 0.102 ms with 1 / 2 / 3 per CU,
+  // 1024^2 0.0252 / 0.0265 / 0.0299
+  const long px = (long)a.geo.uM * a.geo.uN;
+  static const int per_cu_env = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 0;
+  const int per_cu = per_cu_env > 0 ? per_cu_env : (px >= 12000000L ? 3 : (px >= 1500000L ? 2 : 1));
   static int cus[64] = {};   // per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
