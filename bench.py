@@ -327,7 +327,7 @@ def main():
             oc["configs[3] blind 6144^2 31x31 (shipped loop)"] = timed_run(ctx, 6144, 31, True, 0, conv, 25, 5)
             oc["configs[3] blind 6144^2 31x31 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 6144, 31, True, 3, conv, 25, 5)
             out["other_configs"] = oc
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and grp.size == 1:   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args.mode, MK, M)
         print(json.dumps(out))
     grp.close()

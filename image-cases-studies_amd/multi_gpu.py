@@ -50,15 +50,24 @@ class Group:
             lib = _native.load()
             dev = int(os.environ.get("ICS_DEVICE", self.local_rank)) if device is None else int(device)
             h = C.c_void_p()
-            _native._check(lib.ics_group_create(dev, self.rank, self.size, rendezvous_path().encode(), 180, C.byref(h)))
-            self._h, self._lib, self._check = h, lib, _native._check
-        elif backend == "gloo":
+            rc = lib.ics_group_create(dev, self.rank, self.size, rendezvous_path().encode(), 180, C.byref(h))
+            if rc == 0:
+                self._h, self._lib, self._check = h, lib, _native._check
+            elif os.environ.get("ICS_DIST_FALLBACK", "1") != "0" and os.environ.get("MASTER_ADDR"):
+                # communicator creation is collective and fails on every rank alike (e.g. two ranks on one device): carry on with the
+                # CPU group rather than lose the run; the record it gathers is 4 doubles per rank
+                import sys
+                sys.stderr.write("multi_gpu: RCCL group failed on rank %d (%s); falling back to gloo\n" % (self.rank, lib.ics_last_error().decode("utf-8", "replace")))
+                backend = self.backend = "gloo (RCCL init failed)"
+            else:
+                _native._check(rc)
+        if backend.startswith("gloo"):
             import torch
             import torch.distributed as dist
             if not dist.is_initialized():
                 dist.init_process_group(backend="gloo")
             self.dist, self.torch = dist, torch
-        else:
+        elif backend != "rccl":
             raise ValueError("unknown backend %r (rccl, gloo)" % backend)
 
     def barrier(self):
