@@ -16,16 +16,17 @@
 // that two workgroups still fit a CU:
 //   * the fp32 HWC rows of the tile stay in registers (84 VGPRs) until the third channel is converted; the next tile's rows
 //     are requested right after that and are in flight during the last two matrix phases;
-//   * LDS (77 KB): two buffers of (hi, lo) u planes for one channel (rows grouped by y mod 4 as in ics_conv_mfma.hip), the e'
+//   * LDS (77 KB at K = 15): two buffers of (hi, lo) u planes for one channel (rows grouped by y mod 4 as in ics_conv_mfma.hip), the e'
 //     planes of one channel (64 rows x 80 halves, hi/lo interleaved dword by dword, zero columns left and right so that the
 //     sliding windows of the tile's border need no neighbour), the convolution weights;
 //   * per channel c:  conv(c) -> e'(c) in registers -> [barrier: tile maximum of |e'|] -> e'(c) planes, u planes of c+1 ->
 //     [barrier] -> gradk(c), conv(c+1) ...: two barriers per channel, and a wave runs gradk(c) and conv(c+1) back to back so
 //     the four waves drift apart and overlap their LDS-heavy (gradient) and matrix-heavy (convolution) phases;
-//   * gradient step = one residual row y, one channel, three 32-column chunks of the 80 staged u columns:
+//   * gradient step = one residual row y, one channel, the 80 staged u columns as two 32-column chunks (K = 32 MFMA) and one
+//     16-column chunk (K = 16 MFMA):
 //         D[a][b] += sum_k A[a][k] B[k][b],   A[a][k] = u[y + 2 pad - a][32 X + k],   B[k][b] = e'[y][32 X + k - 2 pad + b]
-//     A = 16 lane rows of the u planes (ds_read_b128), B = sliding window of the e' row (five dword pairs + v_alignbit, as in
-//     ics_gradk_mfma.hip), three MFMAs (hi*hi, hi*lo, lo*hi) per chunk; wave w owns rows 16w..16w+15.
+//     A = 16 lane rows of the u planes (ds_read_b128 / b64), B = sliding window of the e' row (five / three dword pairs +
+//     v_alignbit, as in ics_gradk_mfma.hip), three MFMAs (hi*hi, hi*lo, lo*hi) per chunk; wave w owns rows 16w..16w+15.
 //   * accumulators are folded into fp32 totals per tile and channel with the exact inverse scales; one partial block per
 //     workgroup, reduced in double by k_gradk_reduce (ics_kernels.hip), deterministic.
 #include "ics_kernels.h"
