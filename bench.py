@@ -222,7 +222,7 @@ def main():
     if conv == 0 and os.environ.get("ICS_CONV_PATH", "")[:1] == "v":
         conv = 1
     # which convolution kernels the run resolves to (include/ics_hip.h ICS_CONV_*, csrc ics_conv_mfma_preferred)
-    matrix = (conv == 2 and MK <= 37) or (conv == 0 and (MK <= 17 or 23 <= MK <= 37))
+    matrix = conv in (0, 2) and MK <= 37
 
     ndev = _native.device_count()
     dev = int(os.environ.get("ICS_DEVICE", grp.local_rank))

@@ -25,7 +25,8 @@
 // sets t = q - a = 0..3 IN PLACE, i.e. one LDS fragment read serves up to 4 kernel rows x 3 split terms =
 // 12 MFMAs (a row-contiguous fragment would serve 3 and the kernel would be LDS-bound).
 //
-// Kernel shape: persistent 4-wave workgroups, two per CU, walking 64x64-pixel tiles.
+// Kernel shape: persistent 4-wave workgroups walking 64x64-pixel tiles, two per CU -- or, with fragment rows 2 apart (two
+// accumulator sets per wave instead of four), 32x64 tiles, three per CU: launch_k() below picks per PSF size and frame.
 //   * LDS (75 KB): the tile + halo as six fp16 planes (channel x hi/lo), rows grouped by y mod 4 so that the
 //     16 lane rows of a fragment are consecutive 160-B LDS rows (conflict-free for the b128 lane groups of
 //     gfx950, MI355X_MICROARCH.md LDS).  Two workgroups per CU: one's memory phases (conversion, epilogue)
@@ -67,6 +68,9 @@
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
 #endif
+#ifndef ICS_MFMA_ALL_RS
+#define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
+#endif
 #ifndef ICS_MFMA_ABLATE
 #define ICS_MFMA_ABLATE 0  /* tools/bench_conv_mfma.hip: 1 = no MFMA loop, 2 = no conversion, 4 = no epilogue */
 #endif
@@ -100,14 +104,19 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u3 __attribute__((ext_vector_type(3)));
 
-template <int K>
+// RS = row stride of a fragment = accumulator sets per wave and channel: a tile is 16 * RS rows high.
+//   RS = 4 (64 x 64 tiles, two workgroups per CU up to K = 15): one A-fragment read feeds 12 MFMAs per window.
+//   RS = 2 (32 x 64 tiles): half the planes, a third of the registers less -- three workgroups per CU up to K = 17 and two
+//   instead of one at K = 19, 21; twice the LDS reads per MFMA and 9 % more staged bytes.  launch_k() picks (measured).
+template <int K, int RS_>
 struct MCfg {
   static constexpr int PAD = K / 2;
-  static constexpr int TH = 64, TW = 64, NCB = TW / 16;
+  static constexpr int RS = RS_;
+  static constexpr int TH = 16 * RS, TW = 64, NCB = TW / 16;
   static constexpr int NW = 4, NT = 64 * NW;
   static constexpr int LROWS = TH + K - 1;       // input rows of the tile
   // LDS rows are grouped by (y mod 4): class c holds rows c, c+4, ... contiguously, classes back to back
-  static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
+  static constexpr int cls_rows(int c) { return (LROWS - c + RS - 1) / RS; }
   static constexpr int cls_base(int c) { return c == 0 ? 0 : cls_base(c - 1) + cls_rows(c - 1); }
   // 16 output columns need 16 + K - 1 input columns: one 32-wide MFMA window (NCH = 1, K <= 17) or two (K <= 49)
   static constexpr int NCH = (16 + K - 1 <= 32) ? 1 : 2;
@@ -123,8 +132,9 @@ struct MCfg {
   static constexpr int WZERO = (K + 7) / 2;      // first all-zero dword of a row
   static constexpr int WLDS = 3 * K * 2 * WROWB; // = the global weight table built by k_psf (ics_common.h), copied verbatim
   static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
-  static constexpr int WGS = (2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;   // workgroups (of 4 waves) per CU
-  static constexpr int NQ = K + 3;               // fragments per (channel, column block)
+  static constexpr int WGS_CAP = RS == 4 ? 2 : 3;                      // register budget: 256 / 168 VGPRs
+  static constexpr int WGS = (160 * 1024 / LDS_BYTES) < WGS_CAP ? (160 * 1024 / LDS_BYTES) : WGS_CAP;   // workgroups (of 4 waves) per CU
+  static constexpr int NQ = K + RS - 1;          // fragments per (channel, column block)
   static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
   static constexpr int NTASK = LROWS * XG;
   static constexpr int NIT = (NTASK + NT - 1) / NT;
@@ -180,9 +190,9 @@ __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer
 // vmcnt, i.e. on the whole prefetch in flight)
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
-template <int K, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WGS, MCfg<K>::WGS))) void k_conv_mfma(IcsConvArgs a) {
-  using C = MCfg<K>;
+template <int K, int MODE, int RS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>::WGS, MCfg<K, RS>::WGS))) void k_conv_mfma(IcsConvArgs a) {
+  using C = MCfg<K, RS>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* fscr = reinterpret_cast<float*>(lds + C::SCRATCH);
   const int tid = threadIdx.x;
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   // (8.25 per workgroup = 9 rounds, the last column and row nearly empty) of the u-frame grid.
   constexpr int TORG = MODE == 0 ? C::PAD : 0;
   const int tpr = MODE == 0 ? (a.g.N + C::TW - 1) / C::TW : a.g.tiles_x;   // tiles per row
-  const int ntiles = tpr * (MODE == 0 ? (a.g.M + C::TH - 1) / C::TH : a.g.tiles_y);
+  const int ntiles = tpr * (MODE == 0 ? (a.g.M + C::TH - 1) / C::TH : (a.g.uM + C::TH - 1) / C::TH);
   const int xend = MODE == 0 ? C::PAD + a.g.N : a.g.uN;                    // first column without output
   const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;         // bands (= XCDs when the grid covers them all)
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
@@ -283,8 +293,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         const int t = tidc + k * C::NT;
         if (t < C::NTASK && !((ICS_MFMA_ABLATE & 2) && k > 0)) {
           const int row = t / C::XG, xg = t - row * C::XG;
-          const int rc = row & 3;
-          const int crow = (rc == 0 ? 0 : (rc == 1 ? C::cls_base(1) : (rc == 2 ? C::cls_base(2) : C::cls_base(3)))) + (row >> 2);
+          const int rc = row % C::RS;
+          const int crow = (rc == 0 ? 0 : (rc == 1 ? C::cls_base(1) : (rc == 2 ? C::cls_base(2) : C::cls_base(3)))) + row / C::RS;
           unsigned char* dst = lds + crow * C::ROWB + 8 * xg;
           float f[12];
 #pragma unroll
@@ -327,11 +337,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
     //  threshold for this file; with the default threshold the loop stayed rolled, the B fragments went to scratch and
     //  the kernel was 5x slower: 3.3 vs 0.51 ms at 4096^2 / 31x31.)
     constexpr bool INTERLEAVE = ICS_MFMA_INTERLEAVE != 0;
-    f4 acc[3][4];
+    f4 acc[3][C::RS];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[ch][t] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < C::RS; ++t) acc[ch][t] = (f4){0.f, 0.f, 0.f, 0.f};
     if (x0 + 16 * wv < xend) {   // wave-uniform: a column block right of the output carries none
 #pragma unroll
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 #pragma unroll
           for (int h = 0; h < C::NCH; ++h) { Nh[h] = Ah[h]; Nl[h] = Al[h]; }
           if (q + 1 < C::NQ) {
-            const int off = (C::cls_base((q + 1) & 3) + ((q + 1) >> 2)) * C::ROWB;
+            const int off = (C::cls_base((q + 1) % C::RS) + (q + 1) / C::RS) * C::ROWB;
             if (!(ICS_MFMA_ABLATE & 16)) {   // 16: timing probe without the A-fragment reads
 #pragma unroll
               for (int h = 0; h < C::NCH; ++h) {
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
 #pragma unroll
             for (int h = 0; h < C::NCH; ++h) {
 #pragma unroll
-              for (int t = 0; t < 4; ++t) {
+              for (int t = 0; t < C::RS; ++t) {
                 const int ka = q - t;
                 if (ka < 0 || ka >= K) continue;
                 const h8 av = term == 2 ? Al[h] : Ah[h];
@@ -420,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
           if (INTERLEAVE) {
             int nt = 0;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
+            for (int t = 0; t < C::RS; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
             const int nm = 3 * C::NCH * nt;                                             // MFMAs of this step
             const int nr = ((q + 1 < C::NQ) ? 2 * C::NCH : 0) + ((q + 1 < K) ? 5 * C::NCH : 0);   // LDS reads
             const int nv = (q + 1 < K) ? 8 * C::NCH : 0;                                // funnel shifts
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       const int tide = opaque(tid);
       const int eli = tide & 15, elg = (tide >> 4) & 3;
       const int colx = x0 + 16 * wv + eli;
-      const int voff = 4 * (16 * elg * pitch + 3 * eli);          // lane part of the byte offset
+      const int voff = 4 * (4 * C::RS * elg * pitch + 3 * eli);   // lane part of the byte offset
       const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));      // wave-uniform part (tile origin + column block)
       constexpr int EOPS = (MODE == 0) ? 1 : 2;
       // TB = accumulator sets per batch: the operands of a batch are requested together.  (Measured without gain, and removed:
@@ -462,16 +472,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       // cost the back-projection +40 %)
       const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
       auto run_epi = [&](auto tbc, auto tvc) {
-      constexpr int TB = decltype(tbc)::value;
+      constexpr int TB = decltype(tbc)::value < C::RS ? decltype(tbc)::value : C::RS;
       constexpr bool TVOP = decltype(tvc)::value;
 #pragma unroll
-      for (int t0 = 0; t0 < 4; t0 += TB) {
-      u3 eop[EOPS][4][4], eopT[4][4];
+      for (int t0 = 0; t0 < C::RS; t0 += TB) {
+      u3 eop[EOPS][C::RS][4], eopT[C::RS][4];
 #pragma unroll
       for (int t = t0; t < t0 + TB; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int so = sb + 4 * (t + 4 * r) * pitch;
+          const int so = sb + 4 * (t + C::RS * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
           if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
@@ -482,13 +492,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
         // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
         // shadow of their latency (u and ut only feed the step-size reductions)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < C::RS; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int y = y0 + t + 16 * elg + 4 * r;
+            const int y = y0 + t + 4 * C::RS * elg + C::RS * r;
             if (y < a.g.uM && colx < a.g.uN && !(ICS_MFMA_ABLATE & 8)) {
               const u3 e = {__float_as_uint(acc[0][t][r] * sc), __float_as_uint(acc[1][t][r] * sc), __float_as_uint(acc[2][t][r] * sc)};
-              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, sb + 4 * (t + 4 * r) * pitch, ICS_EPI_STORE_AUX);
+              __builtin_amdgcn_raw_buffer_store_b96(e, rs_o, voff, sb + 4 * (t + C::RS * r) * pitch, ICS_EPI_STORE_AUX);
             }
           }
       }
@@ -496,8 +506,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
       for (int t = t0; t < t0 + TB; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int y = y0 + t + 16 * elg + 4 * r;
-          const int so = sb + 4 * (t + 4 * r) * pitch;
+          const int y = y0 + t + 4 * C::RS * elg + C::RS * r;
+          const int so = sb + 4 * (t + C::RS * r) * pitch;
           float av[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) av[c] = acc[c][t][r] * sc;
@@ -573,14 +583,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K>::WG
   }
 }
 
-template <int K, int MODE>
+template <int K, int MODE, int RS>
 hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
-  using C = MCfg<K>;
+  using C = MCfg<K, RS>;
   static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  auto kern = k_conv_mfma<K, MODE>;
+  auto kern = k_conv_mfma<K, MODE, RS>;
   if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }
@@ -591,7 +601,7 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
     cus[dev] = n;
   }
-  const int ntiles = MODE == 0 ? ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH) : a.g.tiles_x * a.g.tiles_y;
+  const int ntiles = MODE == 0 ? ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH) : a.g.tiles_x * ((a.g.uM + C::TH - 1) / C::TH);
   int grid = C::WGS * cus[dev];              // persistent workgroups: as many as fit the LDS of a CU
 #ifdef ICS_GRID_WGS
   grid = ICS_GRID_WGS * cus[dev];
@@ -604,9 +614,26 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Tile height per PSF size and frame, measured on MI355X (tools/bench_conv_mfma.hip, ms for mode 0 / mode 1, RS = 4 -> RS = 2):
+//   4096^2: K = 9 0.139 / 0.183 -> 0.145 / 0.187, K = 13 level, K = 15 0.169 / 0.218 -> 0.167 / 0.207, K = 17 0.218 / 0.267 ->
+//   0.184 / 0.218, K = 19 0.347 / 0.405 -> 0.325 / 0.364, K = 21 -5 % / -9 %, K = 23 .. 31 +10 .. 14 % (one workgroup per CU
+//   either way, and the A-fragment reads then bound the step); 1024^2 .. 3072^2, K <= 15: RS = 2 ahead by 3 .. 30 % (finer
+//   tiles balance the 256 CUs better).  Hence: K >= 23 -> 4; K = 15 .. 21 -> 2; K <= 13 -> 2 up to 3000 tiles of 64 x 64, else 4.
+template <int K> struct TileRs {
+  static constexpr bool has2 = ICS_MFMA_ALL_RS || K <= 21;
+  static constexpr bool has4 = ICS_MFMA_ALL_RS || K <= 13 || K >= 23;
+};
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
-  return mode == 0 ? launch_one<K, 0>(a, s) : launch_one<K, 1>(a, s);
+  bool rs2 = K <= 21 && (K >= 15 || (long)a.g.tiles_x * a.g.tiles_y <= 3000);
+  if (TileRs<K>::has2 && TileRs<K>::has4) {   // test / harness hook: force a tile height where both are built
+    if (const char* e = getenv("ICS_TEST_CONV_RS")) rs2 = atoi(e) == 2 ? true : (atoi(e) == 4 ? false : rs2);
+  }
+  if constexpr (TileRs<K>::has2) {
+    if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2>(a, s) : launch_one<K, 1, 2>(a, s);
+  }
+  if constexpr (TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 4>(a, s) : launch_one<K, 1, 4>(a, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
@@ -652,9 +679,9 @@ hipError_t ics_launch_conv_mfma_part2(int mode, const IcsConvArgs& a, hipStream_
 #if ICS_MFMA_PART == 0
 bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   // K = 39: planes + weights exceed 160 KB
 
-// Measured on MI355X at 4096^2: with two 32-wide windows per column block (K >= 19) only K/64 of the MACs
-// are useful and the 126 KB of planes leave room for one workgroup per CU; the packed-fp32 kernels are level at K = 19, 21.
-bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K) && K != 19 && K != 21; }
+// Measured on MI355X at 4096^2: ahead of the packed-fp32 kernels at every size built (K = 19, 21 were level with
+// 64-row tiles -- two 32-wide windows per column block, one workgroup per CU -- and are ~8 % ahead with 32-row tiles).
+bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K); }
 
 // weight table: [c][a] rows of 2 * WROWB bytes, hi/lo dword-interleaved (the LDS image), then one float 1/s_w (ics_common.h)
 size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * (((2 * (K + 17) + 3) & ~3) / 4) + 4; }

@@ -59,6 +59,41 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
     job.close()
 
 
+@pytest.mark.parametrize("MK", [3, 9, 13])
+@pytest.mark.parametrize("rs", ["2", "4"])
+def test_matrix_core_convolution_both_tile_heights(MK, rs, monkeypatch):
+    """ics_conv_mfma.hip builds 64-row and 32-row tiles for K <= 13 and picks by frame size (32-row up to 3000 tiles of
+    64 x 64): ICS_TEST_CONV_RS forces either, on a frame several tiles high and wide with ragged edges."""
+    from lib import _native as nv
+    monkeypatch.setenv("ICS_TEST_CONV_RS", rs)
+    M, N = 203, 277
+    job, case, psf = make_job(M, N, MK, seed=MK + 40)
+    rng = np.random.default_rng(9)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False, conv=2)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    full = conv_valid64(u, psf)
+    assert np.max(np.abs(e - (full - case["image"]))) / np.max(np.abs(full)) < CONV_TOL
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    assert rel_err(job.read(nv.BUF_GRADU), corr_full64(e.astype(np.float64), psf)) < CONV_TOL
+    red = job.red_keys()
+    job.close()
+    # the step-size reductions of the back-projection do not depend on the tiling (maxima)
+    monkeypatch.setenv("ICS_TEST_CONV_RS", "4" if rs == "2" else "2")
+    job2, _, _ = make_job(M, N, MK, seed=MK + 40)
+    job2.write(nv.BUF_U, u)
+    job2.write(nv.BUF_UT, case["u0"])
+    job2.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    job2.stage(nv.STAGE_BACKPROJECT, p)
+    red2 = job2.red_keys()
+    job2.close()
+    assert np.array_equal(red[3:6], red2[3:6])          # max u: exact
+    assert np.all(np.abs(red[:3].astype(np.int64) - red2[:3].astype(np.int64)) < 64)   # max |g|: per-tile scales differ in the last bits
+
+
 # conv: 0 = ICS_CONV_AUTO, 1 = fp32 products (vector convolutions, fp32-MFMA gradient), 2 = matrix-core kernels
 @pytest.mark.parametrize("M,N,MK,blind,conv", [(64, 64, 15, False, 0), (65, 191, 15, False, 0), (130, 67, 9, True, 0), (257, 300, 15, True, 0),
                                                (40, 50, 31, False, 0), (100, 90, 45, True, 0), (80, 120, 63, True, 0), (70, 70, 21, True, 0),
