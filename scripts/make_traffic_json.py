@@ -7,7 +7,7 @@ import json
 import re
 import sys
 
-KERNELS = {"k_conv_mfma<15, 0>": "synth_residual", "k_conv_mfma<15, 1>": "backproject", "k_update_rows<0>": "update",
+KERNELS = {"k_conv_mfma<15, 0,": "synth_residual", "k_conv_mfma<15, 1,": "backproject", "k_update_rows<0>": "update",
            "k_gradk_mfma<1>": "psf_gradient", "k_synth_gradk<15>": "synth_gradk"}
 ALGO = {"synth_residual": 36, "backproject": 48, "update": 60, "psf_gradient": 24, "synth_gradk": 60}   # bytes per pixel
 
