@@ -202,3 +202,76 @@ def test_whole_frame_stage_pass_against_float64_fft(S, MK, conv):
         print("   fused A11 + A13: PSF gradient %.2e of max|gradk|" % err2)
         assert err2 < 1e-5
     job.close()
+
+
+@pytest.mark.parametrize("MK", [15, 9])
+def test_largest_accepted_frame_offsets_near_2_gib(MK):
+    """A 12544 x 12544 x 3 frame is 1.9 GB per buffer -- just under the 2 GiB that the kernels' 32-bit byte offsets reach
+    (tests/test_gpu_edges.py: beyond it the job is refused).  Crops at the far corner against float64 direct sums for the
+    synthesis, the back-projection and the fused A11 + A13 pass; the step-size reduction saw every pixel.  (MK = 15 runs the
+    32-row tiles, MK = 9 at this size the 64-row ones.)"""
+    from lib import _native as nv
+    S = 12544
+    pad = MK // 2
+    rng = np.random.default_rng(MK)
+    psf = rand_psf(MK, 3)
+    u = rng.random((S + 2 * pad, S + 2 * pad, 3), dtype=np.float32)
+    job = nv.RLJob(S, S, MK)
+    image = np.zeros((S, S, 3), np.float32)
+    image[-40:, -40:] = rng.random((40, 40, 3), dtype=np.float32)
+    job.upload(image, u, psf)
+    del image
+    p = job.params(pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1, 1e9, 1, 1e-3, 10000.0, blind=True)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    spots = [(0, 0), (S // 2 + 5, S - 16), (S - 16, S // 3), (S - 16, S - 16)]
+
+    def conv_crop(y, x):
+        return np.stack([orc._conv_direct(u[y:y + 16 + 2 * pad, x:x + 16 + 2 * pad, c], psf[..., c], "valid") for c in range(3)], -1)
+
+    for (y, x) in spots:
+        e = job.read_rows(nv.BUF_ERROR, y, 16)[:, x:x + 16]
+        ref = conv_crop(y, x)
+        if y == S - 16 and x == S - 16:
+            ref = ref - job.read_rows(nv.BUF_IMAGE, y, 16)[:, x:x + 16]
+        assert np.max(np.abs(e - ref)) < 5e-6 * np.max(np.abs(conv_crop(y, x))), (y, x)
+    # back-projection of that residual: rows near the end of the u frame, from the residual rows that reach them
+    job.stage(nv.STAGE_MAJORIZE, p)                          # ut = u on the device
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    y0 = S + 2 * pad - 24                                   # u-frame rows [y0, y0 + 24)
+    g = job.read_rows(nv.BUF_GRADU, y0, 24)
+    er = job.read_rows(nv.BUF_ERROR, y0 - 2 * pad, S - (y0 - 2 * pad)).astype(np.float64)   # residual rows y0 - 2 pad .. S - 1
+    for x in (0, S // 2 + 7, S + 2 * pad - 20):
+        # gradu[Y, X] = sum_{a, b} psf[a, b] * e[Y - 2 pad + a, X - 2 pad + b]  (zero outside the M x N residual)
+        ep = np.zeros((24 + 2 * pad, 20 + 2 * pad, 3))
+        for i in range(ep.shape[0]):
+            Yi = y0 - 2 * pad + i
+            if Yi >= S:
+                continue
+            for jx in range(ep.shape[1]):
+                Xj = x - 2 * pad + jx
+                if 0 <= Xj < S:
+                    ep[i, jx] = er[Yi - (y0 - 2 * pad), Xj]
+        ref = np.zeros((24, 20, 3))
+        for a in range(MK):
+            for b in range(MK):
+                ref += psf[a, b].astype(np.float64) * ep[a:a + 24, b:b + 20]
+        assert np.max(np.abs(g[:, x:x + 20] - ref)) < 5e-6 * max(np.max(np.abs(ref)), 1e-3), x
+    del er, g
+    # the reductions of the back-projection cover the whole frame: max u per channel is exact
+    job.stage(nv.STAGE_UPDATE, p)
+    sc = job.scalars()
+    for k in range(3):
+        assert sc["maxu%d" % k] == float(np.max(u[..., k]))
+    # fused A11 + A13 on the original u: the residual it leaves where the statistics read it, and two taps of the gradient
+    job.write_rows(nv.BUF_U, 0, u)
+    job.stage(nv.STAGE_SYNTH_GRADK, p)
+    gk = job.read(nv.BUF_GRADK)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    for (a, b, c) in [(0, 0, 0), (MK - 1, pad, 2)]:
+        acc = 0.0
+        for r0 in range(0, S, 1568):                        # float64 dot product in row blocks (bounded host memory)
+            eb = job.read_rows(nv.BUF_ERROR, r0, 1568)[..., c].astype(np.float64)
+            acc += float(np.sum(eb * u[MK - 1 - a + r0:MK - 1 - a + r0 + 1568, MK - 1 - b:MK - 1 - b + S, c]))
+        ee = 0.25 * S * S                                   # |e|^2 scale: residual ~ conv(u) ~ 0.5
+        assert abs(gk[a, b, c] - acc) < 2e-5 * np.sqrt(ee * S * S / 3), (a, b, c, gk[a, b, c], acc)
+    job.close()
