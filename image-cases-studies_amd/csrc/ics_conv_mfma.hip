@@ -108,12 +108,17 @@ typedef uint32_t u3 __attribute__((ext_vector_type(3)));
 //   RS = 4 (64 x 64 tiles, two workgroups per CU up to K = 15): one A-fragment read feeds 12 MFMAs per window.
 //   RS = 2 (32 x 64 tiles): half the planes, a third of the registers less -- three workgroups per CU up to K = 17 and two
 //   instead of one at K = 19, 21; twice the LDS reads per MFMA and 9 % more staged bytes.  launch_k() picks (measured).
-template <int K, int RS_>
+// NH = 2 (K >= 23, where the planes leave room for one workgroup per CU only): 8 waves per workgroup; the two waves of a column
+//   block split the kernel rows ([0, K/2] and the rest), exchange their partial sums through LDS after the matrix phase and run
+//   the epilogue of two accumulator sets each.  Two waves per SIMD instead of one: every phase of a wave (conversion, LDS
+//   latency of the fragment reads, epilogue) finds another wave to overlap with.
+template <int K, int RS_, int NH_ = 1>
 struct MCfg {
   static constexpr int PAD = K / 2;
-  static constexpr int RS = RS_;
+  static constexpr int RS = RS_, NH = NH_;
+  static constexpr int KSPLIT = NH == 2 ? (K + 1) / 2 : K;   // first kernel row of the second half
   static constexpr int TH = 16 * RS, TW = 64, NCB = TW / 16;
-  static constexpr int NW = 4, NT = 64 * NW;
+  static constexpr int NW = 4 * NH, NT = 64 * NW;
   static constexpr int LROWS = TH + K - 1;       // input rows of the tile
   // LDS rows are grouped by (y mod 4): class c holds rows c, c+4, ... contiguously, classes back to back
   static constexpr int cls_rows(int c) { return (LROWS - c + RS - 1) / RS; }
@@ -185,18 +190,23 @@ __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer
   }
 }
 
+// workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also waits for the global loads in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // a copy of `x` the optimiser cannot trace back: values derived from it are recomputed where they are used
 // instead of being hoisted out of the tile loop (where they were spilled -- and a scratch reload waits on
 // vmcnt, i.e. on the whole prefetch in flight)
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
-template <int K, int MODE, int RS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>::WGS, MCfg<K, RS>::WGS))) void k_conv_mfma(IcsConvArgs a) {
-  using C = MCfg<K, RS>;
+template <int K, int MODE, int RS, int NH>
+__global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS, NH>::WGS * NH, MCfg<K, RS, NH>::WGS * NH))) void k_conv_mfma(IcsConvArgs a) {
+  using C = MCfg<K, RS, NH>;
+  static_assert(NH == 1 || (RS == 4 && MCfg<K, RS, NH>::WGS == 1), "the row split is for the one-workgroup-per-CU sizes, two accumulator sets per wave in the epilogue");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* fscr = reinterpret_cast<float*>(lds + C::SCRATCH);
   const int tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // = column block of this wave
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wv & 3, half = wv >> 2;                      // column block of this wave; which kernel rows it takes (NH = 2)
   const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int pitch = a.g.pitch;
 
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
     wa0[h] = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256) + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
     asm volatile("" : "+v"(wa0[h]));
   }
-  const unsigned char* base_h = lds + li * C::ROWB + (16 * wv + 8 * lg) * 2;
+  const unsigned char* base_h = lds + li * C::ROWB + (16 * cb + 8 * lg) * 2;
 
   float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   uint32_t rflags = 0u;   // bit c: NaN seen in g_c, bit 3+c: NaN seen in u_c, bit 6: any element reduced (one register)
@@ -342,7 +352,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
       for (int t = 0; t < C::RS; ++t) acc[ch][t] = (f4){0.f, 0.f, 0.f, 0.f};
-    if (x0 + 16 * wv < xend) {   // wave-uniform: a column block right of the output carries none
+    // kernel rows [A0, A1) of the three channels: the whole PSF (NH = 1) or this wave's half of it
+    auto matrix_phase = [&](auto a0c, auto a1c) {
+      constexpr int A0 = decltype(a0c)::value, A1 = decltype(a1c)::value;
+      constexpr int Q0 = A0, Q1 = A1 + C::RS - 1;   // fragments q = Q0 .. Q1 - 1 meet these rows
 #pragma unroll
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
         // (re-hidden per tile and channel: the weight reads are tile-invariant and would otherwise be hoisted out
@@ -382,18 +395,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
             Bl[ka][h] = __builtin_bit_cast(h8, wl);
           }
         };
-        issueB(0);
+        issueB(A0);
         h8 Ah[C::NCH], Al[C::NCH];
+        {
+          constexpr int off0 = (C::cls_base(Q0 % C::RS) + Q0 / C::RS) * C::ROWB;
 #pragma unroll
-        for (int h = 0; h < C::NCH; ++h) { Ah[h] = *reinterpret_cast<const h8*>(ph + 64 * h); Al[h] = *reinterpret_cast<const h8*>(pl + 64 * h); }
-        finishB(0);
+          for (int h = 0; h < C::NCH; ++h) { Ah[h] = *reinterpret_cast<const h8*>(ph + off0 + 64 * h); Al[h] = *reinterpret_cast<const h8*>(pl + off0 + 64 * h); }
+        }
+        finishB(A0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < C::NQ; ++q) {
+        for (int q = Q0; q < Q1; ++q) {
           h8 Nh[C::NCH], Nl[C::NCH];
 #pragma unroll
           for (int h = 0; h < C::NCH; ++h) { Nh[h] = Ah[h]; Nl[h] = Al[h]; }
-          if (q + 1 < C::NQ) {
+          if (q + 1 < Q1) {
             const int off = (C::cls_base((q + 1) % C::RS) + (q + 1) / C::RS) * C::ROWB;
             if (!(ICS_MFMA_ABLATE & 16)) {   // 16: timing probe without the A-fragment reads
 #pragma unroll
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
               }
             }
           }
-          if (q + 1 < K) issueB(q + 1);
+          if (q + 1 < A1) issueB(q + 1);
           if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);   // ...all requested before the step's MFMAs start
           // three split terms x windows; the (up to) 4 accumulators of a pass are independent
 #pragma unroll
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
 #pragma unroll
               for (int t = 0; t < C::RS; ++t) {
                 const int ka = q - t;
-                if (ka < 0 || ka >= K) continue;
+                if (ka < A0 || ka >= A1) continue;
                 const h8 av = term == 2 ? Al[h] : Ah[h];
                 const h8 bv = term == 1 ? Bl[ka][h] : Bh[ka][h];
                 acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[ch][t], 0, 0, 0);
@@ -421,7 +437,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
             }
           }
           if (!INTERLEAVE) __builtin_amdgcn_sched_barrier(0);   // ...and consumed behind them
-          if (q + 1 < K) finishB(q + 1);
+          if (q + 1 < A1) finishB(q + 1);
 #pragma unroll
           for (int h = 0; h < C::NCH; ++h) { Ah[h] = Nh[h]; Al[h] = Nl[h]; }
           // issue order inside the step: the LDS reads go into the shadows of the first MFMAs (an MFMA holds the matrix
@@ -430,10 +446,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
           if (INTERLEAVE) {
             int nt = 0;
 #pragma unroll
-            for (int t = 0; t < C::RS; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
+            for (int t = 0; t < C::RS; ++t) nt += (q - t >= A0 && q - t < A1) ? 1 : 0;
             const int nm = 3 * C::NCH * nt;                                             // MFMAs of this step
-            const int nr = ((q + 1 < C::NQ) ? 2 * C::NCH : 0) + ((q + 1 < K) ? 5 * C::NCH : 0);   // LDS reads
-            const int nv = (q + 1 < K) ? 8 * C::NCH : 0;                                // funnel shifts
+            const int nr = ((q + 1 < Q1) ? 2 * C::NCH : 0) + ((q + 1 < A1) ? 5 * C::NCH : 0);   // LDS reads
+            const int nv = (q + 1 < A1) ? 8 * C::NCH : 0;                               // funnel shifts
             const int tail = nv ? (nm > 4 ? 4 : nm) : 0;                                // MFMAs that cover the shifts
             const int head = nm - tail;
 #pragma unroll
@@ -451,19 +467,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
           __builtin_amdgcn_sched_barrier(0);   // keep each step's prefetches in that step (register pressure)
         }
       }
+    };
+    const bool has_out = x0 + 16 * cb < xend;   // wave-uniform: a column block right of the output carries none
+    if (has_out) {
+      if (NH == 1) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, K>{});
+      else if (half == 0) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, C::KSPLIT>{});
+      else matrix_phase(std::integral_constant<int, C::KSPLIT>{}, std::integral_constant<int, K>{});
+    }
+    if (NH == 2) {
+      // partial sums of the two halves: a wave keeps the accumulator sets t = 2 half, 2 half + 1 and hands the other two to its
+      // partner through the plane space (free once every wave has left the matrix phase)
+      lds_barrier();
+      f4* xch = reinterpret_cast<f4*>(lds);
+      auto exchange = [&](auto hc, bool write) {
+        constexpr int H = decltype(hc)::value;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            if (write) xch[(((cb * 2 + (1 - H)) * 3 + ch) * 2 + tt) * 64 + lane] = acc[ch][2 * (1 - H) + tt];
+            else acc[ch][2 * H + tt] += xch[(((cb * 2 + H) * 3 + ch) * 2 + tt) * 64 + lane];
+          }
+      };
+      if (half == 0) exchange(std::integral_constant<int, 0>{}, true); else exchange(std::integral_constant<int, 1>{}, true);
+      lds_barrier();
+      if (half == 0) exchange(std::integral_constant<int, 0>{}, false); else exchange(std::integral_constant<int, 1>{}, false);
     }
     ICS_TICK(1);
     // ---- epilogue straight from the accumulators: lane (li, lg) holds, for each channel, the 16 rows
     // t + 16*lg + 4*r of pixel column 16*wv + li, i.e. one 12-byte HWC pixel per (t, r): operands arrive and
     // results leave as dwordx3 (16 lanes = 192 contiguous bytes of a row), no LDS transpose and no workgroup
     // barrier between the matrix phase and the stores -- the four waves drift apart and overlap their phases.
-    if (x0 + 16 * wv < xend && !(ICS_MFMA_ABLATE & 4)) {
+    if (has_out && !(ICS_MFMA_ABLATE & 4)) {
       const float sc = inv_w * inv_x;   // powers of two
       const int tide = opaque(tid);
       const int eli = tide & 15, elg = (tide >> 4) & 3;
-      const int colx = x0 + 16 * wv + eli;
+      const int colx = x0 + 16 * cb + eli;
       const int voff = 4 * (4 * C::RS * elg * pitch + 3 * eli);   // lane part of the byte offset
-      const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));      // wave-uniform part (tile origin + column block)
+      const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * cb));      // wave-uniform part (tile origin + column block)
       constexpr int EOPS = (MODE == 0) ? 1 : 2;
       // TB = accumulator sets per batch: the operands of a batch are requested together.  (Measured without gain, and removed:
       // requesting the operands before the matrix phase -- the kernel follows its memory traffic, not the epilogue's latency --
@@ -471,11 +512,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
       // TVOP (extended modes): the T frame is a third operand, requested like the others (as per-element scalar loads it
       // cost the back-projection +40 %)
       const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
-      auto run_epi = [&](auto tbc, auto tvc) {
-      constexpr int TB = decltype(tbc)::value < C::RS ? decltype(tbc)::value : C::RS;
+      auto run_epi = [&](auto tbc, auto tvc, auto tloc) {
+      // accumulator sets [TLO, THI) of this wave: all of them, or two (NH = 2)
+      constexpr int TLO = decltype(tloc)::value, THI = TLO + C::RS / NH;
+      constexpr int TB = decltype(tbc)::value < THI - TLO ? decltype(tbc)::value : THI - TLO;
       constexpr bool TVOP = decltype(tvc)::value;
 #pragma unroll
-      for (int t0 = 0; t0 < C::RS; t0 += TB) {
+      for (int t0 = TLO; t0 < THI; t0 += TB) {
       u3 eop[EOPS][C::RS][4], eopT[C::RS][4];
 #pragma unroll
       for (int t = t0; t < t0 + TB; ++t)
@@ -487,12 +530,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
           if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
-      if (t0 == 0) ICS_TICK(3);
-      if (MODE == 1 && t0 == 0) {
+      if (t0 == TLO) ICS_TICK(3);
+      if (MODE == 1 && t0 == TLO) {
         // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
         // shadow of their latency (u and ut only feed the step-size reductions)
 #pragma unroll
-        for (int t = 0; t < C::RS; ++t)
+        for (int t = TLO; t < THI; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int y = y0 + t + 4 * C::RS * elg + C::RS * r;
@@ -543,8 +586,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
         }
       }
       };
-      if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::true_type{});
-      else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{});
+      auto run_all = [&](auto tloc) {
+        if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::true_type{}, tloc);
+        else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{}, tloc);
+      };
+      if (NH == 1 || half == 0) run_all(std::integral_constant<int, 0>{}); else run_all(std::integral_constant<int, C::RS / 2>{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
@@ -583,14 +629,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS>
   }
 }
 
-template <int K, int MODE, int RS>
+template <int K, int MODE, int RS, int NH = 1>
 hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
-  using C = MCfg<K, RS>;
+  using C = MCfg<K, RS, NH>;
   static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
   static int cus[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  auto kern = k_conv_mfma<K, MODE, RS>;
+  auto kern = k_conv_mfma<K, MODE, RS, NH>;
   if (!configured[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     if (e != hipSuccess) { (void)hipGetLastError(); return e; }
@@ -632,7 +678,16 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
   if constexpr (TileRs<K>::has2) {
     if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2>(a, s) : launch_one<K, 1, 2>(a, s);
   }
-  if constexpr (TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 4>(a, s) : launch_one<K, 1, 4>(a, s);
+  if constexpr (TileRs<K>::has4) {
+    if constexpr (K >= 23) {
+      // one workgroup per CU: 8 waves, kernel rows split between the two waves of a column block (MCfg NH = 2).  Measured against the
+      // 4-wave form (ICS_TEST_CONV_NH=1 in a build with ICS_MFMA_ALL_RS): 4096^2 K = 23 0.417 / 0.485 -> 0.390 / 0.448 ms,
+      // 6144^2 K = 31 1.089 / 1.266 -> 1.077 / 1.197 ms
+      const char* e = ICS_MFMA_ALL_RS ? getenv("ICS_TEST_CONV_NH") : nullptr;
+      if (!(e && atoi(e) == 1)) return mode == 0 ? launch_one<K, 0, 4, 2>(a, s) : launch_one<K, 1, 4, 2>(a, s);
+    }
+    if constexpr (K < 23 || ICS_MFMA_ALL_RS) return mode == 0 ? launch_one<K, 0, 4>(a, s) : launch_one<K, 1, 4>(a, s);
+  }
   return hipErrorInvalidValue;
 }
 
