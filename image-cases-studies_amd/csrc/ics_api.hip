@@ -376,6 +376,37 @@ static int rows_io(ics_rl* j, int which, int row0, int nrows, float* host, bool 
 extern "C" int ics_rl_read_rows(ics_rl* j, int which, int row0, int nrows, float* host) { return rows_io(j, which, row0, nrows, host, true); }
 extern "C" int ics_rl_write_rows(ics_rl* j, int which, int row0, int nrows, const float* host) { return rows_io(j, which, row0, nrows, const_cast<float*>(host), false); }
 
+// device-to-device rows between two jobs (lib/banded.py: halo exchange, stop-test gather).  Ordering: the source stream is
+// drained, the copy runs on the destination stream and is waited for -- the band driver is host-synchronous per stage anyway.
+extern "C" int ics_rl_copy_rows(ics_rl* dst, int dst_which, int dst_row0, ics_rl* src, int src_which, int src_row0, int nrows) {
+  if (!dst || !src) return fail(ICS_EINVAL, "NULL argument");
+  float *df, *sf; int drows, dcols, doy, dox, srows, scols, soy, sox;
+  if (frame_of(dst, dst_which, &df, &drows, &dcols, &doy, &dox) != 0) return fail(ICS_EINVAL, "buffer %d is not a frame", dst_which);
+  if (frame_of(src, src_which, &sf, &srows, &scols, &soy, &sox) != 0) return fail(ICS_EINVAL, "buffer %d is not a frame", src_which);
+  if (dcols != scols) return fail(ICS_EINVAL, "row length %d (destination) != %d (source)", dcols, scols);
+  if (nrows < 1 || dst_row0 < 0 || dst_row0 + nrows > drows || src_row0 < 0 || src_row0 + nrows > srows)
+    return fail(ICS_EINVAL, "rows [%d, %d) of %d <- rows [%d, %d) of %d", dst_row0, dst_row0 + nrows, drows, src_row0, src_row0 + nrows, srows);
+  const int dd = dst->ctx->device, sd = src->ctx->device;
+  if (dd != sd) {
+    int can = 0;
+    HIPCHK(hipDeviceCanAccessPeer(&can, dd, sd));
+    if (!can) return fail(ICS_ENOSUP, "device %d cannot access device %d: no peer path", dd, sd);
+    HIPCHK(hipSetDevice(dd));
+    hipError_t pe = hipDeviceEnablePeerAccess(sd, 0);
+    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(ICS_EHIP, "hipDeviceEnablePeerAccess(%d): %s", sd, hipGetErrorString(pe));
+    (void)hipGetLastError();
+  }
+  HIPCHK(hipSetDevice(sd));
+  HIPCHK(hipStreamSynchronize(src->ctx->stream));
+  HIPCHK(hipSetDevice(dd));
+  const float* sp = org(src, sf) + (ptrdiff_t)(soy + src_row0) * src->g.pitch + 3 * sox;
+  float* dp = org(dst, df) + (ptrdiff_t)(doy + dst_row0) * dst->g.pitch + 3 * dox;
+  HIPCHK(hipMemcpy2DAsync(dp, (size_t)dst->g.pitch * 4, sp, (size_t)src->g.pitch * 4, (size_t)dcols * 12, nrows,
+                          dd == sd ? hipMemcpyDeviceToDevice : hipMemcpyDefault, dst->ctx->stream));
+  HIPCHK(hipStreamSynchronize(dst->ctx->stream));
+  return ICS_OK;
+}
+
 // -------------------------------------------------------------------------------------------------
 // stop-test scratch: Gaussian window weights (pyx:393-404), twiddles, P x P x 3 complex buffer
 static int ensure_window(ics_rl* j, const ics_rl_params* p) {

@@ -90,6 +90,7 @@ def load():
     lib.ics_rl_write.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_read_rows.argtypes = [vp, ci, ci, ci, vp]
     lib.ics_rl_write_rows.argtypes = [vp, ci, ci, ci, vp]
+    lib.ics_rl_copy_rows.argtypes = [vp, ci, ci, vp, ci, ci, ci]
     lib.ics_normalize_kernel.argtypes = [vp, vp, ci]
     lib.ics_tv.argtypes = [vp, vp, ci, ci, cf, ci, ci, vp, vp]
     lib.ics_conv2d_symm.argtypes = [vp, vp, ci, ci, vp, ci, ci, vp]
@@ -115,7 +116,7 @@ def load():
     lib.ics_group_allreduce_max.argtypes = [vp, vp, ci]
     lib.ics_group_allgather.argtypes = [vp, vp, ci, vp]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
-                 "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_rl_read_rows", "ics_rl_write_rows", "ics_normalize_kernel",
+                 "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_rl_read_rows", "ics_rl_write_rows", "ics_rl_copy_rows", "ics_normalize_kernel",
                  "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
                  "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
                  "ics_rl_upload_img", "ics_rl_download_img", "ics_group_create", "ics_group_info", "ics_group_barrier",
@@ -384,6 +385,10 @@ class RLJob:
         arr = np.ascontiguousarray(arr, dtype=np.float32)
         assert arr.ndim == 3 and arr.shape[1:] == self._shape(which)[1:], (arr.shape, self._shape(which))
         _check(load().ics_rl_write_rows(self._h, which, int(row0), arr.shape[0], _ptr(arr)))
+
+    def copy_rows_from(self, which, row0, src, src_which, src_row0, nrows):
+        """rows [src_row0, + nrows) of a frame buffer of job `src` -> rows [row0, + nrows) of this job's buffer, device to device"""
+        _check(load().ics_rl_copy_rows(self._h, which, int(row0), src._h, src_which, int(src_row0), int(nrows)))
 
     def red_keys(self):
         """reduction keys of the last stage call: [0..2] max|g_k|, [3..5] max u_k as order-preserving uint32 keys"""

@@ -15,9 +15,11 @@ the whole band job; only the rows the band OWNS come out exact, and three things
      step (pyx:574-589) then runs identically on every band.
 
 The stop-test statistics (pyx:593-654) run on a small job of their own that receives the window's rows of the residual and of
-u from the bands that own them, once per outer iteration (the window may straddle bands).  Transfers go through the
-host (works across devices without peer access; a few hundred KB per inner iteration); band jobs run concurrently, one host
-thread per band (ctypes releases the GIL inside the C calls).  With the fp32 convolution kernels (`conv=1`) a non-blind
+u from the bands that own them, once per outer iteration (the window may straddle bands).  Transfers stay on the
+devices: rows are copied device to device (`ics_rl_copy_rows`: peer access over xGMI between GPUs, a plain device copy when
+bands share a GPU) and fall back to the host where two devices cannot reach each other; the 6 reduction keys and the 3 MK^2
+gradient sums (a few KB) go through the host.  Band jobs run concurrently, one host thread per band (ctypes releases the GIL
+inside the C calls).  With the fp32 convolution kernels (`conv=1`) a non-blind
 banded run is bit-identical to the single-job run; the matrix-core kernels scale per tile, so results agree to ~1e-7.
 """
 from __future__ import annotations
@@ -87,23 +89,37 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
     sj = nv.RLJob(bottom - top, N, MK, nv.Context.get(devices[0]))
     sP = sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv)
 
+    # Rows move between jobs device to device (`ics_rl_copy_rows`: same GPU, or peer access over xGMI); if two devices cannot
+    # reach each other the library says ICS_ENOSUP once and every transfer goes through the host from then on.
+    d2d = [True]
+
+    def move(dst, which, drow, src, srow, n):
+        if d2d[0]:
+            try:
+                dst.copy_rows_from(which, drow, src, which, srow, n)
+                return
+            except nv.NativeError as e:
+                if e.code != nv.ICS_ENOSUP:
+                    raise
+                d2d[0] = False
+        dst.write_rows(which, drow, src.read_rows(which, srow, n))
+
     def gather(which, g0, g1):
-        """global rows [g0, g1) of a frame buffer from the bands that own them (u-frame rows for BUF_U, image rows for BUF_ERROR)"""
-        parts = []
+        """global rows [g0, g1) of a frame buffer, from the bands that own them, into the statistics job (u-frame rows for BUF_U,
+        image rows for BUF_ERROR)"""
         for bd in B:
             o0, o1 = (bd.u0, bd.u1) if which == nv.BUF_U else (bd.y0, bd.y1)
             lo, hi = max(g0, o0), min(g1, o1)
             if lo < hi:
-                parts.append(bd.job.read_rows(which, lo - bd.a, hi - lo))
-        return np.concatenate(parts, axis=0)
+                move(sj, which, lo - g0, bd.job, lo - bd.a, hi - lo)
 
     def key2f(k):
         k = np.uint32(k)
         return (np.uint32(k & np.uint32(0x7FFFFFFF)) if k & np.uint32(0x80000000) else np.uint32(~k)).view(np.float32)
 
     def statistics():
-        sj.write_rows(nv.BUF_ERROR, 0, gather(nv.BUF_ERROR, top, bottom))
-        sj.write_rows(nv.BUF_U, 0, gather(nv.BUF_U, top, bottom + 2 * pad))
+        gather(nv.BUF_ERROR, top, bottom)
+        gather(nv.BUF_U, top, bottom + 2 * pad)
         sj.stage(nv.STAGE_STATS, sP)
         out = sj.scalars()
         # DoF extrema of the last update (printed diagnostics, pyx:593): over the rows of every band job, halos included
@@ -129,15 +145,14 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
                 par(lambda bd: bd.job.stage(nv.STAGE_UPDATE, bd.P()))                     # A5 - A10
                 # (2) halo exchange of the updated u: 2 pad owned rows each way
                 if len(B) > 1:
-                    up = par(lambda bd: None if bd.first else bd.job.read_rows(nv.BUF_U, bd.lu0, 2 * pad))
-                    dn = par(lambda bd: None if bd.last else bd.job.read_rows(nv.BUF_U, bd.lu1 - 2 * pad, 2 * pad))
-
-                    def put(bd):
+                    def halo(bd):   # only halo rows are written, only owned rows are read: the copies of all bands commute
                         if not bd.first:
-                            bd.job.write_rows(nv.BUF_U, bd.lu0 - 2 * pad, dn[bd.index - 1])      # rows above my owned rows
+                            prev = B[bd.index - 1]
+                            move(bd.job, nv.BUF_U, bd.lu0 - 2 * pad, prev.job, prev.lu1 - 2 * pad, 2 * pad)   # rows above my owned rows
                         if not bd.last:
-                            bd.job.write_rows(nv.BUF_U, bd.lu1, up[bd.index + 1])                # rows below them
-                    par(put)
+                            nxt = B[bd.index + 1]
+                            move(bd.job, nv.BUF_U, bd.lu1, nxt.job, nxt.lu0, 2 * pad)                      # rows below them
+                    par(halo)
                 if blind:                                                                 # pyx:555
                     par(lambda bd: bd.job.stage(nv.STAGE_SYNTH_RESIDUAL, bd.P()))         # A11
                     if itt == INNER - 1:

@@ -209,6 +209,10 @@ int ics_rl_write(ics_rl *job, int which, const float *host, size_t count);
 /* Rows [row0, row0 + nrows) of a frame buffer (ICS_BUF_U / UT / GRADU: uN*3 floats per row; IMAGE / ERROR: N*3). */
 int ics_rl_read_rows(ics_rl *job, int which, int row0, int nrows, float *host);
 int ics_rl_write_rows(ics_rl *job, int which, int row0, int nrows, const float *host);
+/* Rows of a frame buffer of one job into a frame buffer of another, device to device (the halo exchange and the stop-test
+   gather of the row-band split, lib/banded.py): the two frames must have the same row length.  Jobs on different GPUs need peer
+   access (xGMI); ICS_ENOSUP if the devices cannot reach each other -- the caller then goes through the host. */
+int ics_rl_copy_rows(ics_rl *dst, int dst_which, int dst_row0, ics_rl *src, int src_which, int src_row0, int nrows);
 
 /* Kernel classes indexing ics_rl_stats.ms_kernel / launches. */
 #define ICS_K_SYNTH 0        /* A1+A2 convolution kernel        */

@@ -94,3 +94,42 @@ def test_stop_test_works_across_bands():
     u2, _, log2, st2 = run_banded(case, M, N, MK, win, 0.0, 40, False, 1, 2)
     assert st1.stopped and st2.stopped and st1.iterations_done == st2.iterations_done
     assert np.array_equal(u1, u2)
+
+
+@pytest.mark.gpu
+def test_device_to_device_rows_between_jobs_and_the_host_fallback(monkeypatch):
+    """`ics_rl_copy_rows` (halo exchange / stop-test gather without the host): same bytes as read_rows + write_rows, argument
+    checks, and a banded run that is told the devices cannot reach each other (ICS_ENOSUP) goes through the host and gives
+    the same frame bit for bit."""
+    from lib import _native as nv
+    rng = np.random.default_rng(8)
+    a, b = nv.RLJob(70, 90, 9), nv.RLJob(40, 90, 9)
+    ua = rng.random((78, 98, 3), dtype=np.float32)
+    a.upload(np.zeros((70, 90, 3), np.float32), ua, orc.gaussian_psf(9))
+    b.upload(np.zeros((40, 90, 3), np.float32), np.zeros((48, 98, 3), np.float32), orc.gaussian_psf(9))
+    b.copy_rows_from(nv.BUF_U, 5, a, nv.BUF_U, 60, 17)
+    got = b.read_rows(nv.BUF_U, 0, 48)
+    assert np.array_equal(got[5:22], ua[60:77]) and not got[:5].any() and not got[22:].any()
+    e = rng.random((70, 90, 3), dtype=np.float32)
+    a.write(nv.BUF_ERROR, e)
+    b.copy_rows_from(nv.BUF_ERROR, 0, a, nv.BUF_ERROR, 30, 40)
+    assert np.array_equal(b.read(nv.BUF_ERROR), e[30:70])
+    with pytest.raises(nv.NativeError):
+        b.copy_rows_from(nv.BUF_U, 40, a, nv.BUF_U, 0, 17)          # past the destination's 48 rows
+    with pytest.raises(nv.NativeError):
+        b.copy_rows_from(nv.BUF_U, 0, a, nv.BUF_ERROR, 0, 4)        # row lengths differ (u frame vs image frame)
+    a.close(); b.close()
+
+    M, N, MK = 150, 120, 9
+    case = orc.synth_case(M, N, MK, seed=6)
+    win = (30, 111, 20, 101)
+    u_dev, psf_dev, log_dev, _ = run_banded(case, M, N, MK, win, 1e9, 2, True, 1, 3)
+    calls = []
+
+    def unreachable(self, *args):
+        calls.append(args)
+        raise nv.NativeError(nv.ICS_ENOSUP, "device 0 cannot access device 1: no peer path (test)")
+    monkeypatch.setattr(nv.RLJob, "copy_rows_from", unreachable)
+    u_host, psf_host, log_host, _ = run_banded(case, M, N, MK, win, 1e9, 2, True, 1, 3)
+    assert 1 <= len(calls) <= 4                                      # asked once (per band thread at most), then the host path for the rest of the run
+    assert np.array_equal(u_dev, u_host) and np.array_equal(psf_dev, psf_host) and log_dev == log_host
