@@ -34,8 +34,8 @@ int main(int argc, char** argv) {
   {
     int nb0 = -1, nb1 = -1;
     if (K == 15) {
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_conv_mfma<15, 0, 2>, 256, MCfg<15, 2>::LDS_BYTES);
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_conv_mfma<15, 1, 2>, 256, MCfg<15, 2>::LDS_BYTES);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_conv_mfma<15, 0, 2, 1>, 256, MCfg<15, 2>::LDS_BYTES);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, k_conv_mfma<15, 1, 2, 1>, 256, MCfg<15, 2>::LDS_BYTES);
       printf("occupancy (workgroups per CU) K=15, 32-row tiles: mode 0 %d, mode 1 %d, LDS %zu B\n", nb0, nb1, (size_t)MCfg<15, 2>::LDS_BYTES);
     }
   }
