@@ -263,3 +263,38 @@ def test_fused_synth_gradk_in_the_loop_matches_two_kernel_path():
     assert rel_err(out[0][0], out[1][0]) < 1e-5 and rel_err(out[0][1], out[1][1]) < 1e-5
     for k in (2, 3, 4):
         assert abs(out[0][k] - out[1][k]) <= 2e-4 * abs(out[1][k])
+
+
+def test_matrix_core_kernels_equal_the_vector_kernels_on_random_shapes():
+    """Ragged frames (1 .. 200 px a side, any tile remainder) x odd PSF sizes 3 .. 37: the matrix-core convolutions (both tile
+    heights, the 8-wave form at K >= 23) and the packed-fp32 ones agree within the stage tolerance on residual and
+    back-projection, and bit for bit on the max-u reduction.  Seeded hypothesis run, 30 cases."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from lib import _native as nv
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(1, 200), st.integers(1, 200), st.integers(1, 18), st.integers(0, 2 ** 31 - 1))
+    def check(M, N, kh, seed):
+        MK = 2 * kh + 1
+        job, case, psf = make_job(M, N, MK, seed=seed % 1000)
+        rng = np.random.default_rng(seed)
+        u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        out = {}
+        job.write(nv.BUF_U, u)
+        job.write(nv.BUF_UT, case["u0"])
+        res = {}
+        for conv in (1, 2):
+            job.stage(nv.STAGE_SYNTH_RESIDUAL, job.params(0, 1, 0, 1, 1e9, 1, 1e-3, 10000.0, blind=False, conv=conv))
+            res[conv] = job.read(nv.BUF_ERROR)
+        for conv in (1, 2):   # both back-project the SAME residual (it is a small difference of large numbers)
+            job.write(nv.BUF_ERROR, res[1])
+            job.stage(nv.STAGE_BACKPROJECT, job.params(0, 1, 0, 1, 1e9, 1, 1e-3, 10000.0, blind=False, conv=conv))
+            out[conv] = (res[conv], job.read(nv.BUF_GRADU), job.red_keys()[3:6].copy())
+        job.close()
+        tol = 2 * CONV_TOL * max(1.0, (MK / 31.0) ** 2)
+        scale = max(float(np.max(np.abs(u))), 1e-6)
+        assert np.max(np.abs(out[1][0] - out[2][0])) <= tol * scale, (M, N, MK)
+        assert np.max(np.abs(out[1][1] - out[2][1])) <= tol * max(float(np.max(np.abs(out[1][1]))), 1e-6), (M, N, MK)
+        assert np.array_equal(out[1][2], out[2][2]), (M, N, MK)
+
+    check()
