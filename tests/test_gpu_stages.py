@@ -298,3 +298,42 @@ def test_matrix_core_kernels_equal_the_vector_kernels_on_random_shapes():
         assert np.array_equal(out[1][2], out[2][2]), (M, N, MK)
 
     check()
+
+
+def test_fused_synth_gradk_equals_the_two_kernel_path_on_random_shapes():
+    """The fused A11 + A13 kernel against the two kernels it replaces over ragged frames (1 .. 260 px a side) and every PSF size
+    it is built for (3 .. 15), with 1 .. 7 persistent workgroups (ICS_TEST_MAX_WGS: tile walk, next-tile prefetch, partial blocks).
+    Seeded hypothesis run, 30 cases."""
+    import os
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from lib import _native as nv
+
+    @settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(1, 260), st.integers(1, 260), st.integers(1, 7), st.integers(0, 7), st.integers(0, 2 ** 31 - 1))
+    def check(M, N, kh, wgs, seed):
+        MK = 2 * kh + 1
+        job, case, psf = make_job(M, N, MK, seed=seed % 1000, blind=True)
+        rng = np.random.default_rng(seed)
+        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        job.write(nv.BUF_U, u)
+        p = job.params(0, M, 0, N, 1e9, 1, 1e-3, 10000.0, blind=True)
+        if wgs:
+            os.environ["ICS_TEST_MAX_WGS"] = str(wgs)
+        try:
+            job.stage(nv.STAGE_SYNTH_GRADK, p)
+            e, gk = job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK)
+        finally:
+            os.environ.pop("ICS_TEST_MAX_WGS", None)
+        job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+        e2 = job.read(nv.BUF_ERROR)
+        job.write(nv.BUF_ERROR, e)                                         # the gradient of the same residual
+        job.stage(nv.STAGE_PSF_GRADIENT, p)
+        gk2 = job.read(nv.BUF_GRADK)
+        job.close()
+        scale = max(float(np.max(np.abs(u))), 1e-6)
+        assert np.max(np.abs(e - e2)) <= 2e-6 * scale, (M, N, MK, wgs)
+        ref = gradk64(u.astype(np.float64), e.astype(np.float64))
+        gs = max(float(np.max(np.abs(ref))), 1e-12)
+        assert np.max(np.abs(gk - ref)) <= 2e-5 * gs and np.max(np.abs(gk2 - ref)) <= 2e-5 * gs, (M, N, MK, wgs)
+
+    check()
