@@ -245,3 +245,33 @@ def test_normalize_kernel_golden(golden_dir):
         k = z["in_%d" % MK].copy()
         dc.normalize_kernel(k, MK)
         assert np.array_equal(k, z["out_%d" % MK]), MK
+
+
+@pytest.mark.gpu
+def test_whole_call_against_the_oracle_on_random_small_problems():
+    """`richardson_lucy_MM` end to end against the pinned oracle on ragged frames the goldens do not hold: 20 .. 90 px a side,
+    PSF 3 .. 11, blind and not, random stats windows, two outer iterations (ten inner).  Seeded hypothesis run, 16 cases; gate =
+    the north-star 1e-4 on u (relative to its maximum) and on the PSF."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+    from lib import deconvolution as dc
+
+    @settings(max_examples=16, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(20, 90), st.integers(20, 90), st.integers(1, 5), st.booleans(), st.integers(0, 10 ** 6), st.data())
+    def check(M, N, kh, blind, seed, data):
+        MK = 2 * kh + 1
+        top = data.draw(st.integers(0, M - 9)); bottom = data.draw(st.integers(top + 8, M))
+        left = data.draw(st.integers(0, N - 9)); right = data.draw(st.integers(left + 8, N))
+        case = orc.synth_case(M, N, MK, seed=seed, blind=blind)
+        args = (top, bottom, left, right, 0.0, M, N, 3, MK, 2, 1e-3, 10000.0)
+        u_o, psf_o = case["u0"].copy(), case["psf0"].copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            orc.richardson_lucy_MM(case["image"].copy(), u_o, psf_o, *args, blind=blind)
+        u_g, psf_g = case["u0"].copy(), case["psf0"].copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            dc.richardson_lucy_MM(case["image"].copy(), u_g, psf_g, *args, blind=blind)
+        st_ = dc.richardson_lucy_MM.last
+        assert st_.iterations_done == 2
+        assert np.max(np.abs(u_g - u_o)) <= TRAJ_TOL * np.max(np.abs(u_o)), (M, N, MK, blind, (top, bottom, left, right))
+        assert np.max(np.abs(psf_g - psf_o)) <= TRAJ_TOL * np.max(np.abs(psf_o)), (M, N, MK, blind)
+
+    check()
