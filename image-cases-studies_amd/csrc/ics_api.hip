@@ -517,10 +517,7 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
   const bool matrix = mode != 2 && use_matrix_conv(j, p);
   a.bt = matrix ? (mode == 1 ? j->bt_corr : j->bt_conv) : nullptr;
-  // dynamic tile claiming: measured on MI355X -- back-projection 0.2196 -> 0.2144 ms at 4096^2, but 0.063 -> 0.067 ms (and the
-  // synthesis 0.045 -> 0.050 ms) at 2048^2, where a workgroup owns two tiles and the claim's round trip is exposed: off by default
-  static const int dyn = [] { const char* e = getenv("ICS_DYNAMIC_TILES"); return (e && e[0] == '1') ? 1 : 0; }();
-  a.sched = (matrix && dyn) ? j->sched : nullptr;
+  a.sched = matrix ? j->sched : nullptr;   // counters of the dynamic tile walk: the launcher decides per launch (ics_conv_mfma.hip)
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
   if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
   else HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));

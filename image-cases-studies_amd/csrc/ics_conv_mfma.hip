@@ -656,7 +656,18 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   // test hook: fewer persistent workgroups, so that small frames make every workgroup walk several tiles (next-tile
   // prefetch, band split) -- tests/test_gpu_rl.py::test_blind_golden_576x520_multi_tile_walk
   if (const char* e = getenv("ICS_TEST_MAX_WGS")) { const int m = atoi(e); if (m > 0 && grid > m) grid = m; }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, a);
+  // Dynamic tile claiming (a.sched) pays when a workgroup walks many tiles -- the edge tiles are cheaper and the static walk leaves
+  // a partial last round -- and costs when it walks few (the claim's round trip is exposed).  Measured on MI355X, static -> dynamic,
+  // ms per inner iteration: 4096^2 15x15 (10.7 tiles per workgroup) blind 0.868 -> 0.847, non-blind 0.551 -> 0.545; 6144^2 31x31
+  // (36) blind 4.45 -> 4.36; 3072^2 (6) level; 2560^2 (4.2) 0.385 -> 0.395; 2048^2 (2.7) non-blind 0.169 -> 0.180.
+  // Hence: from 8 tiles per workgroup on.  ICS_DYNAMIC_TILES=0|1 forces either.
+  IcsConvArgs b = a;
+  if (b.sched) {
+    const char* e = getenv("ICS_DYNAMIC_TILES");
+    const bool on = e ? e[0] == '1' : ntiles >= 8 * grid;
+    if (!on) b.sched = nullptr;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, b);
   return hipGetLastError();
 }
 

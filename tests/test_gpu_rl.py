@@ -180,13 +180,15 @@ def test_config1_512_k9_20_outer(golden_dir):
     assert abs(uf.sum() - z["moments"][0]) / abs(z["moments"][0]) < 1e-5
 
 
-@pytest.mark.parametrize("max_wgs,conv,flags", [(8, 0, 0), (8, 0, 1), (3, 0, 0), (0, 0, 0), (8, 1, 0)],
-                         ids=["8wg-fused", "8wg-two-kernel", "3wg-fused", "full-grid", "8wg-fp32"])
-def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, conv, flags):
+@pytest.mark.parametrize("max_wgs,conv,flags,dyn", [(8, 0, 0, None), (8, 0, 1, None), (3, 0, 0, None), (0, 0, 0, None), (8, 1, 0, None), (3, 0, 0, "0"), (0, 0, 0, "1")],
+                         ids=["8wg-fused", "8wg-two-kernel", "3wg-fused", "full-grid", "8wg-fp32", "3wg-static-walk", "full-grid-dynamic-walk"])
+def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, conv, flags, dyn):
     """Blind reference golden on a 9 x 9-tile frame (oracle/make_golden_large.py).  With ICS_TEST_MAX_WGS = 8 (3) every
     persistent workgroup of the matrix-core convolutions, of the PSF-gradient kernel and of the fused A11 + A13 kernel
     walks 8-11 (24-27) tiles: next-tile register prefetch, band split and the interior-origin grid run under a reference
-    trajectory, which the 129^2 goldens (<= 3 x 3 tiles, one tile per workgroup) cannot do."""
+    trajectory, which the 129^2 goldens (<= 3 x 3 tiles, one tile per workgroup) cannot do.  From 8 tiles per workgroup on the
+    convolutions claim their tiles from a counter (dynamic walk): the 8- and 3-workgroup cases run that path, ICS_DYNAMIC_TILES
+    forces the static walk with 3 workgroups and the dynamic one on the full grid."""
     import json
     import os
     from lib import deconvolution as dc
@@ -196,6 +198,8 @@ def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, 
     case = orc.synth_case(M, N, MK, seed=meta["seed"], blind=True)
     if max_wgs:
         monkeypatch.setenv("ICS_TEST_MAX_WGS", str(max_wgs))
+    if dyn is not None:
+        monkeypatch.setenv("ICS_DYNAMIC_TILES", dyn)
     dc._drop_jobs()                # the workgroup count of the gradient kernels is fixed when the job is created
     for n in (1, 2):
         u, psf = case["u0"].copy(), case["psf0"].copy()
