@@ -103,6 +103,32 @@ static inline float* ut_of(ics_rl* j) { return j->ut_is_u ? j->u : j->ut; }
 
 // -------------------------------------------------------------------------------------------------
 extern "C" int ics_abi_version(void) { return ICS_ABI_VERSION; }
+extern "C" size_t ics_rl_params_size(void) { return sizeof(ics_rl_params); }
+extern "C" size_t ics_rl_stats_size(void) { return sizeof(ics_rl_stats); }
+
+// test / measurement switches (ics_common.h IcsDebug): exported, deliberately absent from include/ics_hip.h
+extern "C" int ics_debug_set(const char* name, int value) {
+  if (!name) return -1;
+  IcsDebug& d = ics_debug();
+  struct { const char* n; std::atomic<int>* v; } tab[] = {
+      {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
+      {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
+      {"planar_image", &d.planar_image}};
+  for (auto& t : tab)
+    if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); return 0; }
+  return -1;
+}
+extern "C" int ics_debug_get(const char* name, int* value) {
+  if (!name || !value) return -1;
+  IcsDebug& d = ics_debug();
+  struct { const char* n; std::atomic<int>* v; } tab[] = {
+      {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
+      {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
+      {"planar_image", &d.planar_image}};
+  for (auto& t : tab)
+    if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
+  return -1;
+}
 extern "C" const char* ics_last_error(void) { return g_err; }
 
 extern "C" int ics_device_count(int* count) {
@@ -410,12 +436,13 @@ extern "C" int ics_rl_copy_rows(ics_rl* dst, int dst_which, int dst_row0, ics_rl
 // -------------------------------------------------------------------------------------------------
 // stop-test scratch: Gaussian window weights (pyx:393-404), twiddles, P x P x 3 complex buffer
 static int ensure_window(ics_rl* j, const ics_rl_params* p) {
-  if (j->z && j->wt == p->top && j->wb == p->bottom && j->wl == p->left && j->wr == p->right) return ICS_OK;
   const int H = p->bottom - p->top, W = p->right - p->left;
   // an empty window: the reference slices error[top:bottom, left:right] into an empty array and every statistic is NaN
-  // (numpy warns, pyx:600-601,627-638 do not raise); the stop test then never fires
+  // (numpy warns, pyx:600-601,627-638 do not raise); the stop test then never fires.  Decided BEFORE the cache check: jobs are
+  // reused across calls (lib/deconvolution.py keeps them), and window W -> empty window -> W must not leave the flag set.
   j->win_empty = (H < 1 || W < 1);
   if (j->win_empty) return ICS_OK;
+  if (j->z && j->wt == p->top && j->wb == p->bottom && j->wl == p->left && j->wr == p->right) return ICS_OK;
   if (p->top < 0 || p->left < 0 || p->bottom > j->g.M || p->right > j->g.N)
     return fail(ICS_EINVAL, "stats window [%d:%d, %d:%d] outside the %dx%d image", p->top, p->bottom, p->left, p->right, j->g.M, j->g.N);
   const int need = 2 * (H > W ? H : W) - 1;
@@ -501,7 +528,7 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
   if (!j->bt_conv) return false;
   if (p->conv == ICS_CONV_VECTOR) return false;
   if (p->conv == ICS_CONV_MATRIX) return true;
-  static const int env = [] { const char* e = getenv("ICS_CONV_PATH"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+  const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
   return env == 2 || (env == 0 && ics_conv_mfma_preferred(j->g.K));
 }
 
@@ -565,8 +592,7 @@ static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
 static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
   if (!ics_gradk_mfma_supported(j->g.K) || p->conv == ICS_CONV_VECTOR) return false;
   if (p->conv == ICS_CONV_MATRIX) return true;
-  static const int env = [] { const char* e = getenv("ICS_CONV_PATH"); return !e ? 0 : (e[0] == 'v' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
-  return env != 1;
+  return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
@@ -584,8 +610,7 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
 static bool use_fused_gradk(const ics_rl* j, const ics_rl_params* p) {
   if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return false;
   if (p->flags & ICS_FLAG_NO_FUSED_GRADK) return false;
-  static const int env = [] { const char* e = getenv("ICS_FUSED_GRADK"); return (e && e[0] == '0') ? 0 : 1; }();
-  return env && use_matrix_conv(j, p) && use_matrix_gradk(j, p);
+  return ics_debug().fused_gradk.load(std::memory_order_relaxed) != 0 && use_matrix_conv(j, p) && use_matrix_gradk(j, p);
 }
 
 static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof& pr) {
@@ -639,7 +664,11 @@ static int reset_dofkeys(ics_rl* j) {
 }
 
 static int check_params(ics_rl* j, const ics_rl_params* p) {
-  if (!j || !p) return fail(ICS_EINVAL, "NULL argument");
+  if (!p) return fail(ICS_EINVAL, "params is NULL");
+  if (p->struct_size != sizeof(ics_rl_params))   // first of all: nothing else of *p may be trusted otherwise
+    return fail(ICS_EINVAL, "ics_rl_params.struct_size = %u but this library (ABI %d) expects %zu: the caller was built against another include/ics_hip.h",
+                p->struct_size, ICS_ABI_VERSION, sizeof(ics_rl_params));
+  if (!j) return fail(ICS_EINVAL, "job is NULL");
   if (p->tv_mode < ICS_TV_SHIPPED || p->tv_mode > ICS_TV_PAM_COLLAB)
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
@@ -651,15 +680,23 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
 }
 
 extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
-  RC(check_params(j, p));
   if (!st) return fail(ICS_EINVAL, "stats is NULL");
+  if (p && p->struct_size == sizeof(ics_rl_params) && st->struct_size != sizeof(ics_rl_stats))
+    return fail(ICS_EINVAL, "ics_rl_stats.struct_size = %u but this library (ABI %d) expects %zu", st->struct_size, ICS_ABI_VERSION, sizeof(ics_rl_stats));
+  RC(check_params(j, p));
+  if (st->trace_cap < 0) return fail(ICS_EINVAL, "ics_rl_stats.trace_cap = %d", st->trace_cap);
   if (!j->uploaded) return fail(ICS_ESTATE, "ics_rl_run before ics_rl_upload");
   HIPCHK(hipSetDevice(j->ctx->device));
   hipStream_t s = j->ctx->stream;
   RC(ensure_window(j, p));
   const bool tv = p->tv_mode != ICS_TV_SHIPPED;
   if (tv) RC(ensure_tv(j));
-  memset(st, 0, sizeof *st);
+  {  // everything but the caller's in-fields is overwritten
+    ics_rl_stats in = *st;
+    memset(st, 0, sizeof *st);
+    st->struct_size = in.struct_size; st->trace_cap = in.trace_cap;
+    st->trace_M_r = in.trace_M_r; st->trace_Hu = in.trace_Hu; st->trace_varu = in.trace_varu; st->trace_dof_min = in.trace_dof_min; st->trace_dof_max = in.trace_dof_max;
+  }
   j->ut_is_u = false;
   Prof pr_on{j, p->profile != 0};       // (per-outer kernels are always bracketed when profiling)
   Prof pr_off{j, false};
@@ -720,15 +757,20 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     M_r = p->stop_test ? j->h_scal[ICS_SC_MR] : nanf("");
     Hu = j->h_scal[ICS_SC_HU]; varu = j->h_scal[ICS_SC_VARU];
     dmin = j->h_scal[ICS_SC_DOFMIN]; dmax = j->h_scal[ICS_SC_DOFMAX];
-    const int slot = it < ICS_MAX_TRACE ? it : ICS_MAX_TRACE - 1;
-    st->trace_M_r[slot] = M_r; st->trace_Hu[slot] = Hu; st->trace_varu[slot] = varu;
-    st->trace_dof_min[slot] = dmin; st->trace_dof_max[slot] = dmax;
-    st->trace_len = slot + 1;
+    if (it < st->trace_cap) {
+      if (st->trace_M_r) st->trace_M_r[it] = M_r;
+      if (st->trace_Hu) st->trace_Hu[it] = Hu;
+      if (st->trace_varu) st->trace_varu[it] = varu;
+      if (st->trace_dof_min) st->trace_dof_min[it] = dmin;
+      if (st->trace_dof_max) st->trace_dof_max[it] = dmax;
+      st->trace_len = it + 1;
+    }
     if (it > 1 && p->stop_test == 1) {                        // pyx:643-654 (stop_test 2: evaluate only)
       if (p->blind) { if (M_r > M_r_prev) stop = 1; }
       else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
     }
     ++it;
+    if (p->progress) p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu);   // pyx:593,648,658-659: where the reference prints
   }
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));

@@ -20,6 +20,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <atomic>
 
 #define ICS_TILE 64 /* tile edge in pixels; frames are padded to a multiple of it */
 
@@ -53,6 +56,68 @@ static inline IcsGeom ics_make_geom(int M, int N, int K) {
 }
 static inline size_t ics_frame_floats(const IcsGeom& g) { return (size_t)g.rows * g.pitch; }
 static inline size_t ics_origin_offset(const IcsGeom& g) { return (size_t)g.ay * g.pitch + 3 * (size_t)g.ax; }
+
+// ---- per-device launcher state ----------------------------------------------------------------------------------------
+// The launchers keep two things per device: the compute-unit count and "the dynamic-LDS attribute of this kernel is set".
+// lib/banded.py drives one job per band from one host thread each, so these are atomics; the attribute call is idempotent, a
+// lost race only repeats it.
+#define ICS_MAX_DEVICES 64
+static inline int ics_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= ICS_MAX_DEVICES) dev = 0;
+  return dev;
+}
+static inline int ics_device_cus(int dev) {
+  static std::atomic<int> cus[ICS_MAX_DEVICES];   // static storage: zero
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+// `done` = one std::atomic<bool> per device, static in the launcher (one array per kernel instance)
+template <typename Kern>
+static inline hipError_t ics_configure_lds(std::atomic<bool>* done, int dev, Kern kern, size_t bytes) {
+  if (done[dev].load(std::memory_order_acquire)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return e; }   // do not leave a sticky error behind
+  done[dev].store(true, std::memory_order_release);
+  return hipSuccess;
+}
+
+// ---- process-wide switches for tests and A/B measurements (ics_debug.h; NOT part of include/ics_hip.h) -------------------
+// Read from the environment ONCE (first use), changed at run time through ics_debug_set(): no getenv on any launch path.
+struct IcsDebug {
+  std::atomic<int> max_wgs;           // ICS_TEST_MAX_WGS      cap on persistent workgroups, 0 = none (tests: many tiles per workgroup)
+  std::atomic<int> dynamic_tiles;     // ICS_DYNAMIC_TILES     -1 launcher decides, 0 static walk, 1 dynamic tile claiming
+  std::atomic<int> conv_rs;           // ICS_TEST_CONV_RS      0 launcher decides, 2 / 4 = force 32- / 64-row tiles where both are built
+  std::atomic<int> conv_nh;           // ICS_TEST_CONV_NH      harness builds only: 1 = 4-wave form of the K >= 23 kernels
+  std::atomic<int> conv_path;         // ICS_CONV_PATH         what ICS_CONV_AUTO resolves to: 0 default, 1 vector, 2 matrix
+  std::atomic<int> fused_gradk;       // ICS_FUSED_GRADK       0 = two-kernel A11 + A13 (like ICS_FLAG_NO_FUSED_GRADK)
+  std::atomic<int> update_wg_per_cu;  // ICS_UPDATE_WG_PER_CU  0 launcher decides
+  std::atomic<int> update_kernel;     // ICS_UPDATE_KERNEL     0 = the pixel-group kernel everywhere
+  std::atomic<int> fused_rs;          // ICS_FUSED_RS          0 launcher decides, 2 / 4 = tile height of the fused A11 + A13 kernel
+  std::atomic<int> planar_image;      // ICS_PLANAR_IMAGE      0 = epilogues read the HWC image frame (no accumulator-order copy)
+  static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
+  IcsDebug() {
+    max_wgs = env_int("ICS_TEST_MAX_WGS", 0);
+    dynamic_tiles = env_int("ICS_DYNAMIC_TILES", -1);
+    conv_rs = env_int("ICS_TEST_CONV_RS", 0);
+    conv_nh = env_int("ICS_TEST_CONV_NH", 0);
+    const char* cp = getenv("ICS_CONV_PATH");
+    conv_path = !cp ? 0 : (cp[0] == 'v' ? 1 : (cp[0] == 'm' ? 2 : 0));
+    fused_gradk = env_int("ICS_FUSED_GRADK", 1);
+    update_wg_per_cu = env_int("ICS_UPDATE_WG_PER_CU", 0);
+    update_kernel = env_int("ICS_UPDATE_KERNEL", 1);
+    fused_rs = env_int("ICS_FUSED_RS", 0);
+    planar_image = env_int("ICS_PLANAR_IMAGE", 1);
+  }
+};
+// one instance per process (inline function, function-local static: initialised once, thread-safe)
+inline IcsDebug& ics_debug() { static IcsDebug d; return d; }
+// extern "C" int ics_debug_set(const char* name, int value) -- exported by libics_hip.so for the tests (lib/_native.py
+// debug_set), declared here only: names = the lower-case field names above; returns 0, or -1 for an unknown name
 
 // Order-preserving float <-> uint32 key so that atomicMax/atomicMin on the key is a float max/min.
 // Key 0 is below every float (used as the "empty" value for max), 0xFFFFFFFF above (for min).

@@ -412,18 +412,13 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
 template <int K, int R, int MODE, int NTY>
 hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   using C = ConvCfg<K, R, NTY>;
-  static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];  // per device: the dynamic-LDS attribute is a per-device function property
+  const int dev = ics_current_device();
   // waves per SIMD the kernel is compiled for: 3 (<= 168 VGPRs, single-buffered strips) when three
   // workgroups fit the LDS, else 2 (<= 256 VGPRs, ping-pong strips)
   constexpr int WPE = (NTY == 32) ? 4 : ((3 * C::LDS_BYTES <= 160 * 1024) ? 3 : 2);
   auto kern = k_conv<K, R, MODE, WPE, NTY>;
-  if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return e; }  // do not leave a sticky error behind
-    configured[dev] = true;
-  }
+  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   dim3 grid(a.g.tiles_x * a.g.tiles_y * (ICS_TILE / C::TH));
   hipLaunchKernelGGL(kern, grid, dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();

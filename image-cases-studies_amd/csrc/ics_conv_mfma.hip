@@ -632,30 +632,20 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
 template <int K, int MODE, int RS, int NH = 1>
 hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   using C = MCfg<K, RS, NH>;
-  static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
-  static int cus[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];  // per device: the dynamic-LDS attribute is a per-device function property
+  const int dev = ics_current_device();
   auto kern = k_conv_mfma<K, MODE, RS, NH>;
-  if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-    configured[dev] = true;
-  }
-  if (!cus[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-    cus[dev] = n;
-  }
+  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
+  const int ncu = ics_device_cus(dev);
   const int ntiles = MODE == 0 ? ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH) : a.g.tiles_x * ((a.g.uM + C::TH - 1) / C::TH);
-  int grid = C::WGS * cus[dev];              // persistent workgroups: as many as fit the LDS of a CU
+  int grid = C::WGS * ncu;                   // persistent workgroups: as many as fit the LDS of a CU
 #ifdef ICS_GRID_WGS
-  grid = ICS_GRID_WGS * cus[dev];
+  grid = ICS_GRID_WGS * ncu;
 #endif
   if (grid > ntiles) grid = ntiles;
   // test hook: fewer persistent workgroups, so that small frames make every workgroup walk several tiles (next-tile
   // prefetch, band split) -- tests/test_gpu_rl.py::test_blind_golden_576x520_multi_tile_walk
-  if (const char* e = getenv("ICS_TEST_MAX_WGS")) { const int m = atoi(e); if (m > 0 && grid > m) grid = m; }
+  if (const int m = ics_debug().max_wgs.load(std::memory_order_relaxed); m > 0 && grid > m) grid = m;
   // Dynamic tile claiming (a.sched) pays when a workgroup walks many tiles -- the edge tiles are cheaper and the static walk leaves
   // a partial last round -- and costs when it walks few (the claim's round trip is exposed).  Measured on MI355X, static -> dynamic,
   // ms per inner iteration: 4096^2 15x15 (10.7 tiles per workgroup) blind 0.868 -> 0.847, non-blind 0.551 -> 0.545; 6144^2 31x31
@@ -663,8 +653,8 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
   // Hence: from 8 tiles per workgroup on.  ICS_DYNAMIC_TILES=0|1 forces either.
   IcsConvArgs b = a;
   if (b.sched) {
-    const char* e = getenv("ICS_DYNAMIC_TILES");
-    const bool on = e ? e[0] == '1' : ntiles >= 8 * grid;
+    const int dyn = ics_debug().dynamic_tiles.load(std::memory_order_relaxed);
+    const bool on = dyn >= 0 ? dyn == 1 : ntiles >= 8 * grid;
     if (!on) b.sched = nullptr;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(C::NT), C::LDS_BYTES, s, b);
@@ -684,7 +674,8 @@ template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
   bool rs2 = K <= 21 && (K >= 15 || (long)a.g.tiles_x * a.g.tiles_y <= 3000);
   if (TileRs<K>::has2 && TileRs<K>::has4) {   // test / harness hook: force a tile height where both are built
-    if (const char* e = getenv("ICS_TEST_CONV_RS")) rs2 = atoi(e) == 2 ? true : (atoi(e) == 4 ? false : rs2);
+    const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
+    rs2 = frs == 2 ? true : (frs == 4 ? false : rs2);
   }
   if constexpr (TileRs<K>::has2) {
     if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2>(a, s) : launch_one<K, 1, 2>(a, s);
@@ -694,8 +685,8 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
       // one workgroup per CU: 8 waves, kernel rows split between the two waves of a column block (MCfg NH = 2).  Measured against the
       // 4-wave form (ICS_TEST_CONV_NH=1 in a build with ICS_MFMA_ALL_RS): 4096^2 K = 23 0.417 / 0.485 -> 0.390 / 0.448 ms,
       // 6144^2 K = 31 1.089 / 1.266 -> 1.077 / 1.197 ms
-      const char* e = ICS_MFMA_ALL_RS ? getenv("ICS_TEST_CONV_NH") : nullptr;
-      if (!(e && atoi(e) == 1)) return mode == 0 ? launch_one<K, 0, 4, 2>(a, s) : launch_one<K, 1, 4, 2>(a, s);
+      const int fnh = ICS_MFMA_ALL_RS ? ics_debug().conv_nh.load(std::memory_order_relaxed) : 0;
+      if (fnh != 1) return mode == 0 ? launch_one<K, 0, 4, 2>(a, s) : launch_one<K, 1, 4, 2>(a, s);
     }
     if constexpr (K < 23 || ICS_MFMA_ALL_RS) return mode == 0 ? launch_one<K, 0, 4>(a, s) : launch_one<K, 1, 4>(a, s);
   }

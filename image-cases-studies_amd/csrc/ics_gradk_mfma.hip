@@ -23,8 +23,8 @@
 // planes and rescaled by the ratio of the two tiles' power-of-two scales, which is exact in fp16 barring underflow of the lo
 // terms), and only TH new rows are requested, converted and stored.  A 32-row tile staged 47 rows of u per 32 residual rows
 // (16-row tiles of the 2 x 2-block kernel: 47 per 16): the PSF gradient moved 1.63x its algorithmic bytes (round-1 verdict);
-// with the strip walk u is read ~1.03x.  The scale of a tile covers the new rows and the previous tile's maximum (an upper bound
-// of the carried rows).
+// with the strip walk u is read ~1.03x.  The scale of a tile covers the new rows and the maximum of the carried rows (tracked
+// per tile over exactly those rows, so a bright pixel does not dictate the scale of the tiles below it).
 #include "ics_kernels.h"
 #include <type_traits>
 
@@ -88,6 +88,23 @@ __device__ __forceinline__ float wg_max(float m, float* scr, int wave, int lane)
 #pragma unroll
   for (int w = 0; w < 4; ++w) m = __builtin_fmaxf(m, scr[w]);
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+
+// three workgroup maxima behind ONE barrier (u scale, residual scale, carried-row bound)
+__device__ __forceinline__ void wg_max3(float& a, float& b, float& c, float* scr, int wave, int lane) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a = __builtin_fmaxf(a, __shfl_xor(a, off, 64));
+    b = __builtin_fmaxf(b, __shfl_xor(b, off, 64));
+    c = __builtin_fmaxf(c, __shfl_xor(c, off, 64));
+  }
+  if (lane == 0) { scr[wave] = a; scr[8 + wave] = b; scr[16 + wave] = c; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { a = __builtin_fmaxf(a, scr[w]); b = __builtin_fmaxf(b, scr[8 + w]); c = __builtin_fmaxf(c, scr[16 + w]); }
+  a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)));
+  b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b)));
+  c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c)));
 }
 
 // 4 pixels (12 floats, HWC) -> hi/lo halves of three planes
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int t0 = (int)((long)ntiles * blockIdx.x / gridDim.x), t1 = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
   f32x4u pu[C::UIT][3], pe[C::EIT][3];
   if (t0 < t1) load_tile<NB>(pu, pe, rs_u, rs_e, G, nty, t0, false, tid);
-  float mu_prev = 0.f, s_prev = 1.f;
+  float mu_prev = 0.f, mc_last = 0.f, s_prev = 1.f;
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
     // the tile above in the same strip was the previous tile of this workgroup: its last NT - 1 rows of u are this tile's first
@@ -215,14 +232,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int r0 = carry ? C::NT - 1 : 0;
     const int ntask = (C::UROWS - r0) * C::UXG;
     // ---- the rows of this tile are in registers (requested during the previous tile's MFMA phase) ----------
-    float mu = carry ? mu_prev : 0.f, me = 0.f;
+    // mc: maximum over the rows in registers that the NEXT tile of the strip inherits (staged rows >= TH).  It is the carried bound of the next tile's scale: with the maximum of the whole
+    // tile instead, one bright pixel at the top of a strip set the split scale of every tile below it (round-2 advice).
+    float mu = carry ? mu_prev : 0.f, me = 0.f, mc = 0.f;
 #pragma unroll
     for (int k = 0; k < C::UIT; ++k)
       if (k * C::NTH < ntask) {
+        float mk = 0.f;
 #pragma unroll
         for (int h = 0; h < 3; ++h)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) mu = __builtin_fmaxf(mu, __builtin_fabsf(pu[k][h][e]));
+          for (int e = 0; e < 4; ++e) mk = __builtin_fmaxf(mk, __builtin_fabsf(pu[k][h][e]));
+        mu = __builtin_fmaxf(mu, mk);
+        const int v = tid + k * C::NTH;
+        if (v < ntask && r0 + v / C::UXG >= C::TH) mc = __builtin_fmaxf(mc, mk);
       }
 #pragma unroll
     for (int k = 0; k < C::EIT; ++k)
@@ -231,8 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int e = 0; e < 4; ++e) me = __builtin_fmaxf(me, __builtin_fabsf(pe[k][h][e]));
     __syncthreads();                       // previous tile's planes fully consumed (and fscr free)
-    mu = wg_max(mu, fscr, wave, lane);
-    me = wg_max(me, fscr + 8, wave, lane);
+    wg_max3(mu, me, mc, fscr, wave, lane);
     float s_u, inv_u, s_e, inv_e;
     pow2_scale(mu, s_u, inv_u);
     pow2_scale(me, s_e, inv_e);
@@ -255,14 +277,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
 #pragma unroll
-    for (int k = 0; k < C::UIT; ++k) {
-      const int v = tid + k * C::NTH;
-      if (v < ntask) {
-        const int row = r0 + v / C::UXG, xg = v % C::UXG;
-        split_store(pu[k], s_u, lds + C::UOFF + row * C::UROWB + 8 * xg, C::UPLANE);
-      }
-    }
-#pragma unroll
     for (int k = 0; k < C::EIT; ++k) {
       const int v = tid + k * C::NTH;
       if (v < C::ETASK) {
@@ -270,7 +284,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         split_store_interleaved(pe[k], s_e, lds + C::EOFF + row * (2 * C::EROWB) + 16 * xg, 2 * C::EPLANE);
       }
     }
-    mu_prev = mu; s_prev = s_u;
+    // The new rows land on [NT - 1, UROWS), which contains the SOURCE rows [TH + p0, TH + NT - 1) of the last carry pass: every
+    // wave must have finished reading them (round-2 advice: without this barrier a wave that was done early overwrote rows a
+    // lagging wave had not carried yet -- a mix of old and new u in the gradient, rarely and silently).  The residual planes
+    // above are independent of the carry and are written in front of the barrier.
+    if (carry) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < C::UIT; ++k) {
+      const int v = tid + k * C::NTH;
+      if (v < ntask) {
+        const int row = r0 + v / C::UXG, xg = v % C::UXG;
+        split_store(pu[k], s_u, lds + C::UOFF + row * C::UROWB + 8 * xg, C::UPLANE);
+      }
+    }
+    // NB = 2: TH = 16 < NT - 1 = 31, a row is carried through two tiles -- the inherited rows stem from the new rows of this
+    // tile and of the one before (all rows are new, i.e. in registers, on the first tile of a run or strip)
+    mu_prev = NB == 1 ? mc : __builtin_fmaxf(mc, carry ? mc_last : 0.f);
+    mc_last = mc; s_prev = s_u;
     __syncthreads();
 
     // next tile's rows: in flight during the whole MFMA phase (which issues no vector-memory load)
@@ -420,15 +450,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int NB>
 hipError_t launch_nb(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
   using C = GCfg<NB>;
-  static bool configured[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
   auto kern = k_gradk_mfma<NB>;
-  if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-    configured[dev] = true;
-  }
+  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }

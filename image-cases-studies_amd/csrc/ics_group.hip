@@ -18,13 +18,15 @@
 namespace {
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
-enum { RCCL_SUCCESS = 0, RCCL_MAX = 2, RCCL_FLOAT64 = 8 };
+enum { RCCL_SUCCESS = 0, RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT64 = 8 };
 struct Rccl {
   void* so;
   int (*GetUniqueId)(rcclUniqueId*);
   int (*CommInitRank)(rcclComm_t*, int, rcclUniqueId, int);
   int (*CommDestroy)(rcclComm_t);
+  int (*CommCount)(rcclComm_t, int*);
   const char* (*GetErrorString)(int);
+  char path[256];   // what dlopen resolved
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
   int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
 };
@@ -37,6 +39,7 @@ struct ics_group {
   int rank, world, device;
   bool local;        // world == 1: no communicator (ICS_GROUP_FORCE_RCCL=1 builds one anyway -- plumbing test on a 1-GPU box)
   rcclComm_t comm;
+  int nranks;        // ncclCommCount of the communicator
   hipStream_t stream;
   double* dbuf;      // device staging: (world + 1) * ICS_GROUP_MAX_COUNT doubles
 };
@@ -46,19 +49,26 @@ static int load_rccl() {
   if (g_rccl.so) return ICS_OK;
   const char* names[] = {getenv("ICS_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* so = nullptr;
-  for (const char* n : names) if (n && (so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  const char* used = "";
+  for (const char* n : names) if (n && (so = dlopen(n, RTLD_NOW | RTLD_LOCAL))) { used = n; break; }
   if (!so) return ics_set_error(ICS_ENODEV, "librccl.so not found (%s); set ICS_RCCL_LIB", dlerror());
   Rccl r = {};
   r.so = so;
+  snprintf(r.path, sizeof r.path, "%s", used);
   r.GetUniqueId = (int (*)(rcclUniqueId*))dlsym(so, "ncclGetUniqueId");
   r.CommInitRank = (int (*)(rcclComm_t*, int, rcclUniqueId, int))dlsym(so, "ncclCommInitRank");
   r.CommDestroy = (int (*)(rcclComm_t))dlsym(so, "ncclCommDestroy");
+  r.CommCount = (int (*)(rcclComm_t, int*))dlsym(so, "ncclCommCount");
   r.GetErrorString = (const char* (*)(int))dlsym(so, "ncclGetErrorString");
   r.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(so, "ncclAllReduce");
   r.AllGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))dlsym(so, "ncclAllGather");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.GetErrorString || !r.AllReduce || !r.AllGather) {
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.GetErrorString || !r.AllReduce || !r.AllGather) {
     dlclose(so);
     return ics_set_error(ICS_ENODEV, "librccl.so lacks an expected ncclXxx symbol");
+  }
+  {  // the file behind the handle (for ics_group_describe): the soname alone does not say which RCCL was loaded
+    Dl_info info;
+    if (dladdr((void*)r.GetUniqueId, &info) && info.dli_fname) snprintf(r.path, sizeof r.path, "%s", info.dli_fname);
   }
   g_rccl = r;
   return ICS_OK;
@@ -72,7 +82,7 @@ extern "C" int ics_group_create(int device, int rank, int world, const char* ren
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) return ics_set_error(ICS_EINVAL, "rank %d of %d", rank, world);
   ics_group* g = new ics_group();
-  g->rank = rank; g->world = world; g->device = device; g->comm = nullptr; g->stream = nullptr; g->dbuf = nullptr;
+  g->rank = rank; g->world = world; g->device = device; g->comm = nullptr; g->stream = nullptr; g->dbuf = nullptr; g->nranks = 0;
   const char* force = getenv("ICS_GROUP_FORCE_RCCL");
   g->local = world == 1 && !(force && force[0] == '1');
   if (g->local) { *out = g; return ICS_OK; }   // nothing to exchange: no RCCL, no device
@@ -88,18 +98,25 @@ extern "C" int ics_group_create(int device, int rank, int world, const char* ren
   if (he == hipSuccess) he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
   if (he == hipSuccess) he = hipMalloc((void**)&g->dbuf, (size_t)(world + 1) * ICS_GROUP_MAX_COUNT * sizeof(double));
   if (he != hipSuccess) { ics_group_destroy(g); return ics_set_error(ICS_EHIP, "group setup on device %d: %s", device, hipGetErrorString(he)); }
-  // unique id: rank 0 -> file (written under a temporary name, then renamed) -> the other ranks poll for it
+  // unique id: rank 0 -> file (written under a temporary name, then renamed) -> the other ranks poll for it.  The path must be
+  // unique to the launch (multi_gpu.rendezvous_path: master port + launcher pid + launcher start time): rank 0 removes whatever a
+  // failed earlier launch left under that name BEFORE it publishes, and every failure path below removes the file again.
   rcclUniqueId id;
   memset(&id, 0, sizeof id);
   char tmp[1024];
   snprintf(tmp, sizeof tmp, "%s.tmp", rendezvous);
   if (rank == 0) {
+    unlink(rendezvous); unlink(tmp);
     int r = g_rccl.GetUniqueId(&id);
     if (r != RCCL_SUCCESS) { ics_group_destroy(g); return ics_set_error(ICS_EHIP, "ncclGetUniqueId: %s", g_rccl.GetErrorString(r)); }
     FILE* f = fopen(tmp, "wb");
-    if (!f || fwrite(&id, sizeof id, 1, f) != 1 || fclose(f) != 0 || rename(tmp, rendezvous) != 0) {
+    const bool ok = f && fwrite(&id, sizeof id, 1, f) == 1;
+    const bool closed = f ? fclose(f) == 0 : false;
+    if (!ok || !closed || rename(tmp, rendezvous) != 0) {
+      const int en = errno;
+      unlink(tmp); unlink(rendezvous);
       ics_group_destroy(g);
-      return ics_set_error(ICS_EINVAL, "cannot write the rendezvous file %s: %s", rendezvous, strerror(errno));
+      return ics_set_error(ICS_EINVAL, "cannot write the rendezvous file %s: %s", rendezvous, strerror(en));
     }
   } else {
     bool got = false;
@@ -111,7 +128,21 @@ extern "C" int ics_group_create(int device, int rank, int world, const char* ren
     if (!got) { ics_group_destroy(g); return ics_set_error(ICS_ESTATE, "rank %d: no RCCL id at %s after %d s (is rank 0 running?)", rank, rendezvous, timeout_s); }
   }
   int r = g_rccl.CommInitRank(&g->comm, world, id, rank);
-  if (r != RCCL_SUCCESS) { g->comm = nullptr; ics_group_destroy(g); return ics_set_error(ICS_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r)); }
+  if (r != RCCL_SUCCESS) {
+    g->comm = nullptr; ics_group_destroy(g);
+    if (rank == 0) unlink(rendezvous);
+    return ics_set_error(ICS_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(r));
+  }
+  {  // the communicator must span `world` ranks: a stale id or a partial group would otherwise go unnoticed
+    int n = 0;
+    r = g_rccl.CommCount(g->comm, &n);
+    if (r != RCCL_SUCCESS || n != world) {
+      ics_group_destroy(g);
+      if (rank == 0) unlink(rendezvous);
+      return ics_set_error(ICS_ESTATE, "RCCL communicator spans %d rank(s), expected %d", n, world);
+    }
+    g->nranks = n;
+  }
   *out = g;
   // every rank has read the id once the communicator exists: the file can go
   if (rank == 0) unlink(rendezvous);
@@ -152,15 +183,26 @@ extern "C" int ics_group_allgather(ics_group* g, const double* send, int count, 
   return ICS_OK;
 }
 
-extern "C" int ics_group_allreduce_max(ics_group* g, double* inout, int count) {
+static int allreduce(ics_group* g, double* inout, int count, int op) {
   if (!g || !inout) return ics_set_error(ICS_EINVAL, "NULL argument");
   if (count < 1 || count > ICS_GROUP_MAX_COUNT) return ics_set_error(ICS_EINVAL, "count %d (1..%d)", count, ICS_GROUP_MAX_COUNT);
   if (g->local) return ICS_OK;
   GHIP(hipSetDevice(g->device));
   GHIP(hipMemcpyAsync(g->dbuf, inout, (size_t)count * sizeof(double), hipMemcpyHostToDevice, g->stream));
-  GRCCL(g_rccl.AllReduce(g->dbuf, g->dbuf, (size_t)count, RCCL_FLOAT64, RCCL_MAX, g->comm, g->stream));
+  GRCCL(g_rccl.AllReduce(g->dbuf, g->dbuf, (size_t)count, RCCL_FLOAT64, op, g->comm, g->stream));
   GHIP(hipMemcpyAsync(inout, g->dbuf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, g->stream));
   GHIP(hipStreamSynchronize(g->stream));
+  return ICS_OK;
+}
+extern "C" int ics_group_allreduce_max(ics_group* g, double* inout, int count) { return allreduce(g, inout, count, RCCL_MAX); }
+// (the row-band split adds the bands' 3 K^2 PSF-gradient partial sums with it, in chunks of 64)
+extern "C" int ics_group_allreduce_sum(ics_group* g, double* inout, int count) { return allreduce(g, inout, count, RCCL_SUM); }
+
+extern "C" int ics_group_describe(const ics_group* g, int* backend, int* nranks, char* lib, size_t lib_len) {
+  if (!g) return ics_set_error(ICS_EINVAL, "group is NULL");
+  if (backend) *backend = g->local ? 0 : 1;
+  if (nranks) *nranks = g->local ? 1 : g->nranks;
+  if (lib && lib_len) { snprintf(lib, lib_len, "%s", g->local ? "" : g_rccl.path); }
   return ICS_OK;
 }
 

@@ -753,19 +753,11 @@ hipError_t ics_launch_update(const IcsUpdateArgs& a, hipStream_t s) {
   // ... and at smaller frames fewer still: 2048^2 0.0568 / 0.0526 / 0.0565 ms and 3072^2 0.119 / 0.099 / 0.102 ms with 1 / 2 / 3 per CU,
   // 1024^2 0.0252 / 0.0265 / 0.0299
   const long px = (long)a.geo.uM * a.geo.uN;
-  static const int per_cu_env = getenv("ICS_UPDATE_WG_PER_CU") ? atoi(getenv("ICS_UPDATE_WG_PER_CU")) : 0;
+  const int per_cu_env = ics_debug().update_wg_per_cu.load(std::memory_order_relaxed);
   const int per_cu = per_cu_env > 0 ? per_cu_env : (px >= 12000000L ? 3 : (px >= 1500000L ? 2 : 1));
-  static int cus[64] = {};   // per device
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!cus[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
-    cus[dev] = n;
-  }
-  const long cap = (long)cus[dev] * (per_cu > 0 ? per_cu : 3);
+  const long cap = (long)ics_device_cus(ics_current_device()) * (per_cu > 0 ? per_cu : 3);
   if (blocks > cap) blocks = cap;
-  static const int rows_kernel = getenv("ICS_UPDATE_KERNEL") ? atoi(getenv("ICS_UPDATE_KERNEL")) : 1;   // 0: the pixel-group kernel everywhere
+  const int rows_kernel = ics_debug().update_kernel.load(std::memory_order_relaxed);   // 0: the pixel-group kernel everywhere
   const int tvk = (a.tv && a.tv_kind) ? (a.tv_kind >= 2 ? 2 : 1) : 0;
   if (rows_kernel && tvk == 0) hipLaunchKernelGGL(k_update_rows<0>, dim3((unsigned)cap), dim3(256), 0, s, a);
   else if (rows_kernel && tvk == 1) hipLaunchKernelGGL(k_update_rows<1>, dim3((unsigned)cap), dim3(256), 0, s, a);
@@ -778,7 +770,7 @@ int ics_gradk_blocks(const IcsGeom& g, int cus) {
   const int nb = (g.K + 15) / 16;
   const int tiles = g.tiles_x * g.tiles_y * 2;
   int blocks = cus * (nb <= 2 ? 2 : 1);   // two persistent workgroups per CU where the matrix-core kernel exists
-  if (const char* e = getenv("ICS_TEST_MAX_WGS")) { const int m = atoi(e); if (m > 0 && blocks > m) blocks = m; }   // test hook (ics_conv_mfma.hip)
+  if (const int m = ics_debug().max_wgs.load(std::memory_order_relaxed); m > 0 && blocks > m) blocks = m;   // test hook (ics_debug.h)
   return blocks < tiles ? blocks : tiles;
 }
 
@@ -786,15 +778,10 @@ template <int NB>
 static hipError_t launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
   constexpr int NW = ICS_GRADK_WAVES;
   using C = GradkCfg<NB, NW>;
-  static bool configured[64] = {};  // per device: the dynamic-LDS attribute is a per-device function property
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];  // per device: the dynamic-LDS attribute is a per-device function property
+  const int dev = ics_current_device();
   auto kern = k_gradk<NB, NW>;
-  if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return e; }  // do not leave a sticky error behind
-    configured[dev] = true;
-  }
+  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }

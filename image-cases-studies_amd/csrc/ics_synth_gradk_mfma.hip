@@ -667,15 +667,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int K>
 hipError_t launch_k(const IcsFusedArgs& a, int nblocks, hipStream_t s) {
   using C = FCfg<K>;
-  static bool configured[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
   auto kern = k_synth_gradk<K>;
-  if (!configured[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    if (e != hipSuccess) { (void)hipGetLastError(); return e; }
-    configured[dev] = true;
-  }
+  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   const int ntiles = ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH);
   // every workgroup of the grid writes its partial block (the reduction reads `nblocks` of them): workgroups without a tile
   // write zeros

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libics_hip.so"))
 
-ICS_MAX_TRACE = 1024
+ICS_ABI_VERSION = 3
 ICS_KERNEL_COUNT = 12
 KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth",
                 "synth_gradk", "_9", "_10", "_11")
@@ -31,22 +31,40 @@ SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1"
                 "dof_min", "dof_max", "_")
 
 
+# void (*ics_rl_progress_fn)(void *user, int it, int stopped, float dof_min, float dof_max, float M_r, float Hu, float varu)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float)
+
+
 class RLParams(C.Structure):
-    _fields_ = [("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
+    _fields_ = [("struct_size", C.c_uint32), ("top", C.c_int), ("bottom", C.c_int), ("left", C.c_int), ("right", C.c_int),
                 ("tau", C.c_float), ("iterations", C.c_int), ("step_factor", C.c_float), ("lambd", C.c_float),
                 ("blind", C.c_int), ("correlation", C.c_int), ("channels", C.c_int), ("tv_mode", C.c_int),
-                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("flags", C.c_int), ("band_row0", C.c_int), ("band_row1", C.c_int)]
+                ("stop_test", C.c_int), ("profile", C.c_int), ("fuse", C.c_int), ("conv", C.c_int), ("flags", C.c_int), ("band_row0", C.c_int), ("band_row1", C.c_int),
+                ("progress", PROGRESS_FN), ("progress_user", C.c_void_p)]
 
 
 class RLStats(C.Structure):
-    _fields_ = [("iterations_done", C.c_int), ("stopped", C.c_int), ("has_nan", C.c_int),
+    """struct ics_rl_stats.  The per-outer-iteration traces live in caller-owned arrays (`with_traces(n)` allocates them as
+    numpy arrays and keeps them alive on the object: st.trace_M_r[:st.trace_len] etc. then read as before)."""
+    _fields_ = [("struct_size", C.c_uint32), ("iterations_done", C.c_int), ("stopped", C.c_int), ("has_nan", C.c_int),
                 ("M_r", C.c_float), ("Hu", C.c_float), ("varu", C.c_float),
-                ("dof_min", C.c_float), ("dof_max", C.c_float), ("trace_len", C.c_int),
-                ("trace_M_r", C.c_float * ICS_MAX_TRACE), ("trace_Hu", C.c_float * ICS_MAX_TRACE),
-                ("trace_varu", C.c_float * ICS_MAX_TRACE), ("trace_dof_min", C.c_float * ICS_MAX_TRACE),
-                ("trace_dof_max", C.c_float * ICS_MAX_TRACE),
+                ("dof_min", C.c_float), ("dof_max", C.c_float), ("trace_len", C.c_int), ("trace_cap", C.c_int),
+                ("_p_M_r", C.POINTER(C.c_float)), ("_p_Hu", C.POINTER(C.c_float)), ("_p_varu", C.POINTER(C.c_float)),
+                ("_p_dof_min", C.POINTER(C.c_float)), ("_p_dof_max", C.POINTER(C.c_float)),
                 ("ms_total", C.c_float), ("inner_iterations", C.c_int),
                 ("ms_kernel", C.c_float * ICS_KERNEL_COUNT), ("launches", C.c_int * ICS_KERNEL_COUNT)]
+    TRACES = ("M_r", "Hu", "varu", "dof_min", "dof_max")
+
+    @classmethod
+    def with_traces(cls, cap):
+        st = cls()
+        st.struct_size = C.sizeof(cls)
+        st.trace_cap = max(0, int(cap))
+        for name in cls.TRACES:
+            arr = np.zeros(max(1, st.trace_cap), np.float32)
+            setattr(st, "trace_" + name, arr)                       # plain attribute: keeps the buffer alive
+            setattr(st, "_p_" + name, arr.ctypes.data_as(C.POINTER(C.c_float)))
+        return st
 
 
 class NativeError(RuntimeError):
@@ -114,16 +132,25 @@ def load():
     lib.ics_group_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ics_group_barrier.argtypes = [vp]
     lib.ics_group_allreduce_max.argtypes = [vp, vp, ci]
+    lib.ics_group_allreduce_sum.argtypes = [vp, vp, ci]
+    lib.ics_group_describe.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.c_char_p, C.c_size_t]
+    lib.ics_rl_params_size.restype = C.c_size_t
+    lib.ics_rl_stats_size.restype = C.c_size_t
+    lib.ics_debug_set.argtypes = [C.c_char_p, ci]; lib.ics_debug_set.restype = ci      # csrc/ics_common.h IcsDebug, not in the public header
+    lib.ics_debug_get.argtypes = [C.c_char_p, C.POINTER(ci)]; lib.ics_debug_get.restype = ci
     lib.ics_group_allgather.argtypes = [vp, vp, ci, vp]
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
                  "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_rl_read_rows", "ics_rl_write_rows", "ics_rl_copy_rows", "ics_normalize_kernel",
                  "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
                  "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
                  "ics_rl_upload_img", "ics_rl_download_img", "ics_group_create", "ics_group_info", "ics_group_barrier",
-                 "ics_group_allreduce_max", "ics_group_allgather"):
+                 "ics_group_allreduce_max", "ics_group_allreduce_sum", "ics_group_describe", "ics_group_allgather"):
         getattr(lib, name).restype = ci
-    if lib.ics_abi_version() != 2:
-        raise ImportError("libics_hip.so ABI version %d, expected 2" % lib.ics_abi_version())
+    if lib.ics_abi_version() != ICS_ABI_VERSION:
+        raise ImportError("libics_hip.so ABI version %d, expected %d" % (lib.ics_abi_version(), ICS_ABI_VERSION))
+    if lib.ics_rl_params_size() != C.sizeof(RLParams) or lib.ics_rl_stats_size() != C.sizeof(RLStats):
+        raise ImportError("libics_hip.so struct sizes (%d, %d) differ from this binding's (%d, %d)" % (
+            lib.ics_rl_params_size(), lib.ics_rl_stats_size(), C.sizeof(RLParams), C.sizeof(RLStats)))
     _lib = lib
     return lib
 
@@ -135,6 +162,16 @@ def _check(rc):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def debug_set(name, value):
+    """test / measurement switches of the library (csrc/ics_common.h IcsDebug; e.g. "max_wgs", "dynamic_tiles", "conv_rs"):
+    read from the environment once at first use, changed at run time here.  Returns the previous value."""
+    lib = load()
+    old = C.c_int(0)
+    if lib.ics_debug_get(name.encode(), C.byref(old)) != 0 or lib.ics_debug_set(name.encode(), int(value)) != 0:
+        raise KeyError(name)
+    return old.value
 
 
 def device_count():
@@ -405,6 +442,7 @@ class RLJob:
     def params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation=0, channels=3,
                stop_test=1, profile=0, fuse=0, tv_mode=0, conv=0, flags=0, band_rows=(0, 0)):
         p = RLParams()
+        p.struct_size = C.sizeof(RLParams)
         p.top, p.bottom, p.left, p.right = int(top), int(bottom), int(left), int(right)
         p.tau, p.iterations, p.step_factor, p.lambd = float(tau), int(iterations), float(step_factor), float(lambd)
         p.blind, p.correlation, p.channels, p.tv_mode = int(bool(blind)), int(bool(correlation)), int(channels), int(tv_mode)
@@ -412,9 +450,18 @@ class RLJob:
         p.band_row0, p.band_row1 = int(band_rows[0]), int(band_rows[1])
         return p
 
-    def run(self, params):
-        st = RLStats()
-        _check(load().ics_rl_run(self._h, C.byref(params), C.byref(st)))
+    def run(self, params, progress=None):
+        """ics_rl_run.  `progress(it, stopped, dof_min, dof_max, M_r, Hu, varu)`, if given, is called after every outer iteration."""
+        st = RLStats.with_traces(params.iterations)
+        cb = None
+        if progress is not None:
+            cb = PROGRESS_FN(lambda _user, it, stopped, dmin, dmax, mr, hu, varu: progress(it, stopped, dmin, dmax, mr, hu, varu))
+            params.progress = cb
+        try:
+            _check(load().ics_rl_run(self._h, C.byref(params), C.byref(st)))
+        finally:
+            if cb is not None:
+                params.progress = PROGRESS_FN()     # NULL again: the closure dies with this call
         return st
 
     def stage(self, stage, params):

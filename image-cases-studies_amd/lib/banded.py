@@ -29,7 +29,7 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 
 from . import _native
-from .deconvolution import _check_buffer, _report
+from .deconvolution import _check_buffer, _progress, _report
 
 INNER = 5   # pyx:375
 
@@ -129,7 +129,7 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
         out["dof_max"] = float("nan") if nan else float(key2f(keys[:, 13].max()))
         return out
 
-    st = nv.RLStats()
+    st = nv.RLStats.with_traces(iterations)
     sc = {"Hu": float("nan"), "varu": float("nan")}
     it, stop = 0, 0
     M_r = M_r_prev = 0.0
@@ -170,16 +170,16 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
             if it > 0:
                 M_r_prev = M_r
             M_r = sc["M_r"]
-            slot = min(it, nv.ICS_MAX_TRACE - 1)
-            st.trace_M_r[slot], st.trace_Hu[slot], st.trace_varu[slot] = sc["M_r"], sc["Hu"], sc["varu"]
-            st.trace_dof_min[slot], st.trace_dof_max[slot] = sc["dof_min"], sc["dof_max"]
-            st.trace_len = slot + 1
+            st.trace_M_r[it], st.trace_Hu[it], st.trace_varu[it] = sc["M_r"], sc["Hu"], sc["varu"]
+            st.trace_dof_min[it], st.trace_dof_max[it] = sc["dof_min"], sc["dof_max"]
+            st.trace_len = it + 1
             if it > 1:                                                                    # pyx:643-654
                 if blind:
                     stop = int(M_r > M_r_prev)
                 else:
                     stop = int((M_r - M_r_prev) / (M_r + M_r_prev) > tau)
             it += 1
+            _progress(it, stop, sc["dof_min"], sc["dof_max"], sc["M_r"], sc["Hu"], sc["varu"])  # pyx:593,648,658-659
         # gather: every band's owned rows -> the caller's u (in place, pyx:675), PSF of band 0
         rows = par(lambda bd: bd.job.read_rows(nv.BUF_U, bd.lu0, bd.lu1 - bd.lu0))
         for bd, r in zip(B, rows):

@@ -19,7 +19,8 @@ Behaviour kept from the reference:
     receives the first gradient step because pyx:585 rebinds the local name.
   * `p, norm, order, priority, refocus` are accepted and ignored; `iterations` counts OUTER
     iterations of 5 inner ones (pyx:375).
-  * The reference's progress lines are printed (after the device run, from the returned trace).
+  * The reference's progress lines are printed as the run proceeds (one callback per outer iteration), any number of
+    outer iterations.
 Extras: `richardson_lucy_MM.last` holds the `RLStats` of the most recent call.
 """
 from __future__ import annotations
@@ -76,14 +77,17 @@ def normalize_kernel(kern, MK):
     kern[:MK, :MK, :3] = work
 
 
+def _progress(it, stopped, dof_min, dof_max, M_r, Hu, varu):
+    """the reference's per-outer-iteration lines (pyx:593,648,658-659), printed live from ics_rl_run's callback"""
+    print("DoF : min = %f | max = %f" % (dof_min, dof_max))
+    if stopped:
+        print("white autocorellation condition met")
+    if it % 50 == 0:
+        print("%i iterations completed" % it)
+
+
 def _report(st, top, bottom, left, right, lambd):
-    """the reference's stdout (pyx:593,648,658-672), printed after the device run from the returned trace"""
-    for it in range(st.trace_len):
-        print("DoF : min = %f | max = %f" % (st.trace_dof_min[it], st.trace_dof_max[it]))
-        if st.stopped and it == st.iterations_done - 1:
-            print("white autocorellation condition met")
-        if (it + 1) % 50 == 0:
-            print("%i iterations completed" % (it + 1))
+    """the reference's closing lines (pyx:661-672)"""
     if st.stopped:
         print("Convergence after %i iterations." % st.iterations_done)
     else:
@@ -92,6 +96,25 @@ def _report(st, top, bottom, left, right, lambd):
         1000 * st.M_r / ((bottom - top) * (right - left) * 3), np.float32(lambd), st.Hu, st.varu))
     if st.has_nan:
         print("has NaN after DoF correction")
+
+
+class DeviceWindow:
+    """What `richardson_lucy_MM_device` returns: the counterpart of the reference's returned view u[pad:pad+M, pad:pad+N]
+    (pyx:675) for a device-resident frame -- the image and the rectangle, nothing is copied until `.to_host()` / `.crop()`."""
+
+    def __init__(self, image, y0, x0, H, W):
+        self.image, self.y0, self.x0, self.H, self.W = image, int(y0), int(x0), int(H), int(W)
+        self.shape = (self.H, self.W, 3)
+
+    def crop(self):
+        return self.image.crop(self.y0, self.y0 + self.H, self.x0, self.x0 + self.W)
+
+    def to_host(self):
+        c = self.crop()
+        try:
+            return c.to_host()
+        finally:
+            c.close()
 
 
 def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom, left, right, tau, M, N, C, MK, iterations,
@@ -110,12 +133,14 @@ def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom
     job.upload_img(image, image_origin, u, u_origin, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
                         tv_mode=tv_mode, conv=conv, flags=flags)
-    st = job.run(params)
+    st = job.run(params, progress=_progress)
     job.download_img(u, u_origin)
     if blind:
         psf[...] = job.download_psf_caller()
     _report(st, top, bottom, left, right, lambd)
     richardson_lucy_MM.last = st
+    pad = MK // 2
+    return DeviceWindow(u, u_origin[0] + pad, u_origin[1] + pad, M, N)                       # pyx:675
 
 
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
@@ -146,7 +171,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     job.upload(image, u, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
                         tv_mode=tv_mode, conv=conv, flags=flags)
-    st = job.run(params)
+    st = job.run(params, progress=_progress)
     u_new, _psf_local, psf_caller = job.download()
     u[...] = u_new                                                             # in place, any strides
     if blind:

@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define ICS_ABI_VERSION 2
+#define ICS_ABI_VERSION 3 /* 3: self-describing ics_rl_params / ics_rl_stats (struct_size first), caller-owned traces,
+                             per-outer-iteration callback, ics_group_allreduce_sum */
 
 /* error codes */
 #define ICS_OK 0
@@ -68,9 +69,17 @@ int ics_ctx_info(ics_ctx *ctx, char *name, size_t name_len, int *compute_units, 
 
 /* ---- Richardson-Lucy / MM job (lib/deconvolution.pyx:341-675) --------------------------- */
 
+/* Called by ics_rl_run on the calling thread right after each outer iteration's statistics are known (pyx:593-659: the point
+ * where the reference prints its progress lines), so that a binding can print them live.  `it` = outer iterations completed
+ * (1-based), `stopped` = the stop test fired on this iteration. */
+typedef void (*ics_rl_progress_fn)(void *user, int it, int stopped, float dof_min, float dof_max, float M_r, float Hu, float varu);
+
 /* Arguments of richardson_lucy_MM that are scalars (pyx:341-342).  `p, norm, order, priority,
- * refocus` are accepted and ignored by the reference and therefore absent. */
+ * refocus` are accepted and ignored by the reference and therefore absent.
+ * struct_size MUST be sizeof(ics_rl_params) of the header the caller was built against: the library refuses any other
+ * value with ICS_EINVAL instead of reading fields the caller never wrote (ics_rl_params_size() returns what it expects). */
 typedef struct ics_rl_params {
+  uint32_t struct_size;         /* = sizeof(ics_rl_params)                                 */
   int top, bottom, left, right; /* stats window, image coordinates (pyx:600-601,627)      */
   float tau;                    /* non-blind stop threshold (pyx:652)                      */
   int iterations;               /* max OUTER iterations, 5 inner each (pyx:375,460)        */
@@ -98,7 +107,10 @@ typedef struct ics_rl_params {
   int band_row0, band_row1;     /* ICS_STAGE_BAND_* only: the rows [row0, row1) this job OWNS when one image is split into
                                    row bands over several jobs / GPUs; u-frame rows for BAND_REDUCE,
                                    image rows for BAND_MASK_E.  Ignored everywhere else.                                */
+  ics_rl_progress_fn progress;  /* NULL or the per-outer-iteration callback above (ics_rl_run only)                   */
+  void *progress_user;
 } ics_rl_params;
+size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was built */
 
 #define ICS_FLAG_NO_FUSED_GRADK 1 /* blind, matrix-core path, MK <= 15: run A11 and A13 as two kernels (k_conv_mfma<K,0> +
                                      k_gradk_mfma) instead of the fused k_synth_gradk (ics_synth_gradk_mfma.hip); env
@@ -135,21 +147,20 @@ typedef struct ics_rl_params {
                               pyx:555-589; no majoriser term, no DoF blend (oracle/rl_ext_oracle.py)  */
 #define ICS_TV_PAM_COLLAB 3 /* same with the collaborative L-inf,1,1 RGB TV gradient (README.md:113-114) */
 
-/* Scalars the reference only prints (pyx:593,648,659,665-669).  Arrays are per outer iteration
- * and hold at most ICS_MAX_TRACE entries (later iterations overwrite the last slot). */
-#define ICS_MAX_TRACE 1024
+/* Scalars the reference only prints (pyx:593,648,659,665-669).  The per-outer-iteration traces go into CALLER-OWNED arrays
+ * of `trace_cap` floats each (any of them may be NULL; trace_cap = params.iterations holds every iteration -- the reference
+ * has no limit on the number of outer iterations and neither has this).  struct_size as in ics_rl_params; the library
+ * preserves struct_size, trace_cap and the five pointers and overwrites everything else. */
 typedef struct ics_rl_stats {
+  uint32_t struct_size; /* in: sizeof(ics_rl_stats)                                        */
   int iterations_done; /* `it` at exit                                                    */
   int stopped;         /* stop_flag                                                       */
   int has_nan;         /* np.any(np.isnan(u)) (pyx:671)                                   */
   float M_r, Hu, varu; /* values at exit (pyx:669)                                        */
   float dof_min, dof_max;
-  int trace_len;
-  float trace_M_r[ICS_MAX_TRACE];
-  float trace_Hu[ICS_MAX_TRACE];
-  float trace_varu[ICS_MAX_TRACE];
-  float trace_dof_min[ICS_MAX_TRACE];
-  float trace_dof_max[ICS_MAX_TRACE];
+  int trace_len;       /* out: entries written = min(iterations_done, trace_cap)          */
+  int trace_cap;       /* in                                                              */
+  float *trace_M_r, *trace_Hu, *trace_varu, *trace_dof_min, *trace_dof_max; /* in: arrays of trace_cap floats or NULL */
   /* timing of the last ics_rl_run, measured with HIP events on the job's stream */
   float ms_total;      /* whole run (first launch -> last kernel), device time             */
   int inner_iterations;/* inner iterations executed                                       */
@@ -157,6 +168,7 @@ typedef struct ics_rl_stats {
   float ms_kernel[12];  /* ICS_KERNEL_COUNT */
   int launches[12];
 } ics_rl_stats;
+size_t ics_rl_stats_size(void);
 
 /* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 63):
  * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376. */
@@ -286,6 +298,10 @@ void ics_group_destroy(ics_group *g);
 int ics_group_info(const ics_group *g, int *rank, int *world);
 int ics_group_barrier(ics_group *g);
 int ics_group_allreduce_max(ics_group *g, double *inout, int count);
+int ics_group_allreduce_sum(ics_group *g, double *inout, int count); /* summed in rank order by RCCL (ncclSum, float64) */
+/* How the group is connected: *backend = 0 local (world 1, no communicator), 1 RCCL; *nranks = ranks RCCL reports for the
+ * communicator (ncclCommCount), lib = path or soname of the RCCL library in use ("" when local). */
+int ics_group_describe(const ics_group *g, int *backend, int *nranks, char *lib, size_t lib_len);
 int ics_group_allgather(ics_group *g, const double *send, int count, double *recv /* world * count */);
 
 #ifdef __cplusplus

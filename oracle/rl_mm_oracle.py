@@ -429,6 +429,32 @@ def synth_case(M, N, MK, seed=0, blind=False, noise=1e-3, per_channel_psf=False)
     return dict(image=image, u0=u0, psf0=psf0, psf_true=psf_true.astype(np.float32), pad=pad)
 
 
+def synth_case_large(M, N, MK, seed=0, blind=False, noise=1e-3):
+    """synth_case for BASELINE-size frames (2048^2 ... 6144^2): the same recipe with the true Gaussian PSF applied as a row
+    pass and a column pass (it is an outer product), elementwise float64 operations only -- seconds instead of minutes, and
+    bit-reproducible wherever numpy is.  Used by oracle/make_golden_baseline.py and the tests that read its fixtures."""
+    rng = np.random.default_rng(seed)
+    pad = MK // 2
+    sharp = rng.random((M + 2 * pad, N + 2 * pad, 3), dtype=np.float32).astype(np.float64)
+    sharp = _smooth7(sharp) * 0.8 + 0.1
+    n = np.arange(MK) - (MK - 1) / 2.0
+    w = np.exp(-0.5 * (n / (MK / 6.0)) ** 2)
+    w /= w.sum()
+    t = np.zeros((M, N + 2 * pad, 3))
+    for i in range(MK):
+        t += w[i] * sharp[i:i + M]
+    image = np.zeros((M, N, 3))
+    for i in range(MK):
+        image += w[i] * t[:, i:i + N]
+    del t, sharp
+    image += noise * rng.standard_normal(image.shape)
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    u0 = np.ascontiguousarray(np.pad(image, ((pad, pad), (pad, pad), (0, 0)), mode="edge"), dtype=np.float32)
+    psf_true = gaussian_psf(MK)
+    psf0 = uniform_psf(MK) if blind else psf_true.copy()
+    return dict(image=image, u0=u0, psf0=psf0, psf_true=psf_true, pad=pad)
+
+
 def default_window(M, N, MK, size=255):
     """Stats window as the driver passes it (deconvolve.py:281): (pad+1, size-pad-1) twice, clipped
     so that it stays inside small test frames."""

@@ -32,3 +32,19 @@ def ctx():
     """A libics_hip context on the default device; fails loudly (no CPU fallback) if there is none."""
     from lib import _native
     return _native.Context.get()
+
+
+@pytest.fixture
+def debug_switch():
+    """Sets test / measurement switches of libics_hip.so (csrc/ics_common.h IcsDebug: "max_wgs", "dynamic_tiles", "conv_rs", ...)
+    for the duration of a test: `debug_switch("max_wgs", 8)`.  The library reads its ICS_* environment variables once, at
+    first use; tests change the switches through the (non-public) ics_debug_set entry instead."""
+    from lib import _native
+    undo = []
+
+    def set_(name, value):
+        undo.append((name, _native.debug_set(name, value)))
+
+    yield set_
+    for name, old in reversed(undo):
+        _native.debug_set(name, old)

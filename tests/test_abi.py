@@ -26,21 +26,56 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "libics_hip.so does not export %s" % n
-    assert lib.ics_abi_version() == 2
+    assert lib.ics_abi_version() == 3
+    assert lib.ics_rl_params_size() == ctypes.sizeof(_native.RLParams) and lib.ics_rl_stats_size() == ctypes.sizeof(_native.RLStats)
 
 
 def test_struct_layout_matches_the_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     from lib import _native
     c = tmp_path / "layout.c"
-    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ics_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ics_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                  'sizeof(ics_rl_params), sizeof(ics_rl_stats), offsetof(ics_rl_params, stop_test),'
-                 'offsetof(ics_rl_stats, ms_total), offsetof(ics_rl_stats, launches));return 0;}\n')
+                 'offsetof(ics_rl_stats, ms_total), offsetof(ics_rl_stats, launches), offsetof(ics_rl_params, progress),'
+                 'offsetof(ics_rl_stats, trace_M_r), offsetof(ics_rl_params, top));return 0;}\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert vals == [ctypes.sizeof(_native.RLParams), ctypes.sizeof(_native.RLStats), _native.RLParams.stop_test.offset,
-                    _native.RLStats.ms_total.offset, _native.RLStats.launches.offset]
+                    _native.RLStats.ms_total.offset, _native.RLStats.launches.offset, _native.RLParams.progress.offset,
+                    _native.RLStats._p_M_r.offset, _native.RLParams.top.offset]
+    assert _native.RLParams.struct_size.offset == 0 and _native.RLStats.struct_size.offset == 0
+
+
+def test_debug_switches_are_not_in_the_public_header_and_round_trip():
+    """ICS_TEST_* style hooks live behind ics_debug_set (csrc/ics_common.h), outside include/ics_hip.h, and no launch path
+    calls getenv (round-2 verdict: test hooks in the production launch path)."""
+    from lib import _native
+    assert "ics_debug" not in open(HEADER).read()
+    old = _native.debug_set("max_wgs", 5)
+    assert _native.debug_set("max_wgs", old) == 5
+    with pytest.raises(KeyError):
+        _native.debug_set("no_such_switch", 1)
+    csrc = os.path.join(ROOT, "image-cases-studies_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith(".hip"):
+            txt = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in txt or f == "ics_group.hip", f      # (ICS_RCCL_LIB / ICS_GROUP_FORCE_RCCL: once per group)
+
+
+def test_wrong_struct_size_is_refused_before_anything_else():
+    """A caller built against another header (ics_rl_params grew in ABI 3) must get ICS_EINVAL, not a read past its struct."""
+    from lib import _native
+    lib = _native.load()
+    p = _native.RLParams()                      # struct_size left 0
+    st = _native.RLStats.with_traces(1)
+    fake_job = ctypes.c_void_p(0)
+    assert lib.ics_rl_run(fake_job, ctypes.byref(p), ctypes.byref(st)) == _native.ICS_EINVAL
+    assert b"struct_size" in lib.ics_last_error()
+    p.struct_size = ctypes.sizeof(_native.RLParams)
+    st.struct_size = 12
+    assert lib.ics_rl_run(fake_job, ctypes.byref(p), ctypes.byref(st)) == _native.ICS_EINVAL
+    assert b"ics_rl_stats.struct_size" in lib.ics_last_error()
 
 
 def test_no_silent_cpu_fallback_without_gpu():

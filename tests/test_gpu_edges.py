@@ -122,3 +122,22 @@ def test_empty_stats_window_gives_nan_statistics_like_the_reference():
     assert st_e.iterations_done == 4 and not st_e.stopped
     if not st_w.stopped:
         assert np.array_equal(u_e, u_w)
+
+
+def test_window_then_empty_window_then_window_again_on_one_job():
+    """Round-2 advice: the cached-window early return of ensure_window came before win_empty was recomputed, so the call sequence
+    W, empty window, W on one job (jobs are cached per size by lib/deconvolution.py) left the statistics NaN for good."""
+    from lib import _native as nv
+    M, N, MK = 48, 56, 5
+    case = orc.synth_case(M, N, MK, seed=2)
+    W = orc.default_window(M, N, MK)
+    job = nv.RLJob(M, N, MK)
+    res = []
+    for win in (W, (10, 10, 5, 30), W):
+        job.upload(case["image"], case["u0"], case["psf0"])
+        st = job.run(job.params(*win, 1e9, 3, 1e-3, 1e4, False))
+        res.append((st.M_r, st.Hu, st.varu, job.download()[0]))
+    job.close()
+    assert np.isnan(res[1][0]) and np.isnan(res[1][1]) and np.isnan(res[1][2])
+    assert not np.isnan(res[0][0]) and res[0][:3] == res[2][:3], (res[0][:3], res[2][:3])
+    assert np.array_equal(res[0][3], res[2][3]) and np.array_equal(res[0][3], res[1][3])

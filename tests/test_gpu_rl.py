@@ -182,12 +182,12 @@ def test_config1_512_k9_20_outer(golden_dir):
 
 @pytest.mark.parametrize("max_wgs,conv,flags,dyn", [(8, 0, 0, None), (8, 0, 1, None), (3, 0, 0, None), (0, 0, 0, None), (8, 1, 0, None), (3, 0, 0, "0"), (0, 0, 0, "1")],
                          ids=["8wg-fused", "8wg-two-kernel", "3wg-fused", "full-grid", "8wg-fp32", "3wg-static-walk", "full-grid-dynamic-walk"])
-def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, conv, flags, dyn):
-    """Blind reference golden on a 9 x 9-tile frame (oracle/make_golden_large.py).  With ICS_TEST_MAX_WGS = 8 (3) every
+def test_blind_golden_576x520_multi_tile_walk(golden_dir, debug_switch, max_wgs, conv, flags, dyn):
+    """Blind reference golden on a 9 x 9-tile frame (oracle/make_golden_large.py).  With the debug switch max_wgs = 8 (3) every
     persistent workgroup of the matrix-core convolutions, of the PSF-gradient kernel and of the fused A11 + A13 kernel
     walks 8-11 (24-27) tiles: next-tile register prefetch, band split and the interior-origin grid run under a reference
     trajectory, which the 129^2 goldens (<= 3 x 3 tiles, one tile per workgroup) cannot do.  From 8 tiles per workgroup on the
-    convolutions claim their tiles from a counter (dynamic walk): the 8- and 3-workgroup cases run that path, ICS_DYNAMIC_TILES
+    convolutions claim their tiles from a counter (dynamic walk): the 8- and 3-workgroup cases run that path, the switch dynamic_tiles
     forces the static walk with 3 workgroups and the dynamic one on the full grid."""
     import json
     import os
@@ -197,9 +197,9 @@ def test_blind_golden_576x520_multi_tile_walk(golden_dir, monkeypatch, max_wgs, 
     M, N, MK = meta["M"], meta["N"], meta["MK"]
     case = orc.synth_case(M, N, MK, seed=meta["seed"], blind=True)
     if max_wgs:
-        monkeypatch.setenv("ICS_TEST_MAX_WGS", str(max_wgs))
+        debug_switch("max_wgs", max_wgs)
     if dyn is not None:
-        monkeypatch.setenv("ICS_DYNAMIC_TILES", dyn)
+        debug_switch("dynamic_tiles", int(dyn))
     dc._drop_jobs()                # the workgroup count of the gradient kernels is fixed when the job is created
     for n in (1, 2):
         u, psf = case["u0"].copy(), case["psf0"].copy()

@@ -61,11 +61,11 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
 
 @pytest.mark.parametrize("MK", [3, 9, 13])
 @pytest.mark.parametrize("rs", ["2", "4"])
-def test_matrix_core_convolution_both_tile_heights(MK, rs, monkeypatch):
+def test_matrix_core_convolution_both_tile_heights(MK, rs, debug_switch):
     """ics_conv_mfma.hip builds 64-row and 32-row tiles for K <= 13 and picks by frame size (32-row up to 3000 tiles of
-    64 x 64): ICS_TEST_CONV_RS forces either, on a frame several tiles high and wide with ragged edges."""
+    64 x 64): the debug switch conv_rs forces either, on a frame several tiles high and wide with ragged edges."""
     from lib import _native as nv
-    monkeypatch.setenv("ICS_TEST_CONV_RS", rs)
+    debug_switch("conv_rs", int(rs))
     M, N = 203, 277
     job, case, psf = make_job(M, N, MK, seed=MK + 40)
     rng = np.random.default_rng(9)
@@ -82,7 +82,7 @@ def test_matrix_core_convolution_both_tile_heights(MK, rs, monkeypatch):
     red = job.red_keys()
     job.close()
     # the step-size reductions of the back-projection do not depend on the tiling (maxima)
-    monkeypatch.setenv("ICS_TEST_CONV_RS", "4" if rs == "2" else "2")
+    debug_switch("conv_rs", 4 if rs == "2" else 2)
     job2, _, _ = make_job(M, N, MK, seed=MK + 40)
     job2.write(nv.BUF_U, u)
     job2.write(nv.BUF_UT, case["u0"])
@@ -302,9 +302,8 @@ def test_matrix_core_kernels_equal_the_vector_kernels_on_random_shapes():
 
 def test_fused_synth_gradk_equals_the_two_kernel_path_on_random_shapes():
     """The fused A11 + A13 kernel against the two kernels it replaces over ragged frames (1 .. 260 px a side) and every PSF size
-    it is built for (3 .. 15), with 1 .. 7 persistent workgroups (ICS_TEST_MAX_WGS: tile walk, next-tile prefetch, partial blocks).
+    it is built for (3 .. 15), with 1 .. 7 persistent workgroups (debug switch max_wgs: tile walk, next-tile prefetch, partial blocks).
     Seeded hypothesis run, 30 cases."""
-    import os
     from hypothesis import given, settings, strategies as st, HealthCheck
     from lib import _native as nv
 
@@ -312,18 +311,18 @@ def test_fused_synth_gradk_equals_the_two_kernel_path_on_random_shapes():
     @given(st.integers(1, 260), st.integers(1, 260), st.integers(1, 7), st.integers(0, 7), st.integers(0, 2 ** 31 - 1))
     def check(M, N, kh, wgs, seed):
         MK = 2 * kh + 1
-        job, case, psf = make_job(M, N, MK, seed=seed % 1000, blind=True)
-        rng = np.random.default_rng(seed)
-        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
-        job.write(nv.BUF_U, u)
-        p = job.params(0, M, 0, N, 1e9, 1, 1e-3, 10000.0, blind=True)
-        if wgs:
-            os.environ["ICS_TEST_MAX_WGS"] = str(wgs)
+        # (the workgroup count of the gradient kernels is fixed when the job is created: the switch goes first)
+        old = nv.debug_set("max_wgs", wgs)
         try:
+            job, case, psf = make_job(M, N, MK, seed=seed % 1000, blind=True)
+            rng = np.random.default_rng(seed)
+            u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+            job.write(nv.BUF_U, u)
+            p = job.params(0, M, 0, N, 1e9, 1, 1e-3, 10000.0, blind=True)
             job.stage(nv.STAGE_SYNTH_GRADK, p)
             e, gk = job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK)
         finally:
-            os.environ.pop("ICS_TEST_MAX_WGS", None)
+            nv.debug_set("max_wgs", old)
         job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
         e2 = job.read(nv.BUF_ERROR)
         job.write(nv.BUF_ERROR, e)                                         # the gradient of the same residual
@@ -337,3 +336,36 @@ def test_fused_synth_gradk_equals_the_two_kernel_path_on_random_shapes():
         assert np.max(np.abs(gk - ref)) <= 2e-5 * gs and np.max(np.abs(gk2 - ref)) <= 2e-5 * gs, (M, N, MK, wgs)
 
     check()
+
+
+@pytest.mark.parametrize("MK,M,N", [(15, 700, 200), (31, 520, 150), (23, 300, 330)])
+def test_two_kernel_gradient_strip_carry_is_race_free_and_deterministic(MK, M, N, debug_switch):
+    """k_gradk_mfma walks down 64-column strips and keeps the NT - 1 shared rows of u in LDS between tiles (the carry).  Round-2
+    advice: without a barrier between the last carry pass and the conversion of the new rows a fast wave could overwrite rows
+    a lagging wave had not carried yet.  With 2 / 3 persistent workgroups every workgroup walks tens of tiles of tall narrow
+    frames (the carry runs on nearly every tile; K = 23, 31 carry rows through two tiles); the gradient must equal float64 and be
+    bit-identical over 12 repetitions -- a race shows up as a run that differs."""
+    from lib import _native as nv
+    results = []
+    for wgs in (2, 3):
+        debug_switch("max_wgs", wgs)
+        job, case, psf = make_job(M, N, MK, seed=MK, blind=True)
+        rng = np.random.default_rng(MK)
+        u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        u[40, 33, 1] = 50.0                                 # a bright pixel near the top of a strip: the carried scale bound must not stick
+        job.write(nv.BUF_U, u)
+        p = job.params(1, 9, 1, 9, 1e9, 1, 1e-3, 10000.0, blind=True, conv=2, flags=nv.FLAG_NO_FUSED_GRADK)
+        job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+        e = job.read(nv.BUF_ERROR)
+        ref = gradk64(u.astype(np.float64), e.astype(np.float64))
+        first = None
+        for rep in range(12):
+            job.stage(nv.STAGE_PSF_GRADIENT, p)
+            gk = job.read(nv.BUF_GRADK)
+            if first is None:
+                first = gk
+                assert rel_err(gk, ref) < 1e-5, (MK, wgs, rel_err(gk, ref))
+            assert np.array_equal(gk, first), (MK, wgs, rep)
+        results.append(first)
+        job.close()
+    assert rel_err(results[0], results[1]) < 1e-5
