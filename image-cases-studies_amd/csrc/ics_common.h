@@ -131,6 +131,36 @@ __host__ __device__ static inline float ics_key2f(uint32_t k) {
   return v.f;
 }
 
+// Wave-wide maximum (all 64 lanes receive it) without ds_bpermute: four DPP steps inside each row of 16 lanes, then the four
+// row results through v_readlane.  The shuffle form (__shfl_xor = ds_bpermute) needs one address register per step; inside a
+// persistent tile loop the compiler hoisted those addresses above the loop and, in the 256-register kernels, spilled one of
+// them -- a scratch reload that waits on vmcnt, i.e. on the whole next-tile prefetch in flight.  maxnum semantics (NaN dropped).
+__device__ __forceinline__ float ics_wave_max_f32(float v) {
+#define ICS_DPP_F32(x, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), 0xF, 0xF, true))
+  v = __builtin_fmaxf(v, ICS_DPP_F32(v, 0xB1));    // quad_perm [1, 0, 3, 2]
+  v = __builtin_fmaxf(v, ICS_DPP_F32(v, 0x4E));    // quad_perm [2, 3, 0, 1]
+  v = __builtin_fmaxf(v, ICS_DPP_F32(v, 0x141));   // row_half_mirror
+  v = __builtin_fmaxf(v, ICS_DPP_F32(v, 0x140));   // row_mirror
+#undef ICS_DPP_F32
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+  return __builtin_fmaxf(__builtin_fmaxf(r0, r1), __builtin_fmaxf(r2, r3));
+}
+__device__ __forceinline__ uint32_t ics_wave_max_u32(uint32_t v) {
+#define ICS_DPP_U32(x, ctrl) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), (ctrl), 0xF, 0xF, true)
+  uint32_t o;
+  o = ICS_DPP_U32(v, 0xB1); v = v > o ? v : o;
+  o = ICS_DPP_U32(v, 0x4E); v = v > o ? v : o;
+  o = ICS_DPP_U32(v, 0x141); v = v > o ? v : o;
+  o = ICS_DPP_U32(v, 0x140); v = v > o ? v : o;
+#undef ICS_DPP_U32
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
+}
+
 // Reduction slots written by the back-projection kernel (one set per inner iteration).
 #define ICS_RED_MAXG 0 /* 3 keys: max |gradu_k| after A6 (pyx:524)  */
 #define ICS_RED_MAXU 3 /* 3 keys: max u_k                (pyx:524)  */

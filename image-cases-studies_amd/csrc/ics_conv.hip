@@ -276,7 +276,9 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
   // Software pipeline: K is odd, so the K+1 weight rows are walked in pairs with two strip register sets
   // (ping-pong): the LDS reads of row ap+1 are issued before the FMAs of row ap and land behind them.
   // (Only when both sets fit the VGPR budget of 3 waves/SIMD; otherwise single-buffered.)
-  constexpr bool PINGPONG = (WPE == 2) && ((R / 2) * C::STRIP * 2 + 12 * R <= 200);
+  // (budget 176: at 184 / 192 -- K = 23, 25 -- both sets "fit" 256 VGPRs only with 18 .. 59 spills, and a scratch reload in the
+  //  weight-row loop costs more than the pipeline buys)
+  constexpr bool PINGPONG = (WPE == 2) && ((R / 2) * C::STRIP * 2 + 12 * R <= 176);
   if (PINGPONG) {
     float sa[R / 2][C::STRIP], sb[R / 2][C::STRIP];
     if (wave_has_rows) load_strips<C, R>(sa, lrow0, 0);

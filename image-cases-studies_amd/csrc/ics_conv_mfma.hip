@@ -149,14 +149,7 @@ struct MCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-    v = v > o ? v : o;
-  }
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ics_wave_max_u32(v); }
 
 // power-of-two scale that brings a maximum magnitude m into [2^14, 2^15) (fp16 overflows at 65504);
 // 1 for m = 0 / Inf / NaN.  `inv` is the exact inverse.
@@ -288,8 +281,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         for (int h = 0; h < 3; ++h)
 #pragma unroll
           for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(raw[k][h][e]));
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      m = ics_wave_max_f32(m);
       if (lane == 0) fscr[wv] = m;
       if (a.sched && tid == 0) lds_next[parity] = band0 + nx + (int)atomicAdd(a.sched + xcd, 1u);   // visible behind the second barrier
       __syncthreads();
@@ -619,11 +611,14 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       for (int c = 0; c < 3; ++c) { red_lds[wv * 8 + c] = kg[c]; red_lds[wv * 8 + 3 + c] = ku[c]; }
     }
     __syncthreads();
-    if (tid < 6) {
-      uint32_t m = red_lds[tid];
+    // (lane index re-derived here: computed from `tid` the address of the lane's key was hoisted above the tile loop as a
+    //  64-bit VGPR pair and spilled around it -- 8 bytes of scratch in the K = 9, 11, 29, 35, 37 back-projections)
+    const int tq = opaque(tid);
+    if (tq < 6) {
+      uint32_t m = red_lds[tq];
 #pragma unroll
-      for (int w = 1; w < C::NW; ++w) { const uint32_t o2 = red_lds[w * 8 + tid]; m = m > o2 ? m : o2; }
-      const int slot = tid < 3 ? ICS_RED_MAXG + tid : ICS_RED_MAXU + (tid - 3);
+      for (int w = 1; w < C::NW; ++w) { const uint32_t o2 = red_lds[w * 8 + tq]; m = m > o2 ? m : o2; }
+      const int slot = tq < 3 ? ICS_RED_MAXG + tq : ICS_RED_MAXU + (tq - 3);
       if (m > a.red[slot]) atomicMax(a.red + slot, m);
     }
   }
@@ -745,6 +740,9 @@ size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * (((2 * (K 
 
 hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
   if ((mode != 0 && mode != 1) || !a.bt) return hipErrorInvalidValue;
+#ifdef ICS_MFMA_ONLY_K   /* experiments: one PSF size per build (scripts/isa_one.sh) */
+  return a.g.K == ICS_MFMA_ONLY_K ? launch_k<ICS_MFMA_ONLY_K>(mode, a, s) : hipErrorInvalidValue;
+#else
   switch (a.g.K) {
     case 3: return launch_k<3>(mode, a, s);
     case 5: return launch_k<5>(mode, a, s);
@@ -756,5 +754,6 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 17: return launch_k<17>(mode, a, s);
     default: return a.g.K <= 27 ? ics_launch_conv_mfma_part1(mode, a, s) : ics_launch_conv_mfma_part2(mode, a, s);
   }
+#endif
 }
 #endif

@@ -81,8 +81,7 @@ __device__ __forceinline__ void pow2_scale(float m, float& s, float& inv) {
 }
 
 __device__ __forceinline__ float wg_max(float m, float* scr, int wave, int lane) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+  m = ics_wave_max_f32(m);
   if (lane == 0) scr[wave] = m;
   __syncthreads();
 #pragma unroll
@@ -92,12 +91,7 @@ __device__ __forceinline__ float wg_max(float m, float* scr, int wave, int lane)
 
 // three workgroup maxima behind ONE barrier (u scale, residual scale, carried-row bound)
 __device__ __forceinline__ void wg_max3(float& a, float& b, float& c, float* scr, int wave, int lane) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    a = __builtin_fmaxf(a, __shfl_xor(a, off, 64));
-    b = __builtin_fmaxf(b, __shfl_xor(b, off, 64));
-    c = __builtin_fmaxf(c, __shfl_xor(c, off, 64));
-  }
+  a = ics_wave_max_f32(a); b = ics_wave_max_f32(b); c = ics_wave_max_f32(c);
   if (lane == 0) { scr[wave] = a; scr[8 + wave] = b; scr[16 + wave] = c; }
   __syncthreads();
 #pragma unroll

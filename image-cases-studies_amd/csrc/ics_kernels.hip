@@ -363,12 +363,16 @@ __global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
     }                                                                                               \
   }
 
+  // NB = 4 (PSF sizes 49 .. 63) keeps 3 x 16 accumulator blocks = 192 registers: the staging registers of a prefetched tile do
+  // not fit beside them (77 spills at 512 VGPRs), so there the rows of a tile are requested when it starts
+  constexpr bool PREFETCH = NB < 4;
   const int ntiles = ntx * nty;
-  {
+  if (PREFETCH) {
     const int tfirst = (int)blockIdx.x < ntiles ? (int)blockIdx.x : ntiles - 1;
     GK_PREFETCH(tfirst)
   }
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (!PREFETCH) GK_PREFETCH(t)
     __syncthreads();  // previous tile fully consumed
 #pragma unroll
     for (int k = 0; k < NUIT; ++k) {
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
       }
     }
     __syncthreads();
-    {  // unconditional (clamped) so that the staging registers stay plain SSA values, not scratch
+    if (PREFETCH) {  // unconditional (clamped) so that the staging registers stay plain SSA values, not scratch
       const int tnext = t + (int)gridDim.x < ntiles ? t + (int)gridDim.x : ntiles - 1;
       GK_PREFETCH(tnext)
     }

@@ -296,8 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int h = 0; h < 3; ++h)
 #pragma unroll
           for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(raw[k][h][e]));
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+      m = ics_wave_max_f32(m);
       if (lane == 0) fscr[wv] = m;
       lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
 #pragma unroll
@@ -446,9 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           m = __builtin_fmaxf(m, __builtin_fabsf(e));
           if (store_e && in) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rs_o, voff + 4 * ch, sb + 4 * (t + 4 * r) * pitch, 0);
         }
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
-      return m;
+      return ics_wave_max_f32(m);
     };
 
     // ---- e' -> fp16 (hi, lo) planes: a lane packs (hi | lo << 16), swaps with its column neighbour and stores one dword --
