@@ -21,6 +21,7 @@
 
 #include "../../include/ics_hip.h"
 #include "ics_kernels.h"
+#include "ics_image_acc.h"
 
 // -------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -72,6 +73,8 @@ struct ics_rl {
   size_t frame_floats, origin;
   float *u, *u2, *ut, *gr, *f, *e;     // frame bases (origin = base + origin); u2 = ping-pong partner of u
   float* tvf;                           // TV term frame (tv_mode 1, allocated on first use)
+  float* facc[2];                       // the image in accumulator order for 32-row / 64-row tiles (ics_image_acc.h), allocated on first use
+  bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
@@ -212,7 +215,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial,
+  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -277,6 +280,25 @@ static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px,
   return ICS_OK;
 }
 
+// the accumulator-order copies of the image follow the image frame: every writer of j->f calls this
+static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; }
+
+// (re)build the accumulator-order image for tile height 16 * RS if it is missing or stale; queued on the job's stream
+static int ensure_image_acc(ics_rl* j, int RS) {
+  const int k = RS == 2 ? 0 : 1;
+  if (!j->facc[k]) {
+    hipError_t e = hipMalloc((void**)&j->facc[k], ics_image_acc_floats(j->g, RS) * sizeof(float));
+    if (e != hipSuccess) { (void)hipGetLastError(); j->facc[k] = nullptr; return fail(ICS_ENOMEM, "accumulator-order image: %s", hipGetErrorString(e)); }
+    j->facc_valid[k] = false;
+  }
+  if (!j->facc_valid[k]) {
+    hipError_t e = ics_launch_image_acc(j->f + j->origin, j->g, RS, j->facc[k], j->ctx->stream);
+    if (e != hipSuccess) return fail(ICS_EHIP, "k_image_acc: %s", hipGetErrorString(e));
+    j->facc_valid[k] = true;
+  }
+  return ICS_OK;
+}
+
 static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hipStream_t s) {
   IcsPsfArgs a;
   a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.bt_conv = j->bt_conv; a.bt_corr = j->bt_corr; a.psf_caller = j->psf_caller;
@@ -292,6 +314,7 @@ extern "C" int ics_rl_upload(ics_rl* j, const float* image, const float* u, cons
   hipStream_t s = j->ctx->stream;
   const IcsGeom& g = j->g;
   int rc;
+  if (image) image_changed(j);
   if (image && (rc = copy_in(j, j->f, image, g.M, g.N, g.pad, g.pad)) != ICS_OK) return rc;
   if (u && (rc = copy_in(j, j->u, u, g.uM, g.uN, 0, 0)) != ICS_OK) return rc;
   if (psf) {
@@ -371,6 +394,7 @@ extern "C" int ics_rl_write(ics_rl* j, int which, const float* host, size_t coun
   float* frame; int rows, cols, oy, ox;
   if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) == 0) {
     if (count != (size_t)rows * cols * 3) return fail(ICS_EINVAL, "buffer %d holds %zu floats, got %zu", which, (size_t)rows * cols * 3, count);
+    if (which == ICS_BUF_IMAGE) image_changed(j);
     int rc = copy_in(j, frame, host, rows, cols, oy, ox);
     if (rc != ICS_OK) return rc;
   } else if (which == ICS_BUF_PSF || which == ICS_BUF_GRADK) {
@@ -394,6 +418,7 @@ static int rows_io(ics_rl* j, int which, int row0, int nrows, float* host, bool 
   if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) != 0) return fail(ICS_EINVAL, "buffer %d is not a frame", which);
   if (row0 < 0 || nrows < 1 || row0 + nrows > rows) return fail(ICS_EINVAL, "rows [%d, %d) outside the %d rows of buffer %d", row0, row0 + nrows, rows, which);
   float* dev = org(j, frame) + (ptrdiff_t)(oy + row0) * j->g.pitch + 3 * ox;
+  if (!to_host && which == ICS_BUF_IMAGE) image_changed(j);
   if (to_host) HIPCHK(hipMemcpy2DAsync(host, (size_t)cols * 12, dev, (size_t)j->g.pitch * 4, (size_t)cols * 12, nrows, hipMemcpyDeviceToHost, j->ctx->stream));
   else HIPCHK(hipMemcpy2DAsync(dev, (size_t)j->g.pitch * 4, host, (size_t)cols * 12, (size_t)cols * 12, nrows, hipMemcpyHostToDevice, j->ctx->stream));
   HIPCHK(hipStreamSynchronize(j->ctx->stream));
@@ -412,6 +437,7 @@ extern "C" int ics_rl_copy_rows(ics_rl* dst, int dst_which, int dst_row0, ics_rl
   if (dcols != scols) return fail(ICS_EINVAL, "row length %d (destination) != %d (source)", dcols, scols);
   if (nrows < 1 || dst_row0 < 0 || dst_row0 + nrows > drows || src_row0 < 0 || src_row0 + nrows > srows)
     return fail(ICS_EINVAL, "rows [%d, %d) of %d <- rows [%d, %d) of %d", dst_row0, dst_row0 + nrows, drows, src_row0, src_row0 + nrows, srows);
+  if (dst_which == ICS_BUF_IMAGE) image_changed(dst);
   const int dd = dst->ctx->device, sd = src->ctx->device;
   if (dd != sd) {
     int can = 0;
@@ -532,6 +558,11 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
   return env == 2 || (env == 0 && ics_conv_mfma_preferred(j->g.K));
 }
 
+// tv_mode 1 rewrites the image in every inner iteration (pyx:547-549 live): a copy would have to be rebuilt each time
+static bool use_image_acc(const ics_rl_params* p) {
+  return p->tv_mode != ICS_TV_MM_ACTIVE && ics_debug().planar_image.load(std::memory_order_relaxed) != 0;
+}
+
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   IcsConvArgs a;
   a.g = j->g; a.lambd = p->lambd;
@@ -544,6 +575,11 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
   const bool matrix = mode != 2 && use_matrix_conv(j, p);
   a.bt = matrix ? (mode == 1 ? j->bt_corr : j->bt_conv) : nullptr;
+  a.facc[0] = a.facc[1] = nullptr;
+  if (matrix && mode == 0 && use_image_acc(p)) {   // the image operand of the residual in accumulator order (ics_image_acc.h)
+    const int rs = ics_conv_mfma_rs(j->g.K, j->g);
+    if (rs) { RC(ensure_image_acc(j, rs)); a.facc[rs == 2 ? 0 : 1] = j->facc[rs == 2 ? 0 : 1]; }
+  }
   a.sched = matrix ? j->sched : nullptr;   // counters of the dynamic tile walk: the launcher decides per launch (ics_conv_mfma.hip)
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
   if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
@@ -560,6 +596,7 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
   a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0; a.f_rw = org(j, j->f);
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
+  if (a.tv_kind == ICS_TV_MM_ACTIVE) image_changed(j);          // pyx:547-549: this update also steps the image
   RC(pr.begin(ICS_K_UPDATE));
   HIPCHK(ics_launch_update(a, j->ctx->stream));
   RC(pr.end());
@@ -618,6 +655,8 @@ static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof
   a.u = org(j, j->u); a.f = org(j, j->f); a.e_out = org(j, j->e); a.bt = j->bt_conv; a.partial = j->partial; a.g = j->g;
   a.wy0 = p->top + j->g.pad; a.wy1 = p->bottom + j->g.pad; a.wx0 = p->left + j->g.pad; a.wx1 = p->right + j->g.pad;
   a.store_all = store_all;
+  a.facc = nullptr;
+  if (use_image_acc(p)) { RC(ensure_image_acc(j, 4)); a.facc = j->facc[1]; }
   RC(pr.begin(ICS_K_SYNTH_GRADK));
   HIPCHK(ics_launch_synth_gradk(a, j->gradk_blocks, j->ctx->stream));
   HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
@@ -1166,6 +1205,7 @@ extern "C" int ics_rl_upload_img(ics_rl* j, const ics_img* image, int iy, int ix
   if (!rect_ok(u, uy, ux, g.uM, g.uN)) return fail(ICS_EINVAL, "u window [%d:%d, %d:%d] outside a %d x %d image", uy, uy + g.uM, ux, ux + g.uN, u->H, u->W);
   HIPCHK(hipSetDevice(j->ctx->device));
   hipStream_t s = j->ctx->stream;
+  image_changed(j);
   float* df = org(j, j->f) + (ptrdiff_t)g.pad * g.pitch + 3 * g.pad;
   HIPCHK(hipMemcpy2DAsync(df, (size_t)g.pitch * 4, image->d + ((size_t)iy * image->W + ix) * 3, (size_t)image->W * 12, (size_t)g.N * 12, g.M, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemcpy2DAsync(org(j, j->u), (size_t)g.pitch * 4, u->d + ((size_t)uy * u->W + ux) * 3, (size_t)u->W * 12, (size_t)g.uN * 12, g.uM, hipMemcpyDeviceToDevice, s));

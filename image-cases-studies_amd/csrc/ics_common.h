@@ -201,6 +201,8 @@ struct IcsConvArgs {
   float step;
   int blind, want_dof;
   const void* bt;    // matrix-core path only: Toeplitz fragment table of this orientation (ics_conv_mfma.hip), else NULL
+  const float* facc[2];  // matrix-core path, mode 0: the image in accumulator order for 32-row ([0], RS = 2) and 64-row ([1], RS = 4)
+                         // tiles (ics_image_acc.h); NULL = the epilogue reads the HWC frame
   uint32_t* sched;   // matrix-core path: 9 zeroed words for the dynamic tile walk (8 per-band claim counters + 1 exit counter;
                      // the last workgroup to leave zeroes them again), or NULL = static interleaved walk
   IcsGeom g;
@@ -217,3 +219,4 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_mfma_supported(int K);
 bool ics_conv_mfma_preferred(int K);   // what ICS_CONV_AUTO picks
 size_t ics_conv_mfma_table_floats(int K);
+int ics_conv_mfma_rs(int K, const IcsGeom& g);   // 2 / 4: tile height mode 0 will run with (accumulator-order image layout), 0: none

@@ -47,6 +47,7 @@
 //     results leave as dwordx3 (16 lanes = 192 contiguous bytes), same arithmetic as the VALU kernel (residual /
 //     back-projection + step-size reductions).  Two barriers per tile (scale, planes written).
 #include "ics_common.h"
+#include "ics_image_acc.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -504,6 +505,11 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       // TVOP (extended modes): the T frame is a third operand, requested like the others (as per-element scalar loads it
       // cost the back-projection +40 %)
       const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
+      const float* faccp = MODE == 0 ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
+      const bool use_acc = MODE == 0 && NH == 1 && faccp != nullptr;           // uniform
+      const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(faccp);
+      const int acc_voff = 16 * (tide & 63);
+      const int acc_sb = (tile * 4 + cb) * (3 * C::RS * 1024);                  // bytes: [tile][cb][ch][t][lane] float4
       auto run_epi = [&](auto tbc, auto tvc, auto tloc) {
       // accumulator sets [TLO, THI) of this wave: all of them, or two (NH = 2)
       constexpr int TLO = decltype(tloc)::value, THI = TLO + C::RS / NH;
@@ -518,10 +524,22 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         for (int r = 0; r < 4; ++r) {
           const int so = sb + 4 * (t + C::RS * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
+          if (MODE == 0 && use_acc) continue;   // requested below, per (channel, t)
           eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
           if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
+      if (MODE == 0 && use_acc && !(ICS_MFMA_ABLATE & 8)) {
+        // the image in accumulator order (ics_image_acc.h): one 16-byte load per (channel, accumulator set) instead of four 12-byte ones
+#pragma unroll
+        for (int t = t0; t < t0 + TB; ++t)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eop[0][t][r][c] = v[r];
+          }
+      }
       if (t0 == TLO) ICS_TICK(3);
       if (MODE == 1 && t0 == TLO) {
         // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
@@ -734,6 +752,18 @@ bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   /
 // Measured on MI355X at 4096^2: ahead of the packed-fp32 kernels at every size built (K = 19, 21 were level with
 // 64-row tiles -- two 32-wide windows per column block, one workgroup per CU -- and are ~8 % ahead with 32-row tiles).
 bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K); }
+
+// Tile height (fragment row stride RS = 2: 32 rows, 4: 64 rows) launch_k() picks for this PSF size and frame, 0 for the 8-wave
+// kernels (K >= 23): the caller prepares the accumulator-order image (ics_image_acc.h) of that layout for mode 0.
+int ics_conv_mfma_rs(int K, const IcsGeom& g) {
+  if (K >= 23) return 0;
+  bool rs2 = K <= 21 && (K >= 15 || (long)g.tiles_x * g.tiles_y <= 3000);
+  if (K <= 13) {   // both heights are built
+    const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
+    rs2 = frs == 2 ? true : (frs == 4 ? false : rs2);
+  }
+  return rs2 ? 2 : 4;
+}
 
 // weight table: [c][a] rows of 2 * WROWB bytes, hi/lo dword-interleaved (the LDS image), then one float 1/s_w (ics_common.h)
 size_t ics_conv_mfma_table_floats(int K) { return (size_t)3 * K * 2 * (((2 * (K + 17) + 3) & ~3) / 4) + 4; }

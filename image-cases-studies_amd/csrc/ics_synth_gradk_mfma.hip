@@ -30,6 +30,7 @@
 //   * accumulators are folded into fp32 totals per tile and channel with the exact inverse scales; one partial block per
 //     workgroup, reduced in double by k_gradk_reduce (ics_kernels.hip), deterministic.
 #include "ics_kernels.h"
+#include "ics_image_acc.h"
 #include <type_traits>
 
 #ifndef ICS_FUSED_INTERLEAVE
@@ -54,11 +55,7 @@ __device__ unsigned long long ics_fused_ticks[17];
 #define ICS_FUSED_PRIO 0
 #endif
 #ifndef ICS_FUSED_F01
-#define ICS_FUSED_F01 1   /* image operand of channels 0 and 1 in one dwordx2 request (0: one dword request per channel) */
-#endif
-#ifndef ICS_FUSED_PERM
-#define ICS_FUSED_PERM 0   /* gradient: lane row -> tap permutation + matching class bases (stochastic bank search: 6 instead of 7 LDS cycles per
-                              A read): measured 0.2769 vs 0.2773 ms -- the bank conflicts of the A reads are not on the critical path; off */
+#define ICS_FUSED_F01 0   /* image operand of channels 0 and 1 in one dwordx2 request (0: one dword request per channel) */
 #endif
 #ifndef ICS_FUSED_ABLATE
 #define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand */
@@ -73,14 +70,16 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// row classes of the u planes (rows c, c+4, ... contiguous): sizes and padded byte offsets.  The bases are padded so that the
-// gradient's A fragments (16 consecutive rows = 4 rows of each class) spread over the banks (brute-force search over the
-// offsets modulo 256, ds_read_b128 lane groups of gfx950: 7 LDS cycles on average instead of 12 unpadded; 4 = conflict-free)
+// row classes of the u planes (rows c, c+4, ... contiguous): sizes and padded byte offsets.  The gradient reads 16 CONSECUTIVE rows
+// per A fragment (4 rows of each class) and always starts on an even row (one fragment serves the residual rows 2p and 2p + 1,
+// see gradk_phase); the class bases are padded so that those reads spread over the banks -- brute-force search over the offsets
+// modulo 256 with the ds_read_b128 lane groups of gfx950: 6 LDS cycles on average over the two row phases (8 unpadded; 4 =
+// conflict-free, which the y-mod-4 grouping the convolution needs does not allow for consecutive rows)
 template <int K>
 struct FRows {
   static constexpr int LROWS = 64 + K - 1, ROWB = 160;
   static constexpr int cls_rows(int c) { return (LROWS - c + 3) / 4; }
-  static constexpr int want(int c) { return ICS_FUSED_PERM ? (c == 0 ? 0 : (c == 1 ? 128 : (c == 2 ? 96 : 224))) : (c == 0 ? 0 : (c == 1 ? 32 : (c == 2 ? 96 : 224))); }
+  static constexpr int want(int c) { return c == 0 ? 0 : (c == 1 ? 64 : (c == 2 ? 32 : 96)); }
   static constexpr int cls_off(int c) {
     if (c == 0) return 0;
     int off = cls_off(c - 1) + cls_rows(c - 1) * ROWB;
@@ -88,14 +87,6 @@ struct FRows {
     return off;
   }
 };
-
-// lane row (= row of the 16 x 16 result block) -> PSF tap row a.  Any permutation is valid -- the final write maps back; this one
-// came out of a stochastic search over permutations and class offsets (16 consecutive u rows = 4 rows of each y-mod-4 class):
-// 6 LDS cycles per ds_read_b128 on average over the four row phases (identity: 7; conflict-free would be 4)
-__host__ __device__ constexpr int ics_fused_tap(int lane_row) {
-  constexpr unsigned long long PERM = ICS_FUSED_PERM ? 0x4C51AF3E26B78D09ull : 0xFEDCBA9876543210ull;   // nibble i = tap of lane row i
-  return (int)((PERM >> (4 * lane_row)) & 15ull);
-}
 
 template <int K>
 struct FCfg {
@@ -185,7 +176,7 @@ __device__ __forceinline__ void convert_channel(const f32x4u (&raw)[C::NIT][3], 
   }
 }
 
-template <int K>
+template <int K, bool ACC>   // ACC: the image operand comes from the accumulator-order copy a.facc (ics_image_acc.h)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_synth_gradk(IcsFusedArgs a) {
   using C = FCfg<K>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -206,6 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int tile = band0 + kx;
 
   f4 tot[3];
+  float carry[3] = {0.f, 0.f, 0.f};   // register 0 of the even-row blocks: belongs to tap row 4 lg - 1, i.e. to the lane 16 below (gradk_phase)
 #pragma unroll
   for (int c = 0; c < 3; ++c) tot[c] = (f4){0.f, 0.f, 0.f, 0.f};
 
@@ -234,16 +226,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   // convolution, A operand: lane row li of column block wv, 8 halves at 16 wv + 8 lg
   const uint32_t conv_a = lds0 + (uint32_t)(C::UOFF + li * C::ROWB + (16 * wv + 8 * lg) * 2);
-  // gradient, A operand: lane row li <-> tap a (rows of D), u row (16 wv + i) + 2 pad - a of the staged block, 8 halves at 8 lg
-  // of each 32-column chunk.  For i mod 4 = j the class and the row inside the class are lane constants; i -> i + 4 is one row
-  // further inside the class.
-  uint32_t ga[4];
+  // gradient, A operand.  ONE fragment of 16 consecutive u rows serves TWO residual rows: for the pair (y, y + 1), y = 16 wv + 2 p,
+  // lane row m reads u row (y + 1) + 2 pad - m of the staged block; against the residual row y + 1 that is tap a = m (block D1),
+  // against the residual row y it is tap a = m - 1 (block D0: its row 0 pairs with nothing and is dropped, rows 1 .. 15 are taps
+  // 0 .. 14 -- K <= 15 makes the two tap ranges fit one fragment).  The A reads, the conflicted half of this phase's LDS traffic,
+  // are halved.  8 halves at 8 lg of each 32-column chunk; pairs alternate between two row phases (2 p mod 4), each one row further
+  // inside its classes every second pair.  Lanes beyond the taps (m > 2 pad + 1) repeat the last valid row: their blocks are never read.
+  uint32_t ga[2];
   {
-    const int tp = ics_fused_tap(li);
-    const int ta = tp < K ? tp : K - 1;
+    const int mm = li < 2 * C::PAD + 1 ? li : 2 * C::PAD + 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = j + 2 * C::PAD - ta;                        // >= 0
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * j + 2 * C::PAD + 1 - mm;                // >= 0
       const int rc = r & 3;
       const int coff = C::cls_off(rc) + ((r >> 2) + 4 * wv) * C::ROWB;
       ga[j] = lds0 + (uint32_t)(C::UOFF + coff + 16 * lg);
@@ -313,12 +307,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int voff = 4 * (16 * elg * pitch + 3 * eli);
     const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
 
-    // image operand: channels 0 and 1 arrive together (16 dwordx2 requests instead of 32 dword requests per lane: the TA
-    // processes a request per instruction, and 48 stride-12 dword requests per lane and tile cost 0.037 ms of the 0.29),
-    // channel 1 waits in 16 registers across gradk(0) and conv(1); channel 2 is requested on its own before conv(2)
-    uint32_t fop[4][4], fop1[4][4];
+    // image operand.  With the accumulator-order copy (a.facc, ics_image_acc.h): four 16-byte loads per channel, requested right
+    // before the channel's convolution and consumed behind it.  Without (tv_mode 1 rewrites the image every iteration): channels 0
+    // and 1 arrive together from the HWC frame (16 dwordx2 requests instead of 32 dword requests per lane: the TA processes a
+    // request per instruction, and 48 stride-12 dword requests per lane and tile cost 0.037 ms of the 0.29), channel 1 waits in 16
+    // registers across gradk(0) and conv(1); channel 2 is requested on its own before conv(2)
+    uint32_t fop[4][4], fop1[ACC ? 1 : 4][4];
+    constexpr bool use_acc = ACC;
+    const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(a.facc);
+    const int acc_voff = 16 * (tide & 63);
+    const int acc_sb = (tile * 4 + wv) * (3 * 4 * 1024);          // bytes: [tile][cb][ch][t][lane] float4
+    auto load_acc = [&](int ch) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (ch * 4 + t) * 1024, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fop[t][r] = v[r];
+      }
+    };
     auto load_f01 = [&]() {
-      if (ICS_FUSED_ABLATE & 16) {
+      if constexpr (ACC) return;
+      else if (ICS_FUSED_ABLATE & 16) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -334,10 +343,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto take_f1 = [&]() {
+      if constexpr (!ACC) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fop[t][r] = fop1[t][r];
+          for (int r = 0; r < 4; ++r) fop[t][r] = fop1[t][r];
+      }
     };
     auto load_f = [&](int ch) {
       if (ICS_FUSED_ABLATE & 16) {
@@ -482,13 +493,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
       typedef const volatile __attribute__((address_space(3))) u4* lds_vu4p;
       typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
-      f4 g[3];
+      // [residual row parity][2]: the three column chunks and three split terms of a row are nine summands of the same block; they
+      // alternate between two accumulators so that no MFMA follows one on the same registers (three would cost 8 more VGPRs)
+      f4 g[2][2];
 #pragma unroll
-      for (int X = 0; X < 3; ++X) g[X] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int X = 0; X < 2; ++X) g[h][X] = (f4){0.f, 0.f, 0.f, 0.f};
       if (ICS_FUSED_ABLATE & 1) { tot[ch][0] += scale; return; }
-      uint32_t gav[4], gbv[3];
+      uint32_t gav[2], gbv[3];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
+      for (int j = 0; j < 2; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
 #pragma unroll
       for (int X = 0; X < 3; ++X) { gbv[X] = gb[X]; asm volatile("" : "+v"(gbv[X])); }
       u4 Ah[2], Al[2], nAh[2], nAl[2];
@@ -496,6 +511,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       u2 rB[2][5], rB2[3];
       h8 Bh[2], Bl[2];
       h4 B2h, B2l;
+      // residual row i: its e' windows always; the u fragment of the pair only on even rows
       auto issue = [&](int i) {
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
@@ -508,15 +524,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int k = 0; k < 3; ++k) rB2[k] = ep[k];
         }
-        const uint32_t ar = gav[i & 3] + PB + (uint32_t)((i >> 2) * C::ROWB);
+        if ((i & 1) == 0) {
+          const uint32_t ar = gav[(i >> 1) & 1] + PB + (uint32_t)((i >> 2) * C::ROWB);
 #pragma unroll
-        for (int X = 0; X < 2; ++X) {
-          nAh[X] = *reinterpret_cast<lds_vu4p>(ar + 64 * X);
-          nAl[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE + 64 * X);
+          for (int X = 0; X < 2; ++X) {
+            nAh[X] = *reinterpret_cast<lds_vu4p>(ar + 64 * X);
+            nAl[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE + 64 * X);
+          }
+          // third chunk: columns 64 + 4 lg .. + 3 (the lane address carries 16 lg: back by 8 lg)
+          nA2h = *reinterpret_cast<lds_vu2p>(ar + 128 - ga2);
+          nA2l = *reinterpret_cast<lds_vu2p>(ar + C::PLANE + 128 - ga2);
         }
-        // third chunk: columns 64 + 4 lg .. + 3 (the lane address carries 16 lg: back by 8 lg)
-        nA2h = *reinterpret_cast<lds_vu2p>(ar + 128 - ga2);
-        nA2l = *reinterpret_cast<lds_vu2p>(ar + C::PLANE + 128 - ga2);
       };
       auto finish = [&]() {
 #pragma unroll
@@ -543,6 +561,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (ICS_FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
+        const int hp = i & 1;
         h8 cBh[2], cBl[2];
 #pragma unroll
         for (int X = 0; X < 2; ++X) { cBh[X] = Bh[X]; cBl[X] = Bl[X]; }
@@ -551,31 +570,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int term = 0; term < 3; ++term) {
 #pragma unroll
-          for (int X = 0; X < 2; ++X)
-            g[X] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[X], 0, 0, 0);
-          g[2] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, term == 2 ? A2l : A2h), term == 1 ? cB2l : cB2h, g[2], 0, 0, 0);
+          for (int X = 0; X < 2; ++X) {
+            const int k = (3 * term + X) & 1;
+            g[hp][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[hp][k], 0, 0, 0);
+          }
+          const int k2 = (3 * term + 2) & 1;
+          g[hp][k2] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, term == 2 ? A2l : A2h), term == 1 ? cB2l : cB2h, g[hp][k2], 0, 0, 0);
         }
         if (i + 1 < 16) {
           finish();
+          if (hp) {   // the next row opens a new pair: its fragment was requested in this step
 #pragma unroll
-          for (int X = 0; X < 2; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
-          A2h = nA2h; A2l = nA2l;
+            for (int X = 0; X < 2; ++X) { Ah[X] = nAh[X]; Al[X] = nAl[X]; }
+            A2h = nA2h; A2l = nA2l;
+          }
         }
         if (ICS_FUSED_GK_INTERLEAVE && i + 1 < 16) {
-          // 9 MFMAs, 19 LDS reads (13 e' dword pairs, then 4 + 2 u fragments), 20 funnel shifts
+          // 9 MFMAs; LDS reads of the next row: 13 e' dword pairs, + 4 + 2 u fragments when it opens a pair; 20 funnel shifts
+          if (hp) {
 #pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if (k == 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            if (k >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            for (int k = 0; k < 9; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (k < 6) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              if (k == 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if (k >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              if (k == 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if (k >= 4) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (ICS_FUSED_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+      // block D1 (odd residual rows): row m = tap m.  Block D0 (even rows): row m = tap m - 1, i.e. tap a sits one row further down:
+      // row a + 1 = register r + 1 of the same lane, or -- for r = 3 -- register 0 of the lane 16 above (rows 4 lg + r).  That one
+      // crosses lanes: it is accumulated apart (`carry`) and joins its tap in the final cross-wave reduction, which goes through LDS anyway.
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tot[ch][r] += ((g[0][r] + g[1][r]) + g[2][r]) * scale;
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = g[1][0][r] + g[1][1][r];
+        const float s0n = r < 3 ? g[0][0][r + 1] + g[0][1][r + 1] : 0.f;
+        tot[ch][r] += (s1 + s0n) * scale;
+      }
+      carry[ch] += (g[0][0][0] + g[0][1][0]) * scale;
     };
 
     // ================================ the tile ======================================================================
@@ -583,7 +625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     convert_channel<C, 0>(raw, s_x, up, opaque(tid));
     lds_barrier();                                                     // planes of channel 0 visible
     FTICK(1);
-    if (ICS_FUSED_F01) load_f01(); else load_f(0);
+    if (use_acc) load_acc(0); else if (ICS_FUSED_F01) load_f01(); else load_f(0);
     conv_phase(std::integral_constant<int, 0>{});
     FTICK(2);
     float s_e, inv_e, me;
@@ -605,7 +647,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(6);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
     FTICK(7);
-    if (ICS_FUSED_F01) take_f1(); else load_f(1);
+    if (use_acc) load_acc(1); else if (ICS_FUSED_F01) take_f1(); else load_f(1);
     conv_phase(std::integral_constant<int, 1>{});
     FTICK(2);
 
@@ -616,7 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(6);
     gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
     FTICK(7);
-    load_f(2);
+    if (use_acc) load_acc(2); else load_f(2);
     // the rows of the next tile: in flight during conv(2), gradk(2) (no vector-memory loads in there; the image operand of
     // channel 2 was requested before them and returns first).  (Spreading the 21 requests of a lane over the steps of conv(2)
     // instead of one burst measured slower: 0.315 vs 0.285 ms.)
@@ -641,13 +683,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   FTICK_FLUSH;
   // ---- cross-wave reduction (fixed order) and partial write, one channel per pass ------------------------------------
-  float* red = reinterpret_cast<float*>(lds);   // [wave][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]
+  float* red = reinterpret_cast<float*>(lds);   // [wave][256]: element (row = 4*lg + r, col = li) at [r*64 + lane]; then [wave][64] carries
   float* dst = a.partial + (size_t)blockIdx.x * (3 * 16 * 16);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wv * 256 + r * 64 + lane] = tot[c][r];
+    red[C::NW * 256 + wv * 64 + lane] = carry[c];
     __syncthreads();
     {
       const int v = tid;
@@ -655,7 +698,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int w = 1; w < C::NW; ++w) s += red[w * 256 + v];   // fixed order -> deterministic
       const int l = v & 63, r = (v >> 6) & 3;
-      const int ta = ics_fused_tap(4 * (l >> 4) + r), tb = l & 15;
+      if (r == 3 && l < 48) {                                   // tap row 4 lg + 3 also receives row 0 of the lane group above
+#pragma unroll
+        for (int w = 0; w < C::NW; ++w) s += red[C::NW * 256 + w * 64 + l + 16];
+      }
+      const int ta = 4 * (l >> 4) + r, tb = l & 15;
       dst[(c * 16 + ta) * 16 + tb] = s;
     }
   }
@@ -664,10 +711,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int K>
 hipError_t launch_k(const IcsFusedArgs& a, int nblocks, hipStream_t s) {
   using C = FCfg<K>;
-  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
   const int dev = ics_current_device();
-  auto kern = k_synth_gradk<K>;
-  if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
+  const bool ACC = a.facc != nullptr;
+  auto kern = ACC ? k_synth_gradk<K, true> : k_synth_gradk<K, false>;
+  if (hipError_t e = ics_configure_lds(configured[ACC ? 1 : 0], dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   const int ntiles = ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH);
   // every workgroup of the grid writes its partial block (the reduction reads `nblocks` of them): workgroups without a tile
   // write zeros

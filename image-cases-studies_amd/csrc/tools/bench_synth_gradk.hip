@@ -32,10 +32,13 @@ int main(int argc, char** argv) {
   hipMalloc(&partial, (size_t)nblocks * 768 * 4);
   IcsFusedArgs a = {};
   a.u = u + org; a.f = f + org; a.e_out = e + org; a.bt = bt; a.partial = partial; a.g = g;
+  float* facc = nullptr;
+  if (!getenv("ICS_BENCH_NO_ACC")) { hipMalloc(&facc, ics_image_acc_floats(g, 4) * 4); ics_launch_image_acc(a.f, g, 4, facc, 0); }
+  a.facc = facc;
   a.wy0 = K / 2 + 8; a.wy1 = a.wy0 + 255; a.wx0 = a.wy0; a.wx1 = a.wy1; a.store_all = 0;
   if (K == 15) {
     int nb0 = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_synth_gradk<15>, 256, FCfg<15>::LDS_BYTES);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_synth_gradk<15, true>, 256, FCfg<15>::LDS_BYTES);
     printf("occupancy (workgroups per CU) K=15: %d, LDS %zu B, plane %d B\n", nb0, (size_t)FCfg<15>::LDS_BYTES, FCfg<15>::PLANE);
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
