@@ -116,7 +116,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); return 0; }
   return -1;
@@ -127,7 +127,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;

@@ -99,6 +99,7 @@ struct IcsDebug {
   std::atomic<int> update_kernel;     // ICS_UPDATE_KERNEL     0 = the pixel-group kernel everywhere
   std::atomic<int> fused_rs;          // ICS_FUSED_RS          0 launcher decides, 2 / 4 = tile height of the fused A11 + A13 kernel
   std::atomic<int> planar_image;      // ICS_PLANAR_IMAGE      0 = epilogues read the HWC image frame (no accumulator-order copy)
+  std::atomic<int> pam_exact;         // ICS_PAM_EXACT         1 = PAM TV term with IEEE sqrt / division per value (k_tvterm<2|3>)
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
   IcsDebug() {
     max_wgs = env_int("ICS_TEST_MAX_WGS", 0);
@@ -112,6 +113,7 @@ struct IcsDebug {
     update_kernel = env_int("ICS_UPDATE_KERNEL", 1);
     fused_rs = env_int("ICS_FUSED_RS", 0);
     planar_image = env_int("ICS_PLANAR_IMAGE", 1);
+    pam_exact = env_int("ICS_PAM_EXACT", 0);
   }
 };
 // one instance per process (inline function, function-local static: initialised once, thread-safe)

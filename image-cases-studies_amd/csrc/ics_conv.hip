@@ -368,6 +368,7 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
             mu[c] = __builtin_fmaxf(mu[c], uv[3*p+c]);
             nan_g[c] |= (g != g); nan_u[c] |= (uv[3*p+c] != uv[3*p+c]);
             any = true;
+            if (a.tv_kind >= 2) acc[r][3*p+c] = g;   // PAM: the frame written below is G itself (see ics_conv_mfma.hip)
           }
         }
       }

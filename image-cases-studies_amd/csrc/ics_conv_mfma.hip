@@ -69,6 +69,9 @@
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
 #endif
+#ifndef ICS_EPI_EARLY
+#define ICS_EPI_EARLY 1       /* mode 0, 32-row tiles, accumulator-order image: request the image operand BEFORE the matrix phase (130 of 168 VGPRs in use: room for its 24) */
+#endif
 #ifndef ICS_MFMA_ALL_RS
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
 #endif
@@ -325,6 +328,19 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
 
     // ---- request the next tile's rows: in flight during the whole matrix phase (the loop below issues no
     // vector-memory loads -- they return in order, a weight load behind this prefetch would wait for it) -----
+    // mode 0, 32-row tiles: the image operand of this tile's residual (accumulator order, ics_image_acc.h) is requested here, ahead
+    // of the next tile's rows (loads return in order), and is there when the matrix phase ends
+    constexpr bool EARLY = ICS_EPI_EARLY && MODE == 0 && RS == 2 && NH == 1;
+    u4 fpre[3][C::RS];
+    const float* faccp0 = MODE == 0 ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
+    if (EARLY && faccp0 != nullptr && x0 + 16 * cb < xend) {
+      const __amdgpu_buffer_rsrc_t rs_a0 = make_rsrc(faccp0);
+      const int lv = 16 * (opaque(tid) & 63), sb0 = (tile * 4 + cb) * (3 * C::RS * 1024);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int t = 0; t < C::RS; ++t) fpre[c][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_a0, lv, sb0 + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
+    }
     next_tile = a.sched ? __builtin_amdgcn_readfirstlane(lds_next[parity]) : tile + nx;
     parity ^= 1;
     if (next_tile < band1) {
@@ -515,6 +531,9 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       constexpr int TLO = decltype(tloc)::value, THI = TLO + C::RS / NH;
       constexpr int TB = decltype(tbc)::value < THI - TLO ? decltype(tbc)::value : THI - TLO;
       constexpr bool TVOP = decltype(tvc)::value;
+      // PAM kinds (tv_kind 2, 3): the frame this kernel writes is G = T + lambd * gradu itself -- the update pass then reads u and G
+      // only (no T, no majoriser, no image: 3 frame transits instead of 5), and T is read exactly once, here
+      const bool pam = TVOP && a.tv_kind >= 2;   // uniform
 #pragma unroll
       for (int t0 = TLO; t0 < THI; t0 += TB) {
       u3 eop[EOPS][C::RS][4], eopT[C::RS][4];
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           if (MODE == 0 && use_acc) continue;   // requested below, per (channel, t)
           eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
-          if (MODE == 1) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
+          if (MODE == 1 && !pam) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);   // (PAM has no majoriser term)
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
         }
       if (MODE == 0 && use_acc && !(ICS_MFMA_ABLATE & 8)) {
@@ -535,13 +554,13 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         for (int t = t0; t < t0 + TB; ++t)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
+            const u4 v = EARLY ? fpre[c][t] : __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) eop[0][t][r][c] = v[r];
           }
       }
       if (t0 == TLO) ICS_TICK(3);
-      if (MODE == 1 && t0 == TLO) {
+      if (MODE == 1 && t0 == TLO && !pam) {
         // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
         // shadow of their latency (u and ut only feed the step-size reductions)
 #pragma unroll
@@ -576,9 +595,10 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
             // gradu over the whole u-frame + reductions for the step size (pyx:519,523-524)
             if (y < a.g.uM && colx < a.g.uN && (!(ICS_MFMA_ABLATE & 8) || av[0] + av[1] + av[2] == 12345.678f)) {
               const float lambd = a.lambd;
+              u3 gout;
 #pragma unroll
               for (int c = 0; c < 3; ++c) {
-                const float uv = __uint_as_float(eop[0][t][r][c]), tv = __uint_as_float(eop[EOPS - 1][t][r][c]);
+                const float uv = __uint_as_float(eop[0][t][r][c]), tv = pam ? 0.f : __uint_as_float(eop[EOPS - 1][t][r][c]);
                 float g;
                 const float Tv = TVOP ? __uint_as_float(eopT[t][r][c]) : 0.f;
                 if (TVOP && a.tv_kind >= 2)
@@ -590,7 +610,9 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
                 mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
                 mu[c] = __builtin_fmaxf(mu[c], uv);
                 rflags |= ((g != g) ? (1u << c) : 0u) | ((uv != uv) ? (8u << c) : 0u) | 64u;
+                gout[c] = __float_as_uint(g);
               }
+              if (pam) __builtin_amdgcn_raw_buffer_store_b96(gout, rs_o, voff, so, ICS_EPI_STORE_AUX);
             }
           }
         }

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
       for (int c = 0; c < 3; ++c) {
         const int i = 3 * p + c;
         float g;
-        if (a.tv_kind >= 2)                                                    // PAM: G = T + lambd*gradu, no majoriser term
-          g = (float)((double)Tv[i] + (double)__fmul_rn(lambd, gv[i]));
+        if (a.tv_kind >= 2)                                                    // PAM: the back-projection pass wrote G = T + lambd*gradu
+          g = gv[i];
         else if (a.tv_kind == 1 && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
           g = (float)(((double)Tv[i] + (double)__fmul_rn(lambd, gv[i])) + (double)__fsub_rn(uv[i], tv[i]) / 4.0);
         else
@@ -193,9 +193,45 @@ __device__ __forceinline__ float pam_term(const float (&n)[3][20], int i, int c,
 // once per thread instead of three times; KIND is a template parameter so that the PAM kinds do not load ut at all).
 // (KIND 1 evaluates four stencils with IEEE divisions and square roots per value: bound by VALU latency, it ran slower with
 //  the 164 registers of the walking window -- 0.50 vs 0.44 ms -- and keeps one row per thread.)
-template <int KIND>
+// The MM-TV term of one value, fast form (round 3).  tv_term of oracle/rl_ext_oracle.py evaluates the order-2 stencil four times
+// (u and ut, norm 1 and norm 2: ics_tv_point) with IEEE divisions and square roots -- ~300 vector instructions per value, which
+// made k_tvterm<1> VALU-bound at 2.5x the time of the memory traffic it causes.  The four evaluations share their second
+// differences; those stay exact (double sums of floats, rounded once, as the reference computes them: the term is largest where
+// the image is flattest, i.e. where the differences cancel), everything behind them uses v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within
+// ~1e-6 of the IEEE form relative to max |T| (gate 1e-5, tests/test_tv_mode.py); ICS_TV_EXACT=1 / debug switch tv_exact selects
+// the IEEE form.  n = rows (y-1, y, y+1) of the 20-float windows, i = index of the centre float.
+#ifndef ICS_TVMM_SEG
+#define ICS_TVMM_SEG 8
+#endif
+struct IcsStencil2 { float udx, udy, udd, uda; };
+__device__ __forceinline__ IcsStencil2 ics_second_differences(const float (&n)[3][20], int i) {
+  const double m2c = -2.0 * (double)n[1][i];
+  const float inv = 0.707106769f;   // 1 / 1.41421354f rounded to float
+  IcsStencil2 s;
+  s.udx = (float)((m2c + (double)n[0][i]) + (double)n[2][i]);
+  s.udy = (float)((m2c + (double)n[1][i - 3]) + (double)n[1][i + 3]);
+  s.udd = (float)((m2c + (double)n[0][i - 3]) + (double)n[2][i + 3]) * inv;
+  s.uda = (float)((m2c + (double)n[0][i + 3]) + (double)n[2][i - 3]) * inv;
+  return s;
+}
+__device__ __forceinline__ float ics_tv_mm_term_fast(const float (&nu)[3][20], const float (&nt)[3][20], int i, float eps) {
+  const float a1 = 6.82842731f, a2 = 4.82842731f;            // 4 (1 + 1/sqrt 2), 2 (1 + sqrt 2)
+  const IcsStencil2 su = ics_second_differences(nu, i), st = ics_second_differences(nt, i);
+  const float e2 = eps * eps;
+  const float u1 = ((__builtin_fabsf(su.udx) + __builtin_fabsf(su.udy)) + eps) + ((__builtin_fabsf(su.udd) + __builtin_fabsf(su.uda)) + eps);   // x adjust1
+  const float u2 = __builtin_amdgcn_sqrtf(su.udx * su.udx + su.udy * su.udy + e2) + __builtin_amdgcn_sqrtf(su.udd * su.udd + su.uda * su.uda + e2);   // x adjust2
+  const float t1 = ((__builtin_fabsf(st.udx) + __builtin_fabsf(st.udy)) + eps) + ((__builtin_fabsf(st.udd) + __builtin_fabsf(st.uda)) + eps);
+  const float t2 = __builtin_amdgcn_sqrtf(st.udx * st.udx + st.udy * st.udy + e2) + __builtin_amdgcn_sqrtf(st.udd * st.udd + st.uda * st.uda + e2);
+  const float d = ((-su.udx - su.udy) - su.udd) - su.uda;      // x adjust2 (div carries the norm-2 scaling, pyx:495-496)
+  // T = (div / TV_u_L1) / TV_ut_L1 / 2 + (div / TV_u_L2) / TV_ut_L2 / 2 with div = d / a2, TV_x_L1 = x1 / a1, TV_x_L2 = x2 / a2
+  const float q1 = d * (a1 * a1 / a2) * __builtin_amdgcn_rcpf(u1 * t1);
+  const float q2 = d * a2 * __builtin_amdgcn_rcpf(u2 * t2);
+  return 0.5f * (q1 + q2);
+}
+
+template <int KIND, bool FAST = false>
 __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
-  constexpr int TVSEG = KIND == 1 ? 1 : 16;
+  constexpr int TVSEG = KIND == 1 ? (FAST ? ICS_TVMM_SEG : 1) : 16;   // (the fast MM form is load-bound: it walks rows like the PAM kinds)
   const IcsGeom& G = a.geo;
   const int ngx = G.tiles_x * 16;
   const int nseg = (G.uM + TVSEG - 1) / TVSEG;
@@ -236,6 +272,8 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
         float t = 0.f;
         if (KIND >= 2) {
           if (yact && x >= 1 && x <= G.uN - 2) t = pam_term(nu, i, c, eps, KIND == 3);
+        } else if (FAST && yact && x >= 1 && x <= G.uN - 2) {
+          t = ics_tv_mm_term_fast(nu, nt, i, eps);
         } else if (yact && x >= 1 && x <= G.uN - 2) {
           const IcsTvOut u1 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 1);
           const IcsTvOut u2 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 2);
@@ -285,6 +323,109 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
       if (kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
       if (kf > a.red[ICS_RED_MAXF + c]) atomicMax(a.red + ICS_RED_MAXF + c, kf);
     }
+  }
+}
+
+// =================================================================================================
+// PAM kinds (2 isotropic, 3 collaborative) of the TV term, round 3: the same quantity as pam_term() above -- T = -div(p), p the
+// normalised forward differences -- evaluated ONCE per pixel and direction instead of once per use.  pam_term() recomputes the
+// three norms (own pixel, pixel above, pixel to the left) of every value with IEEE square roots and divisions: ~100 vector
+// instructions per value, which made k_tvterm<2|3> VALU-bound at 0.17 ms for a 4096^2 frame (24 B/px of traffic = 0.07 ms).  Here a
+// thread walks down 16 rows with p_x of the row above in registers and takes p_y of the pixel to the left from its own 5-pixel
+// window; 1 / sqrt comes from v_rsq_f32 (1 ulp).  ~10 instructions per value; results within ~2e-7 of pam_term() relative to
+// max |T| (tests/test_tv_mode.py gates 2e-6 against oracle/rl_ext_oracle.py; these modes have no reference implementation).
+// =================================================================================================
+template <bool COLLAB>
+__global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a) {
+  constexpr int TVSEG = 16;
+  const IcsGeom& G = a.geo;
+  const int ngx = G.tiles_x * 16;
+  const int nseg = (G.uM + TVSEG - 1) / TVSEG;
+  const long total = (long)nseg * ngx;
+  typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  float mt[3] = {0.f, 0.f, 0.f};
+  bool nan_t[3] = {false, false, false};
+  const float e2 = __fmul_rn(a.epsilon, a.epsilon);
+  auto load_row = [&](int y, int xp, float (&row)[20]) {   // pixels xp - 1 .. xp + 5 (20 floats)
+    const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * (xp - 1);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const f32x4u p = *reinterpret_cast<const f32x4u*>(a.u + o + 4 * j);
+      row[4*j] = p.x; row[4*j+1] = p.y; row[4*j+2] = p.z; row[4*j+3] = p.w;
+    }
+  };
+  // p of the row `cur` (with `nxt` below it) at the window pixels j = 0 .. 4 (frame pixels xp - 1 .. xp + 3): px[3 j + c], py[3 j + c]
+  auto normalised = [&](const float (&cur)[20], const float (&nxt)[20], float (&px)[15], float (&py)[15], bool want_y) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float dx[3], dy[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { dx[c] = __fsub_rn(nxt[3*j+c], cur[3*j+c]); dy[c] = __fsub_rn(cur[3*j+c+3], cur[3*j+c]); }
+      if (!COLLAB) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float r = __builtin_amdgcn_rsqf(__fadd_rn(__fadd_rn(__fmul_rn(dx[c], dx[c]), __fmul_rn(dy[c], dy[c])), e2));
+          px[3*j+c] = __fmul_rn(dx[c], r);
+          py[3*j+c] = __fmul_rn(dy[c], r);
+        }
+      } else {   // only the first channel of largest |difference| carries the term, per direction
+        int sx = 0, sy = 0;
+#pragma unroll
+        for (int k = 1; k < 3; ++k) { if (__builtin_fabsf(dx[k]) > __builtin_fabsf(dx[sx])) sx = k; if (__builtin_fabsf(dy[k]) > __builtin_fabsf(dy[sy])) sy = k; }
+        const float vx = sx == 0 ? dx[0] : (sx == 1 ? dx[1] : dx[2]), vy = sy == 0 ? dy[0] : (sy == 1 ? dy[1] : dy[2]);
+        const float qx = __fmul_rn(vx, __builtin_amdgcn_rsqf(__fadd_rn(__fmul_rn(vx, vx), e2)));
+        const float qy = want_y ? __fmul_rn(vy, __builtin_amdgcn_rsqf(__fadd_rn(__fmul_rn(vy, vy), e2))) : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { px[3*j+c] = c == sx ? qx : 0.f; py[3*j+c] = c == sy ? qy : 0.f; }
+      }
+    }
+  };
+  for (long gid = (long)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (long)gridDim.x * 256) {
+    const int seg = (int)(gid / ngx);
+    const int xp = 4 * (int)(gid - (long)seg * ngx);
+    if (xp >= G.uN) continue;
+    const int ybeg = seg * TVSEG, yend = ybeg + TVSEG < G.uM ? ybeg + TVSEG : G.uM;
+    float ra[20], rb[20], rc[20];
+    float pxu[15], px0[15], py0[15], pyd[15];
+    load_row(ybeg - 1, xp, ra); load_row(ybeg, xp, rb);
+    normalised(ra, rb, pxu, pyd, false);                 // p_x of the row above the first one
+    for (int y = ybeg; y < yend; ++y) {
+      load_row(y + 1, xp, rc);
+      normalised(rb, rc, px0, py0, true);
+      const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * xp;
+      const bool yact = (y >= 1) && (y <= G.uM - 2);
+      float T[12];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int x = xp + p;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int i = 3 * (p + 1) + c;                   // window index of (x, c); (x - 1, c) is i - 3
+          float t = 0.f;
+          if (yact && x >= 1 && x <= G.uN - 2) t = -__fadd_rn(__fsub_rn(px0[i], pxu[i]), __fsub_rn(py0[i], py0[i - 3]));
+          T[3*p+c] = t;
+          if (x < G.uN) { mt[c] = __builtin_fmaxf(mt[c], __builtin_fabsf(t)); nan_t[c] |= (t != t); }
+        }
+      }
+      if (xp + 3 < G.uN) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { const f32x4 w = {T[4*j], T[4*j+1], T[4*j+2], T[4*j+3]}; reinterpret_cast<f32x4*>(a.tv + o)[j] = w; }
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (xp + p < G.uN) { a.tv[o + 3*p] = T[3*p]; a.tv[o + 3*p + 1] = T[3*p+1]; a.tv[o + 3*p + 2] = T[3*p+2]; }
+      }
+#pragma unroll
+      for (int k = 0; k < 20; ++k) rb[k] = rc[k];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) pxu[k] = px0[k];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    uint32_t kt = nan_t[c] ? 0xFFC00000u : ics_f2key(mt[c]);
+    kt = wave_max_u32(kt);
+    if ((threadIdx.x & 63) == 0 && kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
   }
 }
 
@@ -627,7 +768,7 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
       if (TVK != 2) tq[s] = (ICS_UPDATE_NT & 2) ? __builtin_nontemporal_load(pt) : *pt;
       gq[s] = (ICS_UPDATE_NT & 4) ? __builtin_nontemporal_load(pg) : *pg;
       if (TVK != 2) fq[s] = (ICS_UPDATE_NT & 8) ? __builtin_nontemporal_load(pf) : *pf;
-      if (TVK != 0) Tq[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.tv + o));
+      if (TVK == 1) Tq[s] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.tv + o));
     }
 #pragma unroll
     for (int s = 0; s < U; ++s) {
@@ -646,8 +787,8 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
         const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
         const float uv = uq[s][e], gv = gq[s][e];
         float g;
-        if (TVK == 2)                                                            // PAM: G = T + lambd*gradu, no majoriser term
-          g = (float)((double)Tq[s][e] + (double)__fmul_rn(lambd, gv));
+        if (TVK == 2)                                                            // PAM: the back-projection pass wrote G = T + lambd*gradu
+          g = gv;
         else if (TVK == 1 && y >= 1 && y <= G.uM - 2 && x >= 1 && x <= G.uN - 2)   // pyx:517 (TV_ut_L1 != 0 and TV_u_L1 != 0)
           g = (float)(((double)Tq[s][e] + (double)__fmul_rn(lambd, gv)) + (double)__fsub_rn(uv, tq[s][e]) / 4.0);
         else
@@ -743,9 +884,15 @@ hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hi
 }
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
-  if (a.kind == 1) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a);
-  else if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a);
+  const bool exact = ics_debug().pam_exact.load(std::memory_order_relaxed) != 0;
+  if (a.kind == 1 && exact) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a);
+  else if (a.kind == 1) hipLaunchKernelGGL((k_tvterm<1, true>), dim3(2048), dim3(256), 0, s, a);
+  else if (exact) {   // the per-value IEEE form (pam_term): kept as the cross-check
+    if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a);
+  }
+  else if (a.kind == 2) hipLaunchKernelGGL(k_tvterm_pam<false>, dim3(2048), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_tvterm_pam<true>, dim3(2048), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -31,6 +31,16 @@ int main(int argc, char** argv) {
   hipMalloc(&bt, tf * 4); hipMemcpy(bt, tab.data(), tf * 4, hipMemcpyHostToDevice);
   IcsConvArgs a = {};
   a.in = in + org; a.out = out + org; a.f = f + org; a.u = u + org; a.ut = ut + org; a.red = red; a.lambd = 1.f; a.bt = bt; a.g = g;
+  if (!getenv("ICS_BENCH_NO_ACC")) {   // the image in accumulator order for both tile heights (ics_image_acc.h)
+    for (int k = 0; k < 2; ++k) {
+      float* p = nullptr;
+      hipMalloc(&p, ics_image_acc_floats(g, k ? 4 : 2) * 4);
+      ics_launch_image_acc(a.f, g, k ? 4 : 2, p, 0);
+      a.facc[k] = p;
+    }
+  }
+  uint32_t* sched = nullptr; hipMalloc(&sched, 64); hipMemset(sched, 0, 64);
+  if (!getenv("ICS_BENCH_NO_SCHED")) a.sched = sched;   // dynamic tile claiming as in the library (the launcher decides per launch)
   {
     int nb0 = -1, nb1 = -1;
     if (K == 15) {
