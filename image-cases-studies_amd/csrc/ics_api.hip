@@ -474,7 +474,7 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
   const int need = 2 * (H > W ? H : W) - 1;
   int P = 2, logP = 1;
   while (P < need) { P <<= 1; ++logP; }
-  if (P > 2048) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 2048, i.e. windows up to 1024 px; deblur_module: mask_size <= 1025)", H, W, P);
+  if (P > 8192) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 8192, i.e. windows up to 4096 px a side)", H, W, P);
   if (j->z) { hipFree(j->z); j->z = nullptr; }
   if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
   if (j->weights) { hipFree(j->weights); j->weights = nullptr; }

@@ -253,8 +253,13 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   }
   const unsigned char* base_h = lds + li * C::ROWB + (16 * cb + 8 * lg) * 2;
 
-  float mg[3] = {0.f, 0.f, 0.f}, mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
-  uint32_t rflags = 0u;   // bit c: NaN seen in g_c, bit 3+c: NaN seen in u_c, bit 6: any element reduced (one register)
+  // Step-size maxima (pyx:523-524).  |g| and |u| are tracked as BIT PATTERNS under an unsigned integer maximum: for non-negative
+  // floats that order is the float order, and every NaN pattern (> 0x7F800000) lies above +Inf, so a NaN propagates by itself like
+  // np.amax does -- two instructions per value instead of the float maximum plus a compare / select / or for a separate flag.
+  // max u (signed) stays a float maximum; its NaN shows in the |u| pattern.
+  uint32_t mgb[3] = {0u, 0u, 0u}, mub[3] = {0u, 0u, 0u};
+  float mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+  uint32_t rflags = 0u;   // bit 6: any element reduced
 
   // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
@@ -607,11 +612,13 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
                   g = (float)(((double)Tv + (double)__fmul_rn(lambd, av[c])) + (double)__fsub_rn(uv, tv) / 4.0);
                 else
                   g = __fadd_rn(__fmul_rn(lambd, av[c]), __fmul_rn(__fsub_rn(uv, tv), 0.5f));
-                mg[c] = __builtin_fmaxf(mg[c], __builtin_fabsf(g));   // maxnum drops NaN: tracked separately
+                const uint32_t gb = __float_as_uint(g) & 0x7FFFFFFFu, ub = __float_as_uint(uv) & 0x7FFFFFFFu;
+                mgb[c] = mgb[c] > gb ? mgb[c] : gb;
+                mub[c] = mub[c] > ub ? mub[c] : ub;
                 mu[c] = __builtin_fmaxf(mu[c], uv);
-                rflags |= ((g != g) ? (1u << c) : 0u) | ((uv != uv) ? (8u << c) : 0u) | 64u;
                 gout[c] = __float_as_uint(g);
               }
+              rflags |= 64u;
               if (pam) __builtin_amdgcn_raw_buffer_store_b96(gout, rs_o, voff, so, ICS_EPI_STORE_AUX);
             }
           }
@@ -641,8 +648,8 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
     uint32_t kg[3], ku[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      kg[c] = (rflags & (1u << c)) ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(mg[c]) : 0u);   // NaN propagates like np.amax
-      ku[c] = (rflags & (8u << c)) ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(mu[c]) : 0u);
+      kg[c] = mgb[c] > 0x7F800000u ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(__uint_as_float(mgb[c])) : 0u);   // NaN propagates like np.amax
+      ku[c] = mub[c] > 0x7F800000u ? 0xFFC00000u : ((rflags & 64u) ? ics_f2key(mu[c]) : 0u);
       kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]);
     }
     uint32_t* red_lds = reinterpret_cast<uint32_t*>(fscr);

@@ -121,15 +121,16 @@ __global__ void k_fftx(FftX f, IcsStatsArgs a) {
   int line = blockIdx.x - plane * f.lines_per_plane;
   line = line < f.n0 ? line : line + f.skip;
   float2* base = f.data + (long)plane * f.plane_stride + (long)line * f.line_stride;
+  // P / 2 butterflies per stage over min(P / 2, 1024) threads: above P = 2048 (stats windows wider than 1024 px; the reference has
+  // no limit, lib/deconvolution.pyx:623-638) a thread takes several
+  const int nthr = blockDim.x;
   if (LOAD == 1) {
     const IcsGeom& G = a.geo;
     const Win w = make_win(a);
     const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
     const float mxk = ics_key2f(a.ukey[0]);                       // max |e - mean| (k_mom2), NaN key kept
     const float mx = (a.ukey[0] == 0xFFC00000u) ? mxk : __fdiv_rn(mxk, std_e);   // = max |(e - mean) / std|
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = tid + h * t;
+    for (int j = tid; j < P; j += nthr) {
       float v = 0.f;
       if (line < w.H && j < w.W) {
         const float e = a.e[(ptrdiff_t)(a.top + G.pad + line) * G.pitch + 3 * (a.left + G.pad + j) + plane];
@@ -138,9 +139,7 @@ __global__ void k_fftx(FftX f, IcsStatsArgs a) {
       x[j] = make_float2(v, 0.f);
     }
   } else {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = tid + h * t;
+    for (int j = tid; j < P; j += nthr) {
       float2 v = make_float2(0.f, 0.f);
       if (LOAD != 2 || j < f.nvalid) v = base[(long)j * f.stride_elem];
       if (LOAD == 3) v = make_float2(v.x * v.x + v.y * v.y, 0.f);
@@ -149,19 +148,20 @@ __global__ void k_fftx(FftX f, IcsStatsArgs a) {
   }
   __syncthreads();
   for (int s = 0, p = 1; s < f.logP; ++s, p <<= 1) {
-    const int k = tid & (p - 1);
-    const int j = ((tid - k) << 1) + k;
-    float2 w = f.tw[k * (t / p)];
-    if (f.inverse) w.y = -w.y;
-    const float2 u0 = x[tid], v = x[tid + t];
-    const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-    y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-    y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    for (int b = tid; b < t; b += nthr) {
+      const int k = b & (p - 1);
+      const int j = ((b - k) << 1) + k;
+      float2 w = f.tw[k * (t / p)];
+      if (f.inverse) w.y = -w.y;
+      const float2 u0 = x[b], v = x[b + t];
+      const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
+      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+    }
     __syncthreads();
     float2* tmp = x; x = y; y = tmp;
   }
-  base[(long)tid * f.stride_elem] = x[tid];
-  base[(long)(tid + t) * f.stride_elem] = x[tid + t];
+  for (int j = tid; j < P; j += nthr) base[(long)j * f.stride_elem] = x[j];
 }
 
 __device__ void stats_final(const IcsStatsArgs& a);
@@ -232,18 +232,28 @@ hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
   if (a.do_mr) {
     const int P = a.P;
     const size_t lds = 2 * (size_t)P * sizeof(float2);
+    const int nthr = P / 2 < 1024 ? P / 2 : 1024;
+    if (lds > 64 * 1024) {   // P = 8192: 128 KB of dynamic LDS (stats windows up to 4096 px)
+      static std::atomic<bool> cfg[4][ICS_MAX_DEVICES];
+      const int dev = ics_current_device();
+      hipError_t e = ics_configure_lds(cfg[0], dev, k_fftx<0>, 128 * 1024);
+      if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_fftx<1>, 128 * 1024);
+      if (e == hipSuccess) e = ics_configure_lds(cfg[2], dev, k_fftx<2>, 128 * 1024);
+      if (e == hipSuccess) e = ics_configure_lds(cfg[3], dev, k_fftx<3>, 128 * 1024);
+      if (e != hipSuccess) return e;
+    }
     const long plane = (long)P * P;
     const int H = a.bottom - a.top;
     // rows: line = row, elements contiguous; columns: line = column, element stride P
     FftX f = {a.z, P, a.logP, 1L, (long)P, H, plane, 0, a.tw, H, 0, H};
-    hipLaunchKernelGGL(k_fftx<1>, dim3(3 * H), dim3(P / 2), lds, s, f, a);                     // rows of the window
+    hipLaunchKernelGGL(k_fftx<1>, dim3(3 * H), dim3(nthr), lds, s, f, a);                     // rows of the window
     f.stride_elem = P; f.line_stride = 1; f.lines_per_plane = P; f.n0 = P;
-    hipLaunchKernelGGL(k_fftx<2>, dim3(3 * P), dim3(P / 2), lds, s, f, a);                     // columns (rows >= H are zero)
+    hipLaunchKernelGGL(k_fftx<2>, dim3(3 * P), dim3(nthr), lds, s, f, a);                     // columns (rows >= H are zero)
     f.inverse = 1;
-    hipLaunchKernelGGL(k_fftx<3>, dim3(3 * P), dim3(P / 2), lds, s, f, a);                     // |Z|^2, inverse columns
+    hipLaunchKernelGGL(k_fftx<3>, dim3(3 * P), dim3(nthr), lds, s, f, a);                     // |Z|^2, inverse columns
     // inverse rows: k_mr reads rows (r - H/2) mod P, r < H:  0 .. H - H/2 - 1  and  P - H/2 .. P - 1
     f.stride_elem = 1; f.line_stride = P; f.lines_per_plane = H; f.n0 = H - H / 2; f.skip = P - H;
-    hipLaunchKernelGGL(k_fftx<0>, dim3(3 * H), dim3(P / 2), lds, s, f, a);
+    hipLaunchKernelGGL(k_fftx<0>, dim3(3 * H), dim3(nthr), lds, s, f, a);
     hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);   // its last workgroup writes the scalars
   } else {
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);

@@ -159,8 +159,23 @@ def pam_tv_term(u, epsilon, collaborative):
     return T
 
 
+def argmax_margin(u):
+    """Per pixel: the smallest gap, over the two directions, between the largest and the second largest |forward difference| of the
+    three channels -- how close the collaborative term's arg-max channel (pam_tv_term) is to flipping.  A pixel whose margin is below
+    the rounding differences of two implementations (~1e-7 x the data range) may legitimately pick different channels."""
+    u = np.asarray(u, np.float32)
+    dx = np.zeros_like(u); dx[:-1] = u[1:] - u[:-1]
+    dy = np.zeros_like(u); dy[:, :-1] = u[:, 1:] - u[:, :-1]
+    out = np.full(u.shape[:2], np.inf, np.float32)
+    for d in (dx, dy):
+        a = np.sort(np.abs(d), axis=2)
+        out = np.minimum(out, a[..., 2] - a[..., 1])
+    return out
+
+
 def richardson_lucy_PAM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
-                        blind=True, correlation=False, *, collaborative=False, conv="direct", trace: Trace | None = None):
+                        blind=True, correlation=False, *, collaborative=False, conv="direct", trace: Trace | None = None,
+                        margins: list | None = None):
     cv = base._conv_scipy if conv == "scipy" else base._conv_direct
     tr = trace if trace is not None else Trace()
     step_factor, lambd, tau = F32(step_factor), F32(lambd), F32(tau)
@@ -180,6 +195,8 @@ def richardson_lucy_PAM(image, u, psf, top, bottom, left, right, tau, M, N, C, M
             error[:] = synth - image
             for k in range(3):
                 gradu[..., k] = cv(error[..., k], psf_rotated[..., k], "full")
+            if margins is not None:
+                margins.append(argmax_margin(u))          # (tests: which pixels are near an arg-max tie in this inner iteration)
             T = pam_tv_term(u, epsilon, collaborative)
             gradu[:] = (T.astype(np.float64) + (lambd * gradu).astype(np.float64)).astype(np.float32)
             for k in range(3):

@@ -7,8 +7,12 @@ import json
 import re
 import sys
 
-KERNELS = {"k_conv_mfma<15, 0,": "synth_residual", "k_conv_mfma<15, 1,": "backproject", "k_update_rows<0>": "update",
-           "k_gradk_mfma<1>": "psf_gradient", "k_synth_gradk<15>": "synth_gradk"}
+def kernel_names(psf):
+    return {"k_conv_mfma<%d, 0," % psf: "synth_residual", "k_conv_mfma<%d, 1," % psf: "backproject", "k_update_rows<0>": "update",
+            "k_gradk_mfma<": "psf_gradient", "k_synth_gradk<%d," % psf: "synth_gradk"}
+
+
+KERNELS = {}
 ALGO = {"synth_residual": 36, "backproject": 48, "update": 60, "psf_gradient": 24, "synth_gradk": 60}   # bytes per pixel
 
 
@@ -24,16 +28,22 @@ def counters(path, name):
 
 
 def main():
-    fetch, write = counters(sys.argv[1], "FETCH_SIZE"), counters(sys.argv[2], "WRITE_SIZE")
-    px = 4096 * 4096
+    """make_traffic_json.py fetch.txt write.txt [fetch_two_kernel.txt] [--size N] [--psf K]   (the workload the passes were run on)"""
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    opt = {sys.argv[i][2:]: int(sys.argv[i + 1]) for i in range(1, len(sys.argv) - 1) if sys.argv[i].startswith("--")}
+    args = [a for a in args if not a.isdigit()]
+    size, psf = opt.get("size", 4096), opt.get("psf", 15)
+    KERNELS.update(kernel_names(psf))
+    fetch, write = counters(args[0], "FETCH_SIZE"), counters(args[1], "WRITE_SIZE")
+    px = size * size
     kern = {}
     for k in fetch:
         w = write.get(k, 0.0)
         kern[k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": w, "hbm_bytes": int((2 * fetch[k] + w) * 1024), "algorithmic_bytes": ALGO[k] * px}
         kern[k]["ratio"] = round(kern[k]["hbm_bytes"] / kern[k]["algorithmic_bytes"], 3)
-    out = {"_comment": __doc__.strip(), "workload": {"size": 4096, "psf": 15}, "kernels_matrix": kern}
-    if len(sys.argv) > 3:   # the two-kernel gradient path (ICS_FUSED_GRADK=0), fetch side only
-        f2 = counters(sys.argv[3], "FETCH_SIZE")
+    out = {"_comment": __doc__.strip(), "workload": {"size": size, "psf": psf}, "kernels_matrix": kern}
+    if len(args) > 2:   # the two-kernel gradient path (ICS_FUSED_GRADK=0), fetch side only
+        f2 = counters(args[2], "FETCH_SIZE")
         out["two_kernel_gradient_path_fetch_KiB"] = {k: f2[k] for k in ("synth_residual", "psf_gradient") if k in f2}
     print(json.dumps(out, indent=1))
 

@@ -164,11 +164,20 @@ def test_psf_update_correlation_quirk():
     job.close()
 
 
-@pytest.mark.parametrize("M,N,MK,win", [(129, 129, 15, (8, 119, 8, 119)), (300, 280, 9, (5, 250, 5, 250)), (65, 49, 9, (5, 42, 5, 42))])
+@pytest.mark.parametrize("M,N,MK,win", [(129, 129, 15, (8, 119, 8, 119)), (300, 280, 9, (5, 250, 5, 250)), (65, 49, 9, (5, 42, 5, 42)),
+                                        (1300, 1250, 5, (20, 1221, 7, 1108)), (2300, 400, 3, (100, 2249, 30, 331))],
+                         ids=["111px", "245px", "37px", "1201x1101px-P4096", "2149x301px-P8192"])
 def test_window_statistics_and_whiteness_metric(M, N, MK, win):
-    """A18/A19 on device (FFT autocorrelation) vs the oracle's numpy/scipy evaluation."""
+    """A18/A19 on device (FFT autocorrelation) vs the oracle's numpy/scipy evaluation.  The last two windows are wider than 1024 px
+    (4096- and 8192-point transforms: several butterflies per thread, 128 KB of LDS) -- the reference has no limit on `mask_size`
+    (deconvolve.py:67, lib/deconvolution.pyx:623-638), round 2 stopped at 1024 px."""
     from lib import _native as nv
-    job, case, psf = make_job(M, N, MK, seed=5)
+    if M > 1000:
+        case = orc.synth_case_large(M, N, MK, seed=5)
+        job = nv.RLJob(M, N, MK)
+        job.upload(case["image"], case["u0"], case["psf0"])
+    else:
+        job, case, psf = make_job(M, N, MK, seed=5)
     pad = MK // 2
     p = job.params(*win, 1e9, 1, 1e-3, 10000.0, blind=False)
     job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
