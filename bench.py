@@ -173,6 +173,51 @@ def timed_run(ctx, M, MK, blind, tv_mode, conv, steps, warm, seed=0):
             "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[mode], "frac_of_8TBps": round(gb / HBM_PEAK_GBPS, 4), "kernels_ms": kern, "steps": steps}
 
 
+def bench_bands(args, grp):
+    """`--bands N`: one frame over N ranks (row bands, lib.banded.BandRank), strong scaling.  Secondary workload: the headline stays
+    one frame per GPU.  Same step definition (one inner iteration), same barrier / max-over-ranks timing."""
+    from lib import _native, banded
+    M = N = args.size if args.size != 4096 else 12288
+    MK = args.psf
+    blind = args.mode == "blind"
+    steps, warm = ((args.steps + 4) // 5) * 5, ((args.warmup + 4) // 5) * 5
+    conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
+    pad = MK // 2
+    win = (M // 2 - 127, M // 2 + 128, N // 2 - 127, N // 2 + 128)      # 255-px window at the centre: straddles the bands for even N
+    image, u0, psf_true, psf_uniform = synth_frame(M, N, MK, seed=0)   # (every rank builds the same frame and takes its rows)
+    br = banded.BandRank(grp, M, N, MK, *win, 1e9, 1e-3, 10000.0, blind=blind, conv=conv, device=int(os.environ.get("ICS_DEVICE", grp.local_rank)),
+                         stop_test=False)
+    br.upload(image, u0, psf_uniform if blind else psf_true)
+    del image, u0
+    if warm:
+        br.run(warm // 5)
+    grp.barrier()
+    t0 = time.perf_counter()
+    st = br.run(steps // 5)
+    grp.barrier()
+    elapsed = grp.max(time.perf_counter() - t0)
+    rec = grp.gather([float(st.iterations_done), float(st.M_r), float(br.bd.y1 - br.bd.y0)])
+    desc = grp.describe()
+    br.close()
+    if grp.rank == 0:
+        ms = elapsed * 1e3 / steps
+        gb = ITER_BYTES_PER_PX[args.mode] * M * N / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "MPixels/sec/iter RL-TV deconv @%d^2x3 fp32, %dx%d PSF, ONE frame over %d row bands" % (M, MK, MK, grp.size),
+            "value": round(M * N * steps / elapsed / 1e6, 1), "unit": "MPixels/s/iter", "n_gpus": grp.size, "steps": steps, "warmup": warm,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 (fp16x2-split MFMA convolutions, fp32 accumulate)" if conv != 1 else "f32",
+            "data": "synthetic",
+            "config": {"workload": "%s Richardson-Lucy MM, ONE %dx%dx3 frame split into %d row bands (one rank per GPU), %dx%d PSF; per inner iteration: "
+                                   "all-reduce(max) of 6 keys, two point-to-point halo exchanges of %d rows, %s; host-synchronous stage calls"
+                                   % (args.mode, M, N, grp.size, MK, MK, 2 * pad, "all-reduce(sum) of 3 K^2 doubles" if blind else "no further exchange"),
+                       "mode": args.mode, "parallelism": "row-bands x%d" % grp.size, "band_rows": [int(r[2]) for r in rec]},
+            "hbm_roofline_iteration": {"algorithmic_bytes_per_px": ITER_BYTES_PER_PX[args.mode], "achieved_GBps": round(gb, 1),
+                                       "frac_of_aggregate_8TBps_x_N": round(gb / (HBM_PEAK_GBPS * grp.size), 4)},
+            "rccl": dict(desc, ranks_gathered=len(rec))}))
+    grp.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,8 +235,12 @@ def main():
     ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` block (25 + 200 extra steps after the timed region)")
+    ap.add_argument("--bands", type=int, default=0, help="N > 0: ONE frame (--size, default 12288 here) split into N row bands, one rank per GPU "
+                    "(lib.banded.BandRank: RCCL max / sum all-reduce + point-to-point halos); strong scaling, a secondary workload (SURVEY.md 8f N4)")
     args = ap.parse_args()
 
+    if args.bands:
+        args.gpus = args.bands
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))   # (no HIP / torch call has happened in this process)
 
@@ -200,6 +249,8 @@ def main():
     grp = multi_gpu.Group()
     if grp.size != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, grp.size))
+    if args.bands:
+        raise SystemExit(bench_bands(args, grp))
     M = N = args.size
     MK = args.psf
     steps = ((args.steps + 4) // 5) * 5

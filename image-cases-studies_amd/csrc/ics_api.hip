@@ -459,6 +459,27 @@ extern "C" int ics_rl_copy_rows(ics_rl* dst, int dst_which, int dst_row0, ics_rl
   return ICS_OK;
 }
 
+// Rows of a frame buffer to / from the same buffer of band jobs on OTHER RANKS (one process per GPU, RCCL point-to-point over xGMI):
+// the halo exchange and the stop-test gather of lib/banded.py in rank mode.  Whole pitch rows travel (the apron columns are
+// zero on both sides).  ics_group_sendrecv_device: ics_group.hip.
+int ics_group_sendrecv_device(ics_group* g, const float* send, size_t send_count, int send_peer, float* recv, size_t recv_count, int recv_peer);
+extern "C" int ics_rl_exchange_rows(ics_rl* j, ics_group* g, int which, int send_row0, int send_rows, int send_peer, int recv_row0, int recv_rows, int recv_peer) {
+  if (!j || !g) return fail(ICS_EINVAL, "NULL argument");
+  float* frame; int rows, cols, oy, ox;
+  if (frame_of(j, which, &frame, &rows, &cols, &oy, &ox) != 0) return fail(ICS_EINVAL, "buffer %d is not a frame", which);
+  if (send_peer >= 0 && (send_row0 < 0 || send_rows < 1 || send_row0 + send_rows > rows)) return fail(ICS_EINVAL, "send rows [%d, %d) of %d", send_row0, send_row0 + send_rows, rows);
+  if (recv_peer >= 0 && (recv_row0 < 0 || recv_rows < 1 || recv_row0 + recv_rows > rows)) return fail(ICS_EINVAL, "receive rows [%d, %d) of %d", recv_row0, recv_row0 + recv_rows, rows);
+  HIPCHK(hipSetDevice(j->ctx->device));
+  HIPCHK(hipStreamSynchronize(j->ctx->stream));          // what is sent has been produced
+  if (recv_peer >= 0 && which == ICS_BUF_IMAGE) image_changed(j);
+  const size_t pitch = (size_t)j->g.pitch;
+  // row r of the buffer = frame row oy + r; a pitch row starts ax pixels left of the frame origin
+  float* base = frame;                                  // allocation start of the frame (origin = base + ay rows + ax pixels)
+  const float* sp = base + (size_t)(j->g.ay + oy + (send_peer >= 0 ? send_row0 : 0)) * pitch;
+  float* rp = base + (size_t)(j->g.ay + oy + (recv_peer >= 0 ? recv_row0 : 0)) * pitch;
+  return ics_group_sendrecv_device(g, sp, send_peer >= 0 ? (size_t)send_rows * pitch : 0, send_peer, rp, recv_peer >= 0 ? (size_t)recv_rows * pitch : 0, recv_peer);
+}
+
 // -------------------------------------------------------------------------------------------------
 // stop-test scratch: Gaussian window weights (pyx:393-404), twiddles, P x P x 3 complex buffer
 static int ensure_window(ics_rl* j, const ics_rl_params* p) {

@@ -18,7 +18,7 @@
 namespace {
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
-enum { RCCL_SUCCESS = 0, RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT64 = 8 };
+enum { RCCL_SUCCESS = 0, RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8 };
 struct Rccl {
   void* so;
   int (*GetUniqueId)(rcclUniqueId*);
@@ -29,6 +29,10 @@ struct Rccl {
   char path[256];   // what dlopen resolved
   int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t);
   int (*AllGather)(const void*, void*, size_t, int, rcclComm_t, hipStream_t);
+  int (*Send)(const void*, size_t, int, int, rcclComm_t, hipStream_t);
+  int (*Recv)(void*, size_t, int, int, rcclComm_t, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
 };
 Rccl g_rccl = {};
 }  // namespace
@@ -62,7 +66,11 @@ static int load_rccl() {
   r.GetErrorString = (const char* (*)(int))dlsym(so, "ncclGetErrorString");
   r.AllReduce = (int (*)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(so, "ncclAllReduce");
   r.AllGather = (int (*)(const void*, void*, size_t, int, rcclComm_t, hipStream_t))dlsym(so, "ncclAllGather");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.GetErrorString || !r.AllReduce || !r.AllGather) {
+  r.Send = (int (*)(const void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(so, "ncclSend");
+  r.Recv = (int (*)(void*, size_t, int, int, rcclComm_t, hipStream_t))dlsym(so, "ncclRecv");
+  r.GroupStart = (int (*)())dlsym(so, "ncclGroupStart");
+  r.GroupEnd = (int (*)())dlsym(so, "ncclGroupEnd");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.CommCount || !r.GetErrorString || !r.AllReduce || !r.AllGather || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) {
     dlclose(so);
     return ics_set_error(ICS_ENODEV, "librccl.so lacks an expected ncclXxx symbol");
   }
@@ -203,6 +211,26 @@ extern "C" int ics_group_describe(const ics_group* g, int* backend, int* nranks,
   if (backend) *backend = g->local ? 0 : 1;
   if (nranks) *nranks = g->local ? 1 : g->nranks;
   if (lib && lib_len) { snprintf(lib, lib_len, "%s", g->local ? "" : g_rccl.path); }
+  return ICS_OK;
+}
+
+// Point-to-point rows between the frames of two band jobs on different ranks (lib/banded.py, rank mode): `count` floats from
+// device pointer `send` to rank send_peer and / or into `recv` from rank recv_peer (peer < 0: that side is absent), one
+// ncclGroup so that neighbours exchanging both ways cannot deadlock.  The caller has drained the stream that produced `send`;
+// the call returns when the transfer is complete.  (ics_rl_exchange_rows in ics_api.hip resolves frame rows to pointers.)
+int ics_group_sendrecv_device(ics_group* g, const float* send, size_t send_count, int send_peer, float* recv, size_t recv_count, int recv_peer) {
+  if (!g) return ics_set_error(ICS_EINVAL, "group is NULL");
+  if (g->local) return ics_set_error(ICS_ESTATE, "a one-rank local group has no peers");
+  if ((send_peer >= g->world) || (recv_peer >= g->world)) return ics_set_error(ICS_EINVAL, "peer out of range");
+  GHIP(hipSetDevice(g->device));
+  GRCCL(g_rccl.GroupStart());
+  int r1 = RCCL_SUCCESS, r2 = RCCL_SUCCESS;
+  if (send_peer >= 0 && send_count) r1 = g_rccl.Send(send, send_count, RCCL_FLOAT32, send_peer, g->comm, g->stream);
+  if (recv_peer >= 0 && recv_count) r2 = g_rccl.Recv(recv, recv_count, RCCL_FLOAT32, recv_peer, g->comm, g->stream);
+  const int r3 = g_rccl.GroupEnd();
+  if (r1 != RCCL_SUCCESS || r2 != RCCL_SUCCESS || r3 != RCCL_SUCCESS)
+    return ics_set_error(ICS_EHIP, "ncclSend / ncclRecv: %s", g_rccl.GetErrorString(r1 != RCCL_SUCCESS ? r1 : (r2 != RCCL_SUCCESS ? r2 : r3)));
+  GHIP(hipStreamSynchronize(g->stream));
   return ICS_OK;
 }
 

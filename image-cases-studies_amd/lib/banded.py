@@ -202,3 +202,159 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
 
 
 richardson_lucy_MM_banded.last = None
+
+
+class BandRank:
+    """One rank's share of a row-band split with ONE PROCESS PER BAND (one rank per GPU; `group` = multi_gpu.Group): rank r owns
+    band r of `group.size` bands.  What crosses bands goes through the group -- RCCL over xGMI on a multi-GPU node, the CPU
+    stand-in where ranks share a GPU:
+      1. the six step-size keys: `group.max_many` (ics_group_allreduce_max) -- order-preserving uint32 keys are exact in float64;
+      2. the halo rows: `group.exchange_rows` (ncclSend / ncclRecv between the band jobs' device frames), both directions;
+      3. blind: the 3 MK^2 PSF-gradient partial sums: `group.sum_many` (ics_group_allreduce_sum, float64);
+      4. the stop-test window: its rows travel to rank 0, which holds the statistics job; the scalars come back with `gather`.
+    upload() once, run() as often as wanted on the resident frames (bench.py --bands times run() alone), download() the owned rows."""
+
+    def __init__(self, group, M, N, MK, top, bottom, left, right, tau, step_factor, lambd, blind=True, correlation=False, C=3, conv=0,
+                 device=None, stop_test=True):
+        nv = _native
+        self.group, self.M, self.N, self.MK = group, int(M), int(N), int(MK)
+        self.pad = pad = self.MK // 2
+        self.R, self.W = group.rank, group.size
+        rows = split_rows(self.M, self.W, pad)
+        self.bd = bd = _Band(self.R, rows[self.R][0], rows[self.R][1], self.M, pad, device if device is not None else nv.default_device())
+        self.bands = [_Band(k, rows[k][0], rows[k][1], self.M, pad, 0) for k in range(self.W)]
+        if not (0 <= top < bottom <= self.M):
+            raise ValueError("stats window rows [%d, %d) outside the %d image rows" % (top, bottom, self.M))
+        self.win, self.tau, self.blind, self.stop_test = (top, bottom, left, right), tau, bool(blind), stop_test
+        ctx = nv.Context.get(bd.device)
+        self.job = nv.RLJob(bd.b - bd.a, self.N, self.MK, ctx)
+        self.sj = nv.RLJob(bottom - top, self.N, self.MK, ctx) if self.R == 0 else None
+        self._P = lambda **kw: self.job.params(top - bd.a, bottom - bd.a, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C,
+                                               conv=conv, flags=nv.FLAG_NO_FUSED_GRADK, **kw)
+        self._sP = self.sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv) if self.sj else None
+
+    def upload(self, image, u, psf):
+        """every rank passes the full arrays and takes its own rows of them"""
+        bd, pad = self.bd, self.pad
+        self.job.upload(np.ascontiguousarray(image[bd.a:bd.b], np.float32), np.ascontiguousarray(u[bd.a:bd.b + 2 * pad], np.float32),
+                        np.ascontiguousarray(psf, np.float32))
+
+    def download(self, u, psf=None):
+        """the rows this rank OWNS into u[u0:u1] (u-frame rows); returns (u0, u1)"""
+        bd = self.bd
+        u[bd.u0:bd.u1] = self.job.read_rows(_native.BUF_U, bd.lu0, bd.lu1 - bd.lu0)
+        if psf is not None and self.blind:
+            psf[...] = self.job.download_psf_caller()
+        return bd.u0, bd.u1
+
+    def close(self):
+        self.job.close()
+        if self.sj is not None:
+            self.sj.close()
+
+    def _gather_window(self, which, g0, g1):
+        """global rows [g0, g1) of a frame buffer -> the statistics job on rank 0, from the ranks that own them, in rank order"""
+        nv, R, bd, sj, job = _native, self.R, self.bd, self.sj, self.job
+        for k, nb in enumerate(self.bands):
+            o0, o1 = (nb.u0, nb.u1) if which == nv.BUF_U else (nb.y0, nb.y1)
+            lo, hi = max(g0, o0), min(g1, o1)
+            if lo >= hi:
+                continue
+            if k == 0 and R == 0:
+                sj.copy_rows_from(which, lo - g0, job, which, lo - bd.a, hi - lo)
+            elif R == 0:
+                self.group.exchange_rows(sj, which, recv=(lo - g0, hi - lo, k))
+            elif R == k:
+                self.group.exchange_rows(job, which, send=(lo - bd.a, hi - lo, 0))
+
+    def _statistics(self):
+        nv = _native
+        top, bottom = self.win[0], self.win[1]
+        self._gather_window(nv.BUF_ERROR, top, bottom)
+        self._gather_window(nv.BUF_U, top, bottom + 2 * self.pad)
+        sc = [0.0, 0.0, 0.0]
+        if self.R == 0:
+            self.sj.stage(nv.STAGE_STATS, self._sP)
+            d = self.sj.scalars()
+            sc = [d["M_r"], d["Hu"], d["varu"]]
+        keys = self.job.red_keys()
+        rec = self.group.gather(sc + [float(keys[12]), float(keys[13]), float(keys[14])])
+        kmin, kmax = min(int(r[3]) for r in rec), max(int(r[4]) for r in rec)
+        nan = any(r[5] for r in rec)
+
+        def key2f(k):
+            k = np.uint32(k)
+            return float((np.uint32(k & np.uint32(0x7FFFFFFF)) if k & np.uint32(0x80000000) else np.uint32(~k)).view(np.float32))
+        return dict(M_r=np.float32(rec[0][0]), Hu=np.float32(rec[0][1]), varu=np.float32(rec[0][2]),
+                    dof_min=float("nan") if nan else key2f(kmin), dof_max=float("nan") if nan else key2f(kmax))
+
+    def run(self, iterations, quiet=True):
+        nv, job, bd, group, R, pad, blind, P = _native, self.job, self.bd, self.group, self.R, self.pad, self.blind, self._P
+        st = nv.RLStats.with_traces(iterations)
+        sc = {"Hu": float("nan"), "varu": float("nan"), "M_r": 0.0, "dof_min": 0.0, "dof_max": 0.0}
+        it, stop = 0, 0
+        M_r = M_r_prev = np.float32(0.0)
+        while it < iterations and not stop:                                               # pyx:460
+            job.stage(nv.STAGE_MAJORIZE, P())                                             # pyx:462
+            for itt in range(INNER):                                                      # pyx:473
+                job.stage(nv.STAGE_SYNTH_RESIDUAL, P())                                   # A1 + A2
+                job.stage(nv.STAGE_BACKPROJECT, P())                                      # A3
+                job.stage(nv.STAGE_BAND_REDUCE, P(band_rows=(bd.lu0, bd.lu1)))
+                keys = group.max_many([float(k) for k in job.red_keys()[:6]])             # (1)
+                job.set_red_keys(np.array(keys, np.float64).astype(np.uint32))
+                job.stage(nv.STAGE_UPDATE, P())                                           # A5 - A10
+                # (2) my first 2 pad owned rows go up, the rows below my owned ones arrive from below; then the other way round
+                up = None if bd.first else (bd.lu0, 2 * pad, R - 1)
+                dn = None if bd.last else (bd.lu1 - 2 * pad, 2 * pad, R + 1)
+                if self.W > 1:
+                    group.exchange_rows(job, nv.BUF_U, send=up, recv=None if bd.last else (bd.lu1, 2 * pad, R + 1))
+                    group.exchange_rows(job, nv.BUF_U, send=dn, recv=None if bd.first else (bd.lu0 - 2 * pad, 2 * pad, R - 1))
+                if blind:                                                                 # pyx:555
+                    job.stage(nv.STAGE_SYNTH_RESIDUAL, P())                               # A11
+                    if itt == INNER - 1:
+                        sc = self._statistics()                                           # A18 + A19 need the unmasked residual
+                    job.stage(nv.STAGE_BAND_MASK_E, P(band_rows=(bd.y0 - bd.a, bd.y1 - bd.a)))
+                    job.stage(nv.STAGE_PSF_GRADIENT, P())                                 # A12 + A13 over the owned rows
+                    gk = np.array(group.sum_many(job.read(nv.BUF_GRADK).astype(np.float64).ravel()), np.float64)   # (3)
+                    job.write(nv.BUF_GRADK, gk.astype(np.float32).reshape(self.MK, self.MK, 3))
+                    job.stage(nv.STAGE_PSF_UPDATE, P())                                   # A14 - A17
+                elif itt == INNER - 1:
+                    sc = self._statistics()
+            if it > 0:
+                M_r_prev = M_r
+            M_r = np.float32(sc["M_r"])
+            st.trace_M_r[it], st.trace_Hu[it], st.trace_varu[it] = sc["M_r"], sc["Hu"], sc["varu"]
+            st.trace_dof_min[it], st.trace_dof_max[it] = sc["dof_min"], sc["dof_max"]
+            st.trace_len = it + 1
+            if it > 1 and self.stop_test:                                                 # pyx:643-654 (the same float32 scalars on every rank)
+                if blind:
+                    stop = int(M_r > M_r_prev)
+                else:
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        stop = int(np.float32(M_r - M_r_prev) / np.float32(M_r + M_r_prev) > np.float32(self.tau))
+            it += 1
+            if R == 0 and not quiet:
+                _progress(it, stop, sc["dof_min"], sc["dof_max"], sc["M_r"], sc["Hu"], sc["varu"])
+        st.iterations_done, st.stopped = it, stop
+        st.M_r, st.Hu, st.varu = float(M_r), float(sc["Hu"]), float(sc["varu"])
+        st.inner_iterations = INNER * it
+        return st
+
+
+def richardson_lucy_MM_band_rank(group, image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd,
+                                 blind=True, correlation=False, *, conv=0, device=None, quiet=False):
+    """`richardson_lucy_MM` for ONE RANK of a row-band split (see BandRank): every rank passes the full arrays; `u` receives the rows
+    this rank OWNS (u-frame rows [u0, u1)) and `psf` the PSF -- assembling a full frame is the caller's business (bench.py --bands
+    does not need it, tests/test_banded.py gathers through files).  Returns (u0, u1, stats)."""
+    _check_buffer("image", image); _check_buffer("u", u); _check_buffer("psf", psf)
+    br = BandRank(group, M, N, MK, top, bottom, left, right, tau, step_factor, lambd, blind=blind, correlation=correlation, C=C, conv=conv, device=device)
+    try:
+        br.upload(image, u, psf)
+        st = br.run(iterations, quiet=quiet)
+        u0, u1 = br.download(u, psf)
+        st.has_nan = int(np.isnan(u[u0:u1]).any())
+    finally:
+        br.close()
+    if group.rank == 0 and not quiet:
+        _report(st, top, bottom, left, right, lambd)
+    return u0, u1, st

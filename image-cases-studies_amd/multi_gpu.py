@@ -214,6 +214,30 @@ class Group:
             return [o.tolist() for o in out]
         return [vals]
 
+    def exchange_rows(self, job, which, send=None, recv=None):
+        """Point-to-point rows of frame buffer `which` between band jobs on different ranks (lib/banded.py rank mode):
+        send = (row0, nrows, peer) leaves this rank's job, recv = (row0, nrows, peer) arrives in it; either may be None.  RCCL
+        backend: ncclSend / ncclRecv between the device frames (ics_rl_exchange_rows); gloo backend (CPU stand-in, ranks sharing a
+        GPU): through the host."""
+        s0, sn, sp = send if send is not None else (0, 0, -1)
+        r0, rn, rp = recv if recv is not None else (0, 0, -1)
+        if self._h is not None:
+            self._check(self._lib.ics_rl_exchange_rows(job._h, self._h, int(which), int(s0), int(sn), int(sp), int(r0), int(rn), int(rp)))
+            return
+        if self.dist is None:
+            raise RuntimeError("exchange_rows needs a group of more than one rank")
+        reqs, buf = [], None
+        if sp >= 0:
+            reqs.append(self.dist.isend(self.torch.from_numpy(job.read_rows(which, s0, sn).copy()), dst=sp))
+        if rp >= 0:
+            import numpy as np
+            buf = np.empty((rn,) + job._shape(which)[1:], np.float32)
+            reqs.append(self.dist.irecv(self.torch.from_numpy(buf), src=rp))
+        for q in reqs:
+            q.wait()
+        if buf is not None:
+            job.write_rows(which, r0, buf)
+
     def close(self):
         if self._h is not None:
             self._lib.ics_group_destroy(self._h)

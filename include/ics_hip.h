@@ -303,6 +303,11 @@ int ics_group_allreduce_sum(ics_group *g, double *inout, int count); /* summed i
  * communicator (ncclCommCount), lib = path or soname of the RCCL library in use ("" when local). */
 int ics_group_describe(const ics_group *g, int *backend, int *nranks, char *lib, size_t lib_len);
 int ics_group_allgather(ics_group *g, const double *send, int count, double *recv /* world * count */);
+/* One image over several ranks (row bands, one process per GPU: lib/banded.py rank mode).  Rows [send_row0, + send_rows) of frame
+ * buffer `which` of this rank's band job go to rank send_peer, rows [recv_row0, + recv_rows) arrive from rank recv_peer (a peer
+ * < 0 switches that side off): RCCL point-to-point over xGMI between the two jobs' device frames, both directions in one group
+ * call so that neighbours exchanging halos cannot deadlock.  Synchronous: returns when the rows are in place. */
+int ics_rl_exchange_rows(ics_rl *job, ics_group *g, int which, int send_row0, int send_rows, int send_peer, int recv_row0, int recv_rows, int recv_peer);
 
 #ifdef __cplusplus
 }

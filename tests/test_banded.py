@@ -133,3 +133,111 @@ def test_device_to_device_rows_between_jobs_and_the_host_fallback(monkeypatch):
     u_host, psf_host, log_host, _ = run_banded(case, M, N, MK, win, 1e9, 2, True, 1, 3)
     assert 1 <= len(calls) <= 4                                      # asked once (per band thread at most), then the host path for the rest of the run
     assert np.array_equal(u_dev, u_host) and np.array_equal(psf_dev, psf_host) and log_dev == log_host
+
+
+RANK_WORKER = r'''
+import contextlib, io, json, os, sys
+ROOT = %(root)r
+for p in ("oracle", "image-cases-studies_amd"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np
+import multi_gpu
+import rl_mm_oracle as orc
+from lib import banded
+cfg = json.loads(%(cfg)r)
+M, N, MK, blind, conv, iters = cfg["M"], cfg["N"], cfg["MK"], cfg["blind"], cfg["conv"], cfg["iters"]
+case = orc.synth_case(M, N, MK, seed=cfg["seed"], blind=blind)
+grp = multi_gpu.Group()
+u, psf = case["u0"].copy(), case["psf0"].copy()
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    u0, u1, st = banded.richardson_lucy_MM_band_rank(grp, case["image"].copy(), u, psf, *cfg["win"], cfg["tau"], M, N, 3, MK, iters, 1e-3, 1e4,
+                                                     blind=blind, conv=conv)
+np.savez(os.path.join(cfg["out"], "rank%%d.npz" %% grp.rank), rows=u[u0:u1], u0=u0, u1=u1, psf=psf, done=st.iterations_done, M_r=st.M_r, Hu=st.Hu,
+         log=np.array(buf.getvalue()), describe=np.array(json.dumps(grp.describe())))
+grp.barrier()
+grp.close()
+'''
+
+
+def run_ranks(tmp_path, cfg, world):
+    import json
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "image-cases-studies_amd"))
+    import multi_gpu
+    cfg = dict(cfg, out=str(tmp_path))
+    script = tmp_path / "band_rank.py"
+    script.write_text(RANK_WORKER % dict(root=ROOT, cfg=json.dumps(cfg)))
+    rc, _ = multi_gpu.launch_ranks([sys.executable, str(script)], world, timeout_s=600, logdir=str(tmp_path / "logs"),
+                                   extra_env={"ICS_DIST_BACKEND": "gloo", "ICS_DEVICE": "0", "OMP_NUM_THREADS": "1"})
+    assert rc == 0, open(str(tmp_path / "logs" / "rank0.stderr")).read()[-3000:]
+    parts = [np.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    u = np.concatenate([p["rows"] for p in parts], axis=0)
+    assert [int(p["u0"]) for p in parts][1:] == [int(p["u1"]) for p in parts][:-1]          # the owned rows tile the frame
+    return u, parts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_mode_bands_one_process_per_band(tmp_path, world):
+    """lib.banded.richardson_lucy_MM_band_rank: one PROCESS per band, everything that crosses bands through multi_gpu.Group (step-size
+    keys: max, halo rows: point-to-point, PSF gradient: sum, stop-test window: gathered on rank 0).  Here the ranks share GPU 0, so the
+    group is the CPU stand-in (RCCL refuses two ranks on one device); the arithmetic, the ownership and the protocol are those of a
+    multi-GPU run.  Non-blind with fp32 products must be BIT-IDENTICAL to the single job, blind within 2e-6."""
+    M, N, MK = 230, 150, 9
+    win = (60, 121, 20, 101)
+    case = orc.synth_case(M, N, MK, seed=4)
+    u1, _, log1, st1 = run_single(case, M, N, MK, win, 1e9, 3, False, 1)
+    u2, parts = run_ranks(tmp_path, dict(M=M, N=N, MK=MK, blind=False, conv=1, iters=3, seed=4, win=win, tau=1e9), world)
+    assert all(int(p["done"]) == 3 for p in parts)
+    assert np.array_equal(u1, u2)
+    assert [l for l in log1.splitlines() if "DoF" not in l] == [l for l in str(parts[0]["log"]).splitlines() if "DoF" not in l]
+    assert "gloo" in str(parts[0]["describe"])
+    # blind
+    M, N, MK = 300, 260, 15
+    win = (110, 191, 60, 201)
+    case = orc.synth_case(M, N, MK, seed=9, blind=True)
+    u1, p1, _, st1 = run_single(case, M, N, MK, win, 0.0, 2, True, 0, flags=1)
+    sub = tmp_path / "blind"; sub.mkdir()
+    u2, parts = run_ranks(sub, dict(M=M, N=N, MK=MK, blind=True, conv=0, iters=2, seed=9, win=win, tau=0.0), world)
+    eu, ep = rel_err(u2, u1), rel_err(parts[0]["psf"], p1)
+    print("rank mode, %d ranks, blind: rel err u %.2e psf %.2e" % (world, eu, ep))
+    assert eu < 2e-6 and ep < 2e-6
+    assert all(np.array_equal(p["psf"], parts[0]["psf"]) for p in parts)                    # every rank holds the same PSF
+    assert abs(float(parts[0]["M_r"]) - st1.M_r) <= 2e-3 * abs(st1.M_r)
+
+
+@pytest.mark.gpu
+def test_rccl_row_exchange_with_a_one_rank_communicator(tmp_path):
+    """ics_rl_exchange_rows over RCCL itself (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd between device frames): all a
+    single-GPU box allows is a communicator of one rank exchanging rows with itself -- rows [3, 8) of the u frame must arrive as
+    rows [20, 25), apron columns and all other rows untouched."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from lib import _native as nv
+        lib = nv.load()
+        h = C.c_void_p()
+        assert lib.ics_group_create(0, 0, 1, %r.encode(), 30, C.byref(h)) == 0, lib.ics_last_error()
+        job = nv.RLJob(40, 33, 5)
+        rng = np.random.default_rng(0)
+        img, u = rng.random((40, 33, 3), dtype=np.float32), rng.random((44, 37, 3), dtype=np.float32)
+        job.upload(img, u, np.full((5, 5, 3), 1 / 25, np.float32))
+        assert lib.ics_rl_exchange_rows(job._h, h, nv.BUF_U, 3, 5, 0, 20, 5, 0) == 0, lib.ics_last_error()
+        got = job.read(nv.BUF_U)
+        want = u.copy(); want[20:25] = u[3:8]
+        assert np.array_equal(got, want)
+        assert lib.ics_rl_exchange_rows(job._h, h, nv.BUF_U, 3, 5, 0, 40, 5, 0) == nv.ICS_EINVAL      # rows outside the frame
+        lib.ics_group_destroy(h); job.close()
+        print("EXCHANGE-OK")
+    """ % (os.path.join(ROOT, "image-cases-studies_amd"), str(tmp_path / "rdzv")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICS_GROUP_FORCE_RCCL="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "EXCHANGE-OK" in out.stdout, out.stderr[-3000:]

@@ -191,3 +191,24 @@ def test_rccl_plumbing_with_a_one_rank_communicator(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICS_GROUP_FORCE_RCCL="1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "RCCL-OK" in out.stdout, out.stderr[-3000:]
     assert not (tmp_path / "rdzv").exists()          # rank 0 removes the id file once the communicator exists
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bands", [1, 2])
+def test_bench_bands_strong_scaling_line(bands):
+    """`bench.py --bands N`: one frame over N ranks (lib.banded.BandRank).  On the single-GPU box: N = 1 in-process, N = 2 as two ranks
+    sharing device 0 through the CPU stand-in of the group.  Checks the JSON contract of that line (strong scaling, one frame)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", ICS_DIST_BACKEND="gloo", ICS_DEVICE="0", OMP_NUM_THREADS="1")
+    cmd = [os.path.join(ROOT, "bench.py"), "--bands", str(bands), "--steps", "10", "--warmup", "5", "--size", "768"]
+    if bands > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % bands, "--master-addr", "127.0.0.1", "--master-port", "29547"] + cmd
+    else:
+        cmd = [sys.executable] + cmd
+        env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == bands and d["scaling"] == "strong" and d["steps"] == 10 and d["unit"] == "MPixels/s/iter"
+    assert sum(d["config"]["band_rows"]) == 768 and len(d["config"]["band_rows"]) == bands
+    assert abs(d["value"] - 768 * 768 * 10 / (d["ms_per_step"] * 10 * 1e-3) / 1e6) < 0.01 * d["value"]
+    assert d["rccl"]["ranks_gathered"] == bands
