@@ -58,7 +58,8 @@ __device__ unsigned long long ics_fused_ticks[17];
 #define ICS_FUSED_F01 0   /* image operand of channels 0 and 1 in one dwordx2 request (0: one dword request per channel) */
 #endif
 #ifndef ICS_FUSED_ABLATE
-#define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand */
+#define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand,
+                                32 no funnel shifts (operands taken unshifted), 64 no MFMAs (operands kept alive), 128 no workgroup barriers */
 #endif
 
 namespace {
@@ -135,7 +136,23 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (vmcnt(0)):
 // with the image operand or the next tile's rows in flight it stalled the whole workgroup for an HBM round trip.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() {
+  if (ICS_FUSED_ABLATE & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// timing probes (ICS_FUSED_ABLATE): the matrix instruction, or a stand-in that keeps its operands alive; the funnel shift or its first operand
+__device__ __forceinline__ f4 f_mfma32(h8 a, h8 b, f4 c) {
+  if (ICS_FUSED_ABLATE & 64) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f4 f_mfma16(h4 a, h4 b, f4 c) {
+  if (ICS_FUSED_ABLATE & 64) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t f_align(uint32_t hi, uint32_t lo, uint32_t sh) {
+  if (ICS_FUSED_ABLATE & 32) return lo;
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
 
 template <typename C>
 __device__ __forceinline__ void load_raw(f32x4u (&v)[C::NIT][3], __amdgpu_buffer_rsrc_t rs, int soff, int tid, int pitch) {
@@ -386,10 +403,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       };
       auto finishB = [&](int ka) {
         const u2* d = rawB;
-        const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, wsh), __builtin_amdgcn_alignbit(d[2].x, d[1].x, wsh),
-                       __builtin_amdgcn_alignbit(d[3].x, d[2].x, wsh), __builtin_amdgcn_alignbit(d[4].x, d[3].x, wsh)};
-        const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, wsh), __builtin_amdgcn_alignbit(d[2].y, d[1].y, wsh),
-                       __builtin_amdgcn_alignbit(d[3].y, d[2].y, wsh), __builtin_amdgcn_alignbit(d[4].y, d[3].y, wsh)};
+        const u4 wh = {f_align(d[1].x, d[0].x, wsh), f_align(d[2].x, d[1].x, wsh),
+                       f_align(d[3].x, d[2].x, wsh), f_align(d[4].x, d[3].x, wsh)};
+        const u4 wl = {f_align(d[1].y, d[0].y, wsh), f_align(d[2].y, d[1].y, wsh),
+                       f_align(d[3].y, d[2].y, wsh), f_align(d[4].y, d[3].y, wsh)};
         Bh[ka] = __builtin_bit_cast(h8, wh);
         Bl[ka] = __builtin_bit_cast(h8, wl);
       };
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           for (int t = 0; t < 4; ++t) {
             const int ka = q - t;
             if (ka < 0 || ka >= K) continue;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 2 ? Al : Ah, term == 1 ? Bl[ka] : Bh[ka], acc[t], 0, 0, 0);
+            acc[t] = f_mfma32(term == 2 ? Al : Ah, term == 1 ? Bl[ka] : Bh[ka], acc[t]);
           }
         if (q + 1 < K) finishB(q + 1);
         Ah = Nh; Al = Nl;
@@ -540,15 +557,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int X = 0; X < 2; ++X) {
           const u2* d = rB[X];
-          const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, gsh[X]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, gsh[X]),
-                         __builtin_amdgcn_alignbit(d[3].x, d[2].x, gsh[X]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, gsh[X])};
-          const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, gsh[X]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, gsh[X]),
-                         __builtin_amdgcn_alignbit(d[3].y, d[2].y, gsh[X]), __builtin_amdgcn_alignbit(d[4].y, d[3].y, gsh[X])};
+          const u4 wh = {f_align(d[1].x, d[0].x, gsh[X]), f_align(d[2].x, d[1].x, gsh[X]),
+                         f_align(d[3].x, d[2].x, gsh[X]), f_align(d[4].x, d[3].x, gsh[X])};
+          const u4 wl = {f_align(d[1].y, d[0].y, gsh[X]), f_align(d[2].y, d[1].y, gsh[X]),
+                         f_align(d[3].y, d[2].y, gsh[X]), f_align(d[4].y, d[3].y, gsh[X])};
           Bh[X] = __builtin_bit_cast(h8, wh);
           Bl[X] = __builtin_bit_cast(h8, wl);
         }
-        const u2 wh2 = {__builtin_amdgcn_alignbit(rB2[1].x, rB2[0].x, gsh[2]), __builtin_amdgcn_alignbit(rB2[2].x, rB2[1].x, gsh[2])};
-        const u2 wl2 = {__builtin_amdgcn_alignbit(rB2[1].y, rB2[0].y, gsh[2]), __builtin_amdgcn_alignbit(rB2[2].y, rB2[1].y, gsh[2])};
+        const u2 wh2 = {f_align(rB2[1].x, rB2[0].x, gsh[2]), f_align(rB2[2].x, rB2[1].x, gsh[2])};
+        const u2 wl2 = {f_align(rB2[1].y, rB2[0].y, gsh[2]), f_align(rB2[2].y, rB2[1].y, gsh[2])};
         B2h = __builtin_bit_cast(h4, wh2);
         B2l = __builtin_bit_cast(h4, wl2);
       };
@@ -572,10 +589,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int X = 0; X < 2; ++X) {
             const int k = (3 * term + X) & 1;
-            g[hp][k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[hp][k], 0, 0, 0);
+            g[hp][k] = f_mfma32(__builtin_bit_cast(h8, term == 2 ? Al[X] : Ah[X]), term == 1 ? cBl[X] : cBh[X], g[hp][k]);
           }
           const int k2 = (3 * term + 2) & 1;
-          g[hp][k2] = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(h4, term == 2 ? A2l : A2h), term == 1 ? cB2l : cB2h, g[hp][k2], 0, 0, 0);
+          g[hp][k2] = f_mfma16(__builtin_bit_cast(h4, term == 2 ? A2l : A2h), term == 1 ? cB2l : cB2h, g[hp][k2]);
         }
         if (i + 1 < 16) {
           finish();

@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE ONLY (data, no reference source).  The COMPILED REFERENCE (o
   * configs[1]  non-blind 2048 x 2048 x 3, 15 x 15 PSF, 2 outer iterations (10 inner),
   * the blind loop at 2048 x 2048, 2 outer iterations,
   * configs[2]  blind 4096 x 4096 x 3, 15 x 15, 1 outer iteration (5 inner) -- the headline workload,
+  * configs[3]  blind 6144 x 6144 x 3, 31 x 31, 1 outer iteration,
 on orc.synth_case_large(seed) inputs, and the fixture keeps what fits a small file: centre / tile-seam / corner crops of u,
 every n-th row and every n-th column of u, float64 moments of the whole frame, the PSF, the reference's stdout and the
 per-outer scalars (from the numpy oracle after asserting it equals the reference bit for bit on these sizes too;
@@ -28,6 +29,8 @@ CASES = [
     dict(name="nb_2048_k15", M=2048, N=2048, MK=15, blind=0, iters=[2], step=1e-3, seed=2048),
     dict(name="bl_2048_k15", M=2048, N=2048, MK=15, blind=1, iters=[2], step=1e-3, seed=2049),
     dict(name="bl_4096_k15", M=4096, N=4096, MK=15, blind=1, iters=[1], step=1e-3, seed=4096),
+    # configs[3]: blind 6144 x 6144 x 3, 31 x 31 PSF, one outer iteration (the reference needs ~6 minutes and ~12 GB for it here)
+    dict(name="bl_6144_k31", M=6144, N=6144, MK=31, blind=1, iters=[1], step=1e-3, seed=6144),
 ]
 
 

@@ -30,6 +30,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.ics_rl_params_size() == ctypes.sizeof(_native.RLParams) and lib.ics_rl_stats_size() == ctypes.sizeof(_native.RLStats)
 
 
+def test_driver_entry_checks_the_current_abi_version():
+    """__graft_entry__.build() asserts the ABI version of the library it has just built: it must name the binding's constant, not a
+    literal that a version bump forgets (round 3 bumped 2 -> 3 and build() still compared with 2)."""
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "_native.ICS_ABI_VERSION" in src
+    from lib import _native
+    hdr = open(HEADER).read()
+    assert re.search(r"#define ICS_ABI_VERSION %d\b" % _native.ICS_ABI_VERSION, hdr)
+
+
 def test_struct_layout_matches_the_header(tmp_path):
     """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
     from lib import _native
