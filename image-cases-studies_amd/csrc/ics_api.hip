@@ -78,6 +78,7 @@ struct ics_rl {
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
+  int fused2_blocks;                    // persistent workgroups of the 32-row fused A11 + A13 kernel: three per CU (capped like gradk_blocks by the test switch)
   uint32_t* red;                        // INNER slots x ICS_RED_STRIDE keys
   uint32_t* dofkeys;                    // 4 words
   uint32_t* sched;                      // 16 words: tile-walk counters of the matrix-core convolutions (IcsConvArgs::sched)
@@ -246,6 +247,8 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   const size_t n = (size_t)3 * MK * MK;
   const int nt = 16 * ((MK + 15) / 16);
   j->gradk_blocks = ics_gradk_blocks(j->g, c->cus);
+  j->fused2_blocks = 3 * c->cus;
+  if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && j->fused2_blocks > mw) j->fused2_blocks = mw;
   int rc;
 #define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
   hipStream_t s = c->stream;
@@ -254,7 +257,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
   if (ics_conv_mfma_supported(MK)) { TRY(dalloc(&j->bt_conv, ics_conv_mfma_table_floats(MK), s)); TRY(dalloc(&j->bt_corr, ics_conv_mfma_table_floats(MK), s)); }
-  TRY(dalloc(&j->partial, (size_t)j->gradk_blocks * 3 * nt * nt, s));
+  TRY(dalloc(&j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, s));
   TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE, s)); TRY(dalloc(&j->dofkeys, (size_t)4, s)); TRY(dalloc(&j->sched, (size_t)16, s));
   TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->dacc, (size_t)8, s)); TRY(dalloc(&j->ukey, (size_t)2, s)); TRY(dalloc(&j->flags, (size_t)4, s));
 #undef TRY
@@ -664,6 +667,9 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   return ICS_OK;
 }
 
+#ifndef ICS_FUSED_DEFAULT_RS
+#define ICS_FUSED_DEFAULT_RS 4
+#endif
 // A11 + A13 in one kernel where it exists (matrix-core path, MK <= 15): ics_synth_gradk_mfma.hip
 static bool use_fused_gradk(const ics_rl* j, const ics_rl_params* p) {
   if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return false;
@@ -676,11 +682,19 @@ static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof
   a.u = org(j, j->u); a.f = org(j, j->f); a.e_out = org(j, j->e); a.bt = j->bt_conv; a.partial = j->partial; a.g = j->g;
   a.wy0 = p->top + j->g.pad; a.wy1 = p->bottom + j->g.pad; a.wx0 = p->left + j->g.pad; a.wx1 = p->right + j->g.pad;
   a.store_all = store_all;
+  // tile height: 32-row tiles with three workgroups per CU, or 64-row tiles with two (ics_synth_gradk_mfma.hip); debug switch fused_rs
+  const int frs = ics_debug().fused_rs.load(std::memory_order_relaxed);
+  a.rs = frs == 2 || frs == 4 ? frs : ICS_FUSED_DEFAULT_RS;
   a.facc = nullptr;
-  if (use_image_acc(p)) { RC(ensure_image_acc(j, 4)); a.facc = j->facc[1]; }
+  if (use_image_acc(p)) { RC(ensure_image_acc(j, a.rs)); a.facc = j->facc[a.rs == 2 ? 0 : 1]; }
+  int nblocks = j->gradk_blocks;
+  if (a.rs == 2) {
+    const int tiles32 = ((j->g.N + 63) / 64) * ((j->g.M + 31) / 32);
+    nblocks = j->fused2_blocks < tiles32 ? j->fused2_blocks : tiles32;
+  }
   RC(pr.begin(ICS_K_SYNTH_GRADK));
-  HIPCHK(ics_launch_synth_gradk(a, j->gradk_blocks, j->ctx->stream));
-  HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
+  HIPCHK(ics_launch_synth_gradk(a, nblocks, j->ctx->stream));
+  HIPCHK(ics_launch_gradk_reduce(j->partial, nblocks, j->gradk, j->g, j->ctx->stream));
   RC(pr.end());
   return ICS_OK;
 }

@@ -56,7 +56,8 @@ struct IcsFusedArgs {
   float* partial;     // [nblocks][3][16][16] per-workgroup partial sums (layout of k_gradk_mfma, reduced by k_gradk_reduce)
   int wy0, wy1, wx0, wx1;   // stats window (pyx:600-601,627) in u-frame coordinates
   int store_all;
-  const float* facc;  // the image in accumulator order, RS = 4 layout (ics_image_acc.h), or NULL: the epilogue reads the HWC frame
+  const float* facc;  // the image in accumulator order (ics_image_acc.h) in the layout of `rs`, or NULL: the epilogue reads the HWC frame
+  int rs;             // tile height: 4 = 64-row tiles, two workgroups per CU (k_synth_gradk); 2 = 32-row tiles, three per CU (k_synth_gradk2)
   IcsGeom g;
 };
 bool ics_synth_gradk_supported(int K);

@@ -725,18 +725,457 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// =====================================================================================================================
+// 32-row tiles, THREE workgroups per CU (round 3).  Same arithmetic as k_synth_gradk above, different shape:
+//   * tiles of 32 x 64 pixels; fragment rows 2 apart (two accumulator sets per wave and channel, as MCfg<K, 2> of
+//     ics_conv_mfma.hip); the u planes hold 32 + K - 1 rows in two row classes (even / odd rows), the class-1 base sits at
+//     128 (mod 256) bytes: the gradient's A fragments -- 16 CONSECUTIVE rows, 8 of each class, always starting on an even row --
+//     are then conflict-free for the ds_read_b128 lane groups (4 LDS cycles; the four-class layout of the 64-row kernel: 6);
+//   * 46 KB of LDS and <= 168 VGPRs -> three resident workgroups per CU (the 64-row kernel: 79 KB, 256 VGPRs, two);
+//   * written for thread-level parallelism instead of instruction-level pipelining: the 64-row kernel hides LDS latency inside a
+//     wave with one-row-deep software pipelines and copies of the operand registers (130 VGPRs in the gradient loop alone);
+//     here a wave requests an operand chunk, waits, shifts, issues its three MFMAs, and the two other waves of the SIMD fill
+//     the gaps -- 70 VGPRs in the gradient loop, which is what makes the third workgroup fit.
+// The ablation of the 64-row kernel that motivates it (tools/bench_synth_gradk.hip -DICS_FUSED_ABLATE, 4096^2, K = 15): without any
+// MFMA the kernel still takes 0.177 of its 0.265 ms -- a wave issues 6.2 k instructions per tile (25 k cycles of its 59 k) and
+// stalls for the rest; two waves per SIMD leave that unhidden.
+// =====================================================================================================================
+#ifndef ICS_FUSED2_PREFETCH
+#define ICS_FUSED2_PREFETCH 2
+#endif
+template <int K>
+struct FCfg2 {
+  static constexpr int PAD = K / 2;
+  static constexpr int TH = 32, TW = 64;
+  static constexpr int NW = 4, NT = 64 * NW;
+  static constexpr int LROWS = TH + K - 1;
+  static constexpr int LCOLS = TW + 16;
+  static constexpr int ROWB = 2 * LCOLS;                                   // 160
+  static constexpr int cls_rows(int c) { return (LROWS - c + 1) / 2; }
+  static constexpr int cls1_off() {
+    int off = cls_rows(0) * ROWB;
+    while (off % 256 != 128) off += 16;
+    return off;
+  }
+  static constexpr int OFF1 = cls1_off();
+  static constexpr int cls_off(int c) { return c == 0 ? 0 : OFF1; }
+  static constexpr int PLANE = ((OFF1 + cls_rows(1) * ROWB + 32 + 15) / 16) * 16;   // + 32: the third chunk over-reads a row
+  static constexpr int UOFF = 0;
+  static constexpr int EROWB = 4 * LCOLS;                                  // 320
+  static constexpr int EOFF = 4 * PLANE;
+  static constexpr int EBYTES = TH * EROWB + 64;
+  static constexpr int SCR = EOFF + EBYTES;
+  static constexpr int WROWB = (2 * (K + 17) + 3) & ~3;
+  static constexpr int WZERO = (K + 7) / 2;
+  static constexpr int WLDS = 3 * K * 2 * WROWB;
+  static constexpr int WOFF = SCR + 256;
+  static constexpr size_t LDS_BYTES = WOFF + WLDS;
+  static constexpr int NQ = K + 1;
+  static constexpr int XG = LCOLS / 4;
+  static constexpr int NTASK = LROWS * XG;
+  static constexpr int NIT = (NTASK + NT - 1) / NT;
+  static_assert(K >= 3 && K <= 15 && (K & 1), "one 32-wide MFMA window per column block, one 16-tap block");
+  static_assert(3 * LDS_BYTES <= 160 * 1024, "three workgroups per CU");
+};
+
+template <typename C>
+__device__ __forceinline__ void load_raw2(f32x4u (&v)[C::NIT][3], __amdgpu_buffer_rsrc_t rs, int soff, int tid, int pitch) {
+#pragma unroll
+  for (int k = 0; k < C::NIT; ++k) {
+    int t = tid + k * C::NT;
+    t = t < C::NTASK ? t : C::NTASK - 1;
+    const int row = t / C::XG, xg = t - row * C::XG;
+    const int toff = 4 * (row * pitch + 12 * xg);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) v[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16 * h, soff, 0));
+  }
+}
+
+// one channel of the staged rows -> (hi, lo) fp16 planes, rows grouped by y mod 2
+template <typename C, int CH>
+__device__ __forceinline__ void convert_channel2(const f32x4u (&raw)[C::NIT][3], float s_x, unsigned char* plane, int tid) {
+#pragma unroll
+  for (int k = 0; k < C::NIT; ++k) {
+    const int t = tid + k * C::NT;
+    if (t < C::NTASK) {
+      const int row = t / C::XG, xg = t - row * C::XG;
+      unsigned char* dst = plane + ((row & 1) ? C::OFF1 : 0) + (row >> 1) * C::ROWB + 8 * xg;
+      h4 hi, lo;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int idx = 3 * p + CH;
+        const float x = raw[k][idx >> 2][idx & 3] * s_x;
+        const _Float16 xh = (_Float16)x;
+        hi[p] = xh;
+        lo[p] = (_Float16)(x - (float)xh);
+      }
+      *reinterpret_cast<h4*>(dst) = hi;
+      *reinterpret_cast<h4*>(dst + C::PLANE) = lo;
+    }
+  }
+}
+
+template <int K, bool ACC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_synth_gradk2(IcsFusedArgs a) {
+  using C = FCfg2<K>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  float* fscr = reinterpret_cast<float*>(lds + C::SCR);
+  const int tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int pitch = a.g.pitch;
+
+  constexpr int TORG = C::PAD;
+  const int tpr = (a.g.N + C::TW - 1) / C::TW;
+  const int ntiles = tpr * ((a.g.M + C::TH - 1) / C::TH);
+  const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+  const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
+  const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;
+  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  int tile = band0 + kx;
+
+  f4 tot[3];
+  float carry[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) tot[c] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  {
+    u4* z = reinterpret_cast<u4*>(lds);
+    for (int i = tid; i < C::WOFF / 16; i += C::NT) z[i] = (u4){0u, 0u, 0u, 0u};
+    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
+    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+  }
+  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
+
+  typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)(lds);
+  const ptrdiff_t orgoff = (ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax;
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.u - orgoff);
+  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(a.f);
+  const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.e_out);
+  const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(a.facc);
+
+  f32x4u raw[C::NIT][3];
+  if (tile < band1) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    load_raw2<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
+  }
+  __syncthreads();   // LDS initialised
+
+#pragma unroll 1
+  for (; tile < band1; tile += nx) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
+    const bool store_e = a.store_all || (y0 < a.wy1 && y0 + C::TH > a.wy0 && x0 < a.wx1 && x0 + C::TW > a.wx0);   // wave-uniform
+
+    // ---- per-tile power-of-two scale of u (all three channels) ---------------------------------------------------
+    float s_x, inv_x;
+    {
+      float m = 0.f;
+#pragma unroll
+      for (int k = 0; k < C::NIT; ++k)
+#pragma unroll
+        for (int h = 0; h < 3; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) m = __builtin_fmaxf(m, __builtin_fabsf(raw[k][h][e]));
+      m = ics_wave_max_f32(m);
+      if (lane == 0) fscr[wv] = m;
+      lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
+#pragma unroll
+      for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
+      pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
+    }
+    const float sc = inv_w * inv_x;
+
+    // lane parts of the addresses, re-derived per tile (opaque: nothing of this may be hoisted above the tile loop and kept)
+    const int tide = opaque(tid);
+    const int eli = tide & 15, elg = (tide >> 4) & 3;
+    const int colx = x0 + 16 * wv + eli;
+    const int voff = 4 * (8 * elg * pitch + 3 * eli);             // rows t + 8 lg + 2 r of pixel column 16 wv + li
+    const int sb = 4 * (y0 * pitch + 3 * (x0 + 16 * wv));
+    const int acc_voff = 16 * (tide & 63);
+    const int acc_sb = (tile * 4 + wv) * (3 * 2 * 1024);          // accumulator-order image, 32-row layout: [tile][cb][ch][t][lane] float4
+    // weights (B operand of the convolution), u planes (A operand), see k_synth_gradk
+    const int bo = 8 * elg - eli + 15;
+    const bool bzero = bo < 8 || bo > K + 14;
+    const uint32_t wsh = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
+    const uint32_t wa0 = lds0 + (uint32_t)C::WOFF + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+    const uint32_t conv_a = lds0 + (uint32_t)(C::UOFF + eli * C::ROWB + (16 * wv + 8 * elg) * 2);
+
+    uint32_t fop[2][4];
+    auto load_img = [&](int ch) {
+      if (ACC) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (ch * 2 + t) * 1024, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fop[t][r] = v[r];
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fop[t][r] = __builtin_amdgcn_raw_buffer_load_b32(rs_f, voff + 4 * ch, sb + 4 * (t + 2 * r) * pitch, 0);
+      }
+    };
+
+    f4 acc[2];
+    // ---- Toeplitz convolution of one channel from plane buffer (ch & 1): fragment q = rows q + 2 i feeds kernel rows q and q - 1 ----
+    // One step ahead: the fragment and the raw weight dwords of step q + 1 are requested before the MFMAs of step q (18 registers;
+    // the reads are volatile so that they stay there), the funnel shifts follow the MFMAs -- the B slot they fill is read by them.
+    auto conv_phase = [&](auto chc) {
+      constexpr int ch = decltype(chc)::value;
+      constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
+      typedef const volatile __attribute__((address_space(3))) u4* lds_vu4p;
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+      acc[0] = (f4){0.f, 0.f, 0.f, 0.f}; acc[1] = (f4){0.f, 0.f, 0.f, 0.f};
+      h8 Bh[2], Bl[2];
+      u2 d[5];
+      u4 Ah, Al, nAh, nAl;
+      auto issue = [&](int q) {     // operands of step q: fragment q, kernel row q
+        const uint32_t off = (uint32_t)(C::cls_off(q & 1) + (q >> 1) * C::ROWB);
+        nAh = *reinterpret_cast<lds_vu4p>(conv_a + PB + off);
+        nAl = *reinterpret_cast<lds_vu4p>(conv_a + PB + C::PLANE + off);
+        if (q < K) {
+          const lds_vu2p r = reinterpret_cast<lds_vu2p>(wa0 + (uint32_t)((ch * K + q) * 2 * C::WROWB));
+#pragma unroll
+          for (int k = 0; k < 5; ++k) d[k] = r[k];
+        }
+      };
+      auto finishB = [&](int q) {   // kernel row q enters with fragment q (set 0) and leaves with fragment q + 1 (set 1)
+        const u4 wh = {f_align(d[1].x, d[0].x, wsh), f_align(d[2].x, d[1].x, wsh), f_align(d[3].x, d[2].x, wsh), f_align(d[4].x, d[3].x, wsh)};
+        const u4 wl = {f_align(d[1].y, d[0].y, wsh), f_align(d[2].y, d[1].y, wsh), f_align(d[3].y, d[2].y, wsh), f_align(d[4].y, d[3].y, wsh)};
+        Bh[q & 1] = __builtin_bit_cast(h8, wh);
+        Bl[q & 1] = __builtin_bit_cast(h8, wl);
+      };
+      issue(0);
+      finishB(0);
+      Ah = nAh; Al = nAl;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < C::NQ; ++q) {
+        if (q + 1 < C::NQ) issue(q + 1);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int ka = q - t;
+            if (ka < 0 || ka >= K) continue;
+            acc[t] = f_mfma32(__builtin_bit_cast(h8, term == 2 ? Al : Ah), term == 1 ? Bl[ka & 1] : Bh[ka & 1], acc[t]);
+          }
+        if (q + 1 < K) finishB(q + 1);
+        Ah = nAh; Al = nAl;
+        __builtin_amdgcn_sched_barrier(0);   // one step's operands at a time: registers are scarce at three waves per SIMD
+      }
+    };
+
+    // ---- e'(ch) = conv - image (0 outside the M x N interior), kept in `acc`; returns the wave's max |e'| ---------------
+    auto residual = [&](int ch) -> float {
+      float m = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int y = y0 + t + 8 * elg + 2 * r;
+          const bool in = y < C::PAD + a.g.M && colx < C::PAD + a.g.N;
+          const float e = in ? __fsub_rn(acc[t][r] * sc, __uint_as_float(fop[t][r])) : 0.f;
+          acc[t][r] = e;
+          m = __builtin_fmaxf(m, __builtin_fabsf(e));
+          if (store_e && in) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rs_o, voff + 4 * ch, sb + 4 * (t + 2 * r) * pitch, 0);
+        }
+      return ics_wave_max_f32(m);
+    };
+
+    // ---- e' -> fp16 (hi, lo) planes (rows t + 8 lg + 2 r), as in k_synth_gradk ---------------------------------------------
+    auto write_e = [&](float s_e) {
+      typedef __attribute__((address_space(3))) uint32_t* lds_wp;
+      const uint32_t ew = lds0 + (uint32_t)(C::EOFF + 8 * elg * C::EROWB + 8 * ((16 * wv + eli + 8) >> 1) + 4 * (eli & 1));
+      const bool odd = (eli & 1) != 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x = acc[t][r] * s_e;
+          const _Float16 xh = (_Float16)x;
+          const _Float16 xl = (_Float16)(x - (float)xh);
+          const uint32_t P = (uint32_t)__builtin_bit_cast(unsigned short, xh) | ((uint32_t)__builtin_bit_cast(unsigned short, xl) << 16);
+          const uint32_t Q = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+          const uint32_t w = odd ? ((Q >> 16) | (P & 0xFFFF0000u)) : ((P & 0xFFFFu) | (Q << 16));
+          *reinterpret_cast<lds_wp>(ew + (uint32_t)((t + 2 * r) * C::EROWB)) = w;
+        }
+    };
+
+    // ---- PSF gradient of one channel: the 8 residual rows of this wave as 4 pairs sharing one u fragment (see k_synth_gradk).
+    // 24 steps (row, column chunk), three MFMAs each; the e' dwords of step s + 1 are requested before the MFMAs of step s, and every
+    // u fragment is re-requested into its own registers right after its last use (two steps before the next pair needs it): no
+    // second register set.  The other two waves of the SIMD fill what is left of the gaps.
+    auto gradk_phase = [&](auto chc, float scale) {
+      constexpr int ch = decltype(chc)::value;
+      constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
+      typedef const volatile __attribute__((address_space(3))) u4* lds_vu4p;
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+      // lane row m reads u row (y + 1) + 2 pad - m, y = 8 wv + 2 p: its class is a lane constant, pairs advance one row inside it
+      const int mm = eli < 2 * C::PAD + 1 ? eli : 2 * C::PAD + 1;
+      const int r0 = 8 * wv + 1 + 2 * C::PAD - mm;
+      const uint32_t ga = lds0 + (uint32_t)(C::UOFF + ((r0 & 1) ? C::OFF1 : 0) + (r0 >> 1) * C::ROWB + 16 * elg) + PB;
+      const int tb = eli < K ? eli : K - 1;
+      uint32_t gb[3], gsh[3];
+#pragma unroll
+      for (int X = 0; X < 3; ++X) {
+        int sx = X < 2 ? 32 * X + 8 * elg + tb - 2 * C::PAD : 64 + 4 * elg + tb - 2 * C::PAD;
+        sx = sx <= -8 ? -8 : (sx >= 64 ? 64 : sx);
+        gsh[X] = (uint32_t)(sx & 1) * 16u;
+        gb[X] = lds0 + (uint32_t)(C::EOFF + 8 * wv * C::EROWB + 8 * ((sx + 8) >> 1));
+      }
+      f4 g[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { g[h][0] = (f4){0.f, 0.f, 0.f, 0.f}; g[h][1] = (f4){0.f, 0.f, 0.f, 0.f}; }
+      u4 Ah[2], Al[2];
+      u2 A2h, A2l;
+      u2 d[5];
+      auto issueA = [&](int pair, int X) {
+        const uint32_t ar = ga + (uint32_t)(pair * C::ROWB);
+        if (X < 2) { Ah[X] = *reinterpret_cast<lds_vu4p>(ar + 64 * X); Al[X] = *reinterpret_cast<lds_vu4p>(ar + C::PLANE + 64 * X); }
+        else { A2h = *reinterpret_cast<lds_vu2p>(ar + 128 - 8 * elg); A2l = *reinterpret_cast<lds_vu2p>(ar + C::PLANE + 128 - 8 * elg); }
+      };
+      auto issueB = [&](int st) {
+        const int i = st / 3, X = st - 3 * i;
+        const lds_vu2p ep = reinterpret_cast<lds_vu2p>(gb[X] + (uint32_t)(i * C::EROWB));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (X < 2 || k < 3) d[k] = ep[k];
+      };
+      issueA(0, 0); issueA(0, 1); issueA(0, 2);
+      issueB(0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < 24; ++st) {
+        const int i = st / 3, X = st - 3 * i, hp = i & 1;
+        h8 Bh, Bl;
+        h4 B2h, B2l;
+        if (X < 2) {
+          const u4 wh = {f_align(d[1].x, d[0].x, gsh[X]), f_align(d[2].x, d[1].x, gsh[X]), f_align(d[3].x, d[2].x, gsh[X]), f_align(d[4].x, d[3].x, gsh[X])};
+          const u4 wl = {f_align(d[1].y, d[0].y, gsh[X]), f_align(d[2].y, d[1].y, gsh[X]), f_align(d[3].y, d[2].y, gsh[X]), f_align(d[4].y, d[3].y, gsh[X])};
+          Bh = __builtin_bit_cast(h8, wh); Bl = __builtin_bit_cast(h8, wl);
+        } else {
+          const u2 wh = {f_align(d[1].x, d[0].x, gsh[2]), f_align(d[2].x, d[1].x, gsh[2])};
+          const u2 wl = {f_align(d[1].y, d[0].y, gsh[2]), f_align(d[2].y, d[1].y, gsh[2])};
+          B2h = __builtin_bit_cast(h4, wh); B2l = __builtin_bit_cast(h4, wl);
+        }
+        if (st + 1 < 24) issueB(st + 1);                     // (d is free: the shifts above consumed it)
+        if (X < 2) {
+          g[hp][0] = f_mfma32(__builtin_bit_cast(h8, Ah[X]), Bh, g[hp][0]);
+          g[hp][1] = f_mfma32(__builtin_bit_cast(h8, Ah[X]), Bl, g[hp][1]);
+          g[hp][0] = f_mfma32(__builtin_bit_cast(h8, Al[X]), Bh, g[hp][0]);
+        } else {
+          g[hp][1] = f_mfma16(__builtin_bit_cast(h4, A2h), B2h, g[hp][1]);
+          g[hp][0] = f_mfma16(__builtin_bit_cast(h4, A2h), B2l, g[hp][0]);
+          g[hp][1] = f_mfma16(__builtin_bit_cast(h4, A2l), B2h, g[hp][1]);
+        }
+        // the fragment of chunk X was last used by the odd row of its pair: the next pair's goes into the same registers now
+        if (hp == 1 && i + 1 < 8) issueA((i + 1) >> 1, X);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = g[1][0][r] + g[1][1][r];
+        const float s0n = r < 3 ? g[0][0][r + 1] + g[0][1][r + 1] : 0.f;
+        tot[ch][r] += (s1 + s0n) * scale;
+      }
+      carry[ch] += (g[0][0][0] + g[0][1][0]) * scale;
+    };
+
+    // ================================ the tile ======================================================================
+    unsigned char* const up = lds + C::UOFF;
+    convert_channel2<C, 0>(raw, s_x, up, opaque(tid));
+    lds_barrier();                                                     // planes of channel 0 visible
+    load_img(0);
+    conv_phase(std::integral_constant<int, 0>{});
+    float s_e, inv_e, me;
+
+#define ICS_FUSED2_CHANNEL(CH)                                                                                          \
+    me = residual(CH);                                                                                                  \
+    if (lane == 0) fscr[8 + 4 * (CH) + wv] = me;                                                                        \
+    lds_barrier();     /* tile maximum; every wave is past the previous gradient phase: e' planes and u buffer free */  \
+    me = __builtin_fmaxf(__builtin_fmaxf(fscr[8 + 4 * (CH)], fscr[9 + 4 * (CH)]), __builtin_fmaxf(fscr[10 + 4 * (CH)], fscr[11 + 4 * (CH)])); \
+    pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me))), s_e, inv_e);      \
+    write_e(s_e);
+
+    ICS_FUSED2_CHANNEL(0)
+    convert_channel2<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
+    lds_barrier();                                                     // e'(0) and planes(1) visible
+    gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
+    load_img(1);
+    conv_phase(std::integral_constant<int, 1>{});
+
+    ICS_FUSED2_CHANNEL(1)
+    convert_channel2<C, 2>(raw, s_x, up, opaque(tid));
+    lds_barrier();                                                     // e'(1) and planes(2) visible
+    gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
+    load_img(2);
+    auto prefetch = [&]() {
+      if (tile + nx < band1) {
+        const int nt = tile + nx;
+        const int nyi = nt / tpr, nxi = nt - nyi * tpr;
+        load_raw2<C>(raw, rs_in, 4 * ((a.g.ay + TORG + nyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + nxi * C::TW - C::PAD)), opaque(tid), pitch);
+      }
+    };
+    if (ICS_FUSED2_PREFETCH == 2) prefetch();                          // the rows of the next tile: in flight during conv(2), gradk(2)
+    conv_phase(std::integral_constant<int, 2>{});
+
+    ICS_FUSED2_CHANNEL(2)
+    lds_barrier();                                                     // e'(2) visible
+    if (ICS_FUSED2_PREFETCH == 1) prefetch();                          // ... during gradk(2) only
+    gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
+    if (ICS_FUSED2_PREFETCH == 0) prefetch();                          // ... not at all: the other two workgroups of the CU cover the latency
+#undef ICS_FUSED2_CHANNEL
+  }
+
+  // ---- cross-wave reduction (fixed order) and partial write, one channel per pass: as k_synth_gradk -------------------------
+  float* red = reinterpret_cast<float*>(lds);
+  float* dst = a.partial + (size_t)blockIdx.x * (3 * 16 * 16);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv * 256 + r * 64 + lane] = tot[c][r];
+    red[C::NW * 256 + wv * 64 + lane] = carry[c];
+    __syncthreads();
+    {
+      const int v = tid;
+      float s = red[v];
+#pragma unroll
+      for (int w = 1; w < C::NW; ++w) s += red[w * 256 + v];
+      const int l = v & 63, r = (v >> 6) & 3;
+      if (r == 3 && l < 48) {
+#pragma unroll
+        for (int w = 0; w < C::NW; ++w) s += red[C::NW * 256 + w * 64 + l + 16];
+      }
+      const int ta = 4 * (l >> 4) + r, tb = l & 15;
+      dst[(c * 16 + ta) * 16 + tb] = s;
+    }
+  }
+}
+
 template <int K>
 hipError_t launch_k(const IcsFusedArgs& a, int nblocks, hipStream_t s) {
-  using C = FCfg<K>;
-  static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
   const int dev = ics_current_device();
   const bool ACC = a.facc != nullptr;
+  if (a.rs == 2) {   // 32-row tiles, three workgroups per CU
+    using C = FCfg2<K>;
+    static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
+    auto kern = ACC ? k_synth_gradk2<K, true> : k_synth_gradk2<K, false>;
+    if (hipError_t e = ics_configure_lds(configured[ACC ? 1 : 0], dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NT), C::LDS_BYTES, s, a);
+    return hipGetLastError();
+  }
+  using C = FCfg<K>;
+  static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
   auto kern = ACC ? k_synth_gradk<K, true> : k_synth_gradk<K, false>;
   if (hipError_t e = ics_configure_lds(configured[ACC ? 1 : 0], dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
-  const int ntiles = ((a.g.N + C::TW - 1) / C::TW) * ((a.g.M + C::TH - 1) / C::TH);
   // every workgroup of the grid writes its partial block (the reduction reads `nblocks` of them): workgroups without a tile
   // write zeros
-  (void)ntiles;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NT), C::LDS_BYTES, s, a);
   return hipGetLastError();
 }

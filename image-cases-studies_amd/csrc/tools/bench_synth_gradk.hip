@@ -28,18 +28,21 @@ int main(int argc, char** argv) {
   reinterpret_cast<float*>(tab.data())[tf - 4] = 1.f / 16384.f;
   hipMalloc(&bt, tf * 4); hipMemcpy(bt, tab.data(), tf * 4, hipMemcpyHostToDevice);
   int cus = 256; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
-  const int nblocks = getenv("ICS_BENCH_WGS") ? atoi(getenv("ICS_BENCH_WGS")) : 2 * cus;
+  const int rs = getenv("ICS_BENCH_RS") ? atoi(getenv("ICS_BENCH_RS")) : 4;   // 4: 64-row tiles, two workgroups per CU; 2: 32-row tiles, three
+  const int nblocks = getenv("ICS_BENCH_WGS") ? atoi(getenv("ICS_BENCH_WGS")) : (rs == 2 ? 3 : 2) * cus;
   hipMalloc(&partial, (size_t)nblocks * 768 * 4);
   IcsFusedArgs a = {};
   a.u = u + org; a.f = f + org; a.e_out = e + org; a.bt = bt; a.partial = partial; a.g = g;
   float* facc = nullptr;
-  if (!getenv("ICS_BENCH_NO_ACC")) { hipMalloc(&facc, ics_image_acc_floats(g, 4) * 4); ics_launch_image_acc(a.f, g, 4, facc, 0); }
-  a.facc = facc;
+  if (!getenv("ICS_BENCH_NO_ACC")) { hipMalloc(&facc, ics_image_acc_floats(g, rs) * 4); ics_launch_image_acc(a.f, g, rs, facc, 0); }
+  a.facc = facc; a.rs = rs;
   a.wy0 = K / 2 + 8; a.wy1 = a.wy0 + 255; a.wx0 = a.wy0; a.wx1 = a.wy1; a.store_all = 0;
   if (K == 15) {
     int nb0 = -1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, k_synth_gradk<15, true>, 256, FCfg<15>::LDS_BYTES);
-    printf("occupancy (workgroups per CU) K=15: %d, LDS %zu B, plane %d B\n", nb0, (size_t)FCfg<15>::LDS_BYTES, FCfg<15>::PLANE);
+    int nb2 = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_synth_gradk2<15, true>, 256, FCfg2<15>::LDS_BYTES);
+    printf("occupancy (workgroups per CU) K=15: 64-row %d (LDS %zu B), 32-row %d (LDS %zu B)\n", nb0, (size_t)FCfg<15>::LDS_BYTES, nb2, (size_t)FCfg2<15>::LDS_BYTES);
   }
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 200; ++i) if (ics_launch_synth_gradk(a, nblocks, 0) != hipSuccess) { printf("launch failed\n"); return 1; }

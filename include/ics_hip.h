@@ -48,7 +48,7 @@ extern "C" {
 #define ICS_EHIP (-3)    /* a HIP runtime call failed (see ics_last_error)       */
 #define ICS_ENOMEM (-4)  /* device or host allocation failed                     */
 #define ICS_ESTATE (-5)  /* call sequence error (e.g. run before upload)         */
-#define ICS_ENOSUP (-6)  /* unsupported size (e.g. stop-test window too large)   */
+#define ICS_ENOSUP (-6)  /* unsupported size: PSF > 63, stats window > 4096 px, frame > 2 GiB */
 
 typedef struct ics_ctx ics_ctx; /* one per (process, device): stream, events, scratch   */
 typedef struct ics_rl ics_rl;   /* one deconvolution job: device-resident frames        */
@@ -171,7 +171,10 @@ typedef struct ics_rl_stats {
 size_t ics_rl_stats_size(void);
 
 /* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 63):
- * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376. */
+ * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376.  Limits (the reference has none; each fails with ICS_ENOSUP and a
+ * message, never silently): PSF sizes above 63 (the reference's own examples go to 45, deconvolve.py:409), stats windows
+ * wider or higher than 4096 px (ics_rl_run; 8192-point transforms in 128 KB of LDS), frames of 2 GiB and more (32-bit
+ * buffer offsets: about 13000 x 13000 px). */
 int ics_rl_create(ics_ctx *ctx, int M, int N, int MK, ics_rl **out);
 void ics_rl_destroy(ics_rl *job);
 /* Host -> device.  image: M*N*3, u: uM*uN*3, psf: MK*MK*3 floats, C-contiguous HWC. */

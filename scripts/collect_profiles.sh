@@ -8,12 +8,13 @@ rm -rf $O; mkdir -p $O
 cd $R
 python3 bench.py > $O/bench_blind.json 2> $O/bench_blind.err
 python3 bench.py --mode nonblind --no-other-configs > $O/bench_nonblind.json 2> $O/bench_nonblind.err
+python3 bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline > $O/bench_blind_driver_style_20_steps.json 2>/dev/null
 python3 bench.py --conv vector --no-cpu-baseline --no-other-configs > $O/bench_blind_vector.json 2>/dev/null
 ICS_FUSED_GRADK=0 python3 bench.py --no-cpu-baseline --no-other-configs > $O/bench_blind_two_kernel_gradk.json 2>/dev/null
 cd /tmp
 ARGS="$R/bench.py --no-cpu-baseline --no-other-configs --no-other-mode"
 rocprofv3 --kernel-trace --stats -d $O/kt -- python3 $ARGS > /dev/null 2>&1
-SHORT="$ARGS --steps 5 --warmup 0 --no-profile"
+SHORT="$ARGS --steps 5 --warmup 0 --no-profile --no-sustained"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -- python3 $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -- python3 $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/sq1 -- python3 $SHORT > /dev/null 2>&1
@@ -22,6 +23,6 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ
 # the two-kernel gradient path for the traffic comparison
 ICS_FUSED_GRADK=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch2k -- python3 $SHORT > /dev/null 2>&1
 for d in kt fetch write sq1 sq2 sq3 fetch2k; do f=$(find $O/$d -name "*.db" | head -1); python3 $R/scripts/rocprof_summary.py $f > $O/$d.txt 2>&1; done
-python3 $R/scripts/make_traffic_json.py $O/fetch.txt $O/write.txt $O/fetch2k.txt > $O/hbm_traffic.json
+python3 $R/scripts/make_traffic_json.py $O/fetch.txt $O/write.txt $O/fetch2k.txt --size 4096 --psf 15 > $O/hbm_traffic.json
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete
 tail -1 $O/bench_blind.json | cut -c1-300; head -12 $O/kt.txt; cat $O/hbm_traffic.json | head -60

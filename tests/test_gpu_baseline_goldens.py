@@ -1,7 +1,7 @@
 """Reference trajectories at the frame sizes BASELINE.json's metric is quoted on (oracle/make_golden_baseline.py): the COMPILED
 REFERENCE (lib/deconvolution.pyx:460-659 itself, not a float64 stage pass) ran configs[1] -- non-blind 2048^2, 15 x 15, two outer
-iterations --, the blind loop at 2048^2 (two outer iterations) and one outer iteration of configs[2] -- blind 4096^2, 15 x 15, the
-headline workload; the fixtures keep crops (centre, a corner shared by four 64 x 64 tiles, frame corner, frame origin), every n-th
+iterations --, the blind loop at 2048^2 (two outer iterations), one outer iteration of configs[2] -- blind 4096^2, 15 x 15, the
+headline workload -- and one of configs[3] -- blind 6144^2, 31 x 31 (two-window 8-wave convolutions, 2 x 2 tap-block gradient); the fixtures keep crops (centre, a corner shared by four 64 x 64 tiles, frame corner, frame origin), every n-th
 row and column, float64 moments and quadrant sums of the whole frame, the PSF and the reference's stdout.  Here the product path
 runs the same calls on the full grid with the default kernels, and with fp32 products (`conv=1`); gate = 1e-5 on u and on the PSF
 (the north-star bar is 1e-4), the whole-frame sums to 1e-6."""
@@ -30,7 +30,7 @@ def case_of(meta):
 
 
 @pytest.mark.parametrize("conv", [0, 1], ids=["default-kernels", "fp32-products"])
-@pytest.mark.parametrize("name", ["nb_2048_k15", "bl_2048_k15", "bl_4096_k15"])
+@pytest.mark.parametrize("name", ["nb_2048_k15", "bl_2048_k15", "bl_4096_k15", "bl_6144_k31"])
 def test_reference_trajectory_at_baseline_size(golden_dir, name, conv):
     from lib import deconvolution as dc
     z = np.load(os.path.join(golden_dir, "rl_%s.npz" % name))
