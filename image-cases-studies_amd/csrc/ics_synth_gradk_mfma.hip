@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // stalls for the rest; two waves per SIMD leave that unhidden.
 // =====================================================================================================================
 #ifndef ICS_FUSED2_PREFETCH
-#define ICS_FUSED2_PREFETCH 2
+#define ICS_FUSED2_PREFETCH 0   /* measured: 0 (request at the start of the tile, 137 VGPRs) 0.2624 ms, 1 0.2669, 2 (ahead of conv(2), 167 VGPRs + spills) 0.2658 */
 #endif
 template <int K>
 struct FCfg2 {

@@ -378,3 +378,46 @@ def test_two_kernel_gradient_strip_carry_is_race_free_and_deterministic(MK, M, N
         results.append(first)
         job.close()
     assert rel_err(results[0], results[1]) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,MK", [(64, 64, 15), (257, 300, 15), (130, 67, 9), (200, 333, 3), (300, 260, 13), (640, 700, 15)])
+def test_fused_synth_gradk_32_row_form(M, N, MK, debug_switch):
+    """k_synth_gradk2 (32-row tiles, three workgroups per CU; debug switch fused_rs = 2) against float64 and against the 64-row form
+    that is the default: same residual within the convolution gate, same gradient within 1e-5 of max |gradk|."""
+    from lib import _native as nv
+    out = {}
+    for rs in (2, 4):
+        debug_switch("fused_rs", rs)
+        job, case, psf = make_job(M, N, MK, seed=M + 2 * N + MK, blind=True)
+        rng = np.random.default_rng(5)
+        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        job.write(nv.BUF_U, u)
+        p = job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 10000.0, blind=True)
+        job.stage(nv.STAGE_SYNTH_GRADK, p)
+        out[rs] = (job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK))
+        job.close()
+    synth = conv_valid64(u, psf)
+    e_ref = synth - case["image"]
+    for rs in (2, 4):
+        e, gk = out[rs]
+        assert np.max(np.abs(e - e_ref)) / np.max(np.abs(synth)) < CONV_TOL, rs
+        assert rel_err(gk, gradk64(u.astype(np.float64), e.astype(np.float64))) < 1e-5, rs
+    assert rel_err(out[2][1], out[4][1]) < 1e-5
+
+
+def test_blind_run_with_the_32_row_fused_kernel_matches_the_reference_golden(golden_dir, debug_switch):
+    """the 129 x 129 blind golden of the compiled reference with fused_rs = 2 (and few workgroups, so that each walks several tiles)"""
+    import contextlib
+    import io
+    from helpers import load_golden
+    from lib import deconvolution as dc
+    z, meta = load_golden(golden_dir, "bl_129x129_k15")
+    debug_switch("fused_rs", 2)
+    debug_switch("max_wgs", 3)
+    dc._drop_jobs()
+    n = meta["snaps"][1]
+    u, psf = z["u0"].copy(), z["psf0"].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dc.richardson_lucy_MM(z["image"].copy(), u, psf, *meta["window"], meta["tau"], meta["M"], meta["N"], 3, meta["MK"], n, meta["step"], meta["lambd"], blind=True)
+    assert rel_err(u, z["u_%d" % n]) < 1e-5 and rel_err(psf, z["psf_%d" % n]) < 1e-5
+    dc._drop_jobs()
