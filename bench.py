@@ -92,13 +92,13 @@ def cpu_baseline(mode, MK, M_full, budget_s=20.0):
         if dt > budget_s * 0.5 or outer >= 8:
             break
     inner = 5 * outer
-    # beside it (never `value`): the same port with scipy's FFT allowed every host core (scipy.fft.set_workers) -- the reference's own
+    # beside it (never `value`): the same port with scipy's FFT allowed up to 8 host cores (scipy.fft.set_workers) -- the reference's own
     # FFT calls are single-threaded, its elementwise loops OpenMP over all cores (lib/deconvolution.pyx:16,484); this bounds what more
     # cores could buy the FFT-dominated loop
     mt = None
     try:
         import scipy.fft
-        ncpu = os.cpu_count() or 1
+        ncpu = min(8, os.cpu_count() or 1)   # (256 workers on a 256-core host ran 6x SLOWER than one: 0.61 vs 3.5 MPix/s/iter; 8 = the survey container's count)
         u2, psf2 = u0.copy(), (psf_uniform if mode == "blind" else psf_true).copy()
         t1 = time.perf_counter()
         with scipy.fft.set_workers(ncpu):
@@ -107,7 +107,7 @@ def cpu_baseline(mode, MK, M_full, budget_s=20.0):
         mt = {"value": round(S * S * 5 / d2 / 1e6, 4), "unit": "MPixels/s/iter", "fft_workers": ncpu, "sample": "1 outer (= 5 inner) iterations, %.1f s" % d2}
     except Exception as exc:   # (a baseline detail must not fail the bench line)
         mt = {"error": str(exc)[:200]}
-    return {"value": round(S * S * inner / dt / 1e6, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port", "all_cores_fft": mt,
+    return {"value": round(S * S * inner / dt / 1e6, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port", "fft_8_workers": mt,
             "host_cores_available": os.cpu_count(),
             "threads": "1 (scipy.signal.convolve -> scipy.fft pocketfft with workers=None = single thread, numpy elementwise single thread; "
                        "OMP_NUM_THREADS=%s)" % os.environ.get("OMP_NUM_THREADS", "unset"),

@@ -314,15 +314,24 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
     }
     }
   }
+  // maxima: wave -> workgroup (LDS) -> one atomic per workgroup and value (per-wave atomics on six words were most of this kernel's
+  // time on small frames)
+  __shared__ uint32_t shk[4][6];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     uint32_t kt = nan_t[c] ? 0xFFC00000u : ics_f2key(mt[c]);
     uint32_t kf = nan_f[c] ? 0xFFC00000u : (any_f ? ics_f2key(mf[c]) : 0u);
     kt = wave_max_u32(kt); kf = wave_max_u32(kf);
-    if ((threadIdx.x & 63) == 0) {
-      if (kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
-      if (kf > a.red[ICS_RED_MAXF + c]) atomicMax(a.red + ICS_RED_MAXF + c, kf);
-    }
+    if ((threadIdx.x & 63) == 0) { shk[threadIdx.x >> 6][c] = kt; shk[threadIdx.x >> 6][3 + c] = kf; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int v = threadIdx.x;
+    uint32_t k = shk[0][v];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) k = k > shk[w][v] ? k : shk[w][v];
+    uint32_t* dst = a.red + (v < 3 ? ICS_RED_MAXT + v : ICS_RED_MAXF + (v - 3));
+    if (k > *dst) atomicMax(dst, k);
   }
 }
 
@@ -336,8 +345,7 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
 // max |T| (tests/test_tv_mode.py gates 2e-6 against oracle/rl_ext_oracle.py; these modes have no reference implementation).
 // =================================================================================================
 template <bool COLLAB>
-__global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a) {
-  constexpr int TVSEG = 16;
+__global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a, int TVSEG /* rows a thread walks: 16 on large frames, fewer where that leaves the chip idle */) {
   const IcsGeom& G = a.geo;
   const int ngx = G.tiles_x * 16;
   const int nseg = (G.uM + TVSEG - 1) / TVSEG;
@@ -421,11 +429,21 @@ __global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a) {
       for (int k = 0; k < 15; ++k) pxu[k] = px0[k];
     }
   }
+  // maxima: wave -> workgroup (LDS) -> one atomic per workgroup and channel, skipped when the running maximum is already there
+  __shared__ uint32_t shk[4][3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     uint32_t kt = nan_t[c] ? 0xFFC00000u : ics_f2key(mt[c]);
     kt = wave_max_u32(kt);
-    if ((threadIdx.x & 63) == 0 && kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
+    if ((threadIdx.x & 63) == 0) shk[threadIdx.x >> 6][c] = kt;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    uint32_t kt = shk[0][c];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) kt = kt > shk[w][c] ? kt : shk[w][c];
+    if (kt > a.red[ICS_RED_MAXT + c]) atomicMax(a.red + ICS_RED_MAXT + c, kt);
   }
 }
 
@@ -822,10 +840,16 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
       }
     }
   }
-  if (a.want_dof) {
+  if (a.want_dof) {   // wave -> workgroup -> one atomic per workgroup and value, skipped where the running extremum already covers it
+    __shared__ uint32_t shd[4][3];
     kmin = wave_min_u32(kmin); kmax = wave_max_u32(kmax); knan = wave_max_u32(knan);
-    if ((threadIdx.x & 63) == 0) {
-      atomicMin(a.dofkeys + 0, kmin); atomicMax(a.dofkeys + 1, kmax);
+    if ((threadIdx.x & 63) == 0) { shd[threadIdx.x >> 6][0] = kmin; shd[threadIdx.x >> 6][1] = kmax; shd[threadIdx.x >> 6][2] = knan; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 1; w < 4; ++w) { kmin = kmin < shd[w][0] ? kmin : shd[w][0]; kmax = kmax > shd[w][1] ? kmax : shd[w][1]; knan |= shd[w][2]; }
+      if (kmin < a.dofkeys[0]) atomicMin(a.dofkeys + 0, kmin);
+      if (kmax > a.dofkeys[1]) atomicMax(a.dofkeys + 1, kmax);
       if (knan) atomicOr(a.dofkeys + 2, 1u);
     }
   }
@@ -891,8 +915,17 @@ hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
     if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a);
   }
-  else if (a.kind == 2) hipLaunchKernelGGL(k_tvterm_pam<false>, dim3(2048), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_tvterm_pam<true>, dim3(2048), dim3(256), 0, s, a);
+  else {
+    // a thread = 4 pixels x `seg` rows; keep >= ~4 waves per SIMD busy: a 2048^2 frame walked 16 rows at a time is one wave per SIMD,
+    // each a serial chain of dependent loads (measured 0.14 ms there against 0.11 ms for the 4096^2 frame)
+    const long cols = (long)a.geo.tiles_x * 16;
+    int seg = (int)(((long)a.geo.uM * cols) / 262144);
+    seg = seg < 2 ? 2 : (seg > 16 ? 16 : seg);
+    const long nthreads = (((long)a.geo.uM + seg - 1) / seg) * cols;
+    long nblk = (nthreads + 255) / 256; nblk = nblk > 2048 ? 2048 : (nblk < 1 ? 1 : nblk);
+    if (a.kind == 2) hipLaunchKernelGGL(k_tvterm_pam<false>, dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+    else hipLaunchKernelGGL(k_tvterm_pam<true>, dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+  }
   return hipGetLastError();
 }
 
