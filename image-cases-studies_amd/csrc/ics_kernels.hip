@@ -7,6 +7,12 @@
 #ifndef ICS_UPDATE_U
 #define ICS_UPDATE_U 4   /* wave segments (1 KiB per frame each) per loop iteration of k_update_rows */
 #endif
+#ifndef ICS_PSF_THREADS
+#define ICS_PSF_THREADS 1024
+#endif
+#ifndef ICS_UPDATE_U_TV
+#define ICS_UPDATE_U_TV 3   /* the same for the active MM-TV form (five frames read, two written) */
+#endif
 #ifndef ICS_UPDATE_NT
 #define ICS_UPDATE_NT 15  /* streaming (nt) loads in k_update_rows: bit 0 u, 1 ut, 2 g, 3 f */
 #endif
@@ -272,8 +278,9 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
         float t = 0.f;
         if (KIND >= 2) {
           if (yact && x >= 1 && x <= G.uN - 2) t = pam_term(nu, i, c, eps, KIND == 3);
-        } else if (FAST && yact && x >= 1 && x <= G.uN - 2) {
-          t = ics_tv_mm_term_fast(nu, nt, i, eps);
+        } else if (FAST) {   // branch-free: the windows of border values lie in the frame's apron, their term is discarded
+          const float tt = ics_tv_mm_term_fast(nu, nt, i, eps);
+          t = (yact && x >= 1 && x <= G.uN - 2) ? tt : 0.f;
         } else if (yact && x >= 1 && x <= G.uN - 2) {
           const IcsTvOut u1 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 1);
           const IcsTvOut u2 = ics_tv_point(nu[1][i], nu[0][i], nu[2][i], nu[1][i-3], nu[1][i+3], nu[0][i-3], nu[2][i+3], nu[0][i+3], nu[2][i-3], eps, 2, 2);
@@ -606,21 +613,37 @@ __global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
   }
 }
 
-// gradk[a][b][c] = float( sum_blocks double(partial) ): 32 lanes per output, fixed order.
-__global__ __launch_bounds__(256) void k_gradk_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ gradk, int K, int NT) {
-  const int o = (blockIdx.x * 256 + threadIdx.x) >> 5, sub = threadIdx.x & 31;
-  const int n = 3 * K * K;
+// gradk[a][b][c] = float( sum_blocks double(partial) ), fixed order.  A wave reads 64 consecutive outputs of one workgroup's
+// partial block (two cache lines per instruction, eight in flight); the 16 waves of the workgroup take the blocks 16 apart and
+// their sums meet in LDS in wave order.  (Round 3: 8.1 -> ~4 us; 32 lanes per output at a 3 KB stride fetched a line per lane.)
+__global__ __launch_bounds__(1024) void k_gradk_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ gradk, int K, int NT) {
+  __shared__ double sh[16][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = 3 * NT * NT;
+  const int o = blockIdx.x * 64 + lane;
+  const size_t stride = (size_t)n;
   double s = 0.0;
-  int c = 0, ta = 0, tb = 0;
   if (o < n) {
-    tb = o % K; ta = (o / K) % K; c = o / (K * K);
-    const size_t stride = (size_t)3 * NT * NT;
-    const float* p = partial + (size_t)(c * NT + ta) * NT + tb;
-    for (int b = sub; b < nblocks; b += 32) s += (double)p[b * stride];
-  }
+    const float* p = partial + o;
+    int b = w;
+    for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+      float v[8];
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 32);
-  if (o < n && sub == 0) gradk[(ta * K + tb) * 3 + c] = (float)s;
+      for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(b + 16 * k) * stride];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += (double)v[k];
+    }
+    for (; b < nblocks; b += 16) s += (double)p[(size_t)b * stride];
+  }
+  sh[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && o < n) {
+    double t = sh[0][lane];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += sh[k][lane];
+    const int tb = o % NT, ta = (o / NT) % NT, c = o / (NT * NT);
+    if (ta < K && tb < K) gradk[(ta * K + tb) * 3 + c] = (float)t;
+  }
 }
 
 // =================================================================================================
@@ -632,20 +655,34 @@ __global__ __launch_bounds__(256) void k_gradk_reduce(const float* __restrict__ 
 //   clamp < 0 -> 0, divide each channel by its sequential float32 sum   (:587 -> :47-70)
 //   psf_rotated = rot180(psf)                                     (:589) -> wconv
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
+__global__ __launch_bounds__(ICS_PSF_THREADS) void k_psf(IcsPsfArgs a) {
+  constexpr int NTHR = ICS_PSF_THREADS;   // one workgroup; the passes below are latency chains, so more lanes = fewer trips
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* p = lds;                       // 3*K*K
   __shared__ uint32_t sred[8];
   __shared__ float ssum[4];
   const int K = a.K, n = 3 * K * K, tid = threadIdx.x;
-  for (int i = tid; i < n; i += 256) p[i] = a.psf[i];
+  // everything the step needs from global memory is requested up front (this kernel is one latency chain: one workgroup, ~8 barriers)
+  constexpr int GR = (3 * 63 * 63 + NTHR - 1) / NTHR;   // gradient values per thread at the largest PSF
+  float gk[GR];
+  int frozen = 0;
+  if (a.do_step) {
+    frozen = *a.frozen;
+#pragma unroll
+    for (int r = 0; r < GR; ++r) { const int i = tid + r * NTHR; gk[r] = i < n ? a.gradk[i] : 0.f; }
+  }
+  for (int i = tid; i < n; i += NTHR) p[i] = a.psf[i];
   if (tid < 8) sred[tid] = 0u;
   __syncthreads();
   if (a.do_step) {
     uint32_t kp = 0u, kg = 0u;
-    for (int i = tid; i < n; i += 256) {
-      const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(a.gradk[i]));
-      kp = kp > k1 ? kp : k1; kg = kg > k2 ? kg : k2;
+#pragma unroll
+    for (int r = 0; r < GR; ++r) {
+      const int i = tid + r * NTHR;
+      if (i < n) {
+        const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(gk[r]));
+        kp = kp > k1 ? kp : k1; kg = kg > k2 ? kg : k2;
+      }
     }
     kp = wave_max_u32(kp); kg = wave_max_u32(kg);
     if ((tid & 63) == 0) { atomicMax(&sred[0], kp); atomicMax(&sred[1], kg); }
@@ -653,29 +690,43 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     const float maxp = ics_key2f(sred[0]), maxg = ics_key2f(sred[1]);
     const float dtpsf = __fdiv_rn(__fmul_rn(__fdiv_rn(a.step, (float)K), maxp), __fadd_rn(maxg, 1e-15f));
     if (tid == 0) a.scal[ICS_SC_DTPSF] = dtpsf;
-    const int frozen = *a.frozen;
-    for (int i = tid; i < n; i += 256) {
-      p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, a.gradk[i]));
-      if (!frozen) a.psf_caller[i] = p[i];
+#pragma unroll
+    for (int r = 0; r < GR; ++r) {
+      const int i = tid + r * NTHR;
+      if (i < n) {
+        p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, gk[r]));
+        if (!frozen) a.psf_caller[i] = p[i];
+      }
     }
     __syncthreads();
     if (a.correlation) {
-      for (int i = tid; i < K * K; i += 256) {
+      for (int i = tid; i < K * K; i += NTHR) {
         const float mval = __fdiv_rn(__fadd_rn(__fadd_rn(p[3*i], p[3*i+1]), p[3*i+2]), 3.0f);
         p[3*i] = mval; p[3*i+1] = mval; p[3*i+2] = mval;
       }
       __syncthreads();
     }
-    for (int i = tid; i < n; i += 256) if (p[i] < 0.f) p[i] = 0.f;
+    for (int i = tid; i < n; i += NTHR) if (p[i] < 0.f) p[i] = 0.f;
     __syncthreads();
     if (tid < 3) {  // sequential float32 sum in the reference's order (i, j) -- pyx:58-64
+      // (the adds are a dependent chain by definition; the LDS reads are not: 32 of them are requested before the adds that use
+      //  them -- one read per add cost ~100 cycles per tap, 10 us of this kernel at 15x15 and 45 us at 31x31)
       float s = 0.f;
-      for (int i = 0; i < K * K; ++i) s = __fadd_rn(s, p[3 * i + tid]);
+      const int KK = K * K;
+      int i = 0;
+      for (; i + 32 <= KK; i += 32) {
+        float v[32];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) v[k] = p[3 * (i + k) + tid];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s = __fadd_rn(s, v[k]);
+      }
+      for (; i < KK; ++i) s = __fadd_rn(s, p[3 * i + tid]);
       ssum[tid] = s;
     }
     __syncthreads();
     const bool detach = a.correlation != 0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += NTHR) {
       p[i] = __fdiv_rn(p[i], ssum[i % 3]);
       a.psf[i] = p[i];
       if (!frozen && !detach) a.psf_caller[i] = p[i];
@@ -686,7 +737,7 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
   // pack the row-pair weights of the convolution kernels (ics_common.h, IcsConvArgs::w):
   //   W_corr[a][b][c] = psf[a][b][c] (A3),  W_conv[a][b][c] = psf[K-1-a][K-1-b][c] (A1, = psf_rotated, pyx:589)
   //   w[ap][(3b+c)*2 + h] = W[ap - h][b][c], ap = 0..K, W[-1] = W[K] = 0; row padding zeroed
-  for (int i = tid; i < (K + 1) * a.wrow; i += 256) {
+  for (int i = tid; i < (K + 1) * a.wrow; i += NTHR) {
     const int ap = i / a.wrow, rc = i - ap * a.wrow;
     float v1 = 0.f, v2 = 0.f;
     if (rc < 6 * K) {
@@ -704,7 +755,7 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
   // kernel row Wp[idx] = W[a][idx - 15][c], i.e. the taps at local halves 7 .. K+6 and zeros around them.
   if (a.bt_conv && a.bt_corr) {
     uint32_t km = 0u;
-    for (int i = tid; i < n; i += 256) { const uint32_t k1 = key_of(__builtin_fabsf(p[i])); km = km > k1 ? km : k1; }
+    for (int i = tid; i < n; i += NTHR) { const uint32_t k1 = key_of(__builtin_fabsf(p[i])); km = km > k1 ? km : k1; }
     km = wave_max_u32(km);
     if ((tid & 63) == 0) atomicMax(&sred[2], km);
     __syncthreads();
@@ -717,7 +768,7 @@ __global__ __launch_bounds__(256) void k_psf(IcsPsfArgs a) {
     _Float16* tr = reinterpret_cast<_Float16*>(a.bt_corr);
     const int rh = ((2 * (K + 17) + 3) & ~3) / 2;      // halves per row (MCfg::WROWB / 2)
     const int nhalf = 3 * K * 2 * rh;
-    for (int i = tid; i < nhalf; i += 256) {
+    for (int i = tid; i < nhalf; i += NTHR) {
       const int ent = i / rh, hh = i - ent * rh;
       const int sp = ent & 1, ca = ent >> 1, c = ca / K, ra = ca - c * K;
       const int b = hh - 7;
@@ -769,7 +820,7 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
   const int nwc = (rowf + 255) / 256;              // wave segments per row
   const long nitems = (long)G.uM * nwc;
   const long gw = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long)gridDim.x * 4;
-  constexpr int U = TVK == 0 ? ICS_UPDATE_U : 2;
+  constexpr int U = TVK == 0 ? ICS_UPDATE_U : (TVK == 1 ? ICS_UPDATE_U_TV : 2);
   for (long it0 = gw * U; it0 < nitems; it0 += nw * U) {
     f32x4 uq[U], tq[U], gq[U], fq[U], Tq[U];
     int ys[U], f0s[U];
@@ -798,11 +849,13 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
       const float dt2r[3] = {r == 0 ? dt2[0] : (r == 1 ? dt2[1] : dt2[2]), r == 0 ? dt2[1] : (r == 1 ? dt2[2] : dt2[0]), r == 0 ? dt2[2] : (r == 1 ? dt2[0] : dt2[1])};
       const bool yin = (y >= G.pad) && (y < G.pad + G.M);
       const ptrdiff_t o = (ptrdiff_t)y * G.pitch + f0;
-      float un4[4];
+      float un4[4], fn4[4];
+      bool in4[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int x = q + ((r + e) >= 3 ? 1 : 0);
         const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
+        in4[e] = inside;
         const float uv = uq[s][e], gv = gq[s][e];
         float g;
         if (TVK == 2)                                                            // PAM: the back-projection pass wrote G = T + lambd*gradu
@@ -819,7 +872,7 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
           if (!a.blind) D = __fdiv_rn(D, lambd);
           if (TVK == 1) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
             fv = __fsub_rn(fv, __fdiv_rn(__fmul_rn(dt2r[e % 3], Tq[s][e]), lambd));
-            a.f_rw[o + e] = fv;
+            fn4[e] = fv;
           }
           un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fv));
           if (a.want_dof) {
@@ -828,6 +881,16 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
           }
         }
         un4[e] = un;
+      }
+      if (TVK == 1) {   // the image step: one 16-byte store where the four floats are image pixels, single floats on the rim
+        if (in4[0] && in4[3]) {
+          const f32x4 w = {fn4[0], fn4[1], fn4[2], fn4[3]};
+          *reinterpret_cast<f32x4*>(a.f_rw + o) = w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (in4[e]) a.f_rw[o + e] = fn4[e];
+        }
       }
       if (f0 + 3 < rowf) {
         const f32x4 w = {un4[0], un4[1], un4[2], un4[3]};
@@ -980,13 +1043,12 @@ hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
 }
 
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s) {
-  const int n = 3 * g.K * g.K;
   const int nt = 16 * ((g.K + 15) / 16);
-  hipLaunchKernelGGL(k_gradk_reduce, dim3((n * 32 + 255) / 256), dim3(256), 0, s, partial, nblocks, gradk, g.K, nt);
+  hipLaunchKernelGGL(k_gradk_reduce, dim3((3 * nt * nt + 63) / 64), dim3(1024), 0, s, partial, nblocks, gradk, g.K, nt);
   return hipGetLastError();
 }
 
 hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_psf, dim3(1), dim3(256), (size_t)3 * a.K * a.K * sizeof(float), s, a);
+  hipLaunchKernelGGL(k_psf, dim3(1), dim3(ICS_PSF_THREADS), (size_t)3 * a.K * a.K * sizeof(float), s, a);
   return hipGetLastError();
 }

@@ -63,13 +63,29 @@ __device__ __forceinline__ float win_u(const IcsStatsArgs& a, const Win& w, int 
 __device__ __forceinline__ float mean_of(double s, int n) { return (float)(s / n); }
 __device__ __forceinline__ float std_of(double d2, int n) { return sqrtf((float)(d2 / n)); }
 
+// A thread takes 8 elements per trip and requests them together: as a plain loop (index arithmetic with two integer divisions, then
+// one load, then the add) every element exposed the full memory latency -- 8 x ~1 us of these passes' 12 and 9 us.  The index of
+// an element past the end is clamped and its value discarded: a conditional load compiles to a branch and a full wait per element.
+#define ICS_MOM_BATCH 8
 __global__ __launch_bounds__(256) void k_mom1(IcsStatsArgs a) {
   __shared__ double shd[4];
   const Win w = make_win(a);
   double s = 0.0, s2 = 0.0, su = 0.0;
   const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-  for (int i = t0; i < w.ne; i += stride) { const float v = win_e(a, w, i); s += v; s2 += (double)v * v; }
-  for (int i = t0; i < w.nu; i += stride) su += win_u(a, w, i);
+  for (int i0 = t0; i0 < w.ne; i0 += ICS_MOM_BATCH * stride) {
+    float v[ICS_MOM_BATCH];
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { const int i = i0 + k * stride; const float t = win_e(a, w, i < w.ne ? i : w.ne - 1); v[k] = i < w.ne ? t : 0.f; }
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { s += v[k]; s2 += (double)v[k] * v[k]; }
+  }
+  for (int i0 = t0; i0 < w.nu; i0 += ICS_MOM_BATCH * stride) {
+    float v[ICS_MOM_BATCH];
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { const int i = i0 + k * stride; const float t = win_u(a, w, i < w.nu ? i : w.nu - 1); v[k] = i < w.nu ? t : 0.f; }
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) su += v[k];
+  }
   s = block_sum(s, shd); s2 = block_sum(s2, shd); su = block_sum(su, shd);
   if (threadIdx.x == 0) { atomicAdd(a.dacc + 0, s); atomicAdd(a.dacc + 1, s2); atomicAdd(a.dacc + 2, su); }
 }
@@ -84,12 +100,24 @@ __global__ __launch_bounds__(256) void k_mom2(IcsStatsArgs a) {
   double d2 = 0.0, du = 0.0;
   float mx = 0.f;
   const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-  for (int i = t0; i < w.ne; i += stride) {
-    const float v = __fsub_rn(win_e(a, w, i), mean_e); d2 += (double)v * v;
-    const float av = __builtin_fabsf(v);
-    mx = (mx > av || mx != mx) ? mx : av;
+  for (int i0 = t0; i0 < w.ne; i0 += ICS_MOM_BATCH * stride) {
+    float e[ICS_MOM_BATCH];
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { const int i = i0 + k * stride; e[k] = win_e(a, w, i < w.ne ? i : w.ne - 1); }
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) {
+      const float v = i0 + k * stride < w.ne ? __fsub_rn(e[k], mean_e) : 0.f; d2 += (double)v * v;
+      const float av = __builtin_fabsf(v);
+      mx = (mx > av || mx != mx) ? mx : av;
+    }
   }
-  for (int i = t0; i < w.nu; i += stride) { const float v = __fsub_rn(win_u(a, w, i), mean_u); du += (double)v * v; }
+  for (int i0 = t0; i0 < w.nu; i0 += ICS_MOM_BATCH * stride) {
+    float e[ICS_MOM_BATCH];
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { const int i = i0 + k * stride; e[k] = win_u(a, w, i < w.nu ? i : w.nu - 1); }
+#pragma unroll
+    for (int k = 0; k < ICS_MOM_BATCH; ++k) { const float v = i0 + k * stride < w.nu ? __fsub_rn(e[k], mean_u) : 0.f; du += (double)v * v; }
+  }
   d2 = block_sum(d2, shd); du = block_sum(du, shd);
   mx = block_maxf(mx, shf);
   if (threadIdx.x == 0) {
@@ -97,93 +125,134 @@ __global__ __launch_bounds__(256) void k_mom2(IcsStatsArgs a) {
     if (a.do_mr) atomicMax(a.ukey, (mx != mx) ? 0xFFC00000u : ics_f2key(mx));
   }
 }
-// One P-point complex FFT per workgroup (P/2 threads), radix-2 Stockham autosort in LDS; element j of a line lives at
-// base + j * stride_elem; forward: exp(-i...), inverse: conjugate, unscaled.  The element-wise passes around the four
-// transforms are folded into the loads, and only the lines that matter are transformed:
-//   LOAD 1: row transform of the normalised window z = ((e - mean)/std)/max|t| straight from the residual frame, zero
-//           padded to P columns; rows >= H of the padded P x P array are zero and are neither written nor transformed
-//   LOAD 2: forward column transform; rows >= H are read as zero
-//   LOAD 3: inverse column transform of |Z|^2 (Wiener-Khinchin)
-//   LOAD 0: inverse row transform of the rows k_mr reads (|row offset| <= H/2, through the line remap)
-// line l of a plane is row/column  l < n0 ? l : l + skip.  (As separate kernels -- window fill, four full transforms,
-// |Z|^2 -- the same arithmetic took six launches and 0.075 ms.)
-struct FftX {
-  float2* data; int P, logP; long stride_elem, line_stride; int lines_per_plane; long plane_stride; int inverse; const float2* tw;
-  int n0, skip, nvalid;
-};
-template <int LOAD>
-__global__ void k_fftx(FftX f, IcsStatsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float2 sm[];
-  float2* x = sm;
-  float2* y = sm + f.P;
-  const int P = f.P, t = P >> 1, tid = threadIdx.x;
-  const int plane = blockIdx.x / f.lines_per_plane;
-  int line = blockIdx.x - plane * f.lines_per_plane;
-  line = line < f.n0 ? line : line + f.skip;
-  float2* base = f.data + (long)plane * f.plane_stride + (long)line * f.line_stride;
-  // P / 2 butterflies per stage over min(P / 2, 1024) threads: above P = 2048 (stats windows wider than 1024 px; the reference has
-  // no limit, lib/deconvolution.pyx:623-638) a thread takes several
-  const int nthr = blockDim.x;
-  if (LOAD == 1) {
-    const IcsGeom& G = a.geo;
-    const Win w = make_win(a);
-    const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
-    const float mxk = ics_key2f(a.ukey[0]);                       // max |e - mean| (k_mom2), NaN key kept
-    const float mx = (a.ukey[0] == 0xFFC00000u) ? mxk : __fdiv_rn(mxk, std_e);   // = max |(e - mean) / std|
-    for (int j = tid; j < P; j += nthr) {
-      float v = 0.f;
-      if (line < w.H && j < w.W) {
-        const float e = a.e[(ptrdiff_t)(a.top + G.pad + line) * G.pitch + 3 * (a.left + G.pad + j) + plane];
-        v = __fdiv_rn(__fdiv_rn(__fsub_rn(e, mean_e), std_e), mx);
-      }
-      x[j] = make_float2(v, 0.f);
-    }
-  } else {
-    for (int j = tid; j < P; j += nthr) {
-      float2 v = make_float2(0.f, 0.f);
-      if (LOAD != 2 || j < f.nvalid) v = base[(long)j * f.stride_elem];
-      if (LOAD == 3) v = make_float2(v.x * v.x + v.y * v.y, 0.f);
-      x[j] = v;
-    }
-  }
-  __syncthreads();
-  for (int s = 0, p = 1; s < f.logP; ++s, p <<= 1) {
-    for (int b = tid; b < t; b += nthr) {
+// Radix-2 Stockham autosort FFTs in LDS.  C lines of P points are transformed together (line c at x + c * LP); P / 2 butterflies per
+// line and stage over the workgroup's threads; forward: exp(-i...), inverse: conjugate, unscaled.  Returns the buffer holding the
+// result.  The element-wise passes around the four transforms are folded into three kernels, and only the lines that matter are
+// transformed:
+//   k_fft_rows : row transform of the normalised window z = ((e - mean)/std)/max|t| straight from the residual frame, zero padded to
+//                P columns; rows >= H of the padded P x P array are zero and are neither written nor transformed
+//   k_fft_cols : forward column transform (rows >= H read as zero), |Z|^2 (Wiener-Khinchin) and the inverse column transform with
+//                the column staying in LDS; a workgroup takes C adjacent columns (32-byte segments of each row instead of 8-byte
+//                ones) and writes back only the rows the last pass reads
+//   k_fft_mr   : inverse row transform of the rows with |row offset| <= H/2 and, from LDS, this row's part of
+//                sum ac^2 w  (pyx:633-638); the last workgroup out writes the scalars of the outer iteration
+// (Round 2 ran this as rows, columns, |Z|^2 + inverse columns, inverse rows, and a separate weighted sum: five launches and two more
+//  round trips of the 6 MB spectrum through L2 / HBM; as six separate element-wise + transform kernels before that.)
+__device__ __forceinline__ float2* fft_lines(float2* x, float2* y, int P, int logP, int C, int LP, const float2* __restrict__ tw, bool inverse) {
+  const int t = P >> 1, tid = threadIdx.x, nthr = blockDim.x, logt = logP - 1;
+  for (int s = 0, p = 1; s < logP; ++s, p <<= 1) {
+    for (int q = tid; q < C * t; q += nthr) {
+      const int cc = q >> logt, b = q & (t - 1);
       const int k = b & (p - 1);
       const int j = ((b - k) << 1) + k;
-      float2 w = f.tw[k * (t / p)];
-      if (f.inverse) w.y = -w.y;
-      const float2 u0 = x[b], v = x[b + t];
+      float2 w = tw[k * (t / p)];
+      if (inverse) w.y = -w.y;
+      const float2* xl = x + cc * LP; float2* yl = y + cc * LP;
+      const float2 u0 = xl[b], v = xl[b + t];
       const float2 u1 = make_float2(v.x * w.x - v.y * w.y, v.x * w.y + v.y * w.x);
-      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+      yl[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      yl[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
     }
     __syncthreads();
     float2* tmp = x; x = y; y = tmp;
   }
-  for (int j = tid; j < P; j += nthr) base[(long)j * f.stride_elem] = x[j];
+  return x;
+}
+
+__global__ void k_fft_rows(IcsStatsArgs a, int C, int LP) {   // grid ceil(3 * H / C), min(C * P / 2, 1024) threads
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  const IcsGeom& G = a.geo;
+  const Win w = make_win(a);
+  const int P = a.P, tid = threadIdx.x, nthr = blockDim.x, NL = 3 * w.H;
+  const float mean_e = mean_of(a.dacc[0], w.ne), std_e = std_of(a.dacc[3], w.ne);
+  const float mxk = ics_key2f(a.ukey[0]);                       // max |e - mean| (k_mom2), NaN key kept
+  const float mx = (a.ukey[0] == 0xFFC00000u) ? mxk : __fdiv_rn(mxk, std_e);   // = max |(e - mean) / std|
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i >> a.logP, j = i & (P - 1), id = blockIdx.x * C + cc;
+    float v = 0.f;
+    if (id < NL && j < w.W) {
+      const int plane = id / w.H, line = id - plane * w.H;
+      const float e = a.e[(ptrdiff_t)(a.top + G.pad + line) * G.pitch + 3 * (a.left + G.pad + j) + plane];
+      v = __fdiv_rn(__fdiv_rn(__fsub_rn(e, mean_e), std_e), mx);
+    }
+    sm[cc * LP + j] = make_float2(v, 0.f);
+  }
+  __syncthreads();
+  const float2* r = fft_lines(sm, sm + C * LP, P, a.logP, C, LP, a.tw, false);
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i >> a.logP, j = i & (P - 1), id = blockIdx.x * C + cc;
+    if (id < NL) {
+      const int plane = id / w.H, line = id - plane * w.H;
+      a.z[((long)plane * P + line) * P + j] = r[cc * LP + j];
+    }
+  }
+}
+
+__global__ void k_fft_cols(IcsStatsArgs a, int C, int LP) {   // grid 3 * P / C, min(C * P / 2, 1024) threads
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  const int P = a.P, tid = threadIdx.x, nthr = blockDim.x;
+  const int H = a.bottom - a.top, n0 = H - H / 2;
+  const int groups = P / C;
+  const int plane = blockIdx.x / groups, c0 = (blockIdx.x - plane * groups) * C;
+  float2* base = a.z + (long)plane * P * P + c0;
+  float2* x = sm;
+  float2* y = sm + C * LP;
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i & (C - 1), j = i / C;
+    x[cc * LP + j] = j < H ? base[(long)j * P + cc] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  float2* r = fft_lines(x, y, P, a.logP, C, LP, a.tw, false);
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i / P, j = i - cc * P;
+    const float2 v = r[cc * LP + j];
+    r[cc * LP + j] = make_float2(v.x * v.x + v.y * v.y, 0.f);
+  }
+  __syncthreads();
+  const float2* q = fft_lines(r, r == x ? y : x, P, a.logP, C, LP, a.tw, true);
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i & (C - 1), j = i / C;
+    if (j < n0 || j >= P - H / 2) base[(long)j * P + cc] = q[cc * LP + j];   // rows (r - H/2) mod P, r < H
+  }
 }
 
 __device__ void stats_final(const IcsStatsArgs& a);
 
-// sum over (H, W, 3) of ac^2 * w,  ac[a][b] = Z[(a - H/2) mod P][(b - W/2) mod P] / P^2
-__global__ __launch_bounds__(256) void k_mr(IcsStatsArgs a) {
-  __shared__ double shd[4];
-  const int H = a.bottom - a.top, W = a.right - a.left, P = a.P;
+// sum over (H, W, 3) of ac^2 * w,  ac[r][b] = Z[(r - H/2) mod P][(b - W/2) mod P] / P^2: C rows (of any channel) per workgroup
+__global__ void k_fft_mr(IcsStatsArgs a, int C, int LP) {   // grid ceil(3 * H / C), min(C * P / 2, 1024) threads
+  extern __shared__ __attribute__((aligned(16))) float2 sm[];
+  __shared__ double shd[16];
+  const int P = a.P, tid = threadIdx.x, nthr = blockDim.x;
+  const int H = a.bottom - a.top, W = a.right - a.left, n0 = H - H / 2, NL = 3 * H;
+  for (int i = tid; i < C * P; i += nthr) {
+    const int cc = i >> a.logP, j = i & (P - 1), id = blockIdx.x * C + cc;
+    float2 v = make_float2(0.f, 0.f);
+    if (id < NL) {
+      const int plane = id / H, l = id - plane * H;
+      const int zr = l < n0 ? l : l + (P - H);
+      v = a.z[((long)plane * P + zr) * P + j];
+    }
+    sm[cc * LP + j] = v;
+  }
+  __syncthreads();
+  const float2* x = fft_lines(sm, sm + C * LP, P, a.logP, C, LP, a.tw, true);
   const float inv = 1.0f / ((float)P * (float)P);
   double s = 0.0;
-  const int n = H * W * 3;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int b = i % W, r = (i / W) % H, c = i / (W * H);
-    const int zr = (r - H / 2 + P) & (P - 1), zc = (b - W / 2 + P) & (P - 1);
-    const float ac = a.z[((long)c * P + zr) * P + zc].x * inv;
-    s += (double)__fmul_rn(__fmul_rn(ac, ac), a.weights[r * W + b]);
+  for (int i = tid; i < C * W; i += nthr) {
+    const int cc = i / W, b = i - cc * W, id = blockIdx.x * C + cc;
+    if (id < NL) {
+      const int l = id % H;
+      const int r = l < n0 ? l + H / 2 : l - n0;
+      const int zc = (b - W / 2 + P) & (P - 1);
+      const float ac = x[cc * LP + zc].x * inv;
+      s += (double)__fmul_rn(__fmul_rn(ac, ac), a.weights[r * W + b]);
+    }
   }
   s = block_sum(s, shd);
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     atomicAdd(a.dacc + 5, s);
-    // the last workgroup out writes the scalars of the outer iteration (one launch less): its own sum is in, and so are all
-    // the others' -- every workgroup adds before it takes a ticket (device-scope atomics on the same L2-resident words)
+    // the last workgroup out writes the scalars of the outer iteration: its own sum is in, and so are all the others' -- every
+    // workgroup adds before it takes a ticket (device-scope atomics on the same L2-resident words)
     __threadfence();
     if (atomicAdd(a.ukey + 1, 1u) == gridDim.x - 1) { __threadfence(); stats_final(a); }
   }
@@ -226,35 +295,29 @@ __global__ __launch_bounds__(256) void k_hasnan(const float* u, IcsGeom G, int* 
 hipError_t ics_launch_stats(const IcsStatsArgs& a, hipStream_t s) {
   // (dacc / ukey are zero: at job creation, and re-armed by the previous call's last kernel)
   const int ne = (a.bottom - a.top) * (a.right - a.left) * 3;
-  int gb = (ne + 256 * 8 - 1) / (256 * 8); if (gb < 1) gb = 1; if (gb > 512) gb = 512;
+  int gb = (ne + 256 * ICS_MOM_BATCH - 1) / (256 * ICS_MOM_BATCH); if (gb < 1) gb = 1; if (gb > 512) gb = 512;
   hipLaunchKernelGGL(k_mom1, dim3(gb), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_mom2, dim3(gb), dim3(256), 0, s, a);
   if (a.do_mr) {
-    const int P = a.P;
-    const size_t lds = 2 * (size_t)P * sizeof(float2);
-    const int nthr = P / 2 < 1024 ? P / 2 : 1024;
-    if (lds > 64 * 1024) {   // P = 8192: 128 KB of dynamic LDS (stats windows up to 4096 px)
-      static std::atomic<bool> cfg[4][ICS_MAX_DEVICES];
+    const int P = a.P, H = a.bottom - a.top;
+    const int C = P < 4 ? 1 : (P <= 1024 ? 4 : (P <= 2048 ? 2 : 1));   // columns per workgroup (LDS: 2 * C * LP * 8 bytes); P >= 2
+    const int LP = P + (C > 1 ? 4 : 0);                       // line pitch in LDS: the transposing accesses spread over the banks
+    const size_t lds = 2 * (size_t)C * LP * sizeof(float2);
+    auto clampt = [](int v) { return v < 64 ? 64 : (v > 1024 ? 1024 : v); };   // whole waves (block_sum), at most 1024 threads
+    const int nthr = clampt(C * (P / 2));
+    if (lds > 64 * 1024) {   // P >= 1024: up to 128 KB of dynamic LDS (stats windows up to 4096 px)
+      static std::atomic<bool> cfg[3][ICS_MAX_DEVICES];
       const int dev = ics_current_device();
-      hipError_t e = ics_configure_lds(cfg[0], dev, k_fftx<0>, 128 * 1024);
-      if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_fftx<1>, 128 * 1024);
-      if (e == hipSuccess) e = ics_configure_lds(cfg[2], dev, k_fftx<2>, 128 * 1024);
-      if (e == hipSuccess) e = ics_configure_lds(cfg[3], dev, k_fftx<3>, 128 * 1024);
+      hipError_t e = ics_configure_lds(cfg[0], dev, k_fft_rows, 132 * 1024);
+      if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_fft_cols, 132 * 1024);
+      if (e == hipSuccess) e = ics_configure_lds(cfg[2], dev, k_fft_mr, 132 * 1024);
       if (e != hipSuccess) return e;
     }
-    const long plane = (long)P * P;
-    const int H = a.bottom - a.top;
-    // rows: line = row, elements contiguous; columns: line = column, element stride P
-    FftX f = {a.z, P, a.logP, 1L, (long)P, H, plane, 0, a.tw, H, 0, H};
-    hipLaunchKernelGGL(k_fftx<1>, dim3(3 * H), dim3(nthr), lds, s, f, a);                     // rows of the window
-    f.stride_elem = P; f.line_stride = 1; f.lines_per_plane = P; f.n0 = P;
-    hipLaunchKernelGGL(k_fftx<2>, dim3(3 * P), dim3(nthr), lds, s, f, a);                     // columns (rows >= H are zero)
-    f.inverse = 1;
-    hipLaunchKernelGGL(k_fftx<3>, dim3(3 * P), dim3(nthr), lds, s, f, a);                     // |Z|^2, inverse columns
-    // inverse rows: k_mr reads rows (r - H/2) mod P, r < H:  0 .. H - H/2 - 1  and  P - H/2 .. P - 1
-    f.stride_elem = 1; f.line_stride = P; f.lines_per_plane = H; f.n0 = H - H / 2; f.skip = P - H;
-    hipLaunchKernelGGL(k_fftx<0>, dim3(3 * H), dim3(nthr), lds, s, f, a);
-    hipLaunchKernelGGL(k_mr, dim3(gb), dim3(256), 0, s, a);   // its last workgroup writes the scalars
+    const int glines = (3 * H + C - 1) / C;
+    // (the forward rows run one line per workgroup: 8.3 us against 10.0 with four -- their loads are the strided ones)
+    hipLaunchKernelGGL(k_fft_rows, dim3(3 * H), dim3(clampt(P / 2)), 2 * (size_t)P * sizeof(float2), s, a, 1, P);
+    hipLaunchKernelGGL(k_fft_cols, dim3(3 * (P / C)), dim3(nthr), lds, s, a, C, LP);
+    hipLaunchKernelGGL(k_fft_mr, dim3(glines), dim3(nthr), lds, s, a, C, LP);   // its last workgroup writes the scalars
   } else {
     hipLaunchKernelGGL(k_stats_final, dim3(1), dim3(1), 0, s, a);
   }
