@@ -92,7 +92,9 @@ struct IcsStatsArgs {
   const float* e;      // residual frame origin
   const float* u;      // u frame origin
   float* scal;         // ICS_SC_MR / HU / VARU written
-  const uint32_t* dofkeys;
+  uint32_t* dofkeys;   // DoF keys of the outer iteration (read; re-armed when `rearm`)
+  uint32_t* red;       // reduction slots of the outer iteration's five inner iterations (8 * ICS_RED_STRIDE words), or nullptr
+  int rearm;           // ics_rl_run: the kernel that writes the scalars also resets dofkeys and red for the next outer iteration
   double* dacc;        // 8 double accumulators (zeroed by the launcher)
   uint32_t* ukey;      // 2 keys (max |t|)
   float2* z;           // [3][P][P] complex scratch

@@ -11,7 +11,7 @@
 #define ICS_PSF_THREADS 1024
 #endif
 #ifndef ICS_UPDATE_U_TV
-#define ICS_UPDATE_U_TV 3   /* the same for the active MM-TV form (five frames read, two written) */
+#define ICS_UPDATE_U_TV 4   /* the same for the active MM-TV form (five frames read, two written) */
 #endif
 #ifndef ICS_UPDATE_NT
 #define ICS_UPDATE_NT 15  /* streaming (nt) loads in k_update_rows: bit 0 u, 1 ut, 2 g, 3 f */
@@ -209,8 +209,12 @@ __device__ __forceinline__ float pam_term(const float (&n)[3][20], int i, int c,
 #ifndef ICS_TVMM_SEG
 #define ICS_TVMM_SEG 8
 #endif
+#ifndef ICS_TVMM_F64_DIFF
+#define ICS_TVMM_F64_DIFF 0   /* second differences as double sums (round 3's first form) */
+#endif
 struct IcsStencil2 { float udx, udy, udd, uda; };
 __device__ __forceinline__ IcsStencil2 ics_second_differences(const float (&n)[3][20], int i) {
+#if ICS_TVMM_F64_DIFF
   const double m2c = -2.0 * (double)n[1][i];
   const float inv = 0.707106769f;   // 1 / 1.41421354f rounded to float
   IcsStencil2 s;
@@ -219,6 +223,19 @@ __device__ __forceinline__ IcsStencil2 ics_second_differences(const float (&n)[3
   s.udd = (float)((m2c + (double)n[0][i - 3]) + (double)n[2][i + 3]) * inv;
   s.uda = (float)((m2c + (double)n[0][i + 3]) + (double)n[2][i - 3]) * inv;
   return s;
+#else
+  // (a - c) + (b - c) in fp32: where the neighbours lie within a factor two of the centre -- every place where the differences
+  // cancel, i.e. where the term is large -- both differences are exact (Sterbenz) and the sum is rounded once, which is what the
+  // double form above returns; elsewhere the result is within an ulp of it.  A third fewer vector instructions per value.
+  const float c = n[1][i];
+  const float inv = 0.707106769f;   // 1 / 1.41421354f rounded to float
+  IcsStencil2 s;
+  s.udx = __fadd_rn(__fsub_rn(n[0][i], c), __fsub_rn(n[2][i], c));
+  s.udy = __fadd_rn(__fsub_rn(n[1][i - 3], c), __fsub_rn(n[1][i + 3], c));
+  s.udd = __fadd_rn(__fsub_rn(n[0][i - 3], c), __fsub_rn(n[2][i + 3], c)) * inv;
+  s.uda = __fadd_rn(__fsub_rn(n[0][i + 3], c), __fsub_rn(n[2][i - 3], c)) * inv;
+  return s;
+#endif
 }
 __device__ __forceinline__ float ics_tv_mm_term_fast(const float (&nu)[3][20], const float (&nt)[3][20], int i, float eps) {
   const float a1 = 6.82842731f, a2 = 4.82842731f;            // 4 (1 + 1/sqrt 2), 2 (1 + sqrt 2)

@@ -273,6 +273,10 @@ __device__ void stats_final(const IcsStatsArgs& a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) dacc[i] = 0.0;
   a.ukey[0] = 0u; a.ukey[1] = 0u;
+  if (a.rearm) {   // what ics_rl_run otherwise queues per outer iteration as a memset and a 16-byte upload (two stream operations, ~15 us)
+    a.dofkeys[0] = 0xFFFFFFFFu; a.dofkeys[1] = 0u; a.dofkeys[2] = 0u; a.dofkeys[3] = 0u;
+    if (a.red) for (int i = 0; i < 8 * ICS_RED_STRIDE; ++i) a.red[i] = 0u;
+  }
 }
 __global__ void k_stats_final(IcsStatsArgs a) { stats_final(a); }
 
