@@ -76,6 +76,7 @@ struct ics_rl {
   float* facc[2];                       // the image in accumulator order for 32-row / 64-row tiles (ics_image_acc.h), allocated on first use
   bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
+  float* psf_work;                      // PSF sizes above 63: working copy of k_psf (3*K*K floats), else NULL
   float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
   int fused2_blocks;                    // persistent workgroups of the 32-row fused A11 + A13 kernel: three per CU (capped like gradk_blocks by the test switch)
@@ -216,7 +217,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial,
+  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -231,7 +232,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   *out = nullptr;
   if (M < 1 || N < 1) return fail(ICS_EINVAL, "image size %dx%d", M, N);
   if (MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "MK must be odd and >= 3 (got %d)", MK);
-  if (!ics_conv_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..63)", MK);
+  if (!ics_conv_supported(MK) && !ics_big_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..127)", MK);
   HIPCHK(hipSetDevice(c->device));
   ics_rl* j = new ics_rl();  // value-initialised: every pointer/flag starts at 0
   j->ctx = c;
@@ -255,6 +256,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(&j->u, j->frame_floats, s)); TRY(dalloc(&j->u2, j->frame_floats, s)); TRY(dalloc(&j->ut, j->frame_floats, s)); TRY(dalloc(&j->gr, j->frame_floats, s));
   TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
   TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
+  if (ics_big_supported(MK)) TRY(dalloc(&j->psf_work, n, s));
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
   if (ics_conv_mfma_supported(MK)) { TRY(dalloc(&j->bt_conv, ics_conv_mfma_table_floats(MK), s)); TRY(dalloc(&j->bt_corr, ics_conv_mfma_table_floats(MK), s)); }
   TRY(dalloc(&j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, s));
@@ -304,7 +306,7 @@ static int ensure_image_acc(ics_rl* j, int RS) {
 
 static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hipStream_t s) {
   IcsPsfArgs a;
-  a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.bt_conv = j->bt_conv; a.bt_corr = j->bt_corr; a.psf_caller = j->psf_caller;
+  a.psf = j->psf; a.gradk = j->gradk; a.wconv = j->wconv; a.wcorr = j->wcorr; a.bt_conv = j->bt_conv; a.bt_corr = j->bt_corr; a.psf_caller = j->psf_caller; a.work = j->psf_work;
   a.scal = j->scal; a.frozen = j->flags; a.step = step; a.K = j->g.K; a.wrow = j->g.wrow;
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
@@ -606,7 +608,10 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   }
   a.sched = matrix ? j->sched : nullptr;   // counters of the dynamic tile walk: the launcher decides per launch (ics_conv_mfma.hip)
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
-  if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
+  if (ics_big_supported(j->g.K)) {   // run-time-sized kernels (ics_big.hip); the maxima of A7 as a pass of their own
+    HIPCHK(ics_launch_conv_big(mode, a, j->psf, j->ctx->stream));
+    if (mode == 1) HIPCHK(ics_launch_band_reduce(a.out, a.u, a.ut, j->g, p->lambd, 0, j->g.uM, a.red, j->ctx->stream));
+  } else if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
   else HIPCHK(ics_launch_conv(mode, a, j->ctx->stream));
   RC(pr.end());
   if (mode == 2) { float* t = j->u; j->u = j->u2; j->u2 = t; }  // the updated frame is now `u`
@@ -660,7 +665,8 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   IcsGradkArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
   RC(pr.begin(ICS_K_PSF_GRADIENT));
-  if (use_matrix_gradk(j, p)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
+  if (ics_big_supported(j->g.K)) HIPCHK(ics_launch_gradk_big(a, j->gradk_blocks, j->ctx->stream));
+  else if (use_matrix_gradk(j, p)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
   else HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
   HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
   RC(pr.end());
@@ -750,6 +756,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 37");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
+  if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 127)", p->tv_mode);
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
 }

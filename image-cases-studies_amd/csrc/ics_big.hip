@@ -1,0 +1,214 @@
+// ics_big.hip -- PSF sizes 65 ... 127: the two convolutions (A1+A2, A3) and the PSF gradient (A12+A13) for any odd size.
+//
+// The reference has no limit on the PSF size (lib/deconvolution.pyx:341: `MK` is whatever the caller's array is; its convolutions
+// are FFTs).  The tuned kernels of this library are compiled per size (matrix cores to 37, packed fp32 to 63); beyond that these
+// two kernels take the size at run time.  Plain fp32 FMA streams out of LDS -- built to be correct and to keep the arithmetic units
+// busy, not tuned per size: at 4096^2 a 65x65 convolution is 4.2e11 flop per pass.
+//
+//   k_conv_big  : out[y, x, c] = sum_{a,b<K} W[a, b, c] * in[y + a - pad, x + b - pad, c]   (u-frame coordinates, as ics_conv.hip)
+//                 W = rot180(psf), out = error - image on the M x N interior (mode 0: pyx:477-488)
+//                 W = psf,         out = gradu on the whole u-frame          (mode 1: pyx:490-491; the maxima of pyx:523-524 are
+//                                                                             taken by k_band_reduce behind it)
+//   k_gradk_big : partial[wg][c][a][b] = sum over the workgroup's tiles of E[y, x, c] * U[y + pad - a, x + pad - b, c]
+//                 (pyx:567-571), reduced in double by k_gradk_reduce like every other gradient kernel.
+#include "ics_kernels.h"
+
+namespace {
+
+constexpr int BIG_TA = 16;                 // kernel rows per staged block
+constexpr int BIG_TH = 32, BIG_TW = 64;    // output tile of the convolution (256 threads: one row x 8 pixels each)
+constexpr int BIG_KMAX = 127;
+constexpr int BIG_K8MAX = 128;
+constexpr int BIG_LW = BIG_TW + BIG_K8MAX + 8;          // staged columns: x0 - pad ... (zero weights cover the padding to K8)
+constexpr int BIG_LR = BIG_TH + BIG_TA - 1;
+constexpr size_t BIG_CONV_LDS = ((size_t)BIG_LR * BIG_LW + (size_t)BIG_TA * BIG_K8MAX) * sizeof(float);
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// in-frame test of a u-frame coordinate (the frames carry an apron of ay rows / ax pixels around the tile grid)
+__device__ __forceinline__ bool in_frame(const IcsGeom& G, int y, int x) {
+  return y >= -G.ay && y < G.rows - G.ay && x >= -G.ax && 3 * (x + G.ax) + 2 < G.pitch;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_big(IcsConvArgs a, const float* __restrict__ psf) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;                       // [BIG_LR][BIG_LW]
+  float* wl = lds + BIG_LR * BIG_LW;       // [BIG_TA][K8]
+  const IcsGeom& G = a.g;
+  const int K = G.K, pad = G.pad, K8 = (K + 7) & ~7;
+  const int tid = threadIdx.x, ty = tid >> 3, tc = tid & 7;
+  // output region: mode 0 the image interior, mode 1 the whole u-frame
+  const int oy0 = MODE == 0 ? pad : 0, ox0 = MODE == 0 ? pad : 0;
+  const int oh = MODE == 0 ? G.M : G.uM, ow = MODE == 0 ? G.N : G.uN;
+  const int ntx = (ow + BIG_TW - 1) / BIG_TW, nty = (oh + BIG_TH - 1) / BIG_TH;
+  for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
+    const int y0 = oy0 + (t / ntx) * BIG_TH, x0 = ox0 + (t % ntx) * BIG_TW;
+    for (int c = 0; c < 3; ++c) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int a0 = 0; a0 < K; a0 += BIG_TA) {
+        const int ta = K - a0 < BIG_TA ? K - a0 : BIG_TA;
+        __syncthreads();   // the previous block's readers are done
+        for (int i = tid; i < (BIG_TH + ta - 1) * BIG_LW; i += 256) {
+          const int r = i / BIG_LW, col = i - r * BIG_LW;
+          const int y = y0 + a0 - pad + r, x = x0 - pad + col;
+          tile[i] = in_frame(G, y, x) ? a.in[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+        }
+        for (int i = tid; i < ta * K8; i += 256) {
+          const int ar = i / K8, b = i - ar * K8, ka = a0 + ar;
+          float w = 0.f;
+          if (b < K) w = MODE == 0 ? psf[((K - 1 - ka) * K + (K - 1 - b)) * 3 + c] : psf[(ka * K + b) * 3 + c];
+          wl[ar * K8 + b] = w;
+        }
+        __syncthreads();
+        for (int ar = 0; ar < ta; ++ar) {
+          const float* row = tile + (ty + ar) * BIG_LW + 8 * tc;
+          const float* wr = wl + ar * K8;
+          float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // one kernel row on its own, then into the total: shorter rounding chains
+          float v[16];
+          { const f4 p = *reinterpret_cast<const f4*>(row), q = *reinterpret_cast<const f4*>(row + 4);
+            v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = q.x; v[13] = q.y; v[14] = q.z; v[15] = q.w; }
+          for (int b0 = 0; b0 < K8; b0 += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[8 + k];
+            { const f4 p = *reinterpret_cast<const f4*>(row + b0 + 8), q = *reinterpret_cast<const f4*>(row + b0 + 12);
+              v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = q.x; v[13] = q.y; v[14] = q.z; v[15] = q.w; }
+            const f4 w0 = *reinterpret_cast<const f4*>(wr + b0), w1 = *reinterpret_cast<const f4*>(wr + b0 + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) r8[i] = __builtin_fmaf(w[bb], v[bb + i], r8[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += r8[i];
+        }
+      }
+      const int y = y0 + ty;
+      if (y < oy0 + oh) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int x = x0 + 8 * tc + i;
+          if (x < ox0 + ow) {
+            const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * x + c;
+            a.out[o] = MODE == 0 ? __fsub_rn(acc[i], a.f[o]) : acc[i];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- PSF gradient -----------------------------------------------------------------------------------------------------------
+constexpr int GB_T = 32;   // residual tile: 32 x 32 pixels of one channel
+struct GradkBig { int K, LWU, ntask, nchunk; };
+
+__global__ __launch_bounds__(256) void k_gradk_big(IcsGradkArgs a, GradkBig cfg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const IcsGeom& G = a.geo;
+  const int K = cfg.K, pad = G.pad, LWU = cfg.LWU, NT = 16 * ((K + 15) / 16);
+  const int UR = GB_T + K - 1;               // staged rows of u
+  float* ul = lds;                           // [UR][LWU], column 0 = u column x0 + pad - (K - 1) - 8
+  float* el = lds + (size_t)UR * LWU;        // [GB_T][GB_T]
+  const int tid = threadIdx.x;
+  // residual tiles over the image interior (outside it the residual is zero)
+  const int ntx = (G.N + GB_T - 1) / GB_T, nty = (G.M + GB_T - 1) / GB_T, ntile = ntx * nty;
+  const int per = (ntile + gridDim.x - 1) / gridDim.x;
+  const int t_begin = blockIdx.x * per, t_end = t_begin + per < ntile ? t_begin + per : ntile;
+  float* dst = a.partial + (size_t)blockIdx.x * (3 * NT * NT);
+  // a thread's tasks: task = chunk * K + ka (consecutive lanes = consecutive kernel rows: LWU is odd, so their LDS rows hit
+  // different banks), eight taps b = 8 chunk ... 8 chunk + 7 each
+  constexpr int MAXQ = (BIG_KMAX * 16 + 255) / 256;   // 8
+  for (int c = 0; c < 3; ++c) {
+    float acc[MAXQ][8];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[q][i] = 0.f;
+    for (int t = t_begin; t < t_end; ++t) {
+      const int y0 = pad + (t / ntx) * GB_T, x0 = pad + (t % ntx) * GB_T;
+      __syncthreads();
+      for (int i = tid; i < UR * LWU; i += 256) {
+        const int r = i / LWU, col = i - r * LWU;
+        const int y = y0 + pad - (K - 1) + r, x = x0 + pad - (K - 1) - 8 + col;
+        ul[i] = in_frame(G, y, x) ? a.u[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+      }
+      for (int i = tid; i < GB_T * GB_T; i += 256) {
+        const int r = i / GB_T, col = i - r * GB_T;
+        const int y = y0 + r, x = x0 + col;
+        el[i] = (y < pad + G.M && x < pad + G.N) ? a.e[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        const int task = tid + 256 * q;
+        if (task < cfg.ntask) {
+          const int chunk = task / K, ka = task - chunk * K;
+          // tap (ka, b) at residual pixel (ey, ex) reads u_l[ey + K - 1 - ka][8 + ex + K - 1 - b]
+          const float* ubase = ul + (size_t)(K - 1 - ka) * LWU + 8 + (K - 1 - 8 * chunk);
+          for (int ey = 0; ey < GB_T; ++ey) {
+            const float* urow = ubase + (size_t)ey * LWU;   // urow[ex - i] for tap b = 8 chunk + i
+            const float* erow = el + ey * GB_T;
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[8 + k] = urow[k - 8];
+            for (int ex0 = 0; ex0 < GB_T; ex0 += 8) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[k] = v[8 + k];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) v[8 + k] = urow[ex0 + k];
+              const f4 e0 = *reinterpret_cast<const f4*>(erow + ex0), e1 = *reinterpret_cast<const f4*>(erow + ex0 + 4);
+              const float e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+              for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(e[k], v[8 + k - i], acc[q][i]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int task = tid + 256 * q;
+      if (task < cfg.ntask) {
+        const int chunk = task / K, ka = task - chunk * K;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int b = 8 * chunk + i;
+          if (b < K) dst[((size_t)c * NT + ka) * NT + b] = acc[q][i];
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool ics_big_supported(int K) { return K > 63 && K <= BIG_KMAX && (K & 1); }
+
+hipError_t ics_launch_conv_big(int mode, const IcsConvArgs& a, const float* psf, hipStream_t s) {
+  if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+  static std::atomic<bool> cfg[2][ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  hipError_t e = ics_configure_lds(cfg[0], dev, k_conv_big<0>, BIG_CONV_LDS);
+  if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_conv_big<1>, BIG_CONV_LDS);
+  if (e != hipSuccess) return e;
+  const int grid = 3 * ics_device_cus(dev);
+  if (mode == 0) hipLaunchKernelGGL(k_conv_big<0>, dim3(grid), dim3(256), BIG_CONV_LDS, s, a, psf);
+  else hipLaunchKernelGGL(k_conv_big<1>, dim3(grid), dim3(256), BIG_CONV_LDS, s, a, psf);
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_gradk_big(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
+  const int K = a.geo.K;
+  GradkBig cfg;
+  cfg.K = K; cfg.nchunk = (K + 7) / 8; cfg.ntask = K * cfg.nchunk;
+  cfg.LWU = (8 + GB_T + K - 1 + 8) | 1;   // odd: consecutive rows start in consecutive banks
+  const size_t lds = ((size_t)(GB_T + K - 1) * cfg.LWU + GB_T * GB_T) * sizeof(float);
+  static std::atomic<bool> done[ICS_MAX_DEVICES];
+  hipError_t e = ics_configure_lds(done, ics_current_device(), k_gradk_big, 160 * 1024);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gradk_big, dim3(nblocks), dim3(256), lds, s, a, cfg);
+  return hipGetLastError();
+}

@@ -78,6 +78,7 @@ struct IcsPsfArgs {
   void* bt_conv;       // Toeplitz fragment tables of the matrix-core convolution (ics_common.h), or NULL
   void* bt_corr;
   float* psf_caller;   // what the caller's array holds (correlation quirk, pyx:585)
+  float* work;         // PSF sizes above 63 only: 3*K*K floats of scratch (the kernel's working copy; LDS below that)
   float* scal;         // ICS_SC_DTPSF recorded
   int* frozen;         // device flag: caller array detached (pyx:585 rebinding)
   float step;
@@ -86,6 +87,10 @@ struct IcsPsfArgs {
   int do_step;         // 0: only (re)pack the weights from psf
 };
 hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s);
+// PSF sizes 65 ... 127 (ics_big.hip): run-time-sized fp32 kernels; the convolution reads the PSF itself (rot180 for mode 0)
+bool ics_big_supported(int K);
+hipError_t ics_launch_conv_big(int mode, const IcsConvArgs& a, const float* psf, hipStream_t s);
+hipError_t ics_launch_gradk_big(const IcsGradkArgs& a, int nblocks, hipStream_t s);
 
 // ---- A18/A19 (pyx:593-638): window statistics and residual-whiteness metric -------------------
 struct IcsStatsArgs {

@@ -672,33 +672,46 @@ __global__ __launch_bounds__(1024) void k_gradk_reduce(const float* __restrict__
 //   clamp < 0 -> 0, divide each channel by its sequential float32 sum   (:587 -> :47-70)
 //   psf_rotated = rot180(psf)                                     (:589) -> wconv
 // =================================================================================================
+// BIG (PSF sizes above 63, ics_big.hip): the working copy of the PSF lives in global memory (a.work; 3 K^2 floats do not fit the LDS
+// at K = 127) -- one workgroup, so its barriers order those accesses too -- and no weight tables are packed: k_conv_big reads the
+// PSF itself.
+template <bool BIG>
 __global__ __launch_bounds__(ICS_PSF_THREADS) void k_psf(IcsPsfArgs a) {
   constexpr int NTHR = ICS_PSF_THREADS;   // one workgroup; the passes below are latency chains, so more lanes = fewer trips
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* p = lds;                       // 3*K*K
+  float* p = BIG ? a.work : lds;        // 3*K*K
   __shared__ uint32_t sred[8];
   __shared__ float ssum[4];
   const int K = a.K, n = 3 * K * K, tid = threadIdx.x;
   // everything the step needs from global memory is requested up front (this kernel is one latency chain: one workgroup, ~8 barriers)
-  constexpr int GR = (3 * 63 * 63 + NTHR - 1) / NTHR;   // gradient values per thread at the largest PSF
+  constexpr int GR = BIG ? 1 : (3 * 63 * 63 + NTHR - 1) / NTHR;   // gradient values per thread at the largest PSF (BIG: read in place)
   float gk[GR];
   int frozen = 0;
   if (a.do_step) {
     frozen = *a.frozen;
+    if (!BIG) {
 #pragma unroll
-    for (int r = 0; r < GR; ++r) { const int i = tid + r * NTHR; gk[r] = i < n ? a.gradk[i] : 0.f; }
+      for (int r = 0; r < GR; ++r) { const int i = tid + r * NTHR; gk[r] = i < n ? a.gradk[i] : 0.f; }
+    }
   }
   for (int i = tid; i < n; i += NTHR) p[i] = a.psf[i];
   if (tid < 8) sred[tid] = 0u;
   __syncthreads();
   if (a.do_step) {
     uint32_t kp = 0u, kg = 0u;
-#pragma unroll
-    for (int r = 0; r < GR; ++r) {
-      const int i = tid + r * NTHR;
-      if (i < n) {
-        const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(gk[r]));
+    if (BIG) {
+      for (int i = tid; i < n; i += NTHR) {
+        const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(a.gradk[i]));
         kp = kp > k1 ? kp : k1; kg = kg > k2 ? kg : k2;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < GR; ++r) {
+        const int i = tid + r * NTHR;
+        if (i < n) {
+          const uint32_t k1 = key_of(p[i]), k2 = key_of(__builtin_fabsf(gk[r]));
+          kp = kp > k1 ? kp : k1; kg = kg > k2 ? kg : k2;
+        }
       }
     }
     kp = wave_max_u32(kp); kg = wave_max_u32(kg);
@@ -707,12 +720,19 @@ __global__ __launch_bounds__(ICS_PSF_THREADS) void k_psf(IcsPsfArgs a) {
     const float maxp = ics_key2f(sred[0]), maxg = ics_key2f(sred[1]);
     const float dtpsf = __fdiv_rn(__fmul_rn(__fdiv_rn(a.step, (float)K), maxp), __fadd_rn(maxg, 1e-15f));
     if (tid == 0) a.scal[ICS_SC_DTPSF] = dtpsf;
-#pragma unroll
-    for (int r = 0; r < GR; ++r) {
-      const int i = tid + r * NTHR;
-      if (i < n) {
-        p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, gk[r]));
+    if (BIG) {
+      for (int i = tid; i < n; i += NTHR) {
+        p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, a.gradk[i]));
         if (!frozen) a.psf_caller[i] = p[i];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < GR; ++r) {
+        const int i = tid + r * NTHR;
+        if (i < n) {
+          p[i] = __fsub_rn(p[i], __fmul_rn(dtpsf, gk[r]));
+          if (!frozen) a.psf_caller[i] = p[i];
+        }
       }
     }
     __syncthreads();
@@ -754,7 +774,7 @@ __global__ __launch_bounds__(ICS_PSF_THREADS) void k_psf(IcsPsfArgs a) {
   // pack the row-pair weights of the convolution kernels (ics_common.h, IcsConvArgs::w):
   //   W_corr[a][b][c] = psf[a][b][c] (A3),  W_conv[a][b][c] = psf[K-1-a][K-1-b][c] (A1, = psf_rotated, pyx:589)
   //   w[ap][(3b+c)*2 + h] = W[ap - h][b][c], ap = 0..K, W[-1] = W[K] = 0; row padding zeroed
-  for (int i = tid; i < (K + 1) * a.wrow; i += NTHR) {
+  for (int i = tid; !BIG && i < (K + 1) * a.wrow; i += NTHR) {
     const int ap = i / a.wrow, rc = i - ap * a.wrow;
     float v1 = 0.f, v2 = 0.f;
     if (rc < 6 * K) {
@@ -1066,6 +1086,11 @@ hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gra
 }
 
 hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_psf, dim3(1), dim3(ICS_PSF_THREADS), (size_t)3 * a.K * a.K * sizeof(float), s, a);
+  if (a.K > 63) {
+    if (!a.work) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_psf<true>, dim3(1), dim3(ICS_PSF_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_psf<false>, dim3(1), dim3(ICS_PSF_THREADS), (size_t)3 * a.K * a.K * sizeof(float), s, a);
+  }
   return hipGetLastError();
 }

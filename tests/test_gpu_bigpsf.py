@@ -1,0 +1,90 @@
+"""PSF sizes above 63 (csrc/ics_big.hip): the reference takes any size (lib/deconvolution.pyx:341, FFT convolutions); the tuned
+kernels of the library are compiled per size up to 63, beyond that run-time-sized fp32 kernels take over, up to 127.
+
+Stage by stage against float64 direct sums (the gate scales with the number of accumulated terms, as for the sizes <= 63 in
+test_gpu_stages.py), whole runs against the pinned oracle, and the refusals (sizes above 127, the extended TV modes)."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import rl_mm_oracle as orc
+from helpers import conv_valid64, corr_full64, gradk64, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def make_job(M, N, MK, seed=0, blind=False):
+    from lib import _native
+    case = orc.synth_case(M, N, MK, seed=seed, blind=blind, per_channel_psf=True)
+    rng = np.random.default_rng(seed + 1)
+    psf = (case["psf0"] * (0.5 + rng.random(case["psf0"].shape, dtype=np.float32))).astype(np.float32)   # no symmetry: flips are detected
+    orc.normalize_kernel(psf, MK)
+    job = _native.RLJob(M, N, MK)
+    job.upload(case["image"], case["u0"], psf)
+    return job, case, psf
+
+
+@pytest.mark.parametrize("MK,M,N", [(65, 150, 131), (67, 40, 300), (99, 97, 70), (127, 140, 150), (127, 31, 33)])
+def test_big_psf_stages_against_float64_direct_sums(MK, M, N):
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=MK + M)
+    rng = np.random.default_rng(7)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=True)
+    tol = 5e-6 * (MK / 31.0) ** 2 / 4          # rows of the kernel are summed on their own: a quarter of the plain chain's bound
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    synth = conv_valid64(u, psf)
+    assert np.max(np.abs(e - (synth - case["image"]))) / np.max(np.abs(synth)) < tol
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    g_ref = corr_full64(e.astype(np.float64), psf)
+    assert g.shape == g_ref.shape
+    assert rel_err(g, g_ref) < tol
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    gk_ref = gradk64(u.astype(np.float64), e.astype(np.float64))
+    assert gk.shape == gk_ref.shape == (MK, MK, 3)
+    assert rel_err(gk, gk_ref) < 1e-5
+    # the maxima of A7 (at these sizes a pass of its own behind the back-projection): the update pass records what it used
+    job.stage(nv.STAGE_UPDATE, p)
+    sc = job.scalars()
+    gfull = (np.float32(10000.0) * g + (u - case["u0"]) * np.float32(0.5)).astype(np.float32)
+    for c in range(3):
+        assert np.float32(sc["maxg%d" % c]) == np.max(np.abs(gfull[..., c]))
+        assert np.float32(sc["maxu%d" % c]) == np.max(u[..., c])
+    job.close()
+
+
+@pytest.mark.parametrize("MK,M,N,blind", [(65, 120, 110, False), (65, 120, 110, True), (71, 100, 150, True), (127, 160, 170, True)])
+def test_big_psf_runs_against_the_oracle(MK, M, N, blind):
+    from lib import deconvolution as dc
+    case = orc.synth_case(M, N, MK, seed=3 + MK, blind=blind)
+    win = (8, M - 10, 8, N - 10)
+    args = (*win, 1e9, M, N, 3, MK, 2, 1e-3, 10000.0)
+    u_ref, psf_ref = case["u0"].copy(), case["psf0"].copy()
+    orc.richardson_lucy_MM(case["image"].copy(), u_ref, psf_ref, *args, blind=blind, quiet=True)
+    u, psf = case["u0"].copy(), case["psf0"].copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dc.richardson_lucy_MM(case["image"].copy(), u, psf, *args, blind=blind)
+    assert rel_err(u, u_ref) < 1e-4
+    assert rel_err(psf, psf_ref) < 1e-4
+
+
+def test_big_psf_refusals():
+    from lib import _native as nv
+    with pytest.raises(nv.NativeError, match="3..127"):
+        nv.RLJob(64, 64, 129)
+    job = nv.RLJob(64, 64, 65)
+    case = orc.synth_case(64, 64, 65, seed=1)
+    job.upload(case["image"], case["u0"], case["psf0"])
+    for tv in (1, 2, 3):
+        with pytest.raises(nv.NativeError, match="PSF sizes <= 63"):
+            job.run(job.params(4, 60, 4, 60, 1e9, 1, 1e-3, 10000.0, False, tv_mode=tv))
+    with pytest.raises(nv.NativeError, match="fuse"):
+        job.run(job.params(4, 60, 4, 60, 1e9, 1, 1e-3, 10000.0, False, fuse=1))
+    job.close()
