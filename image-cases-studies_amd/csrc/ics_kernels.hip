@@ -253,8 +253,9 @@ __device__ __forceinline__ float ics_tv_mm_term_fast(const float (&nu)[3][20], c
 }
 
 template <int KIND, bool FAST = false>
-__global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a) {
-  constexpr int TVSEG = KIND == 1 ? (FAST ? ICS_TVMM_SEG : 1) : 16;   // (the fast MM form is load-bound: it walks rows like the PAM kinds)
+__global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a, int seg_fast) {
+  // rows a thread walks (the fast MM form walks like the PAM kinds, 2 ... ICS_TVMM_SEG rows chosen by frame size: ics_launch_tvterm)
+  const int TVSEG = KIND == 1 ? (FAST ? seg_fast : 1) : 16;
   const IcsGeom& G = a.geo;
   const int ngx = G.tiles_x * 16;
   const int nseg = (G.uM + TVSEG - 1) / TVSEG;
@@ -1009,11 +1010,19 @@ hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hi
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
   const bool exact = ics_debug().pam_exact.load(std::memory_order_relaxed) != 0;
-  if (a.kind == 1 && exact) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a);
-  else if (a.kind == 1) hipLaunchKernelGGL((k_tvterm<1, true>), dim3(2048), dim3(256), 0, s, a);
+  if (a.kind == 1 && exact) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a, 1);
+  else if (a.kind == 1) {
+    // as for the PAM kinds below: enough threads for ~4 waves per SIMD, at most ICS_TVMM_SEG rows per thread
+    const long cols = (long)a.geo.tiles_x * 16;
+    int seg = (int)(((long)a.geo.uM * cols) / 262144);
+    seg = seg < 2 ? 2 : (seg > ICS_TVMM_SEG ? ICS_TVMM_SEG : seg);
+    const long nthreads = (((long)a.geo.uM + seg - 1) / seg) * cols;
+    long nblk = (nthreads + 255) / 256; nblk = nblk > 2048 ? 2048 : (nblk < 1 ? 1 : nblk);
+    hipLaunchKernelGGL((k_tvterm<1, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+  }
   else if (exact) {   // the per-value IEEE form (pam_term): kept as the cross-check
-    if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a);
+    if (a.kind == 2) hipLaunchKernelGGL(k_tvterm<2>, dim3(1024), dim3(256), 0, s, a, 16);
+    else hipLaunchKernelGGL(k_tvterm<3>, dim3(1024), dim3(256), 0, s, a, 16);
   }
   else {
     // a thread = 4 pixels x `seg` rows; keep >= ~4 waves per SIMD busy: a 2048^2 frame walked 16 rows at a time is one wave per SIMD,
