@@ -88,3 +88,35 @@ def test_big_psf_refusals():
     with pytest.raises(nv.NativeError, match="fuse"):
         job.run(job.params(4, 60, 4, 60, 1e9, 1, 1e-3, 10000.0, False, fuse=1))
     job.close()
+
+
+@pytest.mark.parametrize("MK", [39, 45, 59, 63])
+def test_auto_path_above_37_uses_the_run_time_sized_kernels_where_they_win(MK):
+    """ICS_CONV_AUTO (csrc/ics_api.hip, use_big_conv): back-projection from 39 and synthesis from 59 run on ics_big.hip; ICS_CONV_VECTOR
+    keeps the kernels compiled per size.  Both against float64 direct sums with the same gate, and against each other."""
+    from lib import _native as nv
+    M, N = 70 + MK, 131
+    out = {}
+    for conv in (0, 1):
+        job, case, psf = make_job(M, N, MK, seed=MK)
+        rng = np.random.default_rng(7)
+        u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        job.write(nv.BUF_U, u)
+        job.write(nv.BUF_UT, case["u0"])
+        p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=False, conv=conv)
+        job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+        e = job.read(nv.BUF_ERROR)
+        synth = conv_valid64(u, psf)
+        tol = 5e-6 * (MK / 31.0) ** 2
+        assert np.max(np.abs(e - (synth - case["image"]))) / np.max(np.abs(synth)) < tol
+        job.stage(nv.STAGE_BACKPROJECT, p)
+        g = job.read(nv.BUF_GRADU)
+        assert rel_err(g, corr_full64(e.astype(np.float64), psf)) < tol
+        job.stage(nv.STAGE_UPDATE, p)
+        sc = job.scalars()
+        out[conv] = (e, g, job.read(nv.BUF_U), [sc["maxg%d" % c] for c in range(3)], [sc["maxu%d" % c] for c in range(3)])
+        job.close()
+    assert np.max(np.abs(out[0][0] - out[1][0])) / np.max(np.abs(synth)) < 2 * tol   # (the residual is small against the synthesis it is the difference of)
+    assert rel_err(out[0][1], out[1][1]) < 4 * tol
+    assert rel_err(out[0][2], out[1][2]) < 1e-5
+    assert out[0][4] == out[1][4]
