@@ -589,16 +589,16 @@ static bool use_image_acc(const ics_rl_params* p) {
   return p->tv_mode != ICS_TV_MM_ACTIVE && ics_debug().planar_image.load(std::memory_order_relaxed) != 0;
 }
 
-// The run-time-sized fp32 kernels (ics_big.hip) are the only ones above 63, and under ICS_CONV_AUTO they also take over where they
-// beat the kernels compiled per size (shipped loop, 2048^2 non-blind, ms per pass, compiled -> run-time-sized): back-projection
-// 39: 0.98 -> 0.94, 45: 1.32 -> 1.16, 55: 2.08 -> 1.60, 63: 2.88 -> 1.93 (incl. the separate maxima pass); synthesis 39: 0.62 -> 0.82,
-// 55: 1.23 -> 1.32, 63: 1.71 -> 1.59.  ICS_CONV_VECTOR keeps the compiled kernels (tests/test_gpu_stages.py drives them at every size).
+// The run-time-sized fp32 kernels (ics_big.hip) are the only ones above 63, and under ICS_CONV_AUTO they take over from 39 on, where
+// they beat the kernels compiled per size (shipped loop, 2048^2 non-blind, ms per pass, compiled -> run-time-sized): synthesis
+// 39: 0.626 -> 0.594, 45: 0.829 -> 0.756, 55: 1.238 -> 1.013, 63: 1.71 -> 1.27; back-projection (incl. the separate maxima pass)
+// 39: 0.975 -> 0.716, 45: 1.348 -> 0.915, 55: 2.109 -> 1.233, 63: 2.88 -> 1.52.  ICS_CONV_VECTOR keeps the compiled kernels
+// (tests/test_gpu_stages.py drives them at every size).
 static bool use_big_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
   const int K = j->g.K;
   if (ics_big_supported(K)) return true;
-  if (mode == 2 || p->conv != ICS_CONV_AUTO || p->tv_mode != ICS_TV_SHIPPED || K <= 37) return false;
-  if (ics_debug().conv_path.load(std::memory_order_relaxed) == 1) return false;   // ICS_CONV_PATH=vector: as ICS_CONV_VECTOR
-  return mode == 1 ? K >= 39 : K >= 59;
+  if (mode == 2 || p->conv != ICS_CONV_AUTO || p->tv_mode != ICS_TV_SHIPPED || K < 39) return false;
+  return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;   // ICS_CONV_PATH=vector: as ICS_CONV_VECTOR
 }
 
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {

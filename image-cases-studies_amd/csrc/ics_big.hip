@@ -3,7 +3,8 @@
 // The reference has no limit on the PSF size (lib/deconvolution.pyx:341: `MK` is whatever the caller's array is; its convolutions
 // are FFTs).  The tuned kernels of this library are compiled per size (matrix cores to 37, packed fp32 to 63); beyond that these
 // two kernels take the size at run time.  Plain fp32 FMA streams out of LDS -- built to be correct and to keep the arithmetic units
-// busy, not tuned per size: at 4096^2 a 65x65 convolution is 4.2e11 flop per pass.
+// busy, not tuned per size: at 4096^2 a 65x65 convolution is 4.2e11 flop per pass.  Under ICS_CONV_AUTO they also serve the upper part
+// of the compiled range where they are the faster ones (ics_api.hip, use_big_conv).
 //
 //   k_conv_big  : out[y, x, c] = sum_{a,b<K} W[a, b, c] * in[y + a - pad, x + b - pad, c]   (u-frame coordinates, as ics_conv.hip)
 //                 W = rot180(psf), out = error - image on the M x N interior (mode 0: pyx:477-488)
@@ -15,29 +16,39 @@
 
 namespace {
 
-constexpr int BIG_TA = 16;                 // kernel rows per staged block
-constexpr int BIG_TH = 32, BIG_TW = 64;    // output tile of the convolution (256 threads: one row x 8 pixels each)
+constexpr int BIG_TA = 8;                  // kernel rows per staged block
+constexpr int BIG_TH = 64, BIG_TW = 64;    // output tile of the convolution (256 threads: two rows x 8 pixels each)
 constexpr int BIG_KMAX = 127;
 constexpr int BIG_K8MAX = 128;
-constexpr int BIG_LW = BIG_TW + BIG_K8MAX + 8;          // staged columns: x0 - pad ... (zero weights cover the padding to K8)
-constexpr int BIG_LR = BIG_TH + BIG_TA - 1;
-constexpr size_t BIG_CONV_LDS = ((size_t)BIG_LR * BIG_LW + (size_t)BIG_TA * BIG_K8MAX) * sizeof(float);
+// staged columns per row: LW = 64 + K8 + 8 (run time: the LDS a workgroup takes, and with it the workgroups per CU, follow the PSF size)
+constexpr int BIG_RING = BIG_TH + BIG_TA;               // staged rows: a ring, eight new rows per block of kernel rows
+static inline int big_lw(int K) { return BIG_TW + ((K + 7) & ~7) + 8; }
+static inline size_t big_conv_lds(int K) { return (size_t)BIG_RING * big_lw(K) * sizeof(float) + (size_t)(BIG_TA + 1) * ((K + 7) & ~7) * 2 * sizeof(float); }
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // in-frame test of a u-frame coordinate (the frames carry an apron of ay rows / ax pixels around the tile grid)
 __device__ __forceinline__ bool in_frame(const IcsGeom& G, int y, int x) {
   return y >= -G.ay && y < G.rows - G.ay && x >= -G.ax && 3 * (x + G.ax) + 2 < G.pitch;
 }
 
+// One workgroup = a 64 x 64 output tile of one channel at a time; a thread owns two consecutive output rows x 8 pixels, held as
+// PAIRS (row A, row B) so that the arithmetic is v_pk_fma_f32 (the fp32 vector peak on CDNA4 needs the packed form: ics_conv.hip):
+// an input value of row r meets kernel row a in output row A and kernel row a - 1 in output row B, i.e. one broadcast input
+// times the weight pair (W[a][b], W[a-1][b]).  The input rows of the tile sit in an LDS ring of 72 rows: a block of 8 kernel rows
+// walks 9 input rows per thread, the next block replaces the 8 oldest rows.  A thread slides a 16-value register window along an
+// input row: 2 ds_read_b128 of inputs and 4 of weight pairs per 64 packed FMAs.  Each input row's contribution is summed on its
+// own before it enters the total (short rounding chains: the sums run to 16129 terms).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_big(IcsConvArgs a, const float* __restrict__ psf) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tile = lds;                       // [BIG_LR][BIG_LW]
-  float* wl = lds + BIG_LR * BIG_LW;       // [BIG_TA][K8]
   const IcsGeom& G = a.g;
   const int K = G.K, pad = G.pad, K8 = (K + 7) & ~7;
-  const int tid = threadIdx.x, ty = tid >> 3, tc = tid & 7;
+  const int BIG_LW = BIG_TW + K8 + 8;
+  float* tile = lds;                                              // [BIG_RING][BIG_LW]
+  f2* wp = reinterpret_cast<f2*>(lds + BIG_RING * BIG_LW);        // [BIG_TA + 1][K8] pairs (W[a0 + q][b], W[a0 + q - 1][b])
+  const int tid = threadIdx.x, rp = tid >> 3, tc = tid & 7;
   // output region: mode 0 the image interior, mode 1 the whole u-frame
   const int oy0 = MODE == 0 ? pad : 0, ox0 = MODE == 0 ? pad : 0;
   const int oh = MODE == 0 ? G.M : G.uM, ow = MODE == 0 ? G.N : G.uN;
@@ -45,53 +56,76 @@ __global__ __launch_bounds__(256) void k_conv_big(IcsConvArgs a, const float* __
   for (int t = blockIdx.x; t < ntx * nty; t += gridDim.x) {
     const int y0 = oy0 + (t / ntx) * BIG_TH, x0 = ox0 + (t % ntx) * BIG_TW;
     for (int c = 0; c < 3; ++c) {
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      f2 acc[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = (f2){0.f, 0.f};
       for (int a0 = 0; a0 < K; a0 += BIG_TA) {
         const int ta = K - a0 < BIG_TA ? K - a0 : BIG_TA;
         __syncthreads();   // the previous block's readers are done
-        for (int i = tid; i < (BIG_TH + ta - 1) * BIG_LW; i += 256) {
-          const int r = i / BIG_LW, col = i - r * BIG_LW;
-          const int y = y0 + a0 - pad + r, x = x0 - pad + col;
-          tile[i] = in_frame(G, y, x) ? a.in[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+        // input rows [a0, a0 + 64 + ta) of the tile (row 0 = frame row y0 - pad): all of them for the first block, the new ones after
+        const int r_new = a0 == 0 ? 0 : a0 + BIG_TH;            // (ta <= 8 new rows; the first block stages 64 + ta)
+        const int n_new = a0 + BIG_TH + ta - r_new;
+        for (int i = tid; i < n_new * BIG_LW; i += 256) {
+          const int rr = i / BIG_LW, col = i - rr * BIG_LW;
+          const int r = r_new + rr;
+          const int y = y0 - pad + r, x = x0 - pad + col;
+          // (unconditional load from a clamped address, value discarded outside the frame: a conditional load is a branch and a full
+          //  wait per element -- the staging ran as a chain of exposed memory latencies)
+          const bool ok = in_frame(G, y, x);
+          const float val = a.in[ok ? (ptrdiff_t)y * G.pitch + 3 * x + c : (ptrdiff_t)0];
+          tile[(r % BIG_RING) * BIG_LW + col] = ok ? val : 0.f;
         }
-        for (int i = tid; i < ta * K8; i += 256) {
-          const int ar = i / K8, b = i - ar * K8, ka = a0 + ar;
-          float w = 0.f;
-          if (b < K) w = MODE == 0 ? psf[((K - 1 - ka) * K + (K - 1 - b)) * 3 + c] : psf[(ka * K + b) * 3 + c];
-          wl[ar * K8 + b] = w;
+        for (int i = tid; i < (ta + 1) * K8; i += 256) {
+          const int q = i / K8, b = i - q * K8;
+          const int bc = b < K ? b : K - 1;
+          const int ka = a0 + q < K ? a0 + q : K - 1, kb = a0 + q >= 1 ? a0 + q - 1 : 0;   // clamped: loaded unconditionally, masked below
+          const float va = MODE == 0 ? psf[((K - 1 - ka) * K + (K - 1 - bc)) * 3 + c] : psf[(ka * K + bc) * 3 + c];
+          const float vb = MODE == 0 ? psf[((K - 1 - kb) * K + (K - 1 - bc)) * 3 + c] : psf[(kb * K + bc) * 3 + c];
+          wp[q * K8 + b] = (f2){(b < K && q < ta) ? va : 0.f, (b < K && q >= 1) ? vb : 0.f};
         }
         __syncthreads();
-        for (int ar = 0; ar < ta; ++ar) {
-          const float* row = tile + (ty + ar) * BIG_LW + 8 * tc;
-          const float* wr = wl + ar * K8;
-          float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // one kernel row on its own, then into the total: shorter rounding chains
+        for (int q = 0; q <= ta; ++q) {
+          const int r = (a0 + 2 * rp + q) % BIG_RING;
+          const float* row = tile + r * BIG_LW + 8 * tc;
+          const f2* wr = wp + q * K8;
+          f2 r8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) r8[i] = (f2){0.f, 0.f};
           float v[16];
-          { const f4 p = *reinterpret_cast<const f4*>(row), q = *reinterpret_cast<const f4*>(row + 4);
-            v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = q.x; v[13] = q.y; v[14] = q.z; v[15] = q.w; }
+          { const f4 p = *reinterpret_cast<const f4*>(row), s4 = *reinterpret_cast<const f4*>(row + 4);
+            v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = s4.x; v[13] = s4.y; v[14] = s4.z; v[15] = s4.w; }
           for (int b0 = 0; b0 < K8; b0 += 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = v[8 + k];
-            { const f4 p = *reinterpret_cast<const f4*>(row + b0 + 8), q = *reinterpret_cast<const f4*>(row + b0 + 12);
-              v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = q.x; v[13] = q.y; v[14] = q.z; v[15] = q.w; }
-            const f4 w0 = *reinterpret_cast<const f4*>(wr + b0), w1 = *reinterpret_cast<const f4*>(wr + b0 + 4);
-            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            { const f4 p = *reinterpret_cast<const f4*>(row + b0 + 8), s4 = *reinterpret_cast<const f4*>(row + b0 + 12);
+              v[8] = p.x; v[9] = p.y; v[10] = p.z; v[11] = p.w; v[12] = s4.x; v[13] = s4.y; v[14] = s4.z; v[15] = s4.w; }
+            f2 w[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const f4 ww = *reinterpret_cast<const f4*>(wr + b0 + 2 * k);
+              w[2 * k] = (f2){ww.x, ww.y}; w[2 * k + 1] = (f2){ww.z, ww.w};
+            }
 #pragma unroll
             for (int bb = 0; bb < 8; ++bb)
 #pragma unroll
-              for (int i = 0; i < 8; ++i) r8[i] = __builtin_fmaf(w[bb], v[bb + i], r8[i]);
+              for (int i = 0; i < 8; ++i) r8[i] = __builtin_elementwise_fma(w[bb], (f2){v[bb + i], v[bb + i]}, r8[i]);
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[i] += r8[i];
         }
       }
-      const int y = y0 + ty;
-      if (y < oy0 + oh) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int x = x0 + 8 * tc + i;
-          if (x < ox0 + ow) {
-            const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * x + c;
-            a.out[o] = MODE == 0 ? __fsub_rn(acc[i], a.f[o]) : acc[i];
+      for (int h = 0; h < 2; ++h) {
+        const int y = y0 + 2 * rp + h;
+        if (y < oy0 + oh) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int x = x0 + 8 * tc + i;
+            if (x < ox0 + ow) {
+              const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * x + c;
+              const float r = h ? acc[i].y : acc[i].x;
+              a.out[o] = MODE == 0 ? __fsub_rn(r, a.f[o]) : r;
+            }
           }
         }
       }
@@ -131,12 +165,16 @@ __global__ __launch_bounds__(256) void k_gradk_big(IcsGradkArgs a, GradkBig cfg)
       for (int i = tid; i < UR * LWU; i += 256) {
         const int r = i / LWU, col = i - r * LWU;
         const int y = y0 + pad - (K - 1) + r, x = x0 + pad - (K - 1) - 8 + col;
-        ul[i] = in_frame(G, y, x) ? a.u[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+        const bool ok = in_frame(G, y, x);
+        const float val = a.u[ok ? (ptrdiff_t)y * G.pitch + 3 * x + c : (ptrdiff_t)0];
+        ul[i] = ok ? val : 0.f;
       }
       for (int i = tid; i < GB_T * GB_T; i += 256) {
         const int r = i / GB_T, col = i - r * GB_T;
         const int y = y0 + r, x = x0 + col;
-        el[i] = (y < pad + G.M && x < pad + G.N) ? a.e[(ptrdiff_t)y * G.pitch + 3 * x + c] : 0.f;
+        const bool ok = y < pad + G.M && x < pad + G.N;
+        const float val = a.e[ok ? (ptrdiff_t)y * G.pitch + 3 * x + c : (ptrdiff_t)0];
+        el[i] = ok ? val : 0.f;
       }
       __syncthreads();
 #pragma unroll
@@ -191,12 +229,14 @@ hipError_t ics_launch_conv_big(int mode, const IcsConvArgs& a, const float* psf,
   if (mode != 0 && mode != 1) return hipErrorInvalidValue;
   static std::atomic<bool> cfg[2][ICS_MAX_DEVICES];
   const int dev = ics_current_device();
-  hipError_t e = ics_configure_lds(cfg[0], dev, k_conv_big<0>, BIG_CONV_LDS);
-  if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_conv_big<1>, BIG_CONV_LDS);
+  hipError_t e = ics_configure_lds(cfg[0], dev, k_conv_big<0>, big_conv_lds(BIG_KMAX));
+  if (e == hipSuccess) e = ics_configure_lds(cfg[1], dev, k_conv_big<1>, big_conv_lds(BIG_KMAX));
   if (e != hipSuccess) return e;
-  const int grid = 3 * ics_device_cus(dev);
-  if (mode == 0) hipLaunchKernelGGL(k_conv_big<0>, dim3(grid), dim3(256), BIG_CONV_LDS, s, a, psf);
-  else hipLaunchKernelGGL(k_conv_big<1>, dim3(grid), dim3(256), BIG_CONV_LDS, s, a, psf);
+  const size_t lds = big_conv_lds(a.g.K);
+  int per_cu = (int)((160 * 1024) / lds); per_cu = per_cu > 4 ? 4 : (per_cu < 1 ? 1 : per_cu);   // 108 VGPRs: four workgroups of four waves
+  const int grid = per_cu * ics_device_cus(dev);
+  if (mode == 0) hipLaunchKernelGGL(k_conv_big<0>, dim3(grid), dim3(256), lds, s, a, psf);
+  else hipLaunchKernelGGL(k_conv_big<1>, dim3(grid), dim3(256), lds, s, a, psf);
   return hipGetLastError();
 }
 
