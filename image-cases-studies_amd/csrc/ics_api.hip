@@ -589,8 +589,9 @@ static bool use_image_acc(const ics_rl_params* p) {
   return p->tv_mode != ICS_TV_MM_ACTIVE && ics_debug().planar_image.load(std::memory_order_relaxed) != 0;
 }
 
-// The run-time-sized fp32 kernels (ics_big.hip) are the only ones above 63, and under ICS_CONV_AUTO they take over from 39 on, where
-// they beat the kernels compiled per size (shipped loop, 2048^2 non-blind, ms per pass, compiled -> run-time-sized): synthesis
+// The run-time-sized fp32 kernels (ics_big.hip) are the only ones above 63, and under ICS_CONV_AUTO they take over from the packed-fp32
+// kernels compiled per size wherever the matrix-core kernels are not built or not chosen (51 .. 63; 39 .. 49 with ICS_CONV_PATH=...): they
+// beat them (shipped loop, 2048^2 non-blind, ms per pass, compiled -> run-time-sized): synthesis
 // 39: 0.626 -> 0.594, 45: 0.829 -> 0.756, 55: 1.238 -> 1.013, 63: 1.71 -> 1.27; back-projection (incl. the separate maxima pass)
 // 39: 0.975 -> 0.716, 45: 1.348 -> 0.915, 55: 2.109 -> 1.233, 63: 2.88 -> 1.52.  ICS_CONV_VECTOR keeps the compiled kernels
 // (tests/test_gpu_stages.py drives them at every size).
@@ -620,7 +621,7 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   }
   a.sched = matrix ? j->sched : nullptr;   // counters of the dynamic tile walk: the launcher decides per launch (ics_conv_mfma.hip)
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : (mode == 1 ? ICS_K_BACKPROJECT : ICS_K_UPDATE_SYNTH)));
-  if (use_big_conv(j, p, mode)) {   // run-time-sized kernels (ics_big.hip); the maxima of A7 as a pass of their own
+  if (!matrix && use_big_conv(j, p, mode)) {   // run-time-sized kernels (ics_big.hip); the maxima of A7 as a pass of their own
     HIPCHK(ics_launch_conv_big(mode, a, j->psf, j->ctx->stream));
     if (mode == 1) HIPCHK(ics_launch_band_reduce(a.out, a.u, a.ut, j->g, p->lambd, 0, j->g.uM, a.red, j->ctx->stream));
   } else if (matrix) HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
@@ -766,7 +767,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
-  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 37");
+  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 49");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 127)", p->tv_mode);
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");

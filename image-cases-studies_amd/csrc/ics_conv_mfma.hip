@@ -709,12 +709,12 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
 //   either way, and the A-fragment reads then bound the step); 1024^2 .. 3072^2, K <= 15: RS = 2 ahead by 3 .. 30 % (finer
 //   tiles balance the 256 CUs better).  Hence: K >= 23 -> 4; K = 15 .. 21 -> 2; K <= 13 -> 2 up to 3000 tiles of 64 x 64, else 4.
 template <int K> struct TileRs {
-  static constexpr bool has2 = ICS_MFMA_ALL_RS || K <= 21;
-  static constexpr bool has4 = ICS_MFMA_ALL_RS || K <= 13 || K >= 23;
+  static constexpr bool has2 = ICS_MFMA_ALL_RS || K <= 21 || K >= 39;   // 39 .. 49: the planes of a 64-row tile do not fit the LDS
+  static constexpr bool has4 = ICS_MFMA_ALL_RS || K <= 13 || (K >= 23 && K <= 37);
 };
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
-  bool rs2 = K <= 21 && (K >= 15 || (long)a.g.tiles_x * a.g.tiles_y <= 3000);
+  bool rs2 = K >= 39 || (K <= 21 && (K >= 15 || (long)a.g.tiles_x * a.g.tiles_y <= 3000));
   if (TileRs<K>::has2 && TileRs<K>::has4) {   // test / harness hook: force a tile height where both are built
     const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
     rs2 = frs == 2 ? true : (frs == 4 ? false : rs2);
@@ -738,7 +738,7 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 }  // namespace
 
 // Translation units: the 36 kernel instances take minutes to compile, so libics_hip.so builds them in three parts
-// (ICS_MFMA_PART = 0: K <= 17 + the public entry points, 1: K = 19..27, 2: K = 29..37; ics_conv_mfma_p1/_p2.hip include this
+// (ICS_MFMA_PART = 0: K <= 17 + the public entry points, 1: K = 19..27, 2: K = 29..37, 3: K = 39..49; ics_conv_mfma_p1/_p2/_p3.hip include this
 // file).  Without ICS_MFMA_PART (tools/) everything is in one unit.
 #ifndef ICS_MFMA_PART
 #define ICS_MFMA_ALL 1
@@ -749,7 +749,23 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
 
 hipError_t ics_launch_conv_mfma_part1(int mode, const IcsConvArgs& a, hipStream_t s);
 hipError_t ics_launch_conv_mfma_part2(int mode, const IcsConvArgs& a, hipStream_t s);
+hipError_t ics_launch_conv_mfma_part3(int mode, const IcsConvArgs& a, hipStream_t s);
 
+#if ICS_MFMA_ALL || ICS_MFMA_PART == 3
+// 39 .. 49 (round 3): two 32-wide windows still cover the 16 + K - 1 input columns of a column block, so the cost per kernel row is
+// that of 19 .. 37; 32-row tiles, four waves, one workgroup per CU (the six planes + the weight rows take 112 .. 147 KB)
+hipError_t ics_launch_conv_mfma_part3(int mode, const IcsConvArgs& a, hipStream_t s) {
+  switch (a.g.K) {
+    case 39: return launch_k<39>(mode, a, s);
+    case 41: return launch_k<41>(mode, a, s);
+    case 43: return launch_k<43>(mode, a, s);
+    case 45: return launch_k<45>(mode, a, s);
+    case 47: return launch_k<47>(mode, a, s);
+    case 49: return launch_k<49>(mode, a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+#endif
 #if ICS_MFMA_ALL || ICS_MFMA_PART == 1
 hipError_t ics_launch_conv_mfma_part1(int mode, const IcsConvArgs& a, hipStream_t s) {
   switch (a.g.K) {
@@ -776,7 +792,7 @@ hipError_t ics_launch_conv_mfma_part2(int mode, const IcsConvArgs& a, hipStream_
 #endif
 
 #if ICS_MFMA_PART == 0
-bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 37 && (K & 1); }   // K = 39: planes + weights exceed 160 KB
+bool ics_conv_mfma_supported(int K) { return K >= 3 && K <= 49 && (K & 1); }   // 16 + K - 1 <= 64: two MFMA windows per column block
 
 // Measured on MI355X at 4096^2: ahead of the packed-fp32 kernels at every size built (K = 19, 21 were level with
 // 64-row tiles -- two 32-wide windows per column block, one workgroup per CU -- and are ~8 % ahead with 32-row tiles).
@@ -811,7 +827,7 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s) {
     case 13: return launch_k<13>(mode, a, s);
     case 15: return launch_k<15>(mode, a, s);
     case 17: return launch_k<17>(mode, a, s);
-    default: return a.g.K <= 27 ? ics_launch_conv_mfma_part1(mode, a, s) : ics_launch_conv_mfma_part2(mode, a, s);
+    default: return a.g.K <= 27 ? ics_launch_conv_mfma_part1(mode, a, s) : (a.g.K <= 37 ? ics_launch_conv_mfma_part2(mode, a, s) : ics_launch_conv_mfma_part3(mode, a, s));
   }
 #endif
 }

@@ -90,10 +90,10 @@ def test_big_psf_refusals():
     job.close()
 
 
-@pytest.mark.parametrize("MK", [39, 45, 59, 63])
-def test_auto_path_above_37_uses_the_run_time_sized_kernels_where_they_win(MK):
-    """ICS_CONV_AUTO (csrc/ics_api.hip, use_big_conv): from 39 x 39 on both convolutions run on ics_big.hip; ICS_CONV_VECTOR keeps the
-    kernels compiled per size.  Both against float64 direct sums with the same gate, and against each other."""
+@pytest.mark.parametrize("MK", [45, 51, 59, 63])
+def test_auto_path_above_37_against_the_kernels_compiled_per_size(MK):
+    """ICS_CONV_AUTO (csrc/ics_api.hip): matrix-core kernels to 49 x 49, ics_big.hip (use_big_conv) above; ICS_CONV_VECTOR keeps the
+    packed-fp32 kernels compiled per size.  Both against float64 direct sums with the same gate, and against each other."""
     from lib import _native as nv
     M, N = 70 + MK, 131
     out = {}

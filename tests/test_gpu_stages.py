@@ -29,13 +29,13 @@ def make_job(M, N, MK, seed=0, blind=False, per_channel_psf=True):
 
 
 CONV_CASES = [(MK, 1) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 39, 45, 55, 63)] + \
-             [(MK, 2) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37)]
+             [(MK, 2) for MK in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 25, 27, 29, 31, 33, 35, 37, 39, 41, 43, 45, 47, 49)]
 
 
 @pytest.mark.parametrize("MK,conv", CONV_CASES)
 def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
     """conv = 1: packed-fp32 vector kernels (ics_conv.hip); conv = 2: matrix-core kernels with fp16-split
-    operands (ics_conv_mfma.hip, MK <= 37).  Same tolerance for both against float64 direct sums."""
+    operands (ics_conv_mfma.hip, MK <= 49).  Same tolerance for both against float64 direct sums."""
     from lib import _native as nv
     M, N = 70 + MK, 131
     job, case, psf = make_job(M, N, MK, seed=MK)
