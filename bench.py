@@ -406,6 +406,8 @@ def main():
             oc["configs[2] blind 4096^2 15x15 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 4096, 15, True, 3, conv, 50, 5)
             oc["configs[3] blind 6144^2 31x31 (shipped loop)"] = timed_run(ctx, 6144, 31, True, 0, conv, 25, 5)
             oc["configs[3] blind 6144^2 31x31 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 6144, 31, True, 3, conv, 25, 5)
+            # beyond BASELINE.json: the largest PSF of the reference's own examples (deconvolve.py:409, blur width 45)
+            oc["example blind 4096^2 45x45 (shipped loop; reference deconvolve.py:409)"] = timed_run(ctx, 4096, 45, True, 0, conv, 10, 5)
             out["other_configs"] = oc
         if not args.no_cpu_baseline and grp.size == 1:   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args.mode, MK, M)
