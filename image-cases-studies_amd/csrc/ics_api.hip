@@ -674,7 +674,45 @@ static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
   return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
+// PSF sizes 33 ... 49: the fp16-split matrix-core gradient is built for up to 31 x 31 taps (2 x 2 blocks of 16; a third block row does
+// not fit its registers), the fp32-MFMA kernel that took over above runs at a third of its rate.  The gradient is a sum over pixels
+// per tap, so the K x K taps split into four blocks -- rows / columns [0, 31) and [31, K) -- each a gradient of its own:
+//   gradk[a0 + a'][b0 + b'] = sum E[y][x] * U'[y + pad' - a'][x + pad' - b'],   U' = U shifted by (pad - a0 - pad', pad - b0 - pad')
+// i.e. the 31 x 31 (or, for the small corner block, 15 x 15) kernel on a shifted frame pointer with a geometry that differs in K and
+// pad only; the frames' aprons (16 * ceil(K / 16) >= 48 rows / pixels) cover the shifts.  4096^2, 45 x 45: 1.92 -> ~1.2 ms.
+static bool use_split_gradk(const ics_rl* j, const ics_rl_params* p) {
+  const int K = j->g.K;
+  if (K < 33 || K > 49 || p->conv == ICS_CONV_VECTOR) return false;
+  return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
+}
+
+static int do_gradk_split(ics_rl* j, Prof& pr) {
+  const int K = j->g.K, pad = j->g.pad, L1 = 31, L2 = K - 31;
+  const int blk[4][4] = {{0, 0, L1, L1}, {0, L1, L1, L2}, {L1, 0, L2, L1}, {L1, L1, L2, L2}};   // a0, b0, La, Lb
+  RC(pr.begin(ICS_K_PSF_GRADIENT));
+  for (int q = 0; q < 4; ++q) {
+    const int a0 = blk[q][0], b0 = blk[q][1], La = blk[q][2], Lb = blk[q][3];
+    const int Ks = (La <= 15 && Lb <= 15) ? 15 : 31, pads = Ks / 2, nt = Ks == 15 ? 16 : 32;
+    IcsGradkArgs a;
+    a.geo = j->g; a.geo.K = Ks; a.geo.pad = pads;
+    a.e = org(j, j->e);
+    a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads);
+    a.partial = j->partial;
+    // two persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
+    int nblocks = 2 * j->ctx->cus;
+    if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && nblocks > mw) nblocks = mw;
+    const int nt_full = 16 * ((K + 15) / 16);
+    const long cap = (long)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt_full * nt_full / (3L * nt * nt);
+    if (nblocks > cap) nblocks = (int)cap;
+    HIPCHK(ics_launch_gradk_mfma(a, nblocks, j->ctx->stream));
+    HIPCHK(ics_launch_gradk_reduce_block(j->partial, nblocks, j->gradk, nt, La, Lb, K, a0, b0, j->ctx->stream));
+  }
+  RC(pr.end());
+  return ICS_OK;
+}
+
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  if (use_split_gradk(j, p)) return do_gradk_split(j, pr);
   IcsGradkArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
   RC(pr.begin(ICS_K_PSF_GRADIENT));

@@ -64,6 +64,8 @@ bool ics_synth_gradk_supported(int K);
 hipError_t ics_launch_synth_gradk(const IcsFusedArgs& a, int nblocks, hipStream_t s);
 // gradk[a][b][c] = sum over workgroups (double accumulation, fixed order)
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s);
+// one La x Lb tap block (partial blocks of 3 * nt * nt floats) into rows a0.., columns b0.. of a Kf x Kf gradient
+hipError_t ics_launch_gradk_reduce_block(const float* partial, int nblocks, float* gradk, int nt, int La, int Lb, int Kf, int a0, int b0, hipStream_t s);
 
 // ---- row bands: see include/ics_hip.h ICS_STAGE_BAND_* ----------------------------------------------
 hipError_t ics_launch_band_reduce(const float* gr, const float* u, const float* ut, const IcsGeom& g, float lambd, int r0, int r1, uint32_t* red, hipStream_t s);

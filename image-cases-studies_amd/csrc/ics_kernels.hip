@@ -634,7 +634,10 @@ __global__ __launch_bounds__(64 * NW) void k_gradk(IcsGradkArgs a) {
 // gradk[a][b][c] = float( sum_blocks double(partial) ), fixed order.  A wave reads 64 consecutive outputs of one workgroup's
 // partial block (two cache lines per instruction, eight in flight); the 16 waves of the workgroup take the blocks 16 apart and
 // their sums meet in LDS in wave order.  (Round 3: 8.1 -> ~4 us; 32 lanes per output at a 3 KB stride fetched a line per lane.)
-__global__ __launch_bounds__(1024) void k_gradk_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ gradk, int K, int NT) {
+// (La x Lb valid taps of the block land at (a0, b0) of the Kf x Kf gradient: the whole gradient is La = Lb = Kf, a0 = b0 = 0; the
+//  split gradient of PSF sizes 33 ... 49 reduces four tap blocks, ics_api.hip)
+__global__ __launch_bounds__(1024) void k_gradk_reduce(const float* __restrict__ partial, int nblocks, float* __restrict__ gradk, int NT, int La, int Lb,
+                                                      int Kf, int a0, int b0) {
   __shared__ double sh[16][64];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = 3 * NT * NT;
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(1024) void k_gradk_reduce(const float* __restrict__
 #pragma unroll
     for (int k = 1; k < 16; ++k) t += sh[k][lane];
     const int tb = o % NT, ta = (o / NT) % NT, c = o / (NT * NT);
-    if (ta < K && tb < K) gradk[(ta * K + tb) * 3 + c] = (float)t;
+    if (ta < La && tb < Lb) gradk[((a0 + ta) * Kf + (b0 + tb)) * 3 + c] = (float)t;
   }
 }
 
@@ -1090,7 +1093,12 @@ hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
 
 hipError_t ics_launch_gradk_reduce(const float* partial, int nblocks, float* gradk, const IcsGeom& g, hipStream_t s) {
   const int nt = 16 * ((g.K + 15) / 16);
-  hipLaunchKernelGGL(k_gradk_reduce, dim3((3 * nt * nt + 63) / 64), dim3(1024), 0, s, partial, nblocks, gradk, g.K, nt);
+  hipLaunchKernelGGL(k_gradk_reduce, dim3((3 * nt * nt + 63) / 64), dim3(1024), 0, s, partial, nblocks, gradk, nt, g.K, g.K, g.K, 0, 0);
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_gradk_reduce_block(const float* partial, int nblocks, float* gradk, int nt, int La, int Lb, int Kf, int a0, int b0, hipStream_t s) {
+  hipLaunchKernelGGL(k_gradk_reduce, dim3((3 * nt * nt + 63) / 64), dim3(1024), 0, s, partial, nblocks, gradk, nt, La, Lb, Kf, a0, b0);
   return hipGetLastError();
 }
 

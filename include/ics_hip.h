@@ -118,7 +118,7 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      residual frame (ICS_BUF_ERROR) holds e' of pyx:555-565 only on the 64x64 tiles that
                                      meet the stats window -- the only place the loop reads it (pyx:600-601,627)         */
 
-#define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built (convolutions: MK <= 49; PSF gradient: MK <= 31),
+#define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built (convolutions: MK <= 49; PSF gradient: MK <= 31, and 33 .. 49 as four tap blocks),
                              fp32 kernels otherwise (convolutions above 49: run-time-sized, ics_big.hip); env
                              ICS_CONV_PATH=vector|matrix overrides the choice of AUTO                     */
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip) + fp32-MFMA PSF gradient: fp32 products */

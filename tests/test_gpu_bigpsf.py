@@ -120,3 +120,29 @@ def test_auto_path_above_37_against_the_kernels_compiled_per_size(MK):
     assert rel_err(out[0][1], out[1][1]) < 4 * tol
     assert rel_err(out[0][2], out[1][2]) < 1e-5
     assert out[0][4] == out[1][4]
+
+
+@pytest.mark.parametrize("MK,M,N", [(33, 97, 140), (39, 150, 131), (45, 70, 200), (47, 129, 129), (49, 160, 90)])
+def test_split_matrix_core_gradient_33_to_49(MK, M, N):
+    """csrc/ics_api.hip do_gradk_split: the K x K taps as four blocks (rows / columns [0, 31) and [31, K)) on the 31 x 31 / 15 x 15
+    fp16-split kernel with shifted frame pointers.  Against float64 direct sums (the gate of every gradient kernel) and against the
+    fp32-MFMA kernel (conv = ICS_CONV_VECTOR) on the same inputs."""
+    from lib import _native as nv
+    out, e = {}, None
+    for conv in (0, 1):
+        job, case, psf = make_job(M, N, MK, seed=MK + N, blind=True)
+        rng = np.random.default_rng(5)
+        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        job.write(nv.BUF_U, u)
+        p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=True, conv=conv)
+        if e is None:
+            job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+            e = job.read(nv.BUF_ERROR)
+        else:
+            job.write(nv.BUF_ERROR, e)       # the same residual for both gradient kernels (it is a small difference of large numbers)
+        job.stage(nv.STAGE_PSF_GRADIENT, p)
+        gk = job.read(nv.BUF_GRADK)
+        assert rel_err(gk, gradk64(u.astype(np.float64), e.astype(np.float64))) < 1e-5
+        out[conv] = gk
+        job.close()
+    assert rel_err(out[0], out[1]) < 2e-5
