@@ -77,6 +77,11 @@ struct ics_rl {
   bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   float* psf_work;                      // PSF sizes above 63: working copy of k_psf (3*K*K floats), else NULL
+  // PSF sizes 51 ... 127 on the matrix cores as nblk x nblk tap blocks of Kb x Kb (do_conv_blocks): weight tables of both
+  // orientations, a scratch frame for the block results, a frame of zeros (the image operand of the blocks after the first)
+  int blk_n, blk_kb;
+  float *blk_conv, *blk_corr, *blk_scr, *blk_zero;
+  uint32_t* blk_red;                    // reduction slots the block passes may scribble on (the maxima are taken over the sum)
   float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
   int fused2_blocks;                    // persistent workgroups of the 32-row fused A11 + A13 kernel: three per CU (capped like gradk_blocks by the test switch)
@@ -217,7 +222,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work,
+  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -257,6 +262,14 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
   TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
   if (ics_big_supported(MK)) TRY(dalloc(&j->psf_work, n, s));
+  if (MK >= 51) {   // tap blocks: the fewest blocks of a size the matrix-core convolution is built for (odd, <= 33)
+    j->blk_n = (MK + 32) / 33;
+    j->blk_kb = ((MK + j->blk_n - 1) / j->blk_n) | 1;
+    const size_t tf = ics_conv_mfma_table_floats(j->blk_kb);
+    TRY(dalloc(&j->blk_conv, tf * j->blk_n * j->blk_n, s)); TRY(dalloc(&j->blk_corr, tf * j->blk_n * j->blk_n, s));
+    TRY(dalloc(&j->blk_scr, j->frame_floats, s)); TRY(dalloc(&j->blk_zero, j->frame_floats, s));
+    TRY(dalloc(&j->blk_red, (size_t)ICS_RED_STRIDE, s));
+  }
   TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
   if (ics_conv_mfma_supported(MK)) { TRY(dalloc(&j->bt_conv, ics_conv_mfma_table_floats(MK), s)); TRY(dalloc(&j->bt_corr, ics_conv_mfma_table_floats(MK), s)); }
   TRY(dalloc(&j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, s));
@@ -310,6 +323,7 @@ static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hip
   a.scal = j->scal; a.frozen = j->flags; a.step = step; a.K = j->g.K; a.wrow = j->g.wrow;
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
+  if (j->blk_conv) HIPCHK(ics_launch_pack_blocks(j->psf, j->g.K, j->blk_kb, j->blk_n, j->blk_conv, j->blk_corr, ics_conv_mfma_table_floats(j->blk_kb), s));
   return ICS_OK;
 }
 
@@ -602,7 +616,54 @@ static bool use_big_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
   return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;   // ICS_CONV_PATH=vector: as ICS_CONV_VECTOR
 }
 
+// PSF sizes 51 ... 127 on the matrix cores (ICS_CONV_AUTO / ICS_CONV_MATRIX, shipped loop): a convolution is linear in its taps, so
+// the K x K PSF is cut into blk_n x blk_n blocks of Kb x Kb taps (Kb odd, <= 33: sizes k_conv_mfma is built for); block (qa, qb) is
+//     out_q[y][x] = sum_{a',b' < Kb} W[qa Kb + a'][qb Kb + b'] * in'[y + a' - Kb/2][x + b' - Kb/2],   in' = in shifted by (qa Kb + Kb/2 - pad, ...)
+// i.e. the Kb x Kb kernel on a shifted pointer with a geometry that differs in K and pad only (mode 0 tiles start at the kernel's
+// own pad: all three pointers move by pad - Kb/2 so that this is the image origin).  The first block writes the result frame
+// (mode 0: minus the image), the others a scratch frame that is added to it; the maxima of A7 are taken over the sum by
+// k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see DESIGN.md 4c.
+static bool use_block_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
+  if (!j->blk_conv || mode == 2 || p->tv_mode != ICS_TV_SHIPPED || p->conv == ICS_CONV_VECTOR) return false;
+  return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
+}
+
+static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot, Prof& pr) {
+  const IcsGeom& G = j->g;
+  const int Kb = j->blk_kb, nb = j->blk_n, padb = Kb / 2, pad = G.pad;
+  const size_t tf = ics_conv_mfma_table_floats(Kb);
+  float* out = org(j, mode == 1 ? j->gr : j->e);
+  const float* in = org(j, mode == 1 ? j->e : j->u);
+  const ptrdiff_t oshift = mode == 0 ? (ptrdiff_t)(pad - padb) * (G.pitch + 3) : 0;   // mode 0: the kernel's tile origin (padb, padb) = the image origin
+  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
+  for (int q = 0; q < nb * nb; ++q) {
+    const int qa = q / nb, qb = q - qa * nb;
+    IcsConvArgs a;
+    a.g = G; a.g.K = Kb; a.g.pad = padb;
+    a.lambd = p->lambd; a.w = nullptr;
+    a.in = in + oshift + (ptrdiff_t)(qa * Kb + padb - pad) * G.pitch + 3 * (qb * Kb + padb - pad);
+    a.out = (q == 0 ? out : org(j, j->blk_scr)) + oshift;
+    a.f = (q == 0 ? org(j, j->f) : org(j, j->blk_zero)) + oshift;
+    a.u = org(j, j->u); a.ut = org(j, ut_of(j));
+    a.red = j->blk_red;                                   // (per-block maxima mean nothing)
+    a.gr = nullptr; a.u_out = nullptr; a.scal = j->scal; a.dofkeys = j->dofkeys;
+    a.tv = nullptr; a.tv_kind = 0; a.step = p->step_factor; a.blind = p->blind; a.want_dof = 0;
+    a.bt = (mode == 1 ? j->blk_corr : j->blk_conv) + (size_t)q * tf;
+    a.facc[0] = a.facc[1] = nullptr;
+    a.sched = j->sched;
+    HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
+    if (q > 0) {
+      if (mode == 0) HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, pad, pad + G.M, 3 * pad, 3 * (pad + G.N), j->ctx->stream));
+      else HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, 0, G.uM, 0, 3 * G.uN, j->ctx->stream));
+    }
+  }
+  if (mode == 1) HIPCHK(ics_launch_band_reduce(out, org(j, j->u), org(j, ut_of(j)), G, p->lambd, 0, G.uM, j->red + slot * ICS_RED_STRIDE, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
+  if (use_block_conv(j, p, mode)) return do_conv_blocks(j, mode, p, slot, pr);
   IcsConvArgs a;
   a.g = j->g; a.lambd = p->lambd;
   if (mode == 1) { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
@@ -674,39 +735,40 @@ static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
   return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
-// PSF sizes 33 ... 49: the fp16-split matrix-core gradient is built for up to 31 x 31 taps (2 x 2 blocks of 16; a third block row does
+// PSF sizes 33 ... 127: the fp16-split matrix-core gradient is built for up to 31 x 31 taps (2 x 2 blocks of 16; a third block row does
 // not fit its registers), the fp32-MFMA kernel that took over above runs at a third of its rate.  The gradient is a sum over pixels
-// per tap, so the K x K taps split into four blocks -- rows / columns [0, 31) and [31, K) -- each a gradient of its own:
+// per tap, so the K x K taps split into blocks of at most 31 x 31 -- rows / columns [0, 31), [31, 62), ... -- each a gradient of its own:
 //   gradk[a0 + a'][b0 + b'] = sum E[y][x] * U'[y + pad' - a'][x + pad' - b'],   U' = U shifted by (pad - a0 - pad', pad - b0 - pad')
 // i.e. the 31 x 31 (or, for the small corner block, 15 x 15) kernel on a shifted frame pointer with a geometry that differs in K and
-// pad only; the frames' aprons (16 * ceil(K / 16) >= 48 rows / pixels) cover the shifts.  4096^2, 45 x 45: 1.92 -> ~1.2 ms.
+// pad only; the frames' aprons (16 * ceil(K / 16) rows / pixels) cover the shifts.  4096^2, 45 x 45: 1.92 -> 1.22 ms.
 static bool use_split_gradk(const ics_rl* j, const ics_rl_params* p) {
   const int K = j->g.K;
-  if (K < 33 || K > 49 || p->conv == ICS_CONV_VECTOR) return false;
+  if (K < 33 || p->conv == ICS_CONV_VECTOR) return false;
   return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
+// (33 ... 49: 2 x 2 blocks; 51 ... 127: up to 5 x 5 -- 2048^2: 63 x 63 0.98 -> 0.8 ms, 65 x 65 3.3 -> 0.8, 127 x 127 16.3 -> 2.3)
 static int do_gradk_split(ics_rl* j, Prof& pr) {
-  const int K = j->g.K, pad = j->g.pad, L1 = 31, L2 = K - 31;
-  const int blk[4][4] = {{0, 0, L1, L1}, {0, L1, L1, L2}, {L1, 0, L2, L1}, {L1, L1, L2, L2}};   // a0, b0, La, Lb
+  const int K = j->g.K, pad = j->g.pad, L = 31, n = (K + L - 1) / L;
   RC(pr.begin(ICS_K_PSF_GRADIENT));
-  for (int q = 0; q < 4; ++q) {
-    const int a0 = blk[q][0], b0 = blk[q][1], La = blk[q][2], Lb = blk[q][3];
-    const int Ks = (La <= 15 && Lb <= 15) ? 15 : 31, pads = Ks / 2, nt = Ks == 15 ? 16 : 32;
-    IcsGradkArgs a;
-    a.geo = j->g; a.geo.K = Ks; a.geo.pad = pads;
-    a.e = org(j, j->e);
-    a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads);
-    a.partial = j->partial;
-    // two persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
-    int nblocks = 2 * j->ctx->cus;
-    if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && nblocks > mw) nblocks = mw;
-    const int nt_full = 16 * ((K + 15) / 16);
-    const long cap = (long)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt_full * nt_full / (3L * nt * nt);
-    if (nblocks > cap) nblocks = (int)cap;
-    HIPCHK(ics_launch_gradk_mfma(a, nblocks, j->ctx->stream));
-    HIPCHK(ics_launch_gradk_reduce_block(j->partial, nblocks, j->gradk, nt, La, Lb, K, a0, b0, j->ctx->stream));
-  }
+  for (int qa = 0; qa < n; ++qa)
+    for (int qb = 0; qb < n; ++qb) {
+      const int a0 = qa * L, b0 = qb * L, La = K - a0 < L ? K - a0 : L, Lb = K - b0 < L ? K - b0 : L;
+      const int Ks = (La <= 15 && Lb <= 15) ? 15 : 31, pads = Ks / 2, nt = Ks == 15 ? 16 : 32;
+      IcsGradkArgs a;
+      a.geo = j->g; a.geo.K = Ks; a.geo.pad = pads;
+      a.e = org(j, j->e);
+      a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads);
+      a.partial = j->partial;
+      // two persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
+      int nblocks = 2 * j->ctx->cus;
+      if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && nblocks > mw) nblocks = mw;
+      const int nt_full = 16 * ((K + 15) / 16);
+      const long cap = (long)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt_full * nt_full / (3L * nt * nt);
+      if (nblocks > cap) nblocks = (int)cap;
+      HIPCHK(ics_launch_gradk_mfma(a, nblocks, j->ctx->stream));
+      HIPCHK(ics_launch_gradk_reduce_block(j->partial, nblocks, j->gradk, nt, La, Lb, K, a0, b0, j->ctx->stream));
+    }
   RC(pr.end());
   return ICS_OK;
 }
@@ -805,7 +867,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
-  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX is only built for PSF sizes <= 49");
+  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && !j->blk_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX: no matrix-core path for this PSF size");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 127)", p->tv_mode);
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");

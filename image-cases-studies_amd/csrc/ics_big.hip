@@ -232,7 +232,71 @@ __global__ __launch_bounds__(256) void k_gradk_big(IcsGradkArgs a, GradkBig cfg)
   }
 }
 
+// ---- tap blocks on the matrix cores (PSF sizes 51 ... 127) ---------------------------------------------------------------------
+// A convolution is linear in its taps: the K x K PSF is cut into nblk x nblk blocks of Kb x Kb taps (Kb odd, 23 ... 33: sizes the
+// matrix-core convolution is built for), block (qa, qb) is convolved by k_conv_mfma<Kb> with the input pointer shifted by
+// (qa Kb + Kb/2 - pad, qb Kb + Kb/2 - pad), and the block results are added (ics_api.hip, do_conv_blocks).  This kernel packs the
+// block weight tables in the format k_psf packs the whole-PSF tables in (ics_common.h): one workgroup per block, both orientations.
+__global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ psf, int K, int Kb, int nblk, void* tconv, void* tcorr, size_t table_floats) {
+  __shared__ uint32_t smax;
+  const int tid = threadIdx.x, qa = blockIdx.x / nblk, qb = blockIdx.x - qa * nblk, a0 = qa * Kb, b0 = qb * Kb;
+  if (tid == 0) smax = 0u;
+  __syncthreads();
+  uint32_t km = 0u;
+  for (int i = tid; i < 3 * K * K; i += 256) { const uint32_t k1 = __float_as_uint(__builtin_fabsf(psf[i])); km = km > k1 ? km : k1; }   // (bit patterns: NaN on top)
+  km = ics_wave_max_u32(km);
+  if ((tid & 63) == 0) atomicMax(&smax, km);
+  __syncthreads();
+  const float m = __uint_as_float(smax);
+  const uint32_t e = (smax >> 23) & 0xFFu;
+  uint32_t sb = 127u;
+  if (m > 0.f && e != 255u) { sb = 268u - e; sb = sb > 240u ? 240u : sb; }
+  const float s_w = __uint_as_float(sb << 23), inv_w = __uint_as_float((254u - sb) << 23);
+  _Float16* tc = reinterpret_cast<_Float16*>(reinterpret_cast<float*>(tconv) + (size_t)blockIdx.x * table_floats);
+  _Float16* tr = reinterpret_cast<_Float16*>(reinterpret_cast<float*>(tcorr) + (size_t)blockIdx.x * table_floats);
+  const int rh = ((2 * (Kb + 17) + 3) & ~3) / 2;      // halves per row (MCfg::WROWB / 2)
+  const int nhalf = 3 * Kb * 2 * rh;
+  for (int i = tid; i < nhalf; i += 256) {
+    const int ent = i / rh, hh = i - ent * rh;
+    const int sp = ent & 1, ca = ent >> 1, c = ca / Kb, ra = ca - c * Kb;
+    const int b = hh - 7, A = a0 + ra, B = b0 + b;
+    float w1 = 0.f, w2 = 0.f;
+    if (b >= 0 && b < Kb && A < K && B < K) {
+      w1 = psf[(A * K + B) * 3 + c] * s_w;                              // correlation orientation (A3): W = psf
+      w2 = psf[((K - 1 - A) * K + (K - 1 - B)) * 3 + c] * s_w;          // convolution orientation (A1): W = rot180(psf)
+    }
+    const _Float16 h1 = (_Float16)w1, h2 = (_Float16)w2;
+    const int o = ca * 2 * rh + 4 * (hh >> 1) + 2 * sp + (hh & 1);
+    tr[o] = sp ? (_Float16)(w1 - (float)h1) : h1;
+    tc[o] = sp ? (_Float16)(w2 - (float)h2) : h2;
+  }
+  if (tid == 0) {
+    *reinterpret_cast<float*>(tc + nhalf) = inv_w;
+    *reinterpret_cast<float*>(tr + nhalf) = inv_w;
+  }
+}
+
+// out[y][f] += add[y][f] on rows [y0, y1), floats [f0, f1) of a frame row (origin-relative)
+__global__ __launch_bounds__(256) void k_frame_add(float* __restrict__ out, const float* __restrict__ add, int pitch, int y0, int y1, int f0, int f1) {
+  const int w = f1 - f0;
+  const long total = (long)(y1 - y0) * w;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+    const int r = (int)(t / w), f = (int)(t - (long)r * w);
+    const ptrdiff_t o = (ptrdiff_t)(y0 + r) * pitch + f0 + f;
+    out[o] = __fadd_rn(out[o], add[o]);
+  }
+}
+
 }  // namespace
+
+hipError_t ics_launch_pack_blocks(const float* psf, int K, int Kb, int nblk, void* tconv, void* tcorr, size_t table_floats, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_blocks, dim3(nblk * nblk), dim3(256), 0, s, psf, K, Kb, nblk, tconv, tcorr, table_floats);
+  return hipGetLastError();
+}
+hipError_t ics_launch_frame_add(float* out, const float* add, int pitch, int y0, int y1, int f0, int f1, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_add, dim3(2048), dim3(256), 0, s, out, add, pitch, y0, y1, f0, f1);
+  return hipGetLastError();
+}
 
 bool ics_big_supported(int K) { return K > 63 && K <= BIG_KMAX && (K & 1); }
 

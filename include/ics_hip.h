@@ -118,10 +118,10 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      residual frame (ICS_BUF_ERROR) holds e' of pyx:555-565 only on the 64x64 tiles that
                                      meet the stats window -- the only place the loop reads it (pyx:600-601,627)         */
 
-#define ICS_CONV_AUTO 0   /* matrix-core kernels where they are built (convolutions: MK <= 49; PSF gradient: MK <= 31, and 33 .. 49 as four tap blocks),
-                             fp32 kernels otherwise (convolutions above 49: run-time-sized, ics_big.hip); env
+#define ICS_CONV_AUTO 0   /* matrix-core kernels at every size (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33;
+                             PSF gradient: MK <= 31 directly, above as tap blocks of <= 31 x 31); env
                              ICS_CONV_PATH=vector|matrix overrides the choice of AUTO                     */
-#define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip) + fp32-MFMA PSF gradient: fp32 products */
+#define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 49, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
 
@@ -171,8 +171,8 @@ typedef struct ics_rl_stats {
 size_t ics_rl_stats_size(void);
 
 /* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 127):
- * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376.  Sizes to 49 run on the matrix cores, 51 ... 127 on a run-time-sized
- * fp32 kernel (65 ... 127: shipped loop only, tv_mode 0, fuse 0); packed-fp32 kernels compiled per size (3 ... 63) behind ICS_CONV_VECTOR.  Limits (the reference has none; each
+ * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376.  All sizes run on the matrix cores (to 49 directly, above as tap
+ * blocks; 65 ... 127: shipped loop only, tv_mode 0, fuse 0); fp32-product kernels behind ICS_CONV_VECTOR.  Limits (the reference has none; each
  * fails with ICS_ENOSUP and a message, never silently): PSF sizes above 127 (the reference's own examples go to 45,
  * deconvolve.py:409), stats windows
  * wider or higher than 4096 px (ics_rl_run; 8192-point transforms in 128 KB of LDS), frames of 2 GiB and more (32-bit

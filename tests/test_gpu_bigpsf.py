@@ -26,15 +26,18 @@ def make_job(M, N, MK, seed=0, blind=False):
     return job, case, psf
 
 
+@pytest.mark.parametrize("conv", [0, 1])
 @pytest.mark.parametrize("MK,M,N", [(65, 150, 131), (67, 40, 300), (99, 97, 70), (127, 140, 150), (127, 31, 33)])
-def test_big_psf_stages_against_float64_direct_sums(MK, M, N):
+def test_big_psf_stages_against_float64_direct_sums(MK, M, N, conv):
+    """conv = 0 (ICS_CONV_AUTO): tap blocks on the matrix cores -- convolutions as blocks of <= 33 x 33 taps (do_conv_blocks), the
+    gradient as blocks of <= 31 x 31 (do_gradk_split); conv = 1 (ICS_CONV_VECTOR): the run-time-sized fp32 kernels of ics_big.hip."""
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=MK + M)
     rng = np.random.default_rng(7)
     u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
     job.write(nv.BUF_U, u)
     job.write(nv.BUF_UT, case["u0"])
-    p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=True)
+    p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=True, conv=conv)
     tol = 5e-6 * (MK / 31.0) ** 2 / 4          # rows of the kernel are summed on their own: a quarter of the plain chain's bound
     job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
     e = job.read(nv.BUF_ERROR)
@@ -60,9 +63,11 @@ def test_big_psf_stages_against_float64_direct_sums(MK, M, N):
     job.close()
 
 
-@pytest.mark.parametrize("MK,M,N,blind", [(65, 120, 110, False), (65, 120, 110, True), (71, 100, 150, True), (127, 160, 170, True)])
-def test_big_psf_runs_against_the_oracle(MK, M, N, blind):
+@pytest.mark.parametrize("path", ["auto", "vector"])
+@pytest.mark.parametrize("MK,M,N,blind", [(51, 90, 130, True), (65, 120, 110, False), (65, 120, 110, True), (71, 100, 150, True), (127, 160, 170, True)])
+def test_big_psf_runs_against_the_oracle(MK, M, N, blind, path, debug_switch):
     from lib import deconvolution as dc
+    debug_switch("conv_path", 1 if path == "vector" else 0)      # what ICS_CONV_AUTO resolves to (the drop-in call has no conv argument)
     case = orc.synth_case(M, N, MK, seed=3 + MK, blind=blind)
     win = (8, M - 10, 8, N - 10)
     args = (*win, 1e9, M, N, 3, MK, 2, 1e-3, 10000.0)
