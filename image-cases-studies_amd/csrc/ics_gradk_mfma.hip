@@ -257,7 +257,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // lo term drops below the subnormal quantum).  In passes of TH rows: the destination rows of a pass are source rows of
       // EARLIER passes only (dst [p TH, (p+1) TH) <- src [(p+1) TH, (p+2) TH)), so a barrier between the passes is enough.
       constexpr int CH16 = C::UROWB / 16;                         // 16-byte pieces per row
-      const _Float16 ratio = (_Float16)(s_u / s_prev);
+      // (the ratio itself need not fit fp16: a strip whose first tiles are all zero -- scale 1 -- and whose next tile holds values
+      //  below 0.5 -- scale 2^16 -- gave ratio = inf and inf * 0 = NaN in every carried zero.  Outside fp16's power-of-two range
+      //  the rows are rescaled through fp32; the bound on the carried rows keeps every product finite.)
+      const float ratio_f = s_u / s_prev;
+      const bool wide = !(ratio_f <= 32768.f && ratio_f >= 6.103515625e-05f);
+      const _Float16 ratio = wide ? (_Float16)1.f : (_Float16)ratio_f;
 #pragma unroll
       for (int p0 = 0; p0 < C::NT - 1; p0 += C::TH) {
         const int nrow = (C::NT - 1 - p0) < C::TH ? (C::NT - 1 - p0) : C::TH;
@@ -266,7 +271,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int v = tid; v < npiece; v += C::NTH) {
           const int pl = v / (nrow * CH16), rem = v - pl * nrow * CH16;
           unsigned char* base = lds + C::UOFF + pl * C::UPLANE + p0 * C::UROWB + rem * 16;
-          *reinterpret_cast<h8*>(base) = *reinterpret_cast<const h8*>(base + C::TH * C::UROWB) * ratio;
+          h8 val = *reinterpret_cast<const h8*>(base + C::TH * C::UROWB);
+          if (wide) {   // workgroup-uniform, rare
+#pragma unroll
+            for (int i = 0; i < 8; ++i) val[i] = (_Float16)((float)val[i] * ratio_f);
+          } else {
+            val = val * ratio;
+          }
+          *reinterpret_cast<h8*>(base) = val;
         }
       }
     }

@@ -26,6 +26,6 @@ for it in range(n):
     eu = float(np.max(np.abs(u - u_ref)) / np.max(np.abs(u_ref)))
     ep = float(np.max(np.abs(psf - psf_ref)) / np.max(np.abs(psf_ref)))
     worst = max(worst, eu, ep)
-    flag = "" if (eu < 1e-4 and ep < 1e-4) else "   <-- FAIL"
-    print("MK %3d  %3dx%3d blind=%d win=(%d,%d,%d,%d): u %.2e psf %.2e%s" % (MK, M, N, blind, t, b, l, r, eu, ep, flag))
+    flag = "" if (eu < 1e-4 and ep < 1e-4) else "   <-- FAIL (nan in ref u/psf: %d/%d, in ours: %d/%d; case seed in order)" % (np.isnan(u_ref).sum(), np.isnan(psf_ref).sum(), np.isnan(u).sum(), np.isnan(psf).sum())
+    print("MK %3d  %3dx%3d blind=%d win=(%d,%d,%d,%d) it=%d: u %.2e psf %.2e%s" % (MK, M, N, blind, t, b, l, r, args[9], eu, ep, flag))
 print("worst", worst)

@@ -421,3 +421,29 @@ def test_blind_run_with_the_32_row_fused_kernel_matches_the_reference_golden(gol
         dc.richardson_lucy_MM(z["image"].copy(), u, psf, *meta["window"], meta["tau"], meta["M"], meta["N"], 3, meta["MK"], n, meta["step"], meta["lambd"], blind=True)
     assert rel_err(u, z["u_%d" % n]) < 1e-5 and rel_err(psf, z["psf_%d" % n]) < 1e-5
     dc._drop_jobs()
+
+
+@pytest.mark.parametrize("MK,flags", [(31, 0), (23, 0), (15, "no_fused"), (9, "no_fused")])
+@pytest.mark.parametrize("zero_rows,scale", [(70, 0.9), (100, 0.2), (70, 1e-6)])
+def test_gradient_strip_carry_below_an_all_zero_tile(MK, flags, zero_rows, scale, debug_switch):
+    """k_gradk_mfma carries the rows two consecutive tiles of a strip share and rescales them by the ratio of the tiles' power-of-two
+    scales.  A black band at the top of u (all-zero tiles, scale 1) followed by values below 0.5 (scale 2^16 and up) made that ratio
+    overflow fp16: inf * 0 = NaN in every carried zero, i.e. a NaN PSF from an image with a black border (round 3; found by the
+    differential fuzz once the split gradient put all-zero tiles at the head of every strip).  Few workgroups, so that strips are walked."""
+    from lib import _native as nv
+    debug_switch("max_wgs", 3)
+    M, N = 230, 150
+    job, case, psf = make_job(M, N, MK, seed=MK, blind=True)
+    rng = np.random.default_rng(3)
+    u = (case["u0"] * np.float32(scale)).astype(np.float32)
+    u[:zero_rows] = 0.0
+    job.write(nv.BUF_U, u)
+    e = np.zeros((M, N, 3), np.float32)
+    e[:] = (0.01 * scale * rng.standard_normal((M, N, 3))).astype(np.float32)
+    job.write(nv.BUF_ERROR, e)
+    p = job.params(2, M - 2, 2, N - 2, 1e9, 1, 1e-3, 10000.0, blind=True, flags=nv.FLAG_NO_FUSED_GRADK if flags else 0)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    assert np.isfinite(gk).all()
+    assert rel_err(gk, gradk64(u.astype(np.float64), e.astype(np.float64))) < 1e-5
+    job.close()
