@@ -198,7 +198,7 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 template <int K, int MODE, int RS, int NH>
 __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K, RS, NH>::WGS * NH, MCfg<K, RS, NH>::WGS * NH))) void k_conv_mfma(IcsConvArgs a) {
   using C = MCfg<K, RS, NH>;
-  static_assert(NH == 1 || (RS == 4 && MCfg<K, RS, NH>::WGS == 1), "the row split is for the one-workgroup-per-CU sizes, two accumulator sets per wave in the epilogue");
+  static_assert(NH == 1 || MCfg<K, RS, NH>::WGS == 1, "the row split is for the one-workgroup-per-CU sizes (RS / 2 accumulator sets per wave in the epilogue)");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* fscr = reinterpret_cast<float*>(lds + C::SCRATCH);
   const int tid = threadIdx.x;
@@ -498,9 +498,9 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            if (write) xch[(((cb * 2 + (1 - H)) * 3 + ch) * 2 + tt) * 64 + lane] = acc[ch][2 * (1 - H) + tt];
-            else acc[ch][2 * H + tt] += xch[(((cb * 2 + H) * 3 + ch) * 2 + tt) * 64 + lane];
+          for (int tt = 0; tt < C::RS / 2; ++tt) {
+            if (write) xch[(((cb * 2 + (1 - H)) * 3 + ch) * (C::RS / 2) + tt) * 64 + lane] = acc[ch][(C::RS / 2) * (1 - H) + tt];
+            else acc[ch][(C::RS / 2) * H + tt] += xch[(((cb * 2 + H) * 3 + ch) * (C::RS / 2) + tt) * 64 + lane];
           }
       };
       if (half == 0) exchange(std::integral_constant<int, 0>{}, true); else exchange(std::integral_constant<int, 1>{}, true);
@@ -708,6 +708,9 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
 //   0.184 / 0.218, K = 19 0.347 / 0.405 -> 0.325 / 0.364, K = 21 -5 % / -9 %, K = 23 .. 31 +10 .. 14 % (one workgroup per CU
 //   either way, and the A-fragment reads then bound the step); 1024^2 .. 3072^2, K <= 15: RS = 2 ahead by 3 .. 30 % (finer
 //   tiles balance the 256 CUs better).  Hence: K >= 23 -> 4; K = 15 .. 21 -> 2; K <= 13 -> 2 up to 3000 tiles of 64 x 64, else 4.
+#ifndef ICS_MFMA_39_NH2
+#define ICS_MFMA_39_NH2 1
+#endif
 template <int K> struct TileRs {
   static constexpr bool has2 = ICS_MFMA_ALL_RS || K <= 21 || K >= 39;   // 39 .. 49: the planes of a 64-row tile do not fit the LDS
   static constexpr bool has4 = ICS_MFMA_ALL_RS || K <= 13 || (K >= 23 && K <= 37);
@@ -720,7 +723,11 @@ hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
     rs2 = frs == 2 ? true : (frs == 4 ? false : rs2);
   }
   if constexpr (TileRs<K>::has2) {
-    if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2>(a, s) : launch_one<K, 1, 2>(a, s);
+    if constexpr (K >= 39 && ICS_MFMA_39_NH2) {   // 39 .. 49: 32-row tiles with the kernel rows split between two waves per column block
+      if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2, 2>(a, s) : launch_one<K, 1, 2, 2>(a, s);
+    } else {
+      if (rs2 || !TileRs<K>::has4) return mode == 0 ? launch_one<K, 0, 2>(a, s) : launch_one<K, 1, 2>(a, s);
+    }
   }
   if constexpr (TileRs<K>::has4) {
     if constexpr (K >= 23) {
