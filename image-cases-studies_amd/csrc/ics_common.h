@@ -133,6 +133,17 @@ __host__ __device__ static inline float ics_key2f(uint32_t k) {
   return v.f;
 }
 
+// The ratio of the DoF mask, (g - f)/(g + f)  (lib/deconvolution.pyx:499; g = raw back-projection, f = image), IEEE in every
+// case but one: g == f == 0 EXACTLY gives 1, not 0/0 = NaN.  Where image and u are exactly black the reference's g is the rounding
+// noise of its complex64 FFT (~1e-10, either sign) and (g - 0)/(g + 0) == 1 for every non-zero g, so the reference returns a
+// finite picture on frames with black bands; this library's convolutions return exact zeros there, and a single NaN would spread
+// over the whole frame through the next convolution and the NaN-propagating maxima.  g + f == 0 with g != 0 stays +-inf as in
+// the reference.  Contract and measurements: include/ics_hip.h ("DoF ratio"), tests/test_gpu_black.py.
+__device__ __forceinline__ float ics_dof_ratio(float g, float f) {
+  const float d = __fdiv_rn(__fsub_rn(g, f), __fadd_rn(g, f));
+  return (g == 0.f && f == 0.f) ? 1.0f : d;
+}
+
 // Wave-wide maximum (all 64 lanes receive it) without ds_bpermute: four DPP steps inside each row of 16 lanes, then the four
 // row results through v_readlane.  The shuffle form (__shfl_xor = ds_bpermute) needs one address register per step; inside a
 // persistent tile loop the compiler hoisted those addresses above the loop and, in the 256-register kernels, spilled one of

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(16 * NTY) __attribute__((amdgpu_waves_per_eu(WPE, W
             float un = __fsub_rn(uo, __fmul_rn(dtc, g));
             own[jj] = yown && (pxr >= C::PAD) && (pxr < C::PAD + C::TW) && (x < a.g.uN);
             if (yin && (x >= C::PAD) && (x < C::PAD + a.g.N)) {
-              const float d = __fdiv_rn(__fsub_rn(go, fo), __fadd_rn(go, fo));
+              const float d = ics_dof_ratio(go, fo);
               float D = __fmul_rn(d, d);
               if (!a.blind) D = __fdiv_rn(D, lambd);
               un = __fadd_rn(__fmul_rn(__fsub_rn(1.0f, D), un), __fmul_rn(D, fo));

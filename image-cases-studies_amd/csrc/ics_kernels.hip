@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_update(IcsUpdateArgs a) {
           g = __fadd_rn(__fmul_rn(lambd, gv[i]), __fmul_rn(__fsub_rn(uv[i], tv[i]), 0.5f));
         float un = __fsub_rn(uv[i], __fmul_rn(dt[c], g));
         if (inside && a.tv_kind < 2) {   // (PAM has no DoF blend)
-          const float d = __fdiv_rn(__fsub_rn(gv[i], fv[i]), __fadd_rn(gv[i], fv[i]));
+          const float d = ics_dof_ratio(gv[i], fv[i]);
           float D = __fmul_rn(d, d);
           if (!a.blind) D = __fdiv_rn(D, lambd);
           if (a.tv_kind == 1) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void k_update_rows(IcsUpdateArgs a) {
         float un = __fsub_rn(uv, __fmul_rn(dtr[e % 3], g));
         if (inside && TVK != 2) {   // (PAM has no DoF blend)
           float fv = fq[s][e];
-          const float d = __fdiv_rn(__fsub_rn(gv, fv), __fadd_rn(gv, fv));
+          const float d = ics_dof_ratio(gv, fv);
           float D = __fmul_rn(d, d);
           if (!a.blind) D = __fdiv_rn(D, lambd);
           if (TVK == 1) {  // pyx:549: image -= dt*gradu/lambd, then the blend uses the updated image

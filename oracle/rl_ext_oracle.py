@@ -26,7 +26,7 @@ from __future__ import annotations
 import numpy as np
 
 import rl_mm_oracle as base
-from rl_mm_oracle import F32, INNER_ITER, TV, Trace, normalize_kernel, rotate_180, stop_weights, residual_whiteness
+from rl_mm_oracle import F32, INNER_ITER, TV, Trace, dof_ratio, normalize_kernel, rotate_180, stop_weights, residual_whiteness
 
 
 def tv_term(u, ut, epsilon):
@@ -73,7 +73,7 @@ def richardson_lucy_MM_tv(image, u, psf, top, bottom, left, right, tau, M, N, C,
             T, act = tv_term(u, ut, epsilon)
             with np.errstate(divide="ignore", invalid="ignore"):
                 gi = gradu[interior]
-                DoF = ((gi - image) / (gi + image)) ** 2
+                DoF = dof_ratio(gi, image) ** 2      # build-defined modes: 0/0 -> 1 always (rl_mm_oracle.dof_ratio)
                 if not blind:
                     DoF = DoF / lambd
             lg = (lambd * gradu).astype(np.float64)

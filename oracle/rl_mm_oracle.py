@@ -240,16 +240,32 @@ def residual_whiteness(err_win, weights, conv):
 # --------------------------------------------------------------------------------------------
 # the loop
 # --------------------------------------------------------------------------------------------
+def dof_ratio(g, f, zero_rule=1.0):
+    """(g - f)/(g + f) of pyx:499 in float32, IEEE except where g == f == 0 exactly -> `zero_rule` (NaN = plain IEEE).
+    See richardson_lucy_MM's docstring for why the value is 1 wherever the convolutions are exact."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = (g - f) / (g + f)
+    if zero_rule == zero_rule:
+        r = np.where((g == 0) & (f == 0), F32(zero_rule), r).astype(np.float32)
+    return r
+
+
 def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations,
                        step_factor, lambd, blind=True, correlation=False, p=1., norm=1, order=2,
                        priority=0, refocus=0, *, conv="scipy", trace: Trace | None = None,
-                       snapshot_at=(), quiet=False, tv_mode="shipped"):
+                       snapshot_at=(), quiet=False, tv_mode="shipped", dof_zero_rule=None):
     """Restatement of lib/deconvolution.pyx:341-675.  Mutates `u` (always) and `psf` (blind) in
     place and returns a view of `u`, exactly like the reference.
 
     Extra keyword-only arguments (not in the reference): `conv` ("scipy" | "direct"), `trace`
     (collects the printed scalars), `snapshot_at` (outer-iteration counts at which to copy u),
-    `quiet` (suppress prints), `tv_mode` ("shipped" = TV term dead, as the reference behaves).
+    `quiet` (suppress prints), `tv_mode` ("shipped" = TV term dead, as the reference behaves),
+    `dof_zero_rule`: value of the ratio (g - f)/(g + f) of pyx:499 where g == f == 0 EXACTLY.  None -> IEEE (0/0 = NaN)
+    with conv="scipy" -- the reference bit for bit, whatever its FFT's rounding makes of such a pixel -- and 1 with
+    conv="direct".  Why 1: in a region where image and u are exactly 0 the reference's g is the rounding noise of a complex64
+    FFT (~1e-10, either sign), f is 0, and (g - 0)/(g + 0) = 1 for EVERY non-zero g; exact arithmetic (this branch, and the
+    device kernels) produces g = 0 there and IEEE would turn the whole frame into NaN through the next convolution.  The
+    rule touches nothing else: g + f == 0 with g != 0 stays +-inf as in the reference (include/ics_hip.h, "DoF ratio").
     """
     for name, arr in (("image", image), ("u", u), ("psf", psf)):
         if not isinstance(arr, np.ndarray):
@@ -262,6 +278,8 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     if tv_mode != "shipped":
         raise NotImplementedError("extended TV modes live in oracle/rl_ext_oracle.py")
     cv = _conv_scipy if conv == "scipy" else _conv_direct
+    if dof_zero_rule is None:
+        dof_zero_rule = 1.0 if conv == "direct" else float("nan")
     tr = trace if trace is not None else Trace()
 
     def say(s):
@@ -300,7 +318,7 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
             # pyx:495-496 TV(u) x2: outputs unused in the shipped code (A4) -> skipped
             with np.errstate(divide="ignore", invalid="ignore"):
                 gi = gradu[interior]
-                DoF = ((gi - image) / (gi + image)) ** 2                  # pyx:499       (A5)
+                DoF = dof_ratio(gi, image, dof_zero_rule) ** 2            # pyx:499       (A5)
                 if not blind:
                     DoF = DoF / lambd                                     # pyx:501-502
             # pyx:512-519 else-branch (A6): float product + double (u-ut)/2., stored as float
@@ -453,6 +471,45 @@ def synth_case_large(M, N, MK, seed=0, blind=False, noise=1e-3):
     psf_true = gaussian_psf(MK)
     psf0 = uniform_psf(MK) if blind else psf_true.copy()
     return dict(image=image, u0=u0, psf0=psf0, psf_true=psf_true, pad=pad)
+
+
+BLACK_KINDS = ("band_mid", "band_top", "band_bot", "letterbox", "cols_mid", "rect")
+
+
+def black_case(M, N, MK, kind, seed=0, blind=False):
+    """synth_case with an exactly-black region in the image AND in u0 (clipped shadows, letterbox bars, zero borders:
+    deconvolve.py:100-103 maps 0 -> 0).  The region is at least 2 MK + 8 px deep, so that it holds pixels whose whole
+    (2 MK - 1)^2 dependency window is black: there the back-projection of an exact convolution is exactly 0 and pyx:499 is 0/0.
+      band_mid / band_top / band_bot : full-width rows (top / bottom: the edge-padded border of u is black too);
+      letterbox : black bars top and bottom plus a saturated (1.0) 8 x 8 patch in the picture;
+      cols_mid  : full-height columns;   rect : a black rectangle inside the picture.
+    Returns synth_case's dict with `image` / `u0` replaced and `black` = boolean mask of the image pixels set to 0."""
+    case = synth_case(M, N, MK, seed=seed, blind=blind)
+    img = case["image"].copy()
+    d = 2 * MK + 8
+    m = np.zeros((M, N), bool)
+    if kind == "band_mid":
+        m[(M - d) // 2:(M - d) // 2 + d] = True
+    elif kind == "band_top":
+        m[:d] = True
+    elif kind == "band_bot":
+        m[M - d:] = True
+    elif kind == "letterbox":
+        m[:d] = True
+        m[M - d:] = True
+        img[M // 2 - 4:M // 2 + 4, N // 2 - 4:N // 2 + 4] = 1.0
+    elif kind == "cols_mid":
+        m[:, (N - d) // 2:(N - d) // 2 + d] = True
+    elif kind == "rect":
+        m[(M - d) // 2:(M - d) // 2 + d, (N - d) // 2:(N - d) // 2 + d] = True
+    else:
+        raise ValueError(kind)
+    img[m] = 0.0
+    pad = MK // 2
+    case["image"] = img
+    case["u0"] = np.ascontiguousarray(np.pad(img, ((pad, pad), (pad, pad), (0, 0)), mode="edge"), dtype=np.float32)
+    case["black"] = m
+    return case
 
 
 def default_window(M, N, MK, size=255):

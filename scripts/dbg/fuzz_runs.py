@@ -9,6 +9,7 @@ from lib import deconvolution as dc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 worst = 0.0
+nfail = nrefnan = 0
 for it in range(n):
     MK = int(rng.choice([3, 9, 15, 17, 21, 23, 31, 33, 37, 39, 41, 45, 49, 51, 57, 63, 65, 71, 89, 127]))
     M, N = int(rng.integers(max(8, MK // 3), 200)), int(rng.integers(max(8, MK // 3), 200))
@@ -36,21 +37,22 @@ for it in range(n):
     u, psf = case["u0"].copy(), case["psf0"].copy()
     with contextlib.redirect_stdout(io.StringIO()):
         dc.richardson_lucy_MM(case["image"].copy(), u, psf, *args, blind=blind)
-    if np.isnan(u_ref).any() or np.isnan(psf_ref).any():      # the reference's own NaNs: ours must be NaN in the same places
-        same = np.array_equal(np.isnan(u), np.isnan(u_ref)) and np.array_equal(np.isnan(psf), np.isnan(psf_ref))
-        if var in (1, 2, 5): same = same or bool(np.isnan(u).any())      # (a 0/0 band: where the NaNs have spread to after 5 or 10 inner iterations depends on the noise)
-        print("MK %3d  %3dx%3d blind=%d var=%d: reference has NaN (%d / %d), same places: %s%s" % (MK, M, N, blind, var, np.isnan(u_ref).sum(), np.isnan(psf_ref).sum(), same, "" if same else "   <-- FAIL"))
+    if np.isnan(u).any() or np.isnan(psf).any():              # finite inputs: this library never returns NaN (black regions: the 0/0 rule, ics_hip.h)
+        print("MK %3d  %3dx%3d blind=%d var=%d: NaN in the device result (%d / %d)   <-- FAIL" % (MK, M, N, blind, var, np.isnan(u).sum(), np.isnan(psf).sum()))
+        nfail += 1
         continue
-    if var in (1, 2, 5) and np.isnan(u).any():
-        # exact-zero bands: (gradu - image) / (gradu + image) is 0 / 0 there (pyx:499-502).  This library computes exact zeros and gets
-        # NaN (which np.amax-style maxima then spread, as in the reference); the reference's FFT leaves ~1e-10 of noise in such a band
-        # and usually gets D = 1 -- for zero COLUMNS it gets NaN too.  Reported, not counted.
-        print("MK %3d  %3dx%3d blind=%d var=%d: degenerate 0/0 band -> NaN here, finite in the reference (FFT noise)" % (MK, M, N, blind, var))
-        continue
+    if np.isnan(u_ref).any() or np.isnan(psf_ref).any():
+        # the reference met an exact zero in its FFT noise inside a black region (common for black columns, rare for black rows) and lost
+        # the frame; compare with the float64-direct oracle, which carries the rule, instead
+        u_ref, psf_ref = case["u0"].copy(), case["psf0"].copy()
+        orc.richardson_lucy_MM(case["image"].copy(), u_ref, psf_ref, *args, blind=blind, quiet=True, conv="direct")
+        nrefnan += 1
+        print("   (reference = NaN by an exact zero of its FFT noise; compared with the float64-direct oracle)")
     eu = float(np.max(np.abs(u - u_ref)) / max(np.max(np.abs(u_ref)), 1e-30))
     ep = float(np.max(np.abs(psf - psf_ref)) / max(np.max(np.abs(psf_ref)), 1e-30))
     if var != 4: worst = max(worst, eu, ep)
     gate = 5e-3 if var == 4 else 1e-4      # (a flat image: the residual is rounding noise, amplified by lambd = 1e4 on both sides)
+    nfail += not (eu < gate and ep < gate)
     flag = "" if (eu < gate and ep < gate) else "   <-- FAIL (nan in ref u/psf: %d/%d, in ours: %d/%d; case seed in order)" % (np.isnan(u_ref).sum(), np.isnan(psf_ref).sum(), np.isnan(u).sum(), np.isnan(psf).sum())
     print("MK %3d  %3dx%3d blind=%d win=(%d,%d,%d,%d) it=%d var=%d: u %.2e psf %.2e%s" % (MK, M, N, blind, t, b, l, r, args[9], var, eu, ep, flag))
-print("worst", worst)
+print("worst", worst, "failures", nfail, "reference-NaN cases", nrefnan)

@@ -43,7 +43,7 @@ def update_f32(u, ut, g_raw, image, step, lambd, blind, pad):
     inter = (slice(pad, pad + M), slice(pad, pad + N))
     with np.errstate(divide="ignore", invalid="ignore"):
         gi = g_raw[inter]
-        DoF = ((gi - image) / (gi + image)) ** 2
+        DoF = orc.dof_ratio(gi, image) ** 2      # 0/0 -> 1: include/ics_hip.h "DoF ratio"
         if not blind:
             DoF = DoF / lambd
         g = ((lambd * g_raw).astype(np.float64) + (u - ut).astype(np.float64) / 2.0).astype(np.float32)
