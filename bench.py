@@ -37,6 +37,30 @@ BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "ps
 ITER_BYTES_PER_PX = {"nonblind": 144.0, "blind": 204.0}
 
 
+def labels(route, fuse=False):
+    """Precision / kernel-family labels of a run from the LIBRARY's routing (lib._native.describe / RLJob.describe -> ics_rl_route):
+    what the JSON says about arithmetic must be what was launched, at every --psf (round-3 verdict: a K <= 37 test of bench.py's
+    own had drifted from the routing).  Returns dict(matrix, dtype, dtype_note, conv, gradk, traffic_key)."""
+    from lib import _native
+    conv_f = _native.RLRoute.CONV_FAMILIES[route.conv_family]
+    gradk_f = _native.RLRoute.GRADK_FAMILIES[route.gradk_family]
+    split_conv = bool(route.conv_fp16_split) and not fuse
+    split_gradk = bool(route.gradk_fp16_split)
+    if split_conv:
+        dtype = "f32 (fp16x2-split MFMA convolutions, fp32 accumulate)"
+        note = ("frames, sums and every elementwise step in fp32; the two PSF convolutions%s run on the matrix cores%s with each fp32 operand split into "
+                "two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation; `--conv vector` runs fp32 products throughout"
+                % (" and the PSF gradient" if split_gradk else "", " as tap blocks of <= 33 x 33" if route.conv_family == 2 else ""))
+    elif split_gradk:
+        dtype = "f32 (fp32-product convolutions; fp16x2-split MFMA PSF gradient, fp32 accumulate)"
+        note = "fp32 products in the two PSF convolutions (packed-fp32 vector kernels); the PSF gradient on the matrix cores with fp16x2-split operands"
+    else:
+        dtype = "f32"
+        note = "fp32 throughout (packed-fp32 vector convolutions%s)" % (", fp32-MFMA PSF gradient" if route.gradk_family else "")
+    return {"matrix": split_conv, "dtype": dtype, "dtype_note": note, "conv": conv_f if not fuse else "vector (fused update + convolution)", "gradk": gradk_f,
+            "traffic_key": "kernels_matrix" if split_conv else "kernels_vector"}
+
+
 def gaussian_1d(MK):
     n = np.arange(MK) - (MK - 1) / 2.0
     w = np.exp(-0.5 * (n / (MK / 6.0)) ** 2)
@@ -116,6 +140,18 @@ def cpu_baseline(mode, MK, M_full, budget_s=20.0):
             "extrapolation": "measured at 2048^2, NOT at the %d^2 of `value`: per-pixel cost of the FFT loop grows slowly with size, so this is an upper bound for %d^2" % (M_full, M_full),
             "static_notes": {"reference_compiled": "BASELINE.md section 2 holds the compiled reference's own figures (survey container, 8 OpenMP threads); "
                                                    "they are not measured in this run and therefore not repeated here -- the reference cannot travel to the GPU box"}}
+
+
+def mfma_counters(kernel, M, MK):
+    """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/r04_mfma_counters.json, written by
+    scripts/make_mfma_json.py from rocprofv3 --pmc runs): static, NOT measured in this run -- like `traffic`."""
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "r04_mfma_counters.json")))
+        if mj["workload"] == {"size": M, "psf": MK} and kernel in mj["kernels"]:
+            return dict(mj["kernels"][kernel], source="profiles/r04_mfma_counters.json (static: rocprofv3 SQ passes of an earlier run of this command)")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def self_launch(args, argv):
@@ -237,7 +273,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--conv", choices=["auto", "vector", "matrix"], default="auto",
-                    help="convolution kernels: auto = matrix-core (fp16-split MFMA) where built and faster (PSF <= 17, 23..37), else packed-fp32 vector")
+                    help="convolution kernels: auto = matrix cores (fp16-split MFMA) at every PSF size (whole PSF to 49 x 49, tap blocks above); "
+                         "vector = fp32 products everywhere; the JSON's dtype / config.conv come from the library's own routing (ics_rl_describe)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--mode", choices=["blind", "nonblind"], default="blind")
@@ -250,6 +287,7 @@ def main():
     ap.add_argument("--fuse", action="store_true", help="fused update+convolution kernel (opt-in; measured slower)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--no-sustained", action="store_true", help="skip the `sustained` block (25 + 200 extra steps after the timed region)")
+    ap.add_argument("--no-preheat", action="store_true", help="skip the cold-start measurement and the 150-step clock pre-heat in front of the timed region")
     ap.add_argument("--bands", type=int, default=0, help="N > 0: ONE frame (--size, default 12288 here) split into N row bands, one rank per GPU "
                     "(lib.banded.BandRank: RCCL max / sum all-reduce + point-to-point halos); strong scaling, a secondary workload (SURVEY.md 8f N4)")
     args = ap.parse_args()
@@ -274,8 +312,6 @@ def main():
     conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
     if conv == 0 and os.environ.get("ICS_CONV_PATH", "")[:1] == "v":
         conv = 1
-    # which convolution kernels the run resolves to (include/ics_hip.h ICS_CONV_*, csrc ics_conv_mfma_preferred)
-    matrix = conv in (0, 2) and MK <= 37
 
     ndev = _native.device_count()
     dev = int(os.environ.get("ICS_DEVICE", grp.local_rank))
@@ -292,6 +328,27 @@ def main():
         p = job.params(*win, 1e9, n_inner // 5, 1e-3, 10000.0, blind, 0, 3, stop_test=2, profile=profile, fuse=int(args.fuse), tv_mode=args.tv_mode, conv=conv)
         return job.run(p)
 
+    # which kernels the run resolves to: asked of the library (ics_rl_describe), not re-derived here
+    lab = labels(job.describe(job.params(*win, 1e9, 1, 1e-3, 10000.0, blind, 0, 3, stop_test=2, fuse=int(args.fuse), tv_mode=args.tv_mode, conv=conv)), args.fuse)
+    matrix = lab["matrix"]
+
+    # Order of the measurements.  (1) `cold_start`: W warm-up + K steps exactly as they come after the host-side frame synthesis (the GPU
+    # has idled for seconds: the first ~50 steps run while the clocks ramp) -- reported, not `value`.  (2) a clock pre-heat
+    # of PREHEAT untimed steps on EVERY rank at EVERY N (so that N = 1 and N = 8 are measured in the same state).  (3) the contract's
+    # measurement: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides -> `value`.
+    PREHEAT = 0 if args.no_preheat else 150
+    cold = None
+    if PREHEAT:
+        if warm:
+            run(warm, 0)
+        ctx.synchronize()
+        tc = time.perf_counter()
+        run(steps, 0)
+        ctx.synchronize()
+        ec = time.perf_counter() - tc
+        cold = {"ms_per_step": round(ec * 1e3 / steps, 4), "MPixels_per_s_per_iter": round(M * N * steps / ec / 1e6, 1), "steps": steps, "warmup": warm,
+                "note": "the same W + K steps run FIRST, straight after the host-side frame synthesis (GPU idle for seconds, clocks ramping); rank-local, not `value`"}
+        run(PREHEAT, 0)
     if warm:
         run(warm, 0)
     ctx.synchronize()
@@ -352,19 +409,21 @@ def main():
         names = _native.KERNEL_NAMES
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
-        traffic, traffic_file = None, "profiles/r03_hbm_traffic.json"
+        traffic, traffic_file = None, "profiles/r04_hbm_traffic.json"
         try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
             tj = json.load(open(os.path.join(ROOT, traffic_file)))
             if tj["workload"] == {"size": M, "psf": MK}:
-                traffic = tj["kernels_matrix" if matrix and not args.fuse else "kernels_vector"]
+                traffic = tj[lab["traffic_key"]]
         except (OSError, ValueError, KeyError):
             traffic = None
         if kern:
             dom = max((k for k in kern if k in BYTES_PER_PX), key=lambda k: kern[k]["ms"] * kern[k]["launches"])
             bytes_launch = BYTES_PER_PX[dom] * M * N
             ach = bytes_launch / (kern[dom]["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "bound_note": "HBM is the yardstick north_star sets (8 TB/s); the matrix-core kernels themselves are limited by issue / LDS / "
-                    "matrix-pipe time, not by bytes (traffic < algorithmic bytes for the fused kernel; PMC passes under profiles/)", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            roof = {"bound": "hbm", "limiter": ("issue / lds / matrix pipe (hbm is the yardstick)" if matrix else "fp32 valu (hbm is the yardstick)") if dom != "update" else "hbm",
+                    "bound_note": "HBM (8 TB/s) is the yardstick north_star sets and what `achieved` / `peak` / `frac` are quoted against; what LIMITS the matrix-core kernels is issue / LDS / "
+                    "matrix-pipe time, not bytes (traffic < algorithmic bytes for the fused kernel; SQ and FETCH / WRITE passes under profiles/) -- see `mfma`", "kernel": dom,
+                    "mfma": mfma_counters(dom, M, MK), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": (traffic[dom]["hbm_bytes"] if traffic and dom in traffic else None),
                     "traffic_source": "%s (static: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of an earlier run of this command, not measured live)" % traffic_file,
@@ -377,14 +436,13 @@ def main():
             "metric": "MPixels/sec/iter RL-TV deconv @%d^2x3 fp32, %dx%d PSF" % (M, MK, MK),
             "value": round(value, 1), "unit": "MPixels/s/iter", "n_gpus": grp.size, "steps": steps, "warmup": warm,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (fp16x2-split MFMA convolutions, fp32 accumulate)" if matrix and not args.fuse else "f32"), "data": "synthetic",
-            "dtype_note": ("frames, sums and every elementwise step in fp32; the two PSF convolutions and the PSF gradient run on the matrix cores with each "
-                           "fp32 operand split into two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation; "
-                           "`--conv vector` runs fp32 products throughout"
-                           if matrix and not args.fuse else "fp32 throughout (packed-fp32 vector convolutions)"),
+            "dtype": lab["dtype"], "data": "synthetic",
+            "dtype_note": lab["dtype_note"],
+            "order": ("cold_start (W + K steps after idle, reported beside), %d untimed pre-heat steps, then the contract's W warm-up + K timed steps = `value`" % PREHEAT) if PREHEAT else "W warm-up + K timed steps (no pre-heat)",
+            "cold_start": cold,
             "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop as shipped: the TV term is arithmetically dead in the reference, tv_mode %d), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
                                    "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", args.tv_mode, M, N, MK, MK),
-                       "mode": args.mode, "tv_mode": args.tv_mode, "conv": "matrix" if matrix and not args.fuse else "vector", "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size,
+                       "mode": args.mode, "tv_mode": args.tv_mode, "conv": lab["conv"], "psf_gradient": lab["gradk"], "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size,
                        "collective": "none in the iterations; %s barrier / max / all-gather of a 4-double record per rank" % (grp.backend if grp.size > 1 else "no")},
             "hbm_roofline_iteration": {"algorithmic_bytes_per_px": ITER_BYTES_PER_PX[args.mode], "achieved_GBps": round(it_gbps, 1),
                                        "frac_of_8TBps": round(it_gbps / HBM_PEAK_GBPS, 4)},

@@ -99,6 +99,12 @@ struct ics_rl {
   float* h_scal;                        // pinned host mirror of scal (+ flags)
   bool uploaded;
   bool ut_is_u;                         // majoriser aliased to u (first inner iteration of an outer one, no copy made yet)
+  // one hipGraph per outer iteration (small frames, use_graph): the launches of an outer iteration depend on which of the three
+  // frames is u / ut / spare (the rotation of do_update has period 3), so up to three executables, valid for one parameter set
+  struct Graph { float *u, *ut, *u2; hipGraphExec_t exec; };
+  std::vector<Graph> graphs;
+  ics_rl_params graph_sig;              // the parameters baked into the captured kernel arguments
+  int graph_epoch;                      // ... and the state of the debug switches they were captured under
   // profiling
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_class;
@@ -117,15 +123,16 @@ extern "C" size_t ics_rl_params_size(void) { return sizeof(ics_rl_params); }
 extern "C" size_t ics_rl_stats_size(void) { return sizeof(ics_rl_stats); }
 
 // test / measurement switches (ics_common.h IcsDebug): exported, deliberately absent from include/ics_hip.h
+static std::atomic<int> g_debug_epoch{0};   // bumped by every ics_debug_set: captured graphs carry the switches' effects in their kernel arguments
 extern "C" int ics_debug_set(const char* name, int value) {
   if (!name) return -1;
   IcsDebug& d = ics_debug();
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}};
   for (auto& t : tab)
-    if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); return 0; }
+    if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
 }
 extern "C" int ics_debug_get(const char* name, int* value) {
@@ -134,7 +141,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -225,6 +232,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
   for (void* p : ptrs) if (p) hipFree(p);
+  for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
   if (j->h_scal) hipHostFree(j->h_scal);
   for (hipEvent_t e : j->ev) hipEventDestroy(e);
   if (j->ev_begin) hipEventDestroy(j->ev_begin);
@@ -515,13 +523,21 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
   int P = 2, logP = 1;
   while (P < need) { P <<= 1; ++logP; }
   if (P > 8192) return fail(ICS_ENOSUP, "stats window %dx%d needs a %d-point FFT (max 8192, i.e. windows up to 4096 px a side)", H, W, P);
-  if (j->z) { hipFree(j->z); j->z = nullptr; }
-  if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
-  if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
+  // The cached key goes first: if an allocation below fails (z alone is 1.6 GB at P = 8192) the job must not keep the old key with
+  // freed or half-built buffers -- jobs are reused (lib/deconvolution.py), and the next run with the previous window would pass the
+  // cache check and launch the statistics kernels on them.
+  auto drop = [&]() {
+    j->wt = j->wb = j->wl = j->wr = -1; j->P = 0; j->logP = 0;
+    if (j->z) { hipFree(j->z); j->z = nullptr; }
+    if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
+    if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
+  };
+  drop();
   int rc;
-  if ((rc = dalloc(&j->z, (size_t)3 * P * P, j->ctx->stream, false)) != ICS_OK) return rc;
-  if ((rc = dalloc(&j->tw, (size_t)P / 2 + 1, j->ctx->stream, false)) != ICS_OK) return rc;
-  if ((rc = dalloc(&j->weights, (size_t)H * W, j->ctx->stream, false)) != ICS_OK) return rc;
+  const int fail_at = ics_debug().fail_window_alloc.exchange(0, std::memory_order_relaxed);   // test hook: the fail_at-th allocation fails once
+  if ((rc = fail_at == 1 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->z, (size_t)3 * P * P, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
+  if ((rc = fail_at == 2 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->tw, (size_t)P / 2 + 1, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
+  if ((rc = fail_at == 3 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->weights, (size_t)H * W, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
   std::vector<float2> tw(P / 2 + 1);
   for (int k = 0; k < P / 2; ++k) {
     const double ang = -2.0 * M_PI * (double)k / (double)P;
@@ -868,10 +884,60 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && !j->blk_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX: no matrix-core path for this PSF size");
+  if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && p->tv_mode != ICS_TV_SHIPPED)   // (the tap-block path has no TV epilogue; never run the fp32 kernels under an explicit MATRIX request)
+    return fail(ICS_ENOSUP, "ICS_CONV_MATRIX with tv_mode %d: PSF sizes above 49 run on the matrix cores as tap blocks, which exist for the shipped loop only", p->tv_mode);
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
   if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 127)", p->tv_mode);
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
+}
+
+// One submission per outer iteration (round 4).  deblur_module runs its blind phase on a 255-px window at every pyramid level
+// (deconvolve.py:138-141,277-286): 15 ... 35 launches of 5 ... 15 us each per outer iteration, where the host's launch calls and
+// the gaps between dependent dispatches weigh as much as the kernels.  The launches of an outer iteration (pyx:462-638: five inner
+// iterations, the statistics, the copy of the scalars to the pinned host mirror) are captured once per frame rotation and replayed
+// with hipGraphLaunch.  Not with profiling (events between the kernels), not with the opt-in fused update + convolution (its own
+// ping-pong), not with an empty window (host-side NaN upload).  Default: frames up to 1.2 Mpx; debug switch `graph` = 0 / 1 forces.
+static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
+  if (p->profile || p->fuse || j->win_empty) return false;
+  const int g = ics_debug().graph.load(std::memory_order_relaxed);
+  if (g >= 0) return g != 0;
+  return (long)j->g.uM * j->g.uN <= 1200000L;
+}
+
+// ics_rl_describe / ics_describe: the routing predicates above, as the launches below evaluate them
+static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
+  if (!r) return fail(ICS_EINVAL, "route is NULL");
+  if (r->struct_size != sizeof(ics_rl_route)) return fail(ICS_EINVAL, "ics_rl_route.struct_size = %u, expected %zu", r->struct_size, sizeof(ics_rl_route));
+  RC(check_params(j, p));
+  memset(r, 0, sizeof *r);
+  r->struct_size = sizeof(ics_rl_route);
+  const bool blocks = use_block_conv(j, p, 0), matrix = !blocks && use_matrix_conv(j, p);
+  r->conv_family = blocks ? 2 : (matrix ? 1 : (use_big_conv(j, p, 0) ? 4 : 3));
+  r->conv_fp16_split = blocks || matrix;
+  if (p->blind) {
+    const bool fused = !p->fuse && use_fused_gradk(j, p);
+    if (fused) r->gradk_family = 1;
+    else if (use_split_gradk(j, p)) r->gradk_family = 3;
+    else if (ics_big_supported(j->g.K)) r->gradk_family = 5;
+    else r->gradk_family = use_matrix_gradk(j, p) ? 2 : 4;
+    r->gradk_fp16_split = r->gradk_family <= 3;
+  }
+  r->image_in_accumulator_order = (matrix && use_image_acc(p) && ics_conv_mfma_rs(j->g.K, j->g) != 0) || (r->gradk_family == 1 && use_image_acc(p));
+  r->graph = use_graph(j, p) ? 1 : 0;
+  return ICS_OK;
+}
+extern "C" int ics_rl_describe(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) { return describe_impl(j, p, r); }
+// the same for a shape alone: no device, no job (the predicates read the geometry and which weight tables a job of this PSF size owns)
+extern "C" int ics_describe(int M, int N, int MK, const ics_rl_params* p, ics_rl_route* r) {
+  if (M < 1 || N < 1 || MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "bad shape: M=%d N=%d MK=%d (MK odd >= 3)", M, N, MK);
+  if (!ics_conv_supported(MK) && !ics_big_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..127)", MK);
+  ics_rl shell{};
+  shell.g = ics_make_geom(M, N, MK);
+  float dummy = 0.f;                                               // non-NULL markers only: nothing is dereferenced
+  if (ics_conv_mfma_supported(MK)) shell.bt_conv = shell.bt_corr = &dummy;
+  if (MK >= 51) shell.blk_conv = shell.blk_corr = &dummy;
+  return describe_impl(&shell, p, r);
 }
 
 extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
@@ -910,13 +976,10 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf, (size_t)3 * j->g.K * j->g.K * 4, hipMemcpyDeviceToDevice, s));
   RC(pack_weights(j, 0, 0.f, 0, s));
   HIPCHK(hipEventRecord(j->ev_begin, s));
-  while (it < p->iterations && !stop) {                       // pyx:460
+  // the launches of one outer iteration (pyx:462-638), eagerly or into a stream capture
+  auto enqueue_outer = [&]() -> int {
     if (p->fuse) RC(do_majorize(j, pr));                      // pyx:462 (explicit copy only for the fused path)
     else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
-    if (it == 0 || j->win_empty) {   // later outer iterations: re-armed on the device by the kernel that writes the scalars (ics_stats.hip)
-      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
-      RC(reset_dofkeys(j));
-    }
     const bool fuse = p->fuse != 0;
     const bool fused_gk = p->blind && !fuse && use_fused_gradk(j, p);
     bool have_e = false;  // error already produced by a fused update+synth kernel
@@ -948,6 +1011,52 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     }
     RC(do_stats(j, p, pr, 1));                                // A18 + A19
     HIPCHK(hipMemcpyAsync(j->h_scal, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, s));
+    return ICS_OK;
+  };
+  // One hipGraph launch per outer iteration (use_graph): everything captured carries the parameters in its kernel arguments, so the
+  // executables live as long as the parameter set (and the debug switches) stay what they were.
+  const bool graphs_on = use_graph(j, p);
+  if (graphs_on) {
+    ics_rl_params sig;
+    memset(&sig, 0, sizeof sig);
+    sig.top = p->top; sig.bottom = p->bottom; sig.left = p->left; sig.right = p->right; sig.tau = p->tau; sig.step_factor = p->step_factor;
+    sig.lambd = p->lambd; sig.blind = p->blind; sig.correlation = p->correlation; sig.channels = p->channels; sig.tv_mode = p->tv_mode;
+    sig.stop_test = p->stop_test; sig.conv = p->conv; sig.flags = p->flags;
+    const int epoch = g_debug_epoch.load(std::memory_order_relaxed);
+    if (!j->graphs.empty() && (memcmp(&sig, &j->graph_sig, sizeof sig) != 0 || epoch != j->graph_epoch)) {
+      for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
+      j->graphs.clear();
+    }
+    j->graph_sig = sig; j->graph_epoch = epoch;
+  }
+  while (it < p->iterations && !stop) {                       // pyx:460
+    if (it == 0 || j->win_empty) {   // later outer iterations: re-armed on the device by the kernel that writes the scalars (ics_stats.hip)
+      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      RC(reset_dofkeys(j));
+    }
+    if (graphs_on && it > 0) {   // (the first outer iteration of a call runs eagerly: first launches configure kernels and build lazily-allocated copies)
+      hipGraphExec_t exec = nullptr;
+      for (auto& g : j->graphs) if (g.u == j->u && g.ut == j->ut && g.u2 == j->u2) exec = g.exec;
+      if (exec) {
+        HIPCHK(hipGraphLaunch(exec, s));
+        float* old_ut = j->ut;                                // the rotation the captured do_update performed (period 3)
+        j->ut = j->u; j->u = j->u2; j->u2 = old_ut; j->ut_is_u = false;
+        inner_done += INNER;
+      } else {
+        ics_rl::Graph g{j->u, j->ut, j->u2, nullptr};
+        HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc_body = enqueue_outer();
+        hipGraph_t graph = nullptr;
+        const hipError_t e_end = hipStreamEndCapture(s, &graph);   // always: the stream must leave capture mode whatever the body returned
+        if (rc_body != ICS_OK) { if (graph) hipGraphDestroy(graph); return rc_body; }
+        if (e_end != hipSuccess) return fail(ICS_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e_end));
+        const hipError_t e_inst = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (e_inst != hipSuccess) return fail(ICS_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e_inst));
+        j->graphs.push_back(g);
+        HIPCHK(hipGraphLaunch(g.exec, s));
+      }
+    } else RC(enqueue_outer());
     // (the wait's wake-up is not what the device idles on here: an event before the statistics + polling through them measured the
     //  same iteration time, 0.8178 vs 0.8185 ms at 4096^2 and 0.1573 vs 0.1562 at 2048^2 non-blind)
     HIPCHK(hipStreamSynchronize(s));
@@ -969,7 +1078,9 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
     }
     ++it;
-    if (p->progress) p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu);   // pyx:593,648,658-659: where the reference prints
+    // pyx:593,648,658-659: where the reference prints.  A non-zero return leaves the loop with the state of this outer iteration
+    // (deconvolve.py:338-342 keeps the partial result of an interrupted run)
+    if (p->progress && p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu) != 0 && !stop) stop = 2;
   }
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));

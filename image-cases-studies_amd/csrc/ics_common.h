@@ -99,7 +99,9 @@ struct IcsDebug {
   std::atomic<int> update_kernel;     // ICS_UPDATE_KERNEL     0 = the pixel-group kernel everywhere
   std::atomic<int> fused_rs;          // ICS_FUSED_RS          0 launcher decides, 2 / 4 = tile height of the fused A11 + A13 kernel
   std::atomic<int> planar_image;      // ICS_PLANAR_IMAGE      0 = epilogues read the HWC image frame (no accumulator-order copy)
-  std::atomic<int> pam_exact;         // ICS_PAM_EXACT         1 = PAM TV term with IEEE sqrt / division per value (k_tvterm<2|3>)
+  std::atomic<int> pam_exact;         // ICS_PAM_EXACT         1 = the TV term of ALL three extended kinds (tv_mode 1, 2, 3) with IEEE sqrt / division per value
+  std::atomic<int> fail_window_alloc; // (test hook)           n = the n-th allocation of the next ensure_window() fails once with ICS_ENOMEM
+  std::atomic<int> graph;             // ICS_GRAPH             -1 launcher decides (small frames), 0 never, 1 always: one hipGraph launch per outer iteration
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
   IcsDebug() {
     max_wgs = env_int("ICS_TEST_MAX_WGS", 0);
@@ -114,6 +116,8 @@ struct IcsDebug {
     fused_rs = env_int("ICS_FUSED_RS", 0);
     planar_image = env_int("ICS_PLANAR_IMAGE", 1);
     pam_exact = env_int("ICS_PAM_EXACT", 0);
+    fail_window_alloc = 0;
+    graph = env_int("ICS_GRAPH", -1);
   }
 };
 // one instance per process (inline function, function-local static: initialised once, thread-safe)

@@ -204,8 +204,8 @@ __device__ __forceinline__ float pam_term(const float (&n)[3][20], int i, int c,
 // made k_tvterm<1> VALU-bound at 2.5x the time of the memory traffic it causes.  The four evaluations share their second
 // differences; those stay exact (double sums of floats, rounded once, as the reference computes them: the term is largest where
 // the image is flattest, i.e. where the differences cancel), everything behind them uses v_rcp_f32 / v_sqrt_f32 (1 ulp).  Within
-// ~1e-6 of the IEEE form relative to max |T| (gate 1e-5, tests/test_tv_mode.py); ICS_TV_EXACT=1 / debug switch tv_exact selects
-// the IEEE form.  n = rows (y-1, y, y+1) of the 20-float windows, i = index of the centre float.
+// ~1e-6 of the IEEE form relative to max |T| (gate 1e-5, tests/test_tv_mode.py); ICS_PAM_EXACT=1 / debug switch pam_exact (one switch for all
+// three extended kinds, tv_mode 1, 2 and 3: ics_launch_tvterm) selects the IEEE form.  n = rows (y-1, y, y+1) of the 20-float windows, i = index of the centre float.
 #ifndef ICS_TVMM_SEG
 #define ICS_TVMM_SEG 8
 #endif

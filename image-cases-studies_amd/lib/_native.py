@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "libics_hip.so"))
 
-ICS_ABI_VERSION = 3
+ICS_ABI_VERSION = 4
 ICS_KERNEL_COUNT = 12
 KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth",
                 "synth_gradk", "_9", "_10", "_11")
@@ -32,7 +32,7 @@ SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1"
 
 
 # void (*ics_rl_progress_fn)(void *user, int it, int stopped, float dof_min, float dof_max, float M_r, float Hu, float varu)
-PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float)
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float)
 
 
 class RLParams(C.Structure):
@@ -65,6 +65,22 @@ class RLStats(C.Structure):
             setattr(st, "trace_" + name, arr)                       # plain attribute: keeps the buffer alive
             setattr(st, "_p_" + name, arr.ctypes.data_as(C.POINTER(C.c_float)))
         return st
+
+
+class RLRoute(C.Structure):
+    """struct ics_rl_route (ics_rl_describe): which kernel families a run with these parameters launches."""
+    _fields_ = [("struct_size", C.c_uint32), ("conv_family", C.c_int), ("conv_fp16_split", C.c_int), ("gradk_family", C.c_int),
+                ("gradk_fp16_split", C.c_int), ("image_in_accumulator_order", C.c_int), ("graph", C.c_int)]
+    CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big"}
+    GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big"}
+
+
+def describe(M, N, MK, params):
+    """ics_describe: the kernel families a run of an M x N frame with an MK x MK PSF and these parameters launches (no device needed)."""
+    r = RLRoute()
+    r.struct_size = C.sizeof(RLRoute)
+    _check(load().ics_describe(int(M), int(N), int(MK), C.byref(params), C.byref(r)))
+    return r
 
 
 class NativeError(RuntimeError):
@@ -104,6 +120,8 @@ def load():
     lib.ics_rl_download.argtypes = [vp, vp, vp, vp]
     lib.ics_rl_run.argtypes = [vp, C.POINTER(RLParams), C.POINTER(RLStats)]
     lib.ics_rl_stage.argtypes = [vp, ci, C.POINTER(RLParams)]
+    lib.ics_rl_describe.argtypes = [vp, C.POINTER(RLParams), C.POINTER(RLRoute)]; lib.ics_rl_describe.restype = ci
+    lib.ics_describe.argtypes = [ci, ci, ci, C.POINTER(RLParams), C.POINTER(RLRoute)]; lib.ics_describe.restype = ci
     lib.ics_rl_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_write.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_read_rows.argtypes = [vp, ci, ci, ci, vp]
@@ -451,18 +469,40 @@ class RLJob:
         p.band_row0, p.band_row1 = int(band_rows[0]), int(band_rows[1])
         return p
 
+    def describe(self, params):
+        """ics_rl_describe: the kernel families `run(params)` will launch (RLRoute)."""
+        r = RLRoute()
+        r.struct_size = C.sizeof(RLRoute)
+        _check(load().ics_rl_describe(self._h, C.byref(params), C.byref(r)))
+        return r
+
     def run(self, params, progress=None):
-        """ics_rl_run.  `progress(it, stopped, dof_min, dof_max, M_r, Hu, varu)`, if given, is called after every outer iteration."""
+        """ics_rl_run.  `progress(it, stopped, dof_min, dof_max, M_r, Hu, varu)`, if given, is called after every outer iteration;
+        a true return value stops the run after that iteration (stats.stopped = 2).  An exception raised inside it -- a
+        KeyboardInterrupt while a progress line is printed, for instance -- also stops the run there (ctypes would otherwise
+        swallow it and the device loop would run to the end); it is re-raised from here once ics_rl_run has returned, with the
+        statistics of the interrupted run attached as `.ics_stats`, so that the caller can still fetch the partial result the
+        way deconvolve.py:338-342 keeps it.  The caller's `params` struct is left as it was (its own callback included)."""
         st = RLStats.with_traces(params.iterations)
-        cb = None
-        if progress is not None:
-            cb = PROGRESS_FN(lambda _user, it, stopped, dmin, dmax, mr, hu, varu: progress(it, stopped, dmin, dmax, mr, hu, varu))
-            params.progress = cb
-        try:
+        if progress is None:
             _check(load().ics_rl_run(self._h, C.byref(params), C.byref(st)))
-        finally:
-            if cb is not None:
-                params.progress = PROGRESS_FN()     # NULL again: the closure dies with this call
+            return st
+        raised = []
+
+        def trampoline(_user, it, stopped, dmin, dmax, mr, hu, varu):
+            try:
+                return 1 if progress(it, stopped, dmin, dmax, mr, hu, varu) else 0
+            except BaseException as e:      # noqa: BLE001 -- KeyboardInterrupt included, on purpose
+                raised.append(e)
+                return 1
+        cb = PROGRESS_FN(trampoline)
+        mine = RLParams.from_buffer_copy(params)     # run on a copy: the caller's struct keeps its own progress / progress_user
+        mine.progress = cb
+        mine.progress_user = None
+        _check(load().ics_rl_run(self._h, C.byref(mine), C.byref(st)))
+        if raised:
+            raised[0].ics_stats = st
+            raise raised[0]
         return st
 
     def stage(self, stage, params):

@@ -86,6 +86,21 @@ def _progress(it, stopped, dof_min, dof_max, M_r, Hu, varu):
         print("%i iterations completed" % it)
 
 
+def _run_interruptible(job, params):
+    """job.run with the reference's behaviour under Ctrl-C: the reference updates the caller's `u` / `psf` in place as it goes, so
+    a KeyboardInterrupt leaves the partial result in them and deconvolve.py:338-342 keeps it.  Here the frames live on the device:
+    an exception raised while a progress line is printed stops the device loop after that outer iteration (the callback's abort
+    channel, include/ics_hip.h ics_rl_progress_fn), the caller writes the partial `u` / `psf` back as usual and re-raises.
+    Returns (stats, exception or None)."""
+    try:
+        return job.run(params, progress=_progress), None
+    except BaseException as e:      # noqa: BLE001
+        st = getattr(e, "ics_stats", None)
+        if st is None:
+            raise
+        return st, e
+
+
 def _report(st, top, bottom, left, right, lambd):
     """the reference's closing lines (pyx:661-672)"""
     if st.stopped:
@@ -133,10 +148,13 @@ def richardson_lucy_MM_device(image, image_origin, u, u_origin, psf, top, bottom
     job.upload_img(image, image_origin, u, u_origin, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
                         tv_mode=tv_mode, conv=conv, flags=flags)
-    st = job.run(params, progress=_progress)
+    st, interrupt = _run_interruptible(job, params)
     job.download_img(u, u_origin)
     if blind:
         psf[...] = job.download_psf_caller()
+    richardson_lucy_MM.last = st
+    if interrupt is not None:
+        raise interrupt
     _report(st, top, bottom, left, right, lambd)
     richardson_lucy_MM.last = st
     pad = MK // 2
@@ -153,7 +171,8 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     unpinned), in which `image` is also updated in place as pyx:549 intends.
 
     `conv` (keyword-only, not in the reference): include/ics_hip.h ICS_CONV_*: 0 = auto (matrix-core kernels with
-    fp16-split operands where they are built and faster: convolutions MK <= 17 and 23..37, PSF gradient MK <= 31), 1 = fp32 products everywhere, 2 = force the matrix-core kernels.
+    fp16-split operands at every PSF size -- whole PSF to 49 x 49, tap blocks above; `_native.RLJob.describe(params)` reports what a run
+    will use), 1 = fp32 products everywhere, 2 = force the matrix-core kernels.
 
     `flags` (keyword-only, not in the reference): include/ics_hip.h ICS_FLAG_* bits (1 = run A11 and A13 as two kernels
     instead of the fused one)."""
@@ -171,13 +190,16 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     job.upload(image, u, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
                         tv_mode=tv_mode, conv=conv, flags=flags)
-    st = job.run(params, progress=_progress)
+    st, interrupt = _run_interruptible(job, params)
     u_new, _psf_local, psf_caller = job.download()
     u[...] = u_new                                                             # in place, any strides
     if blind:
         psf[...] = psf_caller
-    if tv_mode:
-        image[...] = job.read(_native.BUF_IMAGE)                               # pyx:549 (live in this mode)
+    if tv_mode == 1:
+        image[...] = job.read(_native.BUF_IMAGE)                               # pyx:549 (live in this mode only; the PAM kinds never write it)
+    richardson_lucy_MM.last = st
+    if interrupt is not None:
+        raise interrupt
     _report(st, top, bottom, left, right, lambd)
     richardson_lucy_MM.last = st
     return u[pad:pad + M, pad:pad + N, ...]                                    # pyx:675 (view)

@@ -38,8 +38,10 @@
 extern "C" {
 #endif
 
-#define ICS_ABI_VERSION 3 /* 3: self-describing ics_rl_params / ics_rl_stats (struct_size first), caller-owned traces,
-                             per-outer-iteration callback, ics_group_allreduce_sum */
+#define ICS_ABI_VERSION 4 /* 3: self-describing ics_rl_params / ics_rl_stats (struct_size first), caller-owned traces,
+                             per-outer-iteration callback, ics_group_allreduce_sum
+                             4: the callback returns int (non-zero = stop after this outer iteration, stats.stopped = 2);
+                                ics_rl_describe (which kernel family a run will use); the DoF ratio at exact 0/0 is 1 */
 
 /* error codes */
 #define ICS_OK 0
@@ -71,8 +73,12 @@ int ics_ctx_info(ics_ctx *ctx, char *name, size_t name_len, int *compute_units, 
 
 /* Called by ics_rl_run on the calling thread right after each outer iteration's statistics are known (pyx:593-659: the point
  * where the reference prints its progress lines), so that a binding can print them live.  `it` = outer iterations completed
- * (1-based), `stopped` = the stop test fired on this iteration. */
-typedef void (*ics_rl_progress_fn)(void *user, int it, int stopped, float dof_min, float dof_max, float M_r, float Hu, float varu);
+ * (1-based), `stopped` = the stop test fired on this iteration.
+ * Return value: 0 = go on; non-zero = ABORT: ics_rl_run leaves the loop after this outer iteration exactly as if `iterations`
+ * had been `it` (u, psf and the statistics are those of iteration `it`, downloadable as usual) and reports
+ * ics_rl_stats.stopped = 2.  This is the channel for deconvolve.py:338-342, which swallows a KeyboardInterrupt and keeps the
+ * partial, in-place-updated `u`: a binding turns the interrupt it catches inside the callback into a non-zero return. */
+typedef int (*ics_rl_progress_fn)(void *user, int it, int stopped, float dof_min, float dof_max, float M_r, float Hu, float varu);
 
 /* Arguments of richardson_lucy_MM that are scalars (pyx:341-342).  `p, norm, order, priority,
  * refocus` are accepted and ignored by the reference and therefore absent.
@@ -138,6 +144,18 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
  * has an absolute error of ~1e-7 of the FRAME maximum at every pixel.  There is therefore no data-dependent fall-back to
  * the fp32 kernels in ICS_CONV_AUTO; ICS_CONV_VECTOR remains for callers who want fp32 products regardless. */
 
+/* DoF ratio (lib/deconvolution.pyx:499, A5).  The mask is D = ((g - f)/(g + f))^2 with g the raw back-projection and f the image,
+ * evaluated in IEEE float32 like the reference -- with ONE defined exception: where g == 0 and f == 0 EXACTLY the ratio is 1, not
+ * 0/0 = NaN.  Reason: in a region where image and u are exactly black (clipped shadows, letterbox bars, zero borders of at least
+ * 2 MK - 1 px) the reference's g is the rounding noise of scipy's complex64 FFT (~1e-10, either sign), and (g - 0)/(g + 0) is 1 for
+ * EVERY non-zero g: the reference returns a finite picture there (22 of 24 black-row cases run with the compiled reference,
+ * tests/golden/rl_black.npz) unless one noise value happens to be exactly 0, in which case its whole frame becomes NaN (the 2 other
+ * cases, and most frames with black COLUMNS, whose noise is coarsely quantised).  This library's convolutions are exact sums:
+ * g = 0 there, and IEEE 0/0 would lose every such frame through the next convolution and the NaN-propagating maxima.  With the
+ * rule the results match the reference wherever the reference is finite (u <= 3e-7, psf <= 2e-7; tests/test_gpu_black.py), and
+ * stay finite where it is not.  Nothing else is touched: g + f == 0 with g != 0 is +-inf as in the reference, and a NaN that is
+ * already in the image or in u propagates (and is reported through ics_rl_stats.has_nan) exactly as before. */
+
 #define ICS_TV_SHIPPED 0 /* lib/deconvolution.pyx as shipped: else-branches :519/:545        */
 #define ICS_TV_MM_ACTIVE 1 /* BUILD-DEFINED extension, parity unpinned: the if-branches :517/:543 made
                               reachable (TV_ut from the majoriser, image denoising step :547-549 live);
@@ -154,7 +172,7 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
 typedef struct ics_rl_stats {
   uint32_t struct_size; /* in: sizeof(ics_rl_stats)                                        */
   int iterations_done; /* `it` at exit                                                    */
-  int stopped;         /* stop_flag                                                       */
+  int stopped;         /* stop_flag (1: the stop test fired, pyx:643-654); 2: the progress callback asked to stop */
   int has_nan;         /* np.any(np.isnan(u)) (pyx:671)                                   */
   float M_r, Hu, varu; /* values at exit (pyx:669)                                        */
   float dof_min, dof_max;
@@ -187,6 +205,24 @@ int ics_rl_download(ics_rl *job, float *u, float *psf_local, float *psf_caller);
 /* Runs the whole loop (pyx:460-659) on the device.  Host synchronisation happens once per outer
  * iteration (to read the stop-test scalars), never inside the 5 inner iterations. */
 int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
+
+/* Which kernels ics_rl_run / ics_rl_stage will launch for this job and these parameters (PSF size, params.conv, tv_mode, fuse,
+ * flags, the ICS_CONV_PATH override): the library's own routing predicates, so that a benchmark labels its precision and traffic
+ * figures from what actually runs.  Families:  convolutions A1/A3 -- 1 fp16-split matrix cores (whole PSF), 2 the same as tap blocks
+ * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip);  PSF gradient A13 -- 1 fused with
+ * A11 (k_synth_gradk, MK <= 15), 2 fp16-split matrix cores (k_gradk_mfma), 3 the same as tap blocks (MK >= 33), 4 fp32 MFMA
+ * (k_gradk), 5 run-time-sized fp32 (k_gradk_big); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
+ * stage are formed from two fp16 terms per operand (22 significand bits, fp32 accumulation), 0 = fp32 products. */
+typedef struct ics_rl_route {
+  uint32_t struct_size; /* in: sizeof(ics_rl_route) */
+  int conv_family, conv_fp16_split;
+  int gradk_family, gradk_fp16_split;
+  int image_in_accumulator_order; /* the residual kernels read the read-only accumulator-order copy of the image (ics_image_acc.h) */
+  int graph;                      /* ics_rl_run submits one hipGraph per outer iteration (small frames; ICS_GRAPH=0|1 overrides) */
+} ics_rl_route;
+int ics_rl_describe(ics_rl *job, const ics_rl_params *params, ics_rl_route *route);
+/* The same for a shape alone -- no device and no job needed (a benchmark or a test labels its lines before anything is allocated). */
+int ics_describe(int M, int N, int MK, const ics_rl_params *params, ics_rl_route *route);
 
 /* Stage-level entry points (parity tests, profiling).  They operate on the job's device frames. */
 #define ICS_STAGE_SYNTH_RESIDUAL 1 /* A1+A2: error = conv_valid(u, psf) - image   (pyx:477-488)   */

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "libics_hip.so does not export %s" % n
-    assert lib.ics_abi_version() == 3
+    assert lib.ics_abi_version() == 4
     assert lib.ics_rl_params_size() == ctypes.sizeof(_native.RLParams) and lib.ics_rl_stats_size() == ctypes.sizeof(_native.RLStats)
 
 
@@ -55,6 +55,14 @@ def test_struct_layout_matches_the_header(tmp_path):
                     _native.RLStats.ms_total.offset, _native.RLStats.launches.offset, _native.RLParams.progress.offset,
                     _native.RLStats._p_M_r.offset, _native.RLParams.top.offset]
     assert _native.RLParams.struct_size.offset == 0 and _native.RLStats.struct_size.offset == 0
+    c.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ics_hip.h"\nint main(void){printf("%zu %zu %zu\\n",'
+                 'sizeof(ics_rl_route), offsetof(ics_rl_route, gradk_family), offsetof(ics_rl_route, graph));return 0;}\n')
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert vals == [ctypes.sizeof(_native.RLRoute), _native.RLRoute.gradk_family.offset, _native.RLRoute.graph.offset]
+    # ABI 4: the progress callback returns int (non-zero = stop after this outer iteration)
+    assert _native.PROGRESS_FN._restype_ is ctypes.c_int
+    assert re.search(r"typedef int \(\*ics_rl_progress_fn\)", open(HEADER).read())
 
 
 def test_debug_switches_are_not_in_the_public_header_and_round_trip():

@@ -1,0 +1,57 @@
+"""bench.py's precision / kernel-family labels come from the library's routing (ics_describe, include/ics_hip.h), not from a rule of
+bench.py's own: round 3 shipped `matrix = conv in (0, 2) and MK <= 37` while ICS_CONV_AUTO had been matrix-core at every size for a
+day, so `--psf 39 ... 127` printed "f32" / "vector" for runs that used the fp16-split kernels.  CPU only: ics_describe needs no device."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _route(M, MK, blind, conv=0, tv_mode=0, fuse=0, flags=0):
+    from lib import _native as nv
+    return nv.describe(M, M, MK, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, blind, conv=conv, tv_mode=tv_mode, fuse=fuse, flags=flags))
+
+
+@pytest.mark.parametrize("MK", [15, 31, 45, 65])
+@pytest.mark.parametrize("blind", [False, True])
+def test_labels_follow_the_library_routing(MK, blind):
+    import bench
+    from lib import _native as nv
+    for conv in (nv.CONV_AUTO, nv.CONV_VECTOR):
+        r = _route(2048, MK, blind, conv)
+        lab = bench.labels(r)
+        # the precision label is a statement about the products of the convolutions that ran
+        assert ("fp16x2-split MFMA convolutions" in lab["dtype"]) == bool(r.conv_fp16_split)
+        assert lab["matrix"] == bool(r.conv_fp16_split)
+        assert lab["traffic_key"] == ("kernels_matrix" if r.conv_fp16_split else "kernels_vector")
+        assert lab["conv"] == nv.RLRoute.CONV_FAMILIES[r.conv_family] and lab["gradk"] == nv.RLRoute.GRADK_FAMILIES[r.gradk_family]
+        if conv == nv.CONV_AUTO:      # every PSF size has a matrix-core path since round 3
+            assert r.conv_fp16_split == 1 and r.conv_family == (1 if MK <= 49 else 2)
+            assert r.gradk_family == (0 if not blind else (1 if MK <= 15 else (2 if MK <= 31 else 3)))
+        else:                         # fp32 products everywhere
+            assert r.conv_fp16_split == 0 and r.gradk_fp16_split == 0 and lab["dtype"] == "f32"
+            assert r.conv_family == (3 if MK <= 63 else 4)
+    # the opt-in fused update + convolution kernel is a packed-fp32 kernel whatever AUTO resolves to
+    assert bench.labels(_route(2048, 15, blind, 0, fuse=1), fuse=True)["dtype"] != bench.labels(_route(2048, 15, blind, 0))["dtype"]
+
+
+def test_route_switches():
+    from lib import _native as nv
+    assert _route(4096, 15, True).gradk_family == 1 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK if hasattr(nv, "FLAG_NO_FUSED_GRADK") else 1).gradk_family == 2
+    assert _route(4096, 15, True).image_in_accumulator_order == 1 and _route(4096, 15, True, tv_mode=1).image_in_accumulator_order == 0
+    assert _route(4096, 15, True).graph == 0 and _route(512, 9, False).graph == 1      # one hipGraph per outer iteration on small frames only
+    with pytest.raises(nv.NativeError) as ei:      # an explicit MATRIX request is never served by fp32 kernels
+        _route(512, 55, True, conv=nv.CONV_MATRIX, tv_mode=2)
+    assert ei.value.code == nv.ICS_ENOSUP
+    with pytest.raises(nv.NativeError):
+        _route(512, 129, True)
+
+
+def test_bench_help_and_docs_do_not_restate_a_size_rule():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "MK <= 37" not in src and "23..37" not in src
+    dc = open(os.path.join(ROOT, "image-cases-studies_amd", "lib", "deconvolution.py")).read()
+    assert "23..37" not in dc
