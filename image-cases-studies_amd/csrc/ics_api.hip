@@ -18,6 +18,9 @@
 
 #include <new>
 #include <vector>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 #include "../../include/ics_hip.h"
 #include "ics_kernels.h"
@@ -42,7 +45,56 @@ int ics_set_error(int code, const char* fmt, ...) {
                   hipGetErrorString(e_), __FILE__, __LINE__);                                    \
   } while (0)
 
+// Device memory of a context is recycled, not returned (round 4).  deblur_module creates a job and a handful of images per pyramid
+// level and phase (deconvolve.py:204-313); hipMalloc / hipFree cost 0.1 ... 0.7 ms each and hipFree synchronises the device: the
+// rocprof timeline of a device-resident 2048^2 run showed 42 % of its 0.19 s idle, most of it in front of the first kernel that
+// follows an allocation (profiles/r04_driver_trace_before.txt).  Blocks are rounded up to an eighth of their leading power of two
+// (<= 12.5 % slack), a freed block goes to the free list of its rounded size and serves the next request of that size.  Everything a
+// context allocates is used on its one stream, so a recycled block needs no synchronisation: the new owner's first operation is
+// ordered behind the old owner's last.  The cache is trimmed above `limit` bytes (default: a quarter of the device memory; env
+// ICS_POOL_LIMIT_MB / debug switch pool_limit_mb, read when a context is created) and emptied when an allocation fails.
+struct IcsPool {
+  std::mutex mu;
+  std::multimap<size_t, void*> free_;            // rounded size -> block
+  std::unordered_map<void*, size_t> size_of;     // every block handed out or cached -> rounded size
+  size_t cached = 0, limit = 0;
+  static size_t round_up(size_t b) {
+    if (b < 65536) b = 65536;
+    size_t p2 = 65536;
+    while (p2 * 2 <= b) p2 *= 2;                 // leading power of two
+    const size_t q = p2 / 8;
+    return (b + q - 1) / q * q;
+  }
+  void trim(size_t keep) {                       // (mu held) largest first
+    while (cached > keep && !free_.empty()) {
+      auto it = std::prev(free_.end());
+      hipFree(it->second); size_of.erase(it->second); cached -= it->first; free_.erase(it);
+    }
+  }
+  hipError_t alloc(void** p, size_t bytes) {
+    const size_t r = round_up(bytes);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = free_.find(r);
+    if (it != free_.end()) { *p = it->second; cached -= r; free_.erase(it); return hipSuccess; }
+    hipError_t e = hipMalloc(p, r);
+    if (e != hipSuccess) { (void)hipGetLastError(); trim(0); e = hipMalloc(p, r); }
+    if (e != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return e; }
+    size_of[*p] = r;
+    return hipSuccess;
+  }
+  void release(void* p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = size_of.find(p);
+    if (it == size_of.end()) { hipFree(p); return; }   // not ours
+    free_.emplace(it->second, p); cached += it->second;
+    if (cached > limit) trim(limit / 2);
+  }
+  void clear() { std::lock_guard<std::mutex> g(mu); trim(0); }
+};
+
 struct ics_ctx {
+  IcsPool pool;
   int device;
   hipStream_t stream;
   int cus;
@@ -52,14 +104,21 @@ struct ics_ctx {
   size_t scratch_bytes;
   hipEvent_t ev0, ev1;      // device time of the last standalone operator (kernels only, no transfers)
   float last_ms;
+  // small pinned staging area for host -> device parameters of queued operations (the Gaussian weights of ics_img_resize): the copy
+  // reads it asynchronously, `pin_ev` marks the last copy, the next writer waits for it (long done in practice) -- no stream
+  // synchronisation per operation
+  double* pin = nullptr;
+  hipEvent_t pin_ev = nullptr;
+  bool pin_used = false;
+  static constexpr size_t PIN_DOUBLES = 8192;
 };
 
 // at least `bytes` of device scratch that persists between calls (no hipMalloc / hipFree per filter call)
 static int ctx_scratch(ics_ctx* c, size_t bytes, void** p) {
   if (c->scratch_bytes < bytes) {
-    if (c->scratch) { hipStreamSynchronize(c->stream); hipFree(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
+    if (c->scratch) { c->pool.release(c->scratch); c->scratch = nullptr; c->scratch_bytes = 0; }
     const size_t want = bytes + bytes / 4;
-    hipError_t e = hipMalloc(&c->scratch, want);
+    hipError_t e = c->pool.alloc(&c->scratch, want);
     if (e != hipSuccess) { (void)hipGetLastError(); c->scratch = nullptr; return ICS_ENOMEM; }
     c->scratch_bytes = want;
   }
@@ -130,7 +189,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -141,7 +200,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -173,6 +232,10 @@ extern "C" int ics_ctx_create(int device, ics_ctx** out) {
   ics_ctx* c = new ics_ctx();
   c->device = device;
   c->scratch = nullptr; c->scratch_bytes = 0; c->last_ms = 0.f;
+  {
+    const int lim = ics_debug().pool_limit_mb.load(std::memory_order_relaxed);   // ICS_POOL_LIMIT_MB, read once per process
+    c->pool.limit = lim >= 0 ? (size_t)lim << 20 : (size_t)prop.totalGlobalMem / 4;
+  }
   hipEventCreate(&c->ev0); hipEventCreate(&c->ev1);
   c->cus = prop.multiProcessorCount;
   c->hbm = prop.totalGlobalMem;
@@ -187,7 +250,10 @@ extern "C" void ics_ctx_destroy(ics_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  if (c->scratch) hipFree(c->scratch);
+  if (c->scratch) c->pool.release(c->scratch);
+  c->pool.clear();
+  if (c->pin) hipHostFree(c->pin);
+  if (c->pin_ev) hipEventDestroy(c->pin_ev);
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
   delete c;
@@ -218,10 +284,11 @@ extern "C" int ics_ctx_info(ics_ctx* c, char* name, size_t name_len, int* cus, u
 // Device allocation, zero-filled ON THE GIVEN STREAM: the job's stream is non-blocking, so a
 // null-stream hipMemset would not be ordered with the uploads/kernels that follow on it.
 template <typename T>
-static int dalloc(T** p, size_t count, hipStream_t s, bool zero = true) {
+static int dalloc(ics_ctx* c, T** p, size_t count, bool zero = true) {
   *p = nullptr;
-  HIPCHK(hipMalloc((void**)p, count * sizeof(T)));
-  if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), s));
+  if (hipError_t e = c->pool.alloc((void**)p, count * sizeof(T)); e != hipSuccess)
+    return fail(ICS_ENOMEM, "device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+  if (zero) HIPCHK(hipMemsetAsync(*p, 0, count * sizeof(T), c->stream));
   return ICS_OK;
 }
 
@@ -231,7 +298,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
   if (j->h_scal) hipHostFree(j->h_scal);
   for (hipEvent_t e : j->ev) hipEventDestroy(e);
@@ -266,23 +333,23 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   int rc;
 #define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
   hipStream_t s = c->stream;
-  TRY(dalloc(&j->u, j->frame_floats, s)); TRY(dalloc(&j->u2, j->frame_floats, s)); TRY(dalloc(&j->ut, j->frame_floats, s)); TRY(dalloc(&j->gr, j->frame_floats, s));
-  TRY(dalloc(&j->f, j->frame_floats, s)); TRY(dalloc(&j->e, j->frame_floats, s));
-  TRY(dalloc(&j->psf, n, s)); TRY(dalloc(&j->gradk, n, s)); TRY(dalloc(&j->psf_caller, n, s));
-  if (ics_big_supported(MK)) TRY(dalloc(&j->psf_work, n, s));
+  TRY(dalloc(c, &j->u, j->frame_floats)); TRY(dalloc(c, &j->u2, j->frame_floats)); TRY(dalloc(c, &j->ut, j->frame_floats)); TRY(dalloc(c, &j->gr, j->frame_floats));
+  TRY(dalloc(c, &j->f, j->frame_floats)); TRY(dalloc(c, &j->e, j->frame_floats));
+  TRY(dalloc(c, &j->psf, n)); TRY(dalloc(c, &j->gradk, n)); TRY(dalloc(c, &j->psf_caller, n));
+  if (ics_big_supported(MK)) TRY(dalloc(c, &j->psf_work, n));
   if (MK >= 51) {   // tap blocks: the fewest blocks of a size the matrix-core convolution is built for (odd, <= 33)
     j->blk_n = (MK + 32) / 33;
     j->blk_kb = ((MK + j->blk_n - 1) / j->blk_n) | 1;
     const size_t tf = ics_conv_mfma_table_floats(j->blk_kb);
-    TRY(dalloc(&j->blk_conv, tf * j->blk_n * j->blk_n, s)); TRY(dalloc(&j->blk_corr, tf * j->blk_n * j->blk_n, s));
-    TRY(dalloc(&j->blk_scr, j->frame_floats, s)); TRY(dalloc(&j->blk_zero, j->frame_floats, s));
-    TRY(dalloc(&j->blk_red, (size_t)ICS_RED_STRIDE, s));
+    TRY(dalloc(c, &j->blk_conv, tf * j->blk_n * j->blk_n)); TRY(dalloc(c, &j->blk_corr, tf * j->blk_n * j->blk_n));
+    TRY(dalloc(c, &j->blk_scr, j->frame_floats)); TRY(dalloc(c, &j->blk_zero, j->frame_floats));
+    TRY(dalloc(c, &j->blk_red, (size_t)ICS_RED_STRIDE));
   }
-  TRY(dalloc(&j->wconv, (size_t)(MK + 1) * j->g.wrow, s)); TRY(dalloc(&j->wcorr, (size_t)(MK + 1) * j->g.wrow, s));
-  if (ics_conv_mfma_supported(MK)) { TRY(dalloc(&j->bt_conv, ics_conv_mfma_table_floats(MK), s)); TRY(dalloc(&j->bt_corr, ics_conv_mfma_table_floats(MK), s)); }
-  TRY(dalloc(&j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, s));
-  TRY(dalloc(&j->red, (size_t)8 * ICS_RED_STRIDE, s)); TRY(dalloc(&j->dofkeys, (size_t)4, s)); TRY(dalloc(&j->sched, (size_t)16, s));
-  TRY(dalloc(&j->scal, (size_t)ICS_SC_COUNT, s)); TRY(dalloc(&j->dacc, (size_t)8, s)); TRY(dalloc(&j->ukey, (size_t)2, s)); TRY(dalloc(&j->flags, (size_t)4, s));
+  TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow));
+  if (ics_conv_mfma_supported(MK)) { TRY(dalloc(c, &j->bt_conv, ics_conv_mfma_table_floats(MK))); TRY(dalloc(c, &j->bt_corr, ics_conv_mfma_table_floats(MK))); }
+  TRY(dalloc(c, &j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt));
+  TRY(dalloc(c, &j->red, (size_t)8 * ICS_RED_STRIDE)); TRY(dalloc(c, &j->dofkeys, (size_t)4)); TRY(dalloc(c, &j->sched, (size_t)16));
+  TRY(dalloc(c, &j->scal, (size_t)ICS_SC_COUNT)); TRY(dalloc(c, &j->dacc, (size_t)8)); TRY(dalloc(c, &j->ukey, (size_t)2)); TRY(dalloc(c, &j->flags, (size_t)4));
 #undef TRY
   hipError_t e = hipHostMalloc((void**)&j->h_scal, (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);
   if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -313,7 +380,7 @@ static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1
 static int ensure_image_acc(ics_rl* j, int RS) {
   const int k = RS == 2 ? 0 : 1;
   if (!j->facc[k]) {
-    hipError_t e = hipMalloc((void**)&j->facc[k], ics_image_acc_floats(j->g, RS) * sizeof(float));
+    hipError_t e = j->ctx->pool.alloc((void**)&j->facc[k], ics_image_acc_floats(j->g, RS) * sizeof(float));
     if (e != hipSuccess) { (void)hipGetLastError(); j->facc[k] = nullptr; return fail(ICS_ENOMEM, "accumulator-order image: %s", hipGetErrorString(e)); }
     j->facc_valid[k] = false;
   }
@@ -528,16 +595,16 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
   // cache check and launch the statistics kernels on them.
   auto drop = [&]() {
     j->wt = j->wb = j->wl = j->wr = -1; j->P = 0; j->logP = 0;
-    if (j->z) { hipFree(j->z); j->z = nullptr; }
-    if (j->tw) { hipFree(j->tw); j->tw = nullptr; }
-    if (j->weights) { hipFree(j->weights); j->weights = nullptr; }
+    if (j->z) { j->ctx->pool.release(j->z); j->z = nullptr; }
+    if (j->tw) { j->ctx->pool.release(j->tw); j->tw = nullptr; }
+    if (j->weights) { j->ctx->pool.release(j->weights); j->weights = nullptr; }
   };
   drop();
   int rc;
   const int fail_at = ics_debug().fail_window_alloc.exchange(0, std::memory_order_relaxed);   // test hook: the fail_at-th allocation fails once
-  if ((rc = fail_at == 1 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->z, (size_t)3 * P * P, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
-  if ((rc = fail_at == 2 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->tw, (size_t)P / 2 + 1, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
-  if ((rc = fail_at == 3 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(&j->weights, (size_t)H * W, j->ctx->stream, false)) != ICS_OK) { drop(); return rc; }
+  if ((rc = fail_at == 1 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(j->ctx, &j->z, (size_t)3 * P * P, false)) != ICS_OK) { drop(); return rc; }
+  if ((rc = fail_at == 2 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(j->ctx, &j->tw, (size_t)P / 2 + 1, false)) != ICS_OK) { drop(); return rc; }
+  if ((rc = fail_at == 3 ? fail(ICS_ENOMEM, "stats window: allocation failed (test hook)") : dalloc(j->ctx, &j->weights, (size_t)H * W, false)) != ICS_OK) { drop(); return rc; }
   std::vector<float2> tw(P / 2 + 1);
   for (int k = 0; k < P / 2; ++k) {
     const double ang = -2.0 * M_PI * (double)k / (double)P;
@@ -729,7 +796,7 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
 
 static int ensure_tv(ics_rl* j) {
   if (j->tvf) return ICS_OK;
-  int rc = dalloc(&j->tvf, j->frame_floats, j->ctx->stream);
+  int rc = dalloc(j->ctx, &j->tvf, j->frame_floats);
   return rc;
 }
 
@@ -1187,12 +1254,12 @@ extern "C" int ics_normalize_kernel(ics_ctx* c, float* kern, int MK) {
   HIPCHK(hipSetDevice(c->device));
   const size_t n = (size_t)3 * MK * MK;
   float* d = nullptr;
-  HIPCHK(hipMalloc((void**)&d, n * 4));
+  HIPCHK(c->pool.alloc((void**)&d, n * 4));
   hipError_t e = hipMemcpyAsync(d, kern, n * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) { hipLaunchKernelGGL(k_normalize, dim3(1), dim3(256), 0, c->stream, d, MK); e = hipGetLastError(); }
   if (e == hipSuccess) e = hipMemcpyAsync(kern, d, n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(d);
+  c->pool.release(d);
   if (e != hipSuccess) return fail(ICS_EHIP, "normalize_kernel: %s", hipGetErrorString(e));
   return ICS_OK;
 }
@@ -1204,9 +1271,9 @@ extern "C" int ics_tv(ics_ctx* c, const float* u, int M, int N, float eps, int o
   HIPCHK(hipSetDevice(c->device));
   const size_t n = (size_t)M * N * 3;
   float *du = nullptr, *dout = nullptr, *ddiv = nullptr;
-  hipError_t e = hipMalloc((void**)&du, n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 4);
-  if (e == hipSuccess) e = hipMalloc((void**)&ddiv, n * 4);
+  hipError_t e = c->pool.alloc((void**)&du, n * 4);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&dout, n * 4);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&ddiv, n * 4);
   if (e == hipSuccess) e = hipMemcpyAsync(du, u, n * 4, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(dout, 0, n * 4, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(ddiv, 0, n * 4, c->stream);
@@ -1214,7 +1281,7 @@ extern "C" int ics_tv(ics_ctx* c, const float* u, int M, int N, float eps, int o
   if (e == hipSuccess) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(div, ddiv, n * 4, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  hipFree(du); hipFree(dout); hipFree(ddiv);
+  c->pool.release(du); c->pool.release(dout); c->pool.release(ddiv);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "tv: %s", hipGetErrorString(e));
   return ICS_OK;
 }
@@ -1324,10 +1391,10 @@ extern "C" int ics_resize_bicubic(ics_ctx* c, const double* src, int H, int W, i
   if (smooth && sy > 1e-15) ry = weights(sy, hwy);
   if (smooth && sx > 1e-15) rx = weights(sx, hwx);
   double *ds = nullptr, *scr = nullptr, *dout = nullptr, *dw = nullptr;
-  hipError_t e = hipMalloc((void**)&ds, n * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&scr, ics_resize_scratch_doubles(H, W, C) * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, no * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
+  hipError_t e = c->pool.alloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&scr, ics_resize_scratch_doubles(H, W, C) * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&dout, no * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
   if (e == hipSuccess) e = hipMemcpyAsync(ds, src, n * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && !hwy.empty()) e = hipMemcpyAsync(dw, hwy.data(), hwy.size() * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, c->stream);
@@ -1337,7 +1404,7 @@ extern "C" int ics_resize_bicubic(ics_ctx* c, const double* src, int H, int W, i
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, dout, no * 8, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // (also keeps hwy / hwx alive until the copies are done)
-  hipFree(ds); hipFree(scr); hipFree(dout); hipFree(dw);
+  c->pool.release(ds); c->pool.release(scr); c->pool.release(dout); c->pool.release(dw);
   if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "resize: %s", hipGetErrorString(e));
   return ICS_OK;
 }
@@ -1358,8 +1425,8 @@ static int img_new(ics_ctx* c, int H, int W, ics_img** out) {
   HIPCHK(hipSetDevice(c->device));
   ics_img* m = new (std::nothrow) ics_img{c, H, W, nullptr};
   if (!m) return fail(ICS_ENOMEM, "host allocation failed");
-  hipError_t e = hipMalloc((void**)&m->d, (size_t)H * W * 3 * 4);
-  if (e != hipSuccess) { delete m; (void)hipGetLastError(); return fail(ICS_ENOMEM, "hipMalloc of a %d x %d image: %s", H, W, hipGetErrorString(e)); }
+  hipError_t e = c->pool.alloc((void**)&m->d, (size_t)H * W * 3 * 4);
+  if (e != hipSuccess) { delete m; return fail(ICS_ENOMEM, "device allocation of a %d x %d image: %s", H, W, hipGetErrorString(e)); }
   *out = m;
   return ICS_OK;
 }
@@ -1367,9 +1434,7 @@ static int img_new(ics_ctx* c, int H, int W, ics_img** out) {
 extern "C" int ics_img_create(ics_ctx* c, int H, int W, ics_img** out) { return img_new(c, H, W, out); }
 extern "C" void ics_img_destroy(ics_img* m) {
   if (!m) return;
-  hipSetDevice(m->ctx->device);
-  hipStreamSynchronize(m->ctx->stream);
-  hipFree(m->d);
+  m->ctx->pool.release(m->d);   // (operations on the image are queued on the context's stream; so is whatever reuses the block)
   delete m;
 }
 extern "C" int ics_img_shape(const ics_img* m, int* H, int* W) {
@@ -1451,17 +1516,33 @@ extern "C" int ics_img_resize(const ics_img* src, int OH, int OW, ics_img** out)
   if (sy > 1e-15) ry = weights(sy, hwy);
   if (sx > 1e-15) rx = weights(sx, hwx);
   double *ds = nullptr, *scr = nullptr, *dout = nullptr, *dw = nullptr;
-  hipError_t e = hipMalloc((void**)&ds, n * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&scr, ics_resize_scratch_doubles(H, W, 3) * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dout, no * 8);
-  if (e == hipSuccess) e = hipMalloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
-  if (e == hipSuccess && !hwy.empty()) e = hipMemcpyAsync(dw, hwy.data(), hwy.size() * 8, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, s);
+  hipError_t e = c->pool.alloc((void**)&ds, n * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&scr, ics_resize_scratch_doubles(H, W, 3) * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&dout, no * 8);
+  if (e == hipSuccess) e = c->pool.alloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
+  const size_t nw = hwy.size() + hwx.size();
+  bool staged = false;
+  if (e == hipSuccess && nw) {
+    if (nw <= ics_ctx::PIN_DOUBLES) {          // through the context's pinned staging area: nothing to wait for afterwards
+      if (!c->pin) { e = hipHostMalloc((void**)&c->pin, ics_ctx::PIN_DOUBLES * 8, hipHostMallocDefault); if (e == hipSuccess) e = hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming); }
+      if (e == hipSuccess && c->pin_used) e = hipEventSynchronize(c->pin_ev);
+      if (e == hipSuccess) {
+        memcpy(c->pin, hwy.data(), hwy.size() * 8);
+        memcpy(c->pin + hwy.size(), hwx.data(), hwx.size() * 8);
+        e = hipMemcpyAsync(dw, c->pin, nw * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(c->pin_ev, s);
+        c->pin_used = true; staged = true;
+      }
+    } else {
+      if (!hwy.empty()) e = hipMemcpyAsync(dw, hwy.data(), hwy.size() * 8, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, s);
+    }
+  }
   if (e == hipSuccess) e = ics_launch_f32_to_f64(src->d, ds, (long)n, s);
   if (e == hipSuccess) e = ics_launch_resize(ds, H, W, 3, hwy.empty() ? nullptr : dw, ry, hwx.empty() ? nullptr : dw + hwy.size(), rx, scr, dout, OH, OW, s);
   if (e == hipSuccess) e = ics_launch_f64_to_f32(dout, (*out)->d, (long)no, s);
-  if (e == hipSuccess) e = hipStreamSynchronize(s);   // scratch and the host weight vectors are released below
-  hipFree(ds); hipFree(scr); hipFree(dout); hipFree(dw);
+  if (e == hipSuccess && nw && !staged) e = hipStreamSynchronize(s);   // pageable host vectors are released below
+  c->pool.release(ds); c->pool.release(scr); c->pool.release(dout); c->pool.release(dw);
   if (e != hipSuccess) { ics_img_destroy(*out); *out = nullptr; return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "img_resize: %s", hipGetErrorString(e)); }
   return ICS_OK;
 }

@@ -101,7 +101,8 @@ struct IcsDebug {
   std::atomic<int> planar_image;      // ICS_PLANAR_IMAGE      0 = epilogues read the HWC image frame (no accumulator-order copy)
   std::atomic<int> pam_exact;         // ICS_PAM_EXACT         1 = the TV term of ALL three extended kinds (tv_mode 1, 2, 3) with IEEE sqrt / division per value
   std::atomic<int> fail_window_alloc; // (test hook)           n = the n-th allocation of the next ensure_window() fails once with ICS_ENOMEM
-  std::atomic<int> graph;             // ICS_GRAPH             -1 launcher decides (small frames), 0 never, 1 always: one hipGraph launch per outer iteration
+  std::atomic<int> pool_limit_mb;     // ICS_POOL_LIMIT_MB     cap of a context's cache of freed device blocks in MiB (-1: a quarter of the device memory; 0: no caching)
+  std::atomic<int> graph;             // ICS_GRAPH             0 (default) never, 1 always, -1 frames <= 1.2 Mpx: one hipGraph launch per outer iteration (measured: no gain)
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
   IcsDebug() {
     max_wgs = env_int("ICS_TEST_MAX_WGS", 0);
@@ -117,7 +118,8 @@ struct IcsDebug {
     planar_image = env_int("ICS_PLANAR_IMAGE", 1);
     pam_exact = env_int("ICS_PAM_EXACT", 0);
     fail_window_alloc = 0;
-    graph = env_int("ICS_GRAPH", -1);
+    graph = env_int("ICS_GRAPH", 0);
+    pool_limit_mb = env_int("ICS_POOL_LIMIT_MB", -1);
   }
 };
 // one instance per process (inline function, function-local static: initialised once, thread-safe)

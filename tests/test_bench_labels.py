@@ -42,7 +42,7 @@ def test_route_switches():
     from lib import _native as nv
     assert _route(4096, 15, True).gradk_family == 1 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK if hasattr(nv, "FLAG_NO_FUSED_GRADK") else 1).gradk_family == 2
     assert _route(4096, 15, True).image_in_accumulator_order == 1 and _route(4096, 15, True, tv_mode=1).image_in_accumulator_order == 0
-    assert _route(4096, 15, True).graph == 0 and _route(512, 9, False).graph == 1      # one hipGraph per outer iteration on small frames only
+    assert _route(4096, 15, True).graph == 0 and _route(512, 9, False).graph == 0      # one hipGraph per outer iteration: opt-in (ICS_GRAPH=1; measured without gain)
     with pytest.raises(nv.NativeError) as ei:      # an explicit MATRIX request is never served by fp32 kernels
         _route(512, 55, True, conv=nv.CONV_MATRIX, tv_mode=2)
     assert ei.value.code == nv.ICS_ENOSUP
