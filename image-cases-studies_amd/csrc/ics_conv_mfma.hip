@@ -76,7 +76,7 @@
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
 #endif
 #ifndef ICS_MFMA_ABLATE
-#define ICS_MFMA_ABLATE 0  /* tools/bench_conv_mfma.hip: 1 = no MFMA loop, 2 = no conversion, 4 = no epilogue */
+#define ICS_MFMA_ABLATE 0  /* tools/bench_conv_mfma.hip: 1 = no MFMA loop, 2 = no conversion, 4 = no epilogue, 64 = two of the three split terms only */
 #endif
 
 // phase timing probe (tools/bench_conv_mfma.hip -DICS_MFMA_TIMING): per-wave cycle totals between the marks
@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
               for (int t = 0; t < C::RS; ++t) {
                 const int ka = q - t;
                 if (ka < A0 || ka >= A1) continue;
+                if ((ICS_MFMA_ABLATE & 64) && term == 2) continue;   // timing probe: a third of the MFMAs less (results wrong)
                 const h8 av = term == 2 ? Al[h] : Ah[h];
                 const h8 bv = term == 1 ? Bl[ka][h] : Bh[ka][h];
                 acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[ch][t], 0, 0, 0);
