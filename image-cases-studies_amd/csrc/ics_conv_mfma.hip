@@ -72,6 +72,9 @@
 #ifndef ICS_EPI_EARLY
 #define ICS_EPI_EARLY 1       /* mode 0, 32-row tiles, accumulator-order image: request the image operand BEFORE the matrix phase (130 of 168 VGPRs in use: room for its 24) */
 #endif
+#ifndef ICS_MFMA_PAIRS
+#define ICS_MFMA_PAIRS 1   /* two-window sizes up to 33 x 33 (8-wave kernels): two kernel rows per three MFMA windows, see MCfg::PAIR */
+#endif
 #ifndef ICS_MFMA_ALL_RS
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
 #endif
@@ -143,6 +146,16 @@ struct MCfg {
   static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
   static constexpr int WGS_CAP = RS == 4 ? 2 : 3;                      // register budget: 256 / 168 VGPRs
   static constexpr int WGS = (160 * 1024 / LDS_BYTES) < WGS_CAP ? (160 * 1024 / LDS_BYTES) : WGS_CAP;   // workgroups (of 4 waves) per CU
+  // Row pairs (round 4).  With two windows a kernel row costs 2 x 32 columns of MFMA depth for its 16 + K - 1 <= 48 input columns,
+  // and the matrix loop of these kernels runs at 85 % of the MFMA issue rate (without it 0.35 of 1.07 ms at 6144^2 / 31 x 31, with
+  // two of the three split terms 0.83: tools/bench_conv_mfma.hip -DICS_MFMA_ABLATE=64).  Two consecutive kernel rows a, a + 1 of one
+  // accumulator set read input rows r and r + 1; their 2 x 48 columns fill THREE 32-deep windows exactly:
+  //     window 0 = row r cols [0, 32) | window m = row r cols [32, 48) + row r + 1 cols [0, 16) | window 2 = row r + 1 cols [16, 48)
+  // -- 24 % fewer MFMAs at K = 31.  The mixed window's A fragment takes lane groups 0, 1 from one LDS row class and 2, 3 from the next
+  // (a per-lane base address), its B fragment likewise from the weight rows of a and a + 1.  A fragment pair (q, q + 1) then serves
+  // the accumulator sets t = q - a with a EVEN only, so the two waves of a column block no longer split the kernel rows but the
+  // sets: wave `half` owns t = half and half + 2 for all rows -- no exchange of partial sums, two workgroup barriers less per tile.
+  static constexpr bool PAIR = ICS_MFMA_PAIRS && NH == 2 && RS == 4 && (16 + K - 1 > 32) && (16 + K - 1 <= 48);
   static constexpr int NQ = K + RS - 1;          // fragments per (channel, column block)
   static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
   static constexpr int NTASK = LROWS * XG;
@@ -483,13 +496,148 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         }
       }
     };
+    // MCfg::PAIR: accumulator sets H and H + 2 of this wave, all kernel rows: pairs (2s, 2s + 1), s < NP, then the single row K - 1
+    // (classic two windows).  Step s' works on the fragments f = 2s' + H, f + 1: set H takes item s', set H + 2 item s' - 1 (same
+    // fragments, since (2s' - 2) + (H + 2) = f), so the B fragments of an item are built once and used in two consecutive steps.
+    auto matrix_phase_pairs = [&](auto hc) {
+      constexpr int H = decltype(hc)::value;
+      constexpr int NP = (K - 1) / 2;
+      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+      // B windows of a lane: start half bo of the zero-padded weight row (as in the classic loop), four kinds:
+      //   0: Toeplitz rows [0, 32) of row a      1: rows [32, 64) of row a (single row only)      2: rows [16, 48) of row a + 1
+      //   3 (mixed): lane groups 0, 1 rows [32, 48) of row a, lane groups 2, 3 rows [0, 16) of row a + 1
+      const uint32_t wbase = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256);
+      auto wof = [&](int bo, int rowadd) -> uint32_t {
+        const bool z = bo < 8 || bo > K + 14;
+        return wbase + 8u * (uint32_t)(z ? C::WZERO : ((bo - 8) >> 1)) + (z ? 0u : (uint32_t)(rowadd * 2 * C::WROWB));
+      };
+      uint32_t wk[4] = {wof(8 * lg - li + 15, 0), wof(32 + 8 * lg - li + 15, 0), wof(16 + 8 * lg - li + 15, 0),
+                        lg < 2 ? wof(32 + 8 * lg - li + 15, 0) : wof(8 * (lg - 2) - li + 15, 1)};
+      const uint32_t sh = (uint32_t)((8 * lg - li + 15) & 1) * 16u;   // (every start above has this parity)
+      // A fragments: `base_h` = lane row li, columns 16 cb + 8 lg of LDS row 0.  The mixed fragment's lane groups 2, 3 sit 16
+      // columns to the left in the NEXT input row: the distance between the LDS rows of fragments f and f + 1 depends on f mod 4
+      // only (row classes), and f mod 4 is H or H + 2 here -- two per-lane offsets
+      constexpr int DA = (C::cls_base((H + 1) % 4) + (H + 1) / 4 - C::cls_base(H % 4) - H / 4) * C::ROWB;
+      constexpr int DB = (C::cls_base((H + 3) % 4) + (H + 3) / 4 - C::cls_base((H + 2) % 4) - (H + 2) / 4) * C::ROWB;
+      int mixA = lg < 2 ? 64 : DA - 32, mixB = lg < 2 ? 64 : DB - 32;
+      asm volatile("" : "+v"(mixA), "+v"(mixB));
+#pragma unroll
+      for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
+        uint32_t wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wb[k] = wk[k]; asm volatile("" : "+v"(wb[k])); }
+        const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
+        const unsigned char* pl = ph + C::PLANE;
+        // item i < NP: pair (2i, 2i + 1) -> kinds 0, 3, 2; item NP: single row K - 1 -> kinds 0, 1
+        u2 rawB[3][5];
+        h8 Bc[3][2], Bp[3][2];                       // [window][hi, lo] of the current item (set H) and of the previous one (set H + 2)
+        auto issueB = [&](int item) {
+          const int a = 2 * item;
+          const int kinds[3] = {0, item < NP ? 3 : 1, 2};
+#pragma unroll
+          for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
+            const int arow = a + (w == 2 ? 1 : 0);   // (the mixed window adds its second row per lane, in wk[3])
+            const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb[kinds[w]] + (uint32_t)((ch * K + arow) * 2 * C::WROWB));
+#pragma unroll
+            for (int d = 0; d < 5; ++d) rawB[w][d] = r[d];
+          }
+        };
+        auto finishB = [&](int item, h8 (&B)[3][2]) {
+#pragma unroll
+          for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
+            const u2* d = rawB[w];
+            u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, sh), __builtin_amdgcn_alignbit(d[2].x, d[1].x, sh),
+                     __builtin_amdgcn_alignbit(d[3].x, d[2].x, sh), __builtin_amdgcn_alignbit(d[4].x, d[3].x, sh)};
+            u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, sh), __builtin_amdgcn_alignbit(d[2].y, d[1].y, sh),
+                     __builtin_amdgcn_alignbit(d[3].y, d[2].y, sh), __builtin_amdgcn_alignbit(d[4].y, d[3].y, sh)};
+            B[w][0] = __builtin_bit_cast(h8, wh);
+            B[w][1] = __builtin_bit_cast(h8, wl);
+          }
+        };
+        // A fragments of step s': [0] row f cols [0, 32), [1] mixed (item < NP) or row f cols [32, 64) (single), [2] row f + 1 cols [16, 48)
+        auto loadA = [&](int sp, h8 (&A)[3][2], bool need_pair, bool need_single, h8 (&A1)[2]) {
+          const int f = 2 * sp + H;
+          const int off = (C::cls_base(f % 4) + f / 4) * C::ROWB;
+          const int off1 = (C::cls_base((f + 1) % 4) + (f + 1) / 4) * C::ROWB;
+          A[0][0] = *reinterpret_cast<const h8*>(ph + off); A[0][1] = *reinterpret_cast<const h8*>(pl + off);
+          if (need_pair) {
+            const int mix = (f % 4 == H) ? mixA : mixB;
+            A[1][0] = *reinterpret_cast<const h8*>(ph + off + mix); A[1][1] = *reinterpret_cast<const h8*>(pl + off + mix);
+            A[2][0] = *reinterpret_cast<const h8*>(ph + off1 + 32); A[2][1] = *reinterpret_cast<const h8*>(pl + off1 + 32);
+          }
+          if (need_single) { A1[0] = *reinterpret_cast<const h8*>(ph + off + 64); A1[1] = *reinterpret_cast<const h8*>(pl + off + 64); }
+        };
+        // which items run at step sp: set H item sp (pair if sp < NP, single if sp == NP), set H + 2 item sp - 1
+        auto pair_at = [](int sp) { return sp < NP || (sp >= 1 && sp - 1 < NP); };
+        auto single_at = [](int sp) { return sp == NP || sp - 1 == NP; };
+        h8 Ac[3][2], As[2];
+        issueB(0);
+        loadA(0, Ac, pair_at(0), single_at(0), As);
+        finishB(0, Bc);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sp = 0; sp <= NP + 1; ++sp) {
+          h8 An[3][2], Asn[2];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { An[w][0] = Ac[w][0]; An[w][1] = Ac[w][1]; }
+          Asn[0] = As[0]; Asn[1] = As[1];
+          if (sp + 1 <= NP + 1) loadA(sp + 1, An, pair_at(sp + 1), single_at(sp + 1), Asn);
+          if (sp + 1 <= NP) issueB(sp + 1);
+          int nm = 0;
+          // three split terms; the two sets' accumulators alternate
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            const int ia = term == 2 ? 1 : 0, ib = term == 1 ? 1 : 0;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              if ((ICS_MFMA_ABLATE & 64) && term == 2) continue;
+              // set H: item sp
+              if (sp < NP) { acc[ch][H] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ac[w][ia], Bc[w][ib], acc[ch][H], 0, 0, 0); ++nm; }
+              else if (sp == NP && w < 2) { acc[ch][H] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w == 0 ? Ac[0][ia] : As[ia], Bc[w][ib], acc[ch][H], 0, 0, 0); ++nm; }
+              // set H + 2: item sp - 1
+              if (sp >= 1 && sp - 1 < NP) { acc[ch][H + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ac[w][ia], Bp[w][ib], acc[ch][H + 2], 0, 0, 0); ++nm; }
+              else if (sp - 1 == NP && w < 2) { acc[ch][H + 2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w == 0 ? Ac[0][ia] : As[ia], Bp[w][ib], acc[ch][H + 2], 0, 0, 0); ++nm; }
+            }
+          }
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { Bp[w][0] = Bc[w][0]; Bp[w][1] = Bc[w][1]; }
+          if (sp + 1 <= NP) finishB(sp + 1, Bc);
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { Ac[w][0] = An[w][0]; Ac[w][1] = An[w][1]; }
+          As[0] = Asn[0]; As[1] = Asn[1];
+          if (ICS_MFMA_INTERLEAVE) {   // LDS reads behind the first MFMAs of the step, the funnel shifts behind the last four
+            int nr = 0, nv = 0;
+            if (sp + 1 <= NP + 1) nr += 2 + (pair_at(sp + 1) ? 4 : 0) + (single_at(sp + 1) ? 2 : 0);
+            if (sp + 1 <= NP) { nr += 5 * (sp + 1 < NP ? 3 : 2); nv = 8 * (sp + 1 < NP ? 3 : 2); }
+            const int tail = nv ? (nm > 4 ? 4 : nm) : 0, head = nm - tail;
+#pragma unroll
+            for (int i = 0; i < (head > nr ? head : nr); ++i) {
+              if (i < head) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < tail; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+              for (int j = 0; j < (nv / 2 + tail - 1) / tail; ++j) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
     const bool has_out = x0 + 16 * cb < xend;   // wave-uniform: a column block right of the output carries none
     if (has_out) {
-      if (NH == 1) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, K>{});
-      else if (half == 0) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, C::KSPLIT>{});
-      else matrix_phase(std::integral_constant<int, C::KSPLIT>{}, std::integral_constant<int, K>{});
+      if constexpr (C::PAIR) {
+        if (half == 0) matrix_phase_pairs(std::integral_constant<int, 0>{}); else matrix_phase_pairs(std::integral_constant<int, 1>{});
+      } else {
+        if (NH == 1) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, K>{});
+        else if (half == 0) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, C::KSPLIT>{});
+        else matrix_phase(std::integral_constant<int, C::KSPLIT>{}, std::integral_constant<int, K>{});
+      }
     }
-    if (NH == 2) {
+    if (NH == 2 && !C::PAIR) {
       // partial sums of the two halves: a wave keeps the accumulator sets t = 2 half, 2 half + 1 and hands the other two to its
       // partner through the plane space (free once every wave has left the matrix phase)
       lds_barrier();
@@ -533,9 +681,11 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       const int acc_voff = 16 * (tide & 63);
       const int acc_sb = (tile * 4 + cb) * (3 * C::RS * 1024);                  // bytes: [tile][cb][ch][t][lane] float4
       auto run_epi = [&](auto tbc, auto tvc, auto tloc) {
-      // accumulator sets [TLO, THI) of this wave: all of them, or two (NH = 2)
-      constexpr int TLO = decltype(tloc)::value, THI = TLO + C::RS / NH;
-      constexpr int TB = decltype(tbc)::value < THI - TLO ? decltype(tbc)::value : THI - TLO;
+      // accumulator sets of this wave: all of them (NH = 1), two consecutive ones (NH = 2), or TLO and TLO + 2 (row pairs, MCfg::PAIR).
+      // The loops below run over slots i = 0 .. NS - 1 <-> set TLO + i * TSTEP; written with `t` running over [TLO, THI) in steps of TSTEP.
+      constexpr int TSTEP = C::PAIR ? 2 : 1, NS = C::RS / NH;
+      constexpr int TLO = decltype(tloc)::value, THI = TLO + NS * TSTEP;
+      constexpr int TB = (decltype(tbc)::value < NS ? decltype(tbc)::value : NS) * TSTEP;   // sets per batch, in units of t
       constexpr bool TVOP = decltype(tvc)::value;
       // PAM kinds (tv_kind 2, 3): the frame this kernel writes is G = T + lambd * gradu itself -- the update pass then reads u and G
       // only (no T, no majoriser, no image: 3 frame transits instead of 5), and T is read exactly once, here
@@ -544,7 +694,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       for (int t0 = TLO; t0 < THI; t0 += TB) {
       u3 eop[EOPS][C::RS][4], eopT[C::RS][4];
 #pragma unroll
-      for (int t = t0; t < t0 + TB; ++t)
+      for (int t = t0; t < t0 + TB; t += TSTEP)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int so = sb + 4 * (t + C::RS * r) * pitch;
@@ -557,7 +707,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       if (MODE == 0 && use_acc && !(ICS_MFMA_ABLATE & 8)) {
         // the image in accumulator order (ics_image_acc.h): one 16-byte load per (channel, accumulator set) instead of four 12-byte ones
 #pragma unroll
-        for (int t = t0; t < t0 + TB; ++t)
+        for (int t = t0; t < t0 + TB; t += TSTEP)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             const u4 v = EARLY ? fpre[c][t] : __builtin_amdgcn_raw_buffer_load_b128(rs_acc, acc_voff, acc_sb + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
@@ -570,7 +720,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         // the back-projection itself needs no operand: all 16 rows are stored behind the first batch of requests, in the
         // shadow of their latency (u and ut only feed the step-size reductions)
 #pragma unroll
-        for (int t = TLO; t < THI; ++t)
+        for (int t = TLO; t < THI; t += TSTEP)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int y = y0 + t + 4 * C::RS * elg + C::RS * r;
@@ -581,7 +731,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           }
       }
 #pragma unroll
-      for (int t = t0; t < t0 + TB; ++t)
+      for (int t = t0; t < t0 + TB; t += TSTEP)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int y = y0 + t + 4 * C::RS * elg + C::RS * r;
@@ -630,7 +780,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::true_type{}, tloc);
         else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{}, tloc);
       };
-      if (NH == 1 || half == 0) run_all(std::integral_constant<int, 0>{}); else run_all(std::integral_constant<int, C::RS / 2>{});
+      if (NH == 1 || half == 0) run_all(std::integral_constant<int, 0>{}); else run_all(std::integral_constant<int, C::PAIR ? 1 : C::RS / 2>{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
