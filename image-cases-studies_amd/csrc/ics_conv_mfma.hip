@@ -73,7 +73,9 @@
 #define ICS_EPI_EARLY 1       /* mode 0, 32-row tiles, accumulator-order image: request the image operand BEFORE the matrix phase (130 of 168 VGPRs in use: room for its 24) */
 #endif
 #ifndef ICS_MFMA_PAIRS
-#define ICS_MFMA_PAIRS 1   /* two-window sizes up to 33 x 33 (8-wave kernels): two kernel rows per three MFMA windows, see MCfg::PAIR */
+#define ICS_MFMA_PAIRS 2   /* two-window sizes up to 33 x 33 (8-wave kernels): two kernel rows per three MFMA windows, see MCfg::PAIR.
+                              1: the two waves of a column block split the accumulator sets (t = half, half + 2), all kernel rows each;
+                              2: they split the row pairs (items) and keep all four sets: a B fragment then serves four sets */
 #endif
 #ifndef ICS_MFMA_ALL_RS
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
@@ -156,6 +158,8 @@ struct MCfg {
   // the accumulator sets t = q - a with a EVEN only, so the two waves of a column block no longer split the kernel rows but the
   // sets: wave `half` owns t = half and half + 2 for all rows -- no exchange of partial sums, two workgroup barriers less per tile.
   static constexpr bool PAIR = ICS_MFMA_PAIRS && NH == 2 && RS == 4 && (16 + K - 1 > 32) && (16 + K - 1 <= 48);
+  static constexpr bool PAIR_SETS = PAIR && ICS_MFMA_PAIRS == 1;   // waves own accumulator sets (no exchange of partial sums)
+  static constexpr bool PAIR_ITEMS = PAIR && ICS_MFMA_PAIRS == 2;  // waves own row pairs, all four sets (partial sums exchanged as in the classic split)
   static constexpr int NQ = K + RS - 1;          // fragments per (channel, column block)
   static constexpr int XG = LCOLS / 4;           // 4-pixel groups per staged row
   static constexpr int NTASK = LROWS * XG;
@@ -627,9 +631,145 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         }
       }
     };
+    // MCfg::PAIR_ITEMS: this wave takes the items [I0, I1] (item i < NP = row pair (2i, 2i + 1), item NP = the single row K - 1) for
+    // ALL four accumulator sets.  Fragment step f serves the sets t = f mod 2 and t + 2 with the items (f - t) / 2; an item's B
+    // fragments are built once and used in the four steps f = 2i .. 2i + 3 -- half the weight-row reads and funnel shifts per
+    // MFMA of the per-set split above (which ran at the wave's issue limit: 2.8 other instructions per MFMA, 1.00 of 1.06 ms).
+    auto matrix_phase_items = [&](auto i0c, auto i1c) {
+      constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+      constexpr int NP = (K - 1) / 2;
+      typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+      typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
+      const uint32_t wbase = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256);
+      auto wof = [&](int bo, int rowadd) -> uint32_t {
+        const bool z = bo < 8 || bo > K + 14;
+        return wbase + 8u * (uint32_t)(z ? C::WZERO : ((bo - 8) >> 1)) + (z ? 0u : (uint32_t)(rowadd * 2 * C::WROWB));
+      };
+      uint32_t wk[4] = {wof(8 * lg - li + 15, 0), wof(32 + 8 * lg - li + 15, 0), wof(16 + 8 * lg - li + 15, 0),
+                        lg < 2 ? wof(32 + 8 * lg - li + 15, 0) : wof(8 * (lg - 2) - li + 15, 1)};
+      const uint32_t sh = (uint32_t)((8 * lg - li + 15) & 1) * 16u;
+      // mixed A fragment: per-lane offset from fragment f's row to (lane groups 2, 3) fragment f + 1's row, 16 columns to the left; the
+      // row distance depends on f mod 4
+      int mix[4];
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4) {
+        const int d = (C::cls_base((c4 + 1) % 4) + (c4 + 1) / 4 - C::cls_base(c4)) * C::ROWB;
+        mix[c4] = lg < 2 ? 64 : d - 32;
+        asm volatile("" : "+v"(mix[c4]));
+      }
+      constexpr int F0 = 2 * I0, F1 = 2 * I1 + 3;            // fragment steps of this wave
+#pragma unroll
+      for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
+        uint32_t wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { wb[k] = wk[k]; asm volatile("" : "+v"(wb[k])); }
+        const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
+        const unsigned char* pl = ph + C::PLANE;
+        u2 rawB[3][5];
+        h8 Bs[2][3][2];                                        // [item & 1][window][hi, lo]
+        auto issueB = [&](int item) {
+          const int a = 2 * item;
+          const int kinds[3] = {0, item < NP ? 3 : 1, 2};
+#pragma unroll
+          for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
+            const int arow = a + (w == 2 ? 1 : 0);
+            const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb[kinds[w]] + (uint32_t)((ch * K + arow) * 2 * C::WROWB));
+#pragma unroll
+            for (int d = 0; d < 5; ++d) rawB[w][d] = r[d];
+          }
+        };
+        auto finishB = [&](int item) {
+#pragma unroll
+          for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
+            const u2* d = rawB[w];
+            u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, sh), __builtin_amdgcn_alignbit(d[2].x, d[1].x, sh),
+                     __builtin_amdgcn_alignbit(d[3].x, d[2].x, sh), __builtin_amdgcn_alignbit(d[4].x, d[3].x, sh)};
+            u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, sh), __builtin_amdgcn_alignbit(d[2].y, d[1].y, sh),
+                     __builtin_amdgcn_alignbit(d[3].y, d[2].y, sh), __builtin_amdgcn_alignbit(d[4].y, d[3].y, sh)};
+            Bs[item & 1][w][0] = __builtin_bit_cast(h8, wh);
+            Bs[item & 1][w][1] = __builtin_bit_cast(h8, wl);
+          }
+        };
+        // what step f needs: a pair item for some set -> the fragment triple; the single -> windows 0 and 1 of fragment f
+        auto item_of = [](int f, int t) { return (f - t) / 2; };
+        auto active = [&](int f, int t) { return f - t >= 0 && item_of(f, t) >= I0 && item_of(f, t) <= I1; };
+        auto pair_at = [&](int f) { const int t = f & 1; return (active(f, t) && item_of(f, t) < NP) || (active(f, t + 2) && item_of(f, t + 2) < NP); };
+        auto single_at = [&](int f) { const int t = f & 1; return (active(f, t) && item_of(f, t) == NP) || (active(f, t + 2) && item_of(f, t + 2) == NP); };
+        auto loadA = [&](int f, h8 (&A)[3][2], h8 (&A1)[2]) {
+          const int off = (C::cls_base(f % 4) + f / 4) * C::ROWB;
+          const int off1 = (C::cls_base((f + 1) % 4) + (f + 1) / 4) * C::ROWB;
+          A[0][0] = *reinterpret_cast<const h8*>(ph + off); A[0][1] = *reinterpret_cast<const h8*>(pl + off);
+          if (pair_at(f)) {
+            const int m = mix[f % 4];
+            A[1][0] = *reinterpret_cast<const h8*>(ph + off + m); A[1][1] = *reinterpret_cast<const h8*>(pl + off + m);
+            A[2][0] = *reinterpret_cast<const h8*>(ph + off1 + 32); A[2][1] = *reinterpret_cast<const h8*>(pl + off1 + 32);
+          }
+          if (single_at(f)) { A1[0] = *reinterpret_cast<const h8*>(ph + off + 64); A1[1] = *reinterpret_cast<const h8*>(pl + off + 64); }
+        };
+        h8 Ac[3][2], As[2];
+        issueB(I0);
+        loadA(F0, Ac, As);
+        finishB(I0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = F0; f <= F1; ++f) {
+          h8 An[3][2], Asn[2];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { An[w][0] = Ac[w][0]; An[w][1] = Ac[w][1]; }
+          Asn[0] = As[0]; Asn[1] = As[1];
+          if (f + 1 <= F1) loadA(f + 1, An, Asn);
+          // item (f + 1) / 2 starts at the even step f + 1: its weight rows are requested here, shifted behind this step's MFMAs
+          const bool newB = ((f + 1) & 1) == 0 && (f + 1) / 2 > I0 && (f + 1) / 2 <= I1;
+          if (newB) issueB((f + 1) / 2);
+          int nm = 0;
+#pragma unroll
+          for (int term = 0; term < 3; ++term) {
+            const int ia = term == 2 ? 1 : 0, ib = term == 1 ? 1 : 0;
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              if ((ICS_MFMA_ABLATE & 64) && term == 2) continue;
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt) {
+                const int t = (f & 1) + 2 * tt;
+                if (!active(f, t)) continue;
+                const int it = item_of(f, t);
+                if (it < NP) { acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ac[w][ia], Bs[it & 1][w][ib], acc[ch][t], 0, 0, 0); ++nm; }
+                else if (w < 2) { acc[ch][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w == 0 ? Ac[0][ia] : As[ia], Bs[it & 1][w][ib], acc[ch][t], 0, 0, 0); ++nm; }
+              }
+            }
+          }
+          if (newB) finishB((f + 1) / 2);
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { Ac[w][0] = An[w][0]; Ac[w][1] = An[w][1]; }
+          As[0] = Asn[0]; As[1] = Asn[1];
+          if (ICS_MFMA_INTERLEAVE) {
+            int nr = 0, nv = 0;
+            if (f + 1 <= F1) nr += 2 + (pair_at(f + 1) ? 4 : 0) + (single_at(f + 1) ? 2 : 0);
+            if (newB) { const int nw = (f + 1) / 2 < NP ? 3 : 2; nr += 5 * nw; nv = 8 * nw; }
+            const int tail = nv ? (nm > 4 ? 4 : nm) : 0, head = nm - tail;
+#pragma unroll
+            for (int i = 0; i < (head > nr ? head : nr); ++i) {
+              if (i < head) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (i < nr) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < tail; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#pragma unroll
+              for (int j = 0; j < (nv / 2 + tail - 1) / tail; ++j) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
     const bool has_out = x0 + 16 * cb < xend;   // wave-uniform: a column block right of the output carries none
     if (has_out) {
-      if constexpr (C::PAIR) {
+      if constexpr (C::PAIR_ITEMS) {
+        constexpr int NPI = (K - 1) / 2, ISPLIT = (NPI + 1) / 2;          // items 0 .. ISPLIT - 1 | ISPLIT .. NPI (the single row included)
+        if (half == 0) matrix_phase_items(std::integral_constant<int, 0>{}, std::integral_constant<int, ISPLIT - 1>{});
+        else matrix_phase_items(std::integral_constant<int, ISPLIT>{}, std::integral_constant<int, NPI>{});
+      } else if constexpr (C::PAIR_SETS) {
         if (half == 0) matrix_phase_pairs(std::integral_constant<int, 0>{}); else matrix_phase_pairs(std::integral_constant<int, 1>{});
       } else {
         if (NH == 1) matrix_phase(std::integral_constant<int, 0>{}, std::integral_constant<int, K>{});
@@ -637,7 +777,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         else matrix_phase(std::integral_constant<int, C::KSPLIT>{}, std::integral_constant<int, K>{});
       }
     }
-    if (NH == 2 && !C::PAIR) {
+    if (NH == 2 && !C::PAIR_SETS) {
       // partial sums of the two halves: a wave keeps the accumulator sets t = 2 half, 2 half + 1 and hands the other two to its
       // partner through the plane space (free once every wave has left the matrix phase)
       lds_barrier();
@@ -683,7 +823,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       auto run_epi = [&](auto tbc, auto tvc, auto tloc) {
       // accumulator sets of this wave: all of them (NH = 1), two consecutive ones (NH = 2), or TLO and TLO + 2 (row pairs, MCfg::PAIR).
       // The loops below run over slots i = 0 .. NS - 1 <-> set TLO + i * TSTEP; written with `t` running over [TLO, THI) in steps of TSTEP.
-      constexpr int TSTEP = C::PAIR ? 2 : 1, NS = C::RS / NH;
+      constexpr int TSTEP = C::PAIR_SETS ? 2 : 1, NS = C::RS / NH;
       constexpr int TLO = decltype(tloc)::value, THI = TLO + NS * TSTEP;
       constexpr int TB = (decltype(tbc)::value < NS ? decltype(tbc)::value : NS) * TSTEP;   // sets per batch, in units of t
       constexpr bool TVOP = decltype(tvc)::value;
@@ -780,7 +920,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         if (MODE == 1 && a.tv_kind != 0) run_epi(std::integral_constant<int, 1>{}, std::true_type{}, tloc);
         else run_epi(std::integral_constant<int, ICS_EPI_TB(MODE)>{}, std::false_type{}, tloc);
       };
-      if (NH == 1 || half == 0) run_all(std::integral_constant<int, 0>{}); else run_all(std::integral_constant<int, C::PAIR ? 1 : C::RS / 2>{});
+      if (NH == 1 || half == 0) run_all(std::integral_constant<int, 0>{}); else run_all(std::integral_constant<int, C::PAIR_SETS ? 1 : C::RS / 2>{});
     }
     ICS_TICK(5);
     // (the next tile's first barrier, after the per-wave maxima, also orders this tile's fragment reads
