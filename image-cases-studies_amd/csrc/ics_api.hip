@@ -843,8 +843,8 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
       a.e = org(j, j->e);
       a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads);
       a.partial = j->partial;
-      // two persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
-      int nblocks = 2 * j->ctx->cus;
+      // as many persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
+      int nblocks = 2 * j->ctx->cus;                        // (GCfg::WGS of ics_gradk_mfma.hip)
       if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && nblocks > mw) nblocks = mw;
       const int nt_full = 16 * ((K + 15) / 16);
       const long cap = (long)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt_full * nt_full / (3L * nt * nt);

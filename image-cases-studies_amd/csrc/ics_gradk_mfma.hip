@@ -46,8 +46,12 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int NB>
 struct GCfg {
   static constexpr int TW = 64, NT = 16 * NB;        // U columns per tile; taps per axis (padded to 16 NB)
+  // (Round 4 also built 32-row tiles with eight waves and one workgroup per CU for NB = 2 -- half the barriers, staging and carried-row
+  //  moves per MFMA: 0.802 vs 0.807 ms at 6144^2 / 31 x 31 on the same box, i.e. nothing; the per-tile costs are not what bounds the
+  //  kernel, the 2.5 LDS / funnel-shift instructions per MFMA of its sliding B windows are.  Not kept.)
   static constexpr int TH = NB == 1 ? 32 : 16;       // residual rows per tile
   static constexpr int NW = 4, NTH = 64 * NW;
+  static constexpr int WGS = 2;                      // workgroups per CU
   static constexpr int UROWS = TH + NT - 1;          // 47
   static constexpr int ECOLS = TW + 16 * NB;         // E columns [x0 - 8 NB, x0 + 64 + 8 NB)
   static constexpr int UROWB = 160;                  // bytes per LDS row of U: conflict-free for the 16 descending lane rows
@@ -64,7 +68,7 @@ struct GCfg {
   static constexpr int UXG = TW / 4, EXG = ECOLS / 4;         // 4-pixel groups per staged row
   static constexpr int UTASK = UROWS * UXG, ETASK = TH * EXG;
   static constexpr int UIT = (UTASK + NTH - 1) / NTH, EIT = (ETASK + NTH - 1) / NTH;
-  static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+  static_assert(WGS * LDS_BYTES <= 160 * 1024, "workgroups per CU");
 };
 
 #define ICS_BUF_WORD3 0x00020000  /* gfx9 raw buffer: DATA_FORMAT = 32 */
@@ -90,12 +94,13 @@ __device__ __forceinline__ float wg_max(float m, float* scr, int wave, int lane)
 }
 
 // three workgroup maxima behind ONE barrier (u scale, residual scale, carried-row bound)
+template <int NW>
 __device__ __forceinline__ void wg_max3(float& a, float& b, float& c, float* scr, int wave, int lane) {
   a = ics_wave_max_f32(a); b = ics_wave_max_f32(b); c = ics_wave_max_f32(c);
   if (lane == 0) { scr[wave] = a; scr[8 + wave] = b; scr[16 + wave] = c; }
   __syncthreads();
 #pragma unroll
-  for (int w = 0; w < 4; ++w) { a = __builtin_fmaxf(a, scr[w]); b = __builtin_fmaxf(b, scr[8 + w]); c = __builtin_fmaxf(c, scr[16 + w]); }
+  for (int w = 0; w < NW; ++w) { a = __builtin_fmaxf(a, scr[w]); b = __builtin_fmaxf(b, scr[8 + w]); c = __builtin_fmaxf(c, scr[16 + w]); }
   a = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a)));
   b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b)));
   c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c)));
@@ -179,7 +184,7 @@ __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg<NB>::UIT][3], f32x4u
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
 template <int NB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gradk_mfma(IcsGradkArgs a) {
+__global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gradk_mfma(IcsGradkArgs a) {
   using C = GCfg<NB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float* fscr = reinterpret_cast<float*>(lds + C::SCR);
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int e = 0; e < 4; ++e) me = __builtin_fmaxf(me, __builtin_fabsf(pe[k][h][e]));
     __syncthreads();                       // previous tile's planes fully consumed (and fscr free)
-    wg_max3(mu, me, mc, fscr, wave, lane);
+    wg_max3<C::NW>(mu, me, mc, fscr, wave, lane);
     float s_u, inv_u, s_e, inv_e;
     pow2_scale(mu, s_u, inv_u);
     pow2_scale(me, s_e, inv_e);
@@ -303,9 +308,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         split_store(pu[k], s_u, lds + C::UOFF + row * C::UROWB + 8 * xg, C::UPLANE);
       }
     }
-    // NB = 2: TH = 16 < NT - 1 = 31, a row is carried through two tiles -- the inherited rows stem from the new rows of this
-    // tile and of the one before (all rows are new, i.e. in registers, on the first tile of a run or strip)
-    mu_prev = NB == 1 ? mc : __builtin_fmaxf(mc, carry ? mc_last : 0.f);
+    // (were TH < NT - 1, a row would be carried through two tiles: the inherited rows would stem from the new rows of this tile and
+    //  of the one before -- the 16-row tiles of the 2 x 2-block kernel until round 3)
+    mu_prev = C::TH >= C::NT - 1 ? mc : __builtin_fmaxf(mc, carry ? mc_last : 0.f);
     mc_last = mc; s_prev = s_u;
     __syncthreads();
 
@@ -327,35 +332,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ia = 0; ia < NB; ++ia)
 #pragma unroll
           for (int jb = 0; jb < NB; ++jb) acc[c][X][ia][jb] = (f4){0.f, 0.f, 0.f, 0.f};
-    // Software pipeline over the steps (residual row, channel), two steps deep (NB = 1): the LDS operands of step i + 2
-    // are requested, and the funnel shifts of step i + 1 done, in the shadows of the MFMAs of step i.  The reads are
-    // volatile: plain loads were sunk to their first use, and the wave then waited out the LDS latency in front of every
-    // group of MFMAs.
+    // Software pipeline over the steps.  NB = 1: a step is (residual row, channel) with both 32-column chunks, two steps deep -- the
+    // LDS operands of step i + 2 are requested, and the funnel shifts of step i + 1 done, in the shadows of the MFMAs of step i.
+    // NB = 2 (round 4): 12 accumulator blocks leave no registers for that, and until round 3 its operands were requested and used
+    // in the same step -- the wave waited out the LDS latency in front of every group of MFMAs (matrix pipe 41 % busy at 6144^2,
+    // 31 x 31: profiles/r04_6144_31_before_sq2.txt).  A step is now (residual row, channel, ONE chunk): the operands of step i + 1
+    // are requested in front of the 12 MFMAs of step i and shifted behind them; with single-chunk steps that costs no register
+    // more than before (A fragments double-buffered, raw B dwords single, finished B fragments double).
+    // The reads are volatile: plain loads were sunk to their first use.
     typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-    constexpr bool PIPE = NB == 1;   // NB = 2 sits at 256 registers already: operands requested and used in the same step
-    typedef typename std::conditional<PIPE, const volatile __attribute__((address_space(3))) u2*, const __attribute__((address_space(3))) u2*>::type lds_u2p;
-    typedef typename std::conditional<PIPE, const volatile __attribute__((address_space(3))) u4*, const __attribute__((address_space(3))) u4*>::type lds_u4p;
-    constexpr int NSTEP = 3 * (C::TH / C::NW);
-    constexpr int RD = PIPE ? 3 : 1, BD = PIPE ? 2 : 1;   // buffers of raw operands / of finished B fragments
-    u4 rAh[RD][NX][NB], rAl[RD][NX][NB];
-    u2 rB[RD][NX][NB][5];
-    h8 Bh[BD][NX][NB], Bl[BD][NX][NB];
+    constexpr int XS = NB == 1 ? NX : 1;                   // chunks per step
+    constexpr int NSTEP = 3 * (C::TH / C::NW) * (NX / XS);
+    constexpr int DEPTH = NB == 1 ? 2 : 1;                 // steps between request and use
+    typedef const volatile __attribute__((address_space(3))) u2* lds_u2p;
+    typedef const volatile __attribute__((address_space(3))) u4* lds_u4p;
+    constexpr int RA = DEPTH + 1, RB = DEPTH, BD = 2;      // buffers of A fragments / of raw B dwords / of finished B fragments
+    u4 rAh[RA][XS][NB], rAl[RA][XS][NB];
+    u2 rB[RB][XS][NB][5];
+    h8 Bh[BD][XS][NB], Bl[BD][XS][NB];
     auto issue = [&](int i) {
-      const int y = wave * (C::TH / C::NW) + i / 3, c = i % 3, pb = i % RD;
+      const int rc = i / (NX / XS), X0 = (i % (NX / XS)) * XS;      // (row, channel) index and first chunk of the step
+      const int y = wave * (C::TH / C::NW) + rc / 3, c = rc % 3, pa = i % RA, pb = i % RB;
       // A: U row (y + NT - 1 - a) of the staged block for tap a = 16 ia + lane row, columns 32X + 8g .. +7
       const uint32_t arow = (uint32_t)(uintptr_t)(lds_u4p)(lds + C::UOFF) + (uint32_t)((y + C::NT - 1 - li) * C::UROWB + 16 * lg);
       // B: E row y, this lane's 8 halves start at half `bo` of the segment that starts at column 32X
       const uint32_t erow = (uint32_t)(uintptr_t)(lds_u2p)(lds + C::EOFF) + (uint32_t)(y * (2 * C::EROWB) + c * (2 * C::EPLANE));
 #pragma unroll
-      for (int X = 0; X < NX; ++X) {
+      for (int X = 0; X < XS; ++X) {
 #pragma unroll
         for (int ia = 0; ia < NB; ++ia) {
-          rAh[pb][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c) * C::UPLANE + 64 * X));
-          rAl[pb][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c + 1) * C::UPLANE + 64 * X));
+          rAh[pa][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c) * C::UPLANE + 64 * (X0 + X)));
+          rAl[pa][X][ia] = *reinterpret_cast<lds_u4p>(arow - (uint32_t)(16 * ia * C::UROWB) + (uint32_t)((2 * c + 1) * C::UPLANE + 64 * (X0 + X)));
         }
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
-          const lds_u2p ep = reinterpret_cast<lds_u2p>(erow + boff[jb] + (uint32_t)(128 * X));
+          const lds_u2p ep = reinterpret_cast<lds_u2p>(erow + boff[jb] + (uint32_t)(128 * (X0 + X)));
 #pragma unroll
           for (int d = 0; d < 5; ++d) rB[pb][X][jb][d] = ep[d];
         }
@@ -364,10 +375,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // 8 halves from half `bo` of the segment: five (hi, lo) dword pairs from dword bo >> 1, funnel-shifted by the parity
     auto finish = [&](int i) {
 #pragma unroll
-      for (int X = 0; X < NX; ++X)
+      for (int X = 0; X < XS; ++X)
 #pragma unroll
         for (int jb = 0; jb < NB; ++jb) {
-          const u2* d = rB[i % RD][X][jb];
+          const u2* d = rB[i % RB][X][jb];
           const u4 wh = {__builtin_amdgcn_alignbit(d[1].x, d[0].x, bsh[jb]), __builtin_amdgcn_alignbit(d[2].x, d[1].x, bsh[jb]),
                          __builtin_amdgcn_alignbit(d[3].x, d[2].x, bsh[jb]), __builtin_amdgcn_alignbit(d[4].x, d[3].x, bsh[jb])};
           const u4 wl = {__builtin_amdgcn_alignbit(d[1].y, d[0].y, bsh[jb]), __builtin_amdgcn_alignbit(d[2].y, d[1].y, bsh[jb]),
@@ -376,25 +387,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           Bl[i % BD][X][jb] = __builtin_bit_cast(h8, wl);
         }
     };
-    if (PIPE) { issue(0); issue(1); finish(0); __builtin_amdgcn_sched_barrier(0); }
+    if (DEPTH == 2) { issue(0); issue(1); finish(0); } else { issue(0); finish(0); }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NSTEP; ++i) {
-      const int c = i % 3;
-      if (!PIPE) { issue(i); finish(i); }
-      if (PIPE && i + 1 < NSTEP) finish(i + 1);   // requested a step ago
-      if (PIPE && i + 2 < NSTEP) issue(i + 2);
+      const int c = (i / (NX / XS)) % 3, X0 = (i % (NX / XS)) * XS;
+      if (DEPTH == 2 && i + 1 < NSTEP) finish(i + 1);   // requested a step ago
+      if (i + DEPTH < NSTEP) issue(i + DEPTH);
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
-        for (int X = 0; X < NX; ++X)
+        for (int X = 0; X < XS; ++X)
 #pragma unroll
           for (int ia = 0; ia < NB; ++ia)
 #pragma unroll
             for (int jb = 0; jb < NB; ++jb) {
-              const h8 av = __builtin_bit_cast(h8, term == 2 ? rAl[i % RD][X][ia] : rAh[i % RD][X][ia]);
-              acc[c][X % AX][ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, term == 1 ? Bl[i % BD][X][jb] : Bh[i % BD][X][jb], acc[c][X % AX][ia][jb], 0, 0, 0);
+              const h8 av = __builtin_bit_cast(h8, term == 2 ? rAl[i % RA][X][ia] : rAh[i % RA][X][ia]);
+              acc[c][(X0 + X) % AX][ia][jb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, term == 1 ? Bl[i % BD][X][jb] : Bh[i % BD][X][jb], acc[c][(X0 + X) % AX][ia][jb], 0, 0, 0);
             }
-      if (PIPE) {
+      if (DEPTH == 1 && i + 1 < NSTEP) finish(i + 1);   // requested in front of this step's MFMAs
+      if (DEPTH == 2) {
         // issue order of a step: per MFMA (6) two or three of the 14 reads of step i + 2 and three of the 16 shifts of step i + 1
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -408,8 +420,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (k < 4) __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        // 12 MFMAs: the 14 reads of step i + 1 behind the first seven (two each), its 16 shifts behind the last four (four each)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i + 1 < NSTEP) {
+            if (k < 7) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (k >= 8) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     const float sc = inv_u * inv_e;   // powers of two
 #pragma unroll

@@ -24,5 +24,6 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ
 ICS_FUSED_GRADK=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch2k -- python3 $SHORT > /dev/null 2>&1
 for d in kt fetch write sq1 sq2 sq3 fetch2k; do f=$(find $O/$d -name "*.db" | head -1); python3 $R/scripts/rocprof_summary.py $f > $O/$d.txt 2>&1; done
 python3 $R/scripts/make_traffic_json.py $O/fetch.txt $O/write.txt $O/fetch2k.txt --size 4096 --psf 15 > $O/hbm_traffic.json
+python3 $R/scripts/make_mfma_json.py $O/sq2.txt $O/sq3.txt --size 4096 --psf 15 > $O/mfma_counters.json
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete
 tail -1 $O/bench_blind.json | cut -c1-300; head -12 $O/kt.txt; cat $O/hbm_traffic.json | head -60

@@ -18,5 +18,6 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_WAVES -d $O/sq2 -- python3 $SHORT > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_LDS SQ_ACTIVE_INST_MISC SQ_LDS_DATA_FIFO_FULL -d $O/sq3 -- python3 $SHORT > /dev/null 2>&1
 for d in kt fetch write sq1 sq2 sq3; do f=$(find $O/$d -name "*.db" | head -1); python3 $R/scripts/rocprof_summary.py $f > $O/$d.txt 2>&1; done
+python3 $R/scripts/make_mfma_json.py $O/sq2.txt $O/sq3.txt --size $SIZE --psf $PSF > $O/mfma_counters.json
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +200k -delete
 tail -1 $O/bench.json | cut -c1-400; head -14 $O/kt.txt
