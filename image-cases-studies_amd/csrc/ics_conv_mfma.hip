@@ -77,6 +77,9 @@
                               1: the two waves of a column block split the accumulator sets (t = half, half + 2), all kernel rows each;
                               2: they split the row pairs (items) and keep all four sets: a B fragment then serves four sets */
 #endif
+#ifndef ICS_MFMA_WSPLIT
+#define ICS_MFMA_WSPLIT 1   /* see MCfg::WSPLIT */
+#endif
 #ifndef ICS_MFMA_ALL_RS
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
 #endif
@@ -145,7 +148,15 @@ struct MCfg {
   static constexpr int WROWB = (2 * (K + 17) + 3) & ~3;
   static constexpr int WZERO = (K + 7) / 2;      // first all-zero dword of a row
   static constexpr int WLDS = 3 * K * 2 * WROWB; // = the global weight table built by k_psf (ics_common.h), copied verbatim
-  static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS;
+  // PAIR_ITEMS, where the LDS has room (K <= 31): the weight rows are kept as FOUR plain rows per (channel, kernel row) instead of
+  // one hi / lo dword-interleaved row -- hi and lo, each once as it is and once moved up by one half.  A lane then finds its 8
+  // consecutive halves dword-aligned in the copy of its parity and reads them with two 4-byte-aligned 8-byte loads per split term
+  // (ds_read2_b32) straight into the MFMA operand registers: 4 LDS instructions and no funnel shift per B fragment instead of
+  // 5 + 8 (the pair loops run at the wave's issue limit: 2.5 other instructions per MFMA, profiles/r04_6144_31_mfma_counters.json).
+  static constexpr bool WSPLIT_WANTED = ICS_MFMA_PAIRS == 2 && ICS_MFMA_WSPLIT && NH_ == 2 && RS_ == 4 && (16 + K - 1 > 32) && (16 + K - 1 <= 48);
+  static constexpr bool WSPLIT = WSPLIT_WANTED && (size_t)SCRATCH + 256 + 2 * WLDS <= 160 * 1024;
+  static constexpr int WLDS_USED = WSPLIT ? 2 * WLDS : WLDS;
+  static constexpr size_t LDS_BYTES = SCRATCH + 256 + WLDS_USED;
   static constexpr int WGS_CAP = RS == 4 ? 2 : 3;                      // register budget: 256 / 168 VGPRs
   static constexpr int WGS = (160 * 1024 / LDS_BYTES) < WGS_CAP ? (160 * 1024 / LDS_BYTES) : WGS_CAP;   // workgroups (of 4 waves) per CU
   // Row pairs (round 4).  With two windows a kernel row costs 2 x 32 columns of MFMA depth for its 16 + K - 1 <= 48 input columns,
@@ -251,7 +262,21 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   {
     uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::SCRATCH + 256);
     const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
-    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+    if constexpr (C::WSPLIT) {
+      // [c][a] blocks of four rows of RD dwords: hi, lo, hi moved up one half, lo moved up one half (source: hi dword d at 2d, lo at 2d + 1)
+      constexpr int RD = C::WROWB / 4;
+      for (int i = tid; i < 3 * K * RD; i += C::NT) {
+        const int ca = i / RD, d = i - ca * RD;
+        const uint32_t* src = tab + ca * 2 * RD;
+        const uint32_t h0 = src[2 * d], l0 = src[2 * d + 1];
+        const uint32_t h1 = d + 1 < RD ? src[2 * d + 2] : 0u, l1 = d + 1 < RD ? src[2 * d + 3] : 0u;
+        uint32_t* dst = ldsW + ca * 4 * RD + d;
+        dst[0] = h0; dst[RD] = l0;
+        dst[2 * RD] = __builtin_amdgcn_alignbit(h1, h0, 16); dst[3 * RD] = __builtin_amdgcn_alignbit(l1, l0, 16);
+      }
+    } else {
+      for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+    }
   }
   // lane constants of the B operand: in window h this lane's 8 consecutive halves start at half
   // bo = 32h + 8*lg - li + 15 of the zero-padded row; it reads the five dwords that contain them and funnel-shifts
@@ -643,20 +668,20 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       const uint32_t wbase = (uint32_t)(uintptr_t)(lds_u32p)(lds + C::SCRATCH + 256);
       auto wof = [&](int bo, int rowadd) -> uint32_t {
         const bool z = bo < 8 || bo > K + 14;
-        return wbase + 8u * (uint32_t)(z ? C::WZERO : ((bo - 8) >> 1)) + (z ? 0u : (uint32_t)(rowadd * 2 * C::WROWB));
+        if constexpr (C::WSPLIT)   // byte address of the first of the lane's four hi dwords: copy of its parity, dword (bo - 8 - parity) / 2
+          return wbase + 4u * (uint32_t)(z ? C::WZERO : ((bo & 1) * 2 * (C::WROWB / 4) + ((bo - 8 - (bo & 1)) >> 1))) + (z ? 0u : (uint32_t)(rowadd * 4 * C::WROWB));
+        else
+          return wbase + 8u * (uint32_t)(z ? C::WZERO : ((bo - 8) >> 1)) + (z ? 0u : (uint32_t)(rowadd * 2 * C::WROWB));
       };
       uint32_t wk[4] = {wof(8 * lg - li + 15, 0), wof(32 + 8 * lg - li + 15, 0), wof(16 + 8 * lg - li + 15, 0),
                         lg < 2 ? wof(32 + 8 * lg - li + 15, 0) : wof(8 * (lg - 2) - li + 15, 1)};
       const uint32_t sh = (uint32_t)((8 * lg - li + 15) & 1) * 16u;
       // mixed A fragment: per-lane offset from fragment f's row to (lane groups 2, 3) fragment f + 1's row, 16 columns to the left; the
       // row distance depends on f mod 4
-      int mix[4];
-#pragma unroll
-      for (int c4 = 0; c4 < 4; ++c4) {
-        const int d = (C::cls_base((c4 + 1) % 4) + (c4 + 1) / 4 - C::cls_base(c4)) * C::ROWB;
-        mix[c4] = lg < 2 ? 64 : d - 32;
-        asm volatile("" : "+v"(mix[c4]));
-      }
+      // (one lane mask and a constant per f mod 4 instead of four per-lane offsets: three registers less in a 256-register kernel)
+      int mixsel = lg < 2 ? 0 : -1;
+      asm volatile("" : "+v"(mixsel));
+      auto mixoff = [&](int c4) { return 64 + (mixsel & ((C::cls_base((c4 + 1) % 4) + (c4 + 1) / 4 - C::cls_base(c4)) * C::ROWB - 96)); };
       constexpr int F0 = 2 * I0, F1 = 2 * I1 + 3;            // fragment steps of this wave
 #pragma unroll
       for (int ch = 0; ch < ((ICS_MFMA_ABLATE & 1) ? 0 : 3); ++ch) {
@@ -666,19 +691,42 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         const unsigned char* ph = base_h + (2 * ch) * C::PLANE;
         const unsigned char* pl = ph + C::PLANE;
         u2 rawB[3][5];
+        h8 Bn[3][2];                                           // (WSPLIT) the fragments just requested
         h8 Bs[2][3][2];                                        // [item & 1][window][hi, lo]
+        typedef const __attribute__((address_space(3), aligned(4))) u2* lds_u2a4p;   // 8 bytes at 4-byte alignment: ds_read2_b32
         auto issueB = [&](int item) {
           const int a = 2 * item;
           const int kinds[3] = {0, item < NP ? 3 : 1, 2};
 #pragma unroll
           for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
             const int arow = a + (w == 2 ? 1 : 0);
-            const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb[kinds[w]] + (uint32_t)((ch * K + arow) * 2 * C::WROWB));
+            if constexpr (C::WSPLIT) {
+              // (as C++ loads the four 8-byte reads were merged into ds_read2_b64 at 4-byte alignment -- legal in the unaligned access mode
+              //  of gfx950 and 2.8x slower for the whole kernel; ds_read2_b32 is what the alignment allows.  Inline asm results are not
+              //  tracked by the compiler's s_waitcnt insertion: finishB() waits for them)
+              const uint32_t ad = wb[kinds[w]] + (uint32_t)((ch * K + arow) * 4 * C::WROWB);
+              constexpr int RD = C::WROWB / 4;
+              u2 h01, h23, l01, l23;
+              asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(h01) : "v"(ad));
+              asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(h23) : "v"(ad));
+              asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(l01) : "v"(ad), "n"(RD), "n"(RD + 1));
+              asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(l23) : "v"(ad), "n"(RD + 2), "n"(RD + 3));
+              Bn[w][0] = __builtin_bit_cast(h8, (u4){h01.x, h01.y, h23.x, h23.y});   // (into fresh registers: the slot of this item is
+              Bn[w][1] = __builtin_bit_cast(h8, (u4){l01.x, l01.y, l23.x, l23.y});   //  still read by the MFMAs of the step that requests it)
+            } else {
+              const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb[kinds[w]] + (uint32_t)((ch * K + arow) * 2 * C::WROWB));
 #pragma unroll
-            for (int d = 0; d < 5; ++d) rawB[w][d] = r[d];
+              for (int d = 0; d < 5; ++d) rawB[w][d] = r[d];
+            }
           }
         };
         auto finishB = [&](int item) {
+          if constexpr (C::WSPLIT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int w = 0; w < 3; ++w) { Bs[item & 1][w][0] = Bn[w][0]; Bs[item & 1][w][1] = Bn[w][1]; }
+            return;
+          }
 #pragma unroll
           for (int w = 0; w < (item < NP ? 3 : 2); ++w) {
             const u2* d = rawB[w];
@@ -700,7 +748,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           const int off1 = (C::cls_base((f + 1) % 4) + (f + 1) / 4) * C::ROWB;
           A[0][0] = *reinterpret_cast<const h8*>(ph + off); A[0][1] = *reinterpret_cast<const h8*>(pl + off);
           if (pair_at(f)) {
-            const int m = mix[f % 4];
+            const int m = mixoff(f % 4);
             A[1][0] = *reinterpret_cast<const h8*>(ph + off + m); A[1][1] = *reinterpret_cast<const h8*>(pl + off + m);
             A[2][0] = *reinterpret_cast<const h8*>(ph + off1 + 32); A[2][1] = *reinterpret_cast<const h8*>(pl + off1 + 32);
           }
@@ -745,7 +793,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           if (ICS_MFMA_INTERLEAVE) {
             int nr = 0, nv = 0;
             if (f + 1 <= F1) nr += 2 + (pair_at(f + 1) ? 4 : 0) + (single_at(f + 1) ? 2 : 0);
-            if (newB) { const int nw = (f + 1) / 2 < NP ? 3 : 2; nr += 5 * nw; nv = 8 * nw; }
+            if (newB) { const int nw = (f + 1) / 2 < NP ? 3 : 2; nr += (C::WSPLIT ? 4 : 5) * nw; nv = C::WSPLIT ? 0 : 8 * nw; }
             const int tail = nv ? (nm > 4 ? 4 : nm) : 0, head = nm - tail;
 #pragma unroll
             for (int i = 0; i < (head > nr ? head : nr); ++i) {
