@@ -136,6 +136,7 @@ struct ics_rl {
   bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   float* psf_work;                      // PSF sizes above 63: working copy of k_psf (3*K*K floats), else NULL
+  double* gradk64;                      // row bands over several ranks: the gradient sums as float64 for the cross-rank all-reduce (first use)
   // PSF sizes 51 ... 127 on the matrix cores as nblk x nblk tap blocks of Kb x Kb (do_conv_blocks): weight tables of both
   // orientations, a scratch frame for the block results, a frame of zeros (the image operand of the blocks after the first)
   int blk_n, blk_kb;
@@ -297,7 +298,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
-                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights};
+                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64};
   for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -670,6 +671,29 @@ struct Prof {
 };
 
 #define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
+
+// ---- row bands over several ranks: the two per-iteration reductions, in place on the device (lib/banded.py rank mode) -----------
+int ics_group_allreduce_device(ics_group* g, void* buf, size_t count, int kind, hipStream_t stream);   // ics_group.hip
+int ics_group_info_local(const ics_group* g);
+extern "C" int ics_rl_allreduce_keys(ics_rl* j, ics_group* g) {
+  if (!j || !g) return fail(ICS_EINVAL, "NULL argument");
+  HIPCHK(hipSetDevice(j->ctx->device));
+  return ics_group_allreduce_device(g, j->red, 6, 0, j->ctx->stream);      // slot 0: [0..2] max|g_k|, [3..5] max u_k
+}
+extern "C" int ics_rl_allreduce_gradk(ics_rl* j, ics_group* g) {
+  if (!j || !g) return fail(ICS_EINVAL, "NULL argument");
+  int rank = 0, world = 1;
+  RC(ics_group_info(g, &rank, &world));
+  if (world == 1 && ics_group_info_local(g)) return ICS_OK;
+  HIPCHK(hipSetDevice(j->ctx->device));
+  const size_t n = (size_t)3 * j->g.K * j->g.K;
+  if (!j->gradk64) RC(dalloc(j->ctx, &j->gradk64, n, false));
+  HIPCHK(ics_launch_f32_to_f64(j->gradk, j->gradk64, (long)n, j->ctx->stream));
+  RC(ics_group_allreduce_device(g, j->gradk64, n, 1, j->ctx->stream));
+  HIPCHK(ics_launch_f64_to_f32(j->gradk64, j->gradk, (long)n, j->ctx->stream));
+  return ICS_OK;
+}
+
 
 // ICS_CONV_AUTO: matrix-core kernels where they exist and win (ics_conv_mfma_preferred); env ICS_CONV_PATH=vector|matrix
 // overrides AUTO

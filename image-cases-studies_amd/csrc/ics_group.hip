@@ -18,7 +18,7 @@
 namespace {
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void* rcclComm_t;
-enum { RCCL_SUCCESS = 0, RCCL_SUM = 0, RCCL_MAX = 2, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8 };
+enum { RCCL_SUCCESS = 0, RCCL_SUM = 0, RCCL_MAX = 2, RCCL_UINT32 = 3, RCCL_FLOAT32 = 7, RCCL_FLOAT64 = 8 };
 struct Rccl {
   void* so;
   int (*GetUniqueId)(rcclUniqueId*);
@@ -47,7 +47,7 @@ struct ics_group {
   hipStream_t stream;
   double* dbuf;      // device staging: (world + 1) * ICS_GROUP_MAX_COUNT doubles
 };
-#define ICS_GROUP_MAX_COUNT 64
+#define ICS_GROUP_MAX_COUNT 49152   /* doubles per call: >= 3 * 127^2, the PSF-gradient sums of the largest PSF in ONE all-reduce */
 
 static int load_rccl() {
   if (g_rccl.so) return ICS_OK;
@@ -203,7 +203,7 @@ static int allreduce(ics_group* g, double* inout, int count, int op) {
   return ICS_OK;
 }
 extern "C" int ics_group_allreduce_max(ics_group* g, double* inout, int count) { return allreduce(g, inout, count, RCCL_MAX); }
-// (the row-band split adds the bands' 3 K^2 PSF-gradient partial sums with it, in chunks of 64)
+// (host arrays; the row-band split's per-iteration collectives run in place on device buffers: ics_group_allreduce_device)
 extern "C" int ics_group_allreduce_sum(ics_group* g, double* inout, int count) { return allreduce(g, inout, count, RCCL_SUM); }
 
 extern "C" int ics_group_describe(const ics_group* g, int* backend, int* nranks, char* lib, size_t lib_len) {
@@ -233,6 +233,19 @@ int ics_group_sendrecv_device(ics_group* g, const float* send, size_t send_count
   GHIP(hipStreamSynchronize(g->stream));
   return ICS_OK;
 }
+
+// In-place all-reduce of a DEVICE buffer on the caller's stream (no staging, no host synchronisation): the step-size keys and the
+// PSF-gradient sums of the row-band split (ics_rl_allreduce_keys / ics_rl_allreduce_gradk in ics_api.hip).  kind: 0 = uint32 max,
+// 1 = float64 sum.  A local one-rank group has nothing to do.
+int ics_group_allreduce_device(ics_group* g, void* buf, size_t count, int kind, hipStream_t stream) {
+  if (!g || !buf) return ics_set_error(ICS_EINVAL, "NULL argument");
+  if (g->local) return ICS_OK;
+  GHIP(hipSetDevice(g->device));
+  GRCCL(g_rccl.AllReduce(buf, buf, count, kind == 0 ? RCCL_UINT32 : RCCL_FLOAT64, kind == 0 ? RCCL_MAX : RCCL_SUM, g->comm, stream));
+  return ICS_OK;
+}
+
+int ics_group_info_local(const ics_group* g) { return g && g->local ? 1 : 0; }
 
 // all ranks have reached this call (an all-reduce of one double)
 extern "C" int ics_group_barrier(ics_group* g) {

@@ -153,6 +153,8 @@ def load():
     lib.ics_group_allreduce_sum.argtypes = [vp, vp, ci]
     lib.ics_group_describe.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.c_char_p, C.c_size_t]
     lib.ics_rl_exchange_rows.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci]; lib.ics_rl_exchange_rows.restype = ci
+    lib.ics_rl_allreduce_keys.argtypes = [vp, vp]; lib.ics_rl_allreduce_keys.restype = ci
+    lib.ics_rl_allreduce_gradk.argtypes = [vp, vp]; lib.ics_rl_allreduce_gradk.restype = ci
     lib.ics_rl_params_size.restype = C.c_size_t
     lib.ics_rl_stats_size.restype = C.c_size_t
     lib.ics_debug_set.argtypes = [C.c_char_p, ci]; lib.ics_debug_set.restype = ci      # csrc/ics_common.h IcsDebug, not in the public header

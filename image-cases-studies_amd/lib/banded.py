@@ -208,9 +208,9 @@ class BandRank:
     """One rank's share of a row-band split with ONE PROCESS PER BAND (one rank per GPU; `group` = multi_gpu.Group): rank r owns
     band r of `group.size` bands.  What crosses bands goes through the group -- RCCL over xGMI on a multi-GPU node, the CPU
     stand-in where ranks share a GPU:
-      1. the six step-size keys: `group.max_many` (ics_group_allreduce_max) -- order-preserving uint32 keys are exact in float64;
+      1. the six step-size keys: `group.reduce_band_keys` (ics_rl_allreduce_keys: ncclMax on the uint32 keys, in place on the device);
       2. the halo rows: `group.exchange_rows` (ncclSend / ncclRecv between the band jobs' device frames), both directions;
-      3. blind: the 3 MK^2 PSF-gradient partial sums: `group.sum_many` (ics_group_allreduce_sum, float64);
+      3. blind: the 3 MK^2 PSF-gradient partial sums: `group.reduce_band_gradk` (ics_rl_allreduce_gradk: one float64 ncclSum on the device);
       4. the stop-test window: its rows travel to rank 0, which holds the statistics job; the scalars come back with `gather`.
     upload() once, run() as often as wanted on the resident frames (bench.py --bands times run() alone), download() the owned rows."""
 
@@ -300,8 +300,7 @@ class BandRank:
                 job.stage(nv.STAGE_SYNTH_RESIDUAL, P())                                   # A1 + A2
                 job.stage(nv.STAGE_BACKPROJECT, P())                                      # A3
                 job.stage(nv.STAGE_BAND_REDUCE, P(band_rows=(bd.lu0, bd.lu1)))
-                keys = group.max_many([float(k) for k in job.red_keys()[:6]])             # (1)
-                job.set_red_keys(np.array(keys, np.float64).astype(np.uint32))
+                group.reduce_band_keys(job)                                               # (1) in place on the device (RCCL), no host hop
                 job.stage(nv.STAGE_UPDATE, P())                                           # A5 - A10
                 # (2) my first 2 pad owned rows go up, the rows below my owned ones arrive from below; then the other way round
                 up = None if bd.first else (bd.lu0, 2 * pad, R - 1)
@@ -315,8 +314,7 @@ class BandRank:
                         sc = self._statistics()                                           # A18 + A19 need the unmasked residual
                     job.stage(nv.STAGE_BAND_MASK_E, P(band_rows=(bd.y0 - bd.a, bd.y1 - bd.a)))
                     job.stage(nv.STAGE_PSF_GRADIENT, P())                                 # A12 + A13 over the owned rows
-                    gk = np.array(group.sum_many(job.read(nv.BUF_GRADK).astype(np.float64).ravel()), np.float64)   # (3)
-                    job.write(nv.BUF_GRADK, gk.astype(np.float32).reshape(self.MK, self.MK, 3))
+                    group.reduce_band_gradk(job)                                          # (3) one float64 all-reduce on the device
                     job.stage(nv.STAGE_PSF_UPDATE, P())                                   # A14 - A17
                 elif itt == INNER - 1:
                     sc = self._statistics()

@@ -176,8 +176,8 @@ class Group:
         if self._h is not None:
             fn = self._lib.ics_group_allreduce_max if op == "max" else self._lib.ics_group_allreduce_sum
             out = []
-            for i in range(0, len(vals), 64):                    # ICS_GROUP_MAX_COUNT doubles per call
-                chunk = vals[i:i + 64]
+            for i in range(0, len(vals), 49152):                 # ICS_GROUP_MAX_COUNT doubles per call (3 x 127^2 fits in one)
+                chunk = vals[i:i + 49152]
                 x = (C.c_double * len(chunk))(*chunk)
                 self._check(fn(self._h, x, len(chunk)))
                 out.extend(x)
@@ -213,6 +213,32 @@ class Group:
             self.dist.all_gather(out, t)
             return [o.tolist() for o in out]
         return [vals]
+
+    def reduce_band_keys(self, job):
+        """max over the ranks of the six step-size keys of a band job (ICS_BUF_RED [0..5]).  RCCL group (or one local rank): in place on
+        the device buffer, on the job's stream, no host round trip (ics_rl_allreduce_keys); CPU stand-in: through the host."""
+        if self._h is not None:
+            self._check(self._lib.ics_rl_allreduce_keys(job._h, self._h))
+            return
+        if self.dist is None:
+            return
+        import numpy as np
+        keys = self.max_many([float(k) for k in job.red_keys()[:6]])        # (order-preserving uint32 keys are exact in float64)
+        job.set_red_keys(np.array(keys, np.float64).astype(np.uint32))
+
+    def reduce_band_gradk(self, job):
+        """sum over the ranks of a band job's PSF-gradient (ICS_BUF_GRADK), float64 across the ranks, rounded to float32 once
+        (ics_rl_allreduce_gradk: one in-place RCCL call on the device); CPU stand-in: through the host."""
+        if self._h is not None:
+            self._check(self._lib.ics_rl_allreduce_gradk(job._h, self._h))
+            return
+        if self.dist is None:
+            return
+        import numpy as np
+        from lib import _native
+        gk = job.read(_native.BUF_GRADK)
+        tot = np.array(self.sum_many(gk.astype(np.float64).ravel()), np.float64)
+        job.write(_native.BUF_GRADK, tot.astype(np.float32).reshape(gk.shape))
 
     def exchange_rows(self, job, which, send=None, recv=None):
         """Point-to-point rows of frame buffer `which` between band jobs on different ranks (lib/banded.py rank mode):

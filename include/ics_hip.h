@@ -332,7 +332,7 @@ int ics_rl_download_img(ics_rl *job, ics_img *dst, int y, int x);
  * is the gather of a small per-rank record at the end -- RCCL over xGMI, called directly from this library (librccl.so
  * is dlopen'ed by ics_group_create when world > 1).  `rendezvous` is a file path shared by the ranks of the node: rank
  * 0 publishes the RCCL unique id there, the others wait up to `timeout_s` seconds for it.  With world == 1 every call
- * is a local no-op / copy and no device is touched.  count <= 64 doubles per call. */
+ * is a local no-op / copy and no device is touched.  count <= 49152 doubles per call (3 x 127^2 fits). */
 typedef struct ics_group ics_group;
 int ics_group_create(int device, int rank, int world, const char *rendezvous, int timeout_s, ics_group **out);
 void ics_group_destroy(ics_group *g);
@@ -349,6 +349,14 @@ int ics_group_allgather(ics_group *g, const double *send, int count, double *rec
  * < 0 switches that side off): RCCL point-to-point over xGMI between the two jobs' device frames, both directions in one group
  * call so that neighbours exchanging halos cannot deadlock.  Synchronous: returns when the rows are in place. */
 int ics_rl_exchange_rows(ics_rl *job, ics_group *g, int which, int send_row0, int send_rows, int send_peer, int recv_row0, int recv_rows, int recv_peer);
+/* The two per-iteration reductions of the row-band split, IN PLACE on the band job's device buffers and on the job's own stream -- one
+ * RCCL call each, no host staging, no synchronisation (round 3 moved them through the host in chunks of 64 doubles):
+ *   ics_rl_allreduce_keys   the six step-size keys of ICS_BUF_RED [0..5] (order-preserving uint32 keys: ncclMax on ncclUint32 is exact);
+ *   ics_rl_allreduce_gradk  the 3 MK^2 PSF-gradient sums of ICS_BUF_GRADK: widened to float64 on the device, summed over the ranks
+ *                           (ncclSum, float64), rounded to float32 once.
+ * With a one-rank local group both return at once. */
+int ics_rl_allreduce_keys(ics_rl *job, ics_group *g);
+int ics_rl_allreduce_gradk(ics_rl *job, ics_group *g);
 
 #ifdef __cplusplus
 }

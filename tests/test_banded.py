@@ -241,3 +241,46 @@ def test_rccl_row_exchange_with_a_one_rank_communicator(tmp_path):
     """ % (os.path.join(ROOT, "image-cases-studies_amd"), str(tmp_path / "rdzv")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICS_GROUP_FORCE_RCCL="1"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "EXCHANGE-OK" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_rccl_in_place_band_reductions_with_a_one_rank_communicator(tmp_path):
+    """ics_rl_allreduce_keys / ics_rl_allreduce_gradk over RCCL itself (ncclAllReduce on the band job's DEVICE buffers, on the job's
+    stream: ncclMax on the six uint32 keys, ncclSum in float64 on the 3 MK^2 gradient sums): with the one rank a single-GPU box allows,
+    both must leave their buffers exactly as they were (max / sum over one rank), and whatever is queued behind them on the job's stream
+    must see them done.  ADVICE round 3: these steps went through the host in chunks of 64 doubles, 46 collectives per inner iteration
+    at 31 x 31."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import ctypes as C, os, sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from lib import _native as nv
+        lib = nv.load()
+        h = C.c_void_p()
+        assert lib.ics_group_create(0, 0, 1, %r.encode(), 30, C.byref(h)) == 0, lib.ics_last_error()
+        MK = 31
+        job = nv.RLJob(70, 64, MK)
+        rng = np.random.default_rng(0)
+        gk = (rng.standard_normal((MK, MK, 3)) * 1e-3).astype(np.float32)
+        job.write(nv.BUF_GRADK, gk)
+        keys = np.array([0x80000001, 0xBF800000, 7, 0xC0000000, 0x3F800000, 0xFFC00000], np.uint32)
+        job.set_red_keys(keys)
+        for _ in range(3):
+            assert lib.ics_rl_allreduce_keys(job._h, h) == 0, lib.ics_last_error()
+            assert lib.ics_rl_allreduce_gradk(job._h, h) == 0, lib.ics_last_error()
+        assert np.array_equal(job.read(nv.BUF_GRADK), gk)                 # float32 -> float64 -> sum over one rank -> float32: exact
+        assert np.array_equal(job.red_keys()[:6], keys)
+        # 3 * 127^2 doubles in ONE host-array all-reduce (the staging buffer held 64 until round 3)
+        big = (C.c_double * (3 * 127 * 127))(*range(3 * 127 * 127))
+        assert lib.ics_group_allreduce_sum(h, big, 3 * 127 * 127) == 0, lib.ics_last_error()
+        assert big[12345] == 12345.0
+        lib.ics_group_destroy(h); job.close()
+        print("REDUCE-OK")
+    """ % (os.path.join(ROOT, "image-cases-studies_amd"), str(tmp_path / "rdzv")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ICS_GROUP_FORCE_RCCL="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "REDUCE-OK" in out.stdout, out.stderr[-3000:]

@@ -140,7 +140,7 @@ def test_native_group_single_rank_needs_no_device_and_validates_arguments():
     assert lib.ics_group_barrier(h) == 0
     r, w = C.c_int(-1), C.c_int(-1)
     assert lib.ics_group_info(h, C.byref(r), C.byref(w)) == 0 and (r.value, w.value) == (0, 1)
-    assert lib.ics_group_allgather(h, send, 65, recv) == _native.ICS_EINVAL
+    assert lib.ics_group_allgather(h, send, 49153, recv) == _native.ICS_EINVAL      # (the staging buffer holds 49152 doubles: 3 x 127^2 fits)
     lib.ics_group_destroy(h)
     assert lib.ics_group_create(0, 2, 2, b"/tmp/x", 1, C.byref(h)) == _native.ICS_EINVAL       # rank out of range
     assert lib.ics_group_create(0, 1, 2, None, 1, C.byref(h)) == _native.ICS_EINVAL            # no rendezvous path
