@@ -107,6 +107,9 @@ struct ics_ctx {
   // small pinned staging area for host -> device parameters of queued operations (the Gaussian weights of ics_img_resize): the copy
   // reads it asynchronously, `pin_ev` marks the last copy, the next writer waits for it (long done in practice) -- no stream
   // synchronisation per operation
+  // second stream: the stop-test statistics of outer iteration i run here while the job's stream already works on iteration i + 1
+  // (ics_rl_run, "overlap"; the events that order the two streams belong to the job)
+  hipStream_t stream2 = nullptr;
   double* pin = nullptr;
   hipEvent_t pin_ev = nullptr;
   bool pin_used = false;
@@ -136,6 +139,12 @@ struct ics_rl {
   bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
   float* psf_work;                      // PSF sizes above 63: working copy of k_psf (3*K*K floats), else NULL
+  // overlap of the statistics with the next outer iteration: the reduction slots / DoF keys of outer iteration i are the set i & 1
+  // (`par`; the stage API always uses set 0), the residual frame ping-pongs with e2, the PSF of the last finished iteration is kept
+  int par;
+  hipEvent_t ev_body[2], ev_stats[2];   // [i & 1]: iteration i's kernels are done / its scalars are on the host (created with e2)
+  float* e2;                            // second residual frame (first overlapped run)
+  float* psf_bak;                       // psf + psf_caller as they were when the running outer iteration started (blind, overlapped)
   double* gradk64;                      // row bands over several ranks: the gradient sums as float64 for the cross-rank all-reduce (first use)
   // PSF sizes 51 ... 127 on the matrix cores as nblk x nblk tap blocks of Kb x Kb (do_conv_blocks): weight tables of both
   // orientations, a scratch frame for the block results, a frame of zeros (the image operand of the blocks after the first)
@@ -176,6 +185,8 @@ static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
 // majoriser frame: pyx:462 `ut = u.copy()` is realised without a copy -- until the first update of the outer
 // iteration ut IS u; that update writes out of place and the old u frame becomes ut (buffer rotation)
 static inline float* ut_of(ics_rl* j) { return j->ut_is_u ? j->u : j->ut; }
+static inline uint32_t* red_of(ics_rl* j) { return j->red + (size_t)j->par * 8 * ICS_RED_STRIDE; }
+static inline uint32_t* dof_of(ics_rl* j) { return j->dofkeys + 4 * j->par; }
 
 // -------------------------------------------------------------------------------------------------
 extern "C" int ics_abi_version(void) { return ICS_ABI_VERSION; }
@@ -190,7 +201,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -201,7 +212,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -255,6 +266,7 @@ extern "C" void ics_ctx_destroy(ics_ctx* c) {
   c->pool.clear();
   if (c->pin) hipHostFree(c->pin);
   if (c->pin_ev) hipEventDestroy(c->pin_ev);
+  if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
   hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
   hipStreamDestroy(c->stream);
   delete c;
@@ -298,9 +310,11 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
-                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64};
+                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64, j->e2, j->psf_bak};
   for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
+  if (j->ctx->stream2) hipStreamSynchronize(j->ctx->stream2);
+  for (int i = 0; i < 2; ++i) { if (j->ev_body[i]) hipEventDestroy(j->ev_body[i]); if (j->ev_stats[i]) hipEventDestroy(j->ev_stats[i]); }
   if (j->h_scal) hipHostFree(j->h_scal);
   for (hipEvent_t e : j->ev) hipEventDestroy(e);
   if (j->ev_begin) hipEventDestroy(j->ev_begin);
@@ -349,10 +363,10 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow));
   if (ics_conv_mfma_supported(MK)) { TRY(dalloc(c, &j->bt_conv, ics_conv_mfma_table_floats(MK))); TRY(dalloc(c, &j->bt_corr, ics_conv_mfma_table_floats(MK))); }
   TRY(dalloc(c, &j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt));
-  TRY(dalloc(c, &j->red, (size_t)8 * ICS_RED_STRIDE)); TRY(dalloc(c, &j->dofkeys, (size_t)4)); TRY(dalloc(c, &j->sched, (size_t)16));
+  TRY(dalloc(c, &j->red, (size_t)2 * 8 * ICS_RED_STRIDE)); TRY(dalloc(c, &j->dofkeys, (size_t)2 * 4)); TRY(dalloc(c, &j->sched, (size_t)16));   // (two sets: ics_rl::par)
   TRY(dalloc(c, &j->scal, (size_t)ICS_SC_COUNT)); TRY(dalloc(c, &j->dacc, (size_t)8)); TRY(dalloc(c, &j->ukey, (size_t)2)); TRY(dalloc(c, &j->flags, (size_t)4));
 #undef TRY
-  hipError_t e = hipHostMalloc((void**)&j->h_scal, (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);
+  hipError_t e = hipHostMalloc((void**)&j->h_scal, 2 * (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);   // (one mirror per set)
   if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
   hipEventCreate(&j->ev_begin); hipEventCreate(&j->ev_end);
   e = hipStreamSynchronize(s);
@@ -641,6 +655,8 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
 // ---- launch helpers with optional event bracketing -----------------------------------------------
 struct Prof {
   ics_rl* j; bool on;
+  hipStream_t s = nullptr;              // nullptr: the job's stream
+  hipStream_t st() const { return s ? s : j->ctx->stream; }
   int begin(int cls) {
     if (!on) return ICS_OK;
     if (j->ev_used + 2 > j->ev.size()) {
@@ -648,12 +664,12 @@ struct Prof {
     }
     j->ev_class.resize(j->ev.size());
     j->ev_class[j->ev_used] = cls;
-    HIPCHK(hipEventRecord(j->ev[j->ev_used], j->ctx->stream));
+    HIPCHK(hipEventRecord(j->ev[j->ev_used], st()));
     return ICS_OK;
   }
   int end() {
     if (!on) return ICS_OK;
-    HIPCHK(hipEventRecord(j->ev[j->ev_used + 1], j->ctx->stream));
+    HIPCHK(hipEventRecord(j->ev[j->ev_used + 1], st()));
     j->ev_used += 2;
     return ICS_OK;
   }
@@ -666,6 +682,17 @@ struct Prof {
       ms[j->ev_class[i]] += t; launches[j->ev_class[i]] += 1;
     }
     j->ev_used = 0;
+    return ICS_OK;
+  }
+  // overlapped runs: the events [done, upto) are known to be complete; nothing is recycled until the run ends
+  int collect_range(double* ms, int* launches, size_t& done, size_t upto) {
+    if (!on) return ICS_OK;
+    for (size_t i = done; i + 1 < upto; i += 2) {
+      float t = 0.f;
+      HIPCHK(hipEventElapsedTime(&t, j->ev[i], j->ev[i + 1]));
+      ms[j->ev_class[i]] += t; launches[j->ev_class[i]] += 1;
+    }
+    done = upto;
     return ICS_OK;
   }
 };
@@ -753,7 +780,7 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
     a.f = (q == 0 ? org(j, j->f) : org(j, j->blk_zero)) + oshift;
     a.u = org(j, j->u); a.ut = org(j, ut_of(j));
     a.red = j->blk_red;                                   // (per-block maxima mean nothing)
-    a.gr = nullptr; a.u_out = nullptr; a.scal = j->scal; a.dofkeys = j->dofkeys;
+    a.gr = nullptr; a.u_out = nullptr; a.scal = j->scal; a.dofkeys = dof_of(j);
     a.tv = nullptr; a.tv_kind = 0; a.step = p->step_factor; a.blind = p->blind; a.want_dof = 0;
     a.bt = (mode == 1 ? j->blk_corr : j->blk_conv) + (size_t)q * tf;
     a.facc[0] = a.facc[1] = nullptr;
@@ -764,7 +791,7 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
       else HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, 0, G.uM, 0, 3 * G.uN, j->ctx->stream));
     }
   }
-  if (mode == 1) HIPCHK(ics_launch_band_reduce(out, org(j, j->u), org(j, ut_of(j)), G, p->lambd, 0, G.uM, j->red + slot * ICS_RED_STRIDE, j->ctx->stream));
+  if (mode == 1) HIPCHK(ics_launch_band_reduce(out, org(j, j->u), org(j, ut_of(j)), G, p->lambd, 0, G.uM, red_of(j) + slot * ICS_RED_STRIDE, j->ctx->stream));
   RC(pr.end());
   return ICS_OK;
 }
@@ -776,8 +803,8 @@ static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int wa
   if (mode == 1) { a.in = org(j, j->e); a.w = j->wcorr; a.out = org(j, j->gr); }
   else { a.in = org(j, j->u); a.w = j->wconv; a.out = org(j, j->e); }
   a.f = org(j, j->f); a.u = org(j, j->u); a.ut = org(j, ut_of(j));
-  a.red = j->red + slot * ICS_RED_STRIDE;
-  a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.red = red_of(j) + slot * ICS_RED_STRIDE;
+  a.gr = org(j, j->gr); a.u_out = org(j, j->u2); a.scal = j->scal; a.dofkeys = dof_of(j);
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0;
   a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
   const bool matrix = mode != 2 && use_matrix_conv(j, p);
@@ -803,7 +830,7 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
   IcsUpdateArgs a;
   a.u = org(j, j->u); a.ut = org(j, ut_of(j)); a.g = org(j, j->gr); a.f = org(j, j->f);
   a.u_out = org(j, j->ut_is_u ? j->u2 : j->u);
-  a.red = j->red + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = j->dofkeys;
+  a.red = red_of(j) + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = dof_of(j);
   a.tv = (p->tv_mode != ICS_TV_SHIPPED && j->tvf) ? org(j, j->tvf) : nullptr; a.tv_kind = a.tv ? p->tv_mode : 0; a.f_rw = org(j, j->f);
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
   if (a.tv_kind == ICS_TV_MM_ACTIVE) image_changed(j);          // pyx:547-549: this update also steps the image
@@ -827,7 +854,7 @@ static int ensure_tv(ics_rl* j) {
 static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   IcsTvTermArgs a;
   a.u = org(j, j->u); a.ut = org(j, ut_of(j)); a.f = org(j, j->f); a.tv = org(j, j->tvf);
-  a.red = j->red + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.kind = p->tv_mode; a.geo = j->g;
+  a.red = red_of(j) + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.kind = p->tv_mode; a.geo = j->g;
   RC(pr.begin(ICS_K_UPDATE));   // accounted with the elementwise class
   HIPCHK(ics_launch_tvterm(a, j->ctx->stream));
   RC(pr.end());
@@ -940,20 +967,21 @@ static int do_majorize(ics_rl* j, Prof& pr) {
   return ICS_OK;
 }
 
-static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr, int rearm = 0) {
+static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr, int rearm = 0, hipStream_t st = nullptr) {
+  if (!st) st = j->ctx->stream;
   if (j->win_empty) {
     static const float nan3[3] = {nanf(""), nanf(""), nanf("")};   // M_r, Hu, varu
     HIPCHK(hipMemcpyAsync(j->scal + ICS_SC_MR, nan3, sizeof nan3, hipMemcpyHostToDevice, j->ctx->stream));
     return ICS_OK;
   }
   IcsStatsArgs a;
-  a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = j->dofkeys; a.dacc = j->dacc; a.ukey = j->ukey;
+  a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = dof_of(j); a.dacc = j->dacc; a.ukey = j->ukey;
   a.z = j->z; a.tw = j->tw; a.weights = j->weights;
   a.top = p->top; a.bottom = p->bottom; a.left = p->left; a.right = p->right;
   a.P = j->P; a.logP = j->logP; a.do_mr = p->stop_test != 0; a.geo = j->g;
-  a.red = j->red; a.rearm = rearm;
+  a.red = red_of(j); a.rearm = rearm;
   RC(pr.begin(ICS_K_STATS));
-  HIPCHK(ics_launch_stats(a, j->ctx->stream));
+  HIPCHK(ics_launch_stats(a, st));
   RC(pr.end());
   return ICS_OK;
 }
@@ -961,6 +989,7 @@ static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr, int rearm = 0) 
 static int reset_dofkeys(ics_rl* j) {
   static const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
   HIPCHK(hipMemcpyAsync(j->dofkeys, init, sizeof init, hipMemcpyHostToDevice, j->ctx->stream));
+  HIPCHK(hipMemcpyAsync(j->dofkeys + 4, init, sizeof init, hipMemcpyHostToDevice, j->ctx->stream));
   return ICS_OK;
 }
 
@@ -994,6 +1023,19 @@ static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
   const int g = ics_debug().graph.load(std::memory_order_relaxed);
   if (g >= 0) return g != 0;
   return (long)j->g.uM * j->g.uN <= 1200000L;
+}
+
+// Statistics of outer iteration i overlapped with iteration i + 1 (ics_rl_run).  Not with the opt-in fused update + convolution (its
+// own u ping-pong), not with tv_mode 1 (the image is stepped too: nothing to fall back on), not with an empty window, not for a
+// single iteration.  Debug switch `overlap` = 0 restores the drain at every outer boundary.
+// Measured (MI355X, ms per inner iteration, drained -> overlapped): non-blind 512^2 / 9x9 0.044 -> 0.040 (0.060 -> 0.040 after a long run of
+// small launches, when the device has clocked down), non-blind 2048^2 / 15x15 0.160 -> 0.152; blind 4096^2 / 15x15 0.808 -> 0.804 without
+// and 0.810 -> 0.821 with event brackets in the timed region: on frames that fill the device the statistics' small kernels only compete
+// with the persistent workgroups of the convolutions.  Hence by default up to 9 Mpx (switch = 1), everywhere with switch = 2.
+static bool use_overlap(const ics_rl* j, const ics_rl_params* p) {
+  if (p->fuse || p->tv_mode == ICS_TV_MM_ACTIVE || j->win_empty || p->iterations < 2) return false;
+  const int sw = ics_debug().overlap.load(std::memory_order_relaxed);
+  return sw == 2 || (sw == 1 && (long)j->g.uM * j->g.uN <= 9000000L);
 }
 
 // ics_rl_describe / ics_describe: the routing predicates above, as the launches below evaluate them
@@ -1067,8 +1109,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf, (size_t)3 * j->g.K * j->g.K * 4, hipMemcpyDeviceToDevice, s));
   RC(pack_weights(j, 0, 0.f, 0, s));
   HIPCHK(hipEventRecord(j->ev_begin, s));
-  // the launches of one outer iteration (pyx:462-638), eagerly or into a stream capture
-  auto enqueue_outer = [&]() -> int {
+  // the launches of one outer iteration (pyx:462-591) ...
+  auto enqueue_body = [&]() -> int {
     if (p->fuse) RC(do_majorize(j, pr));                      // pyx:462 (explicit copy only for the fused path)
     else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
     const bool fuse = p->fuse != 0;
@@ -1100,9 +1142,17 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       }
       ++inner_done;
     }
-    RC(do_stats(j, p, pr, 1));                                // A18 + A19
-    HIPCHK(hipMemcpyAsync(j->h_scal, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, s));
     return ICS_OK;
+  };
+  // ... and its statistics (A18 + A19) with the copy of the scalars to the pinned host mirror `hs`, on stream `st`
+  auto enqueue_stats = [&](hipStream_t st, float* hs, Prof& prs) -> int {
+    RC(do_stats(j, p, prs, 1, st));
+    HIPCHK(hipMemcpyAsync(hs, j->scal, ICS_SC_COUNT * 4, hipMemcpyDeviceToHost, st));
+    return ICS_OK;
+  };
+  auto enqueue_outer = [&]() -> int {
+    RC(enqueue_body());
+    return enqueue_stats(s, j->h_scal, pr);
   };
   // One hipGraph launch per outer iteration (use_graph): everything captured carries the parameters in its kernel arguments, so the
   // executables live as long as the parameter set (and the debug switches) stay what they were.
@@ -1120,8 +1170,99 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     }
     j->graph_sig = sig; j->graph_epoch = epoch;
   }
+  // what the host does once the scalars of an outer iteration are in `hs`: traces, stop decision (pyx:643-654), progress callback
+  auto consume = [&](const float* hs) {
+    if (it > 0) M_r_prev = M_r;                               // pyx:623-624
+    M_r = p->stop_test ? hs[ICS_SC_MR] : nanf("");
+    Hu = hs[ICS_SC_HU]; varu = hs[ICS_SC_VARU];
+    dmin = hs[ICS_SC_DOFMIN]; dmax = hs[ICS_SC_DOFMAX];
+    if (it < st->trace_cap) {
+      if (st->trace_M_r) st->trace_M_r[it] = M_r;
+      if (st->trace_Hu) st->trace_Hu[it] = Hu;
+      if (st->trace_varu) st->trace_varu[it] = varu;
+      if (st->trace_dof_min) st->trace_dof_min[it] = dmin;
+      if (st->trace_dof_max) st->trace_dof_max[it] = dmax;
+      st->trace_len = it + 1;
+    }
+    if (it > 1 && p->stop_test == 1) {                        // pyx:643-654 (stop_test 2: evaluate only)
+      if (p->blind) { if (M_r > M_r_prev) stop = 1; }
+      else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
+    }
+    ++it;
+    // pyx:593,648,658-659: where the reference prints.  A non-zero return leaves the loop with the state of this outer iteration
+    // (deconvolve.py:338-342 keeps the partial result of an interrupted run)
+    if (p->progress && p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu) != 0 && !stop) stop = 2;
+  };
+  j->par = 0;
+  HIPCHK(hipMemsetAsync(j->red, 0, 2 * 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));   // both sets; later outer iterations: re-armed on the
+  RC(reset_dofkeys(j));                                                               // device by the kernel that writes the scalars
+  if (use_overlap(j, p) && !graphs_on) {
+    // ---- statistics of iteration i on a second stream, iteration i + 1 already running on the job's stream (round 4) -------------------
+    // The stop decision of iteration i needs M_r(i) on the host, so until round 3 the device drained at every outer boundary: five
+    // small dependent kernels (0.06 ms) and a round trip with nothing else in flight -- a quarter of a 512^2 step, 7 % at 2048^2.
+    // Now iteration i + 1 is queued before M_r(i) is known.  What that needs: iteration i + 1 may not touch what the statistics of i
+    // read or re-arm -- the residual frame ping-pongs (e / e2), the reduction slots and DoF keys come in two sets (i & 1), u(i) is
+    // the untouched majoriser of i + 1 anyway (frame rotation) -- and, if the stop test fires at i (or the callback asks to stop),
+    // iteration i + 1 is undone: its u is dropped for the majoriser frame (= u(i)), the PSF comes back from the copy taken when i + 1
+    // started.  At most one outer iteration is ever ahead, and only the run's last decision costs a wasted one.
+    ics_ctx* c = j->ctx;
+    if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!j->ev_body[0])
+      for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&j->ev_body[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&j->ev_stats[i], hipEventDisableTiming)); }
+    if (!j->e2) RC(dalloc(c, &j->e2, j->frame_floats));
+    const size_t npsf = (size_t)3 * j->g.K * j->g.K;
+    if (p->blind && !j->psf_bak) RC(dalloc(c, &j->psf_bak, 2 * npsf, false));
+    Prof pr_s2{j, p->profile != 0, c->stream2};
+    size_t ev_mark[2] = {0, 0}, ev_done = 0;
+    int enq = 0;                                              // outer iterations queued; `it` = outer iterations whose scalars were consumed
+    auto undo = [&]() -> int {                                // drops iteration enq - 1 (queued, possibly running)
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(hipStreamSynchronize(c->stream2));
+      { float* t = j->u; j->u = j->ut; j->ut = t; }           // the majoriser frame of the dropped iteration is u of the one before
+      { float* t = j->e; j->e = j->e2; j->e2 = t; }
+      if (p->blind) {
+        HIPCHK(hipMemcpyAsync(j->psf, j->psf_bak, npsf * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf_bak + npsf, npsf * 4, hipMemcpyDeviceToDevice, s));
+        RC(pack_weights(j, 0, 0.f, 0, s));
+      }
+      inner_done -= INNER;
+      return ICS_OK;
+    };
+    while (enq < p->iterations && !stop) {                    // pyx:460
+      j->par = enq & 1;
+      if (enq > 0) {
+        { float* t = j->e; j->e = j->e2; j->e2 = t; }         // the statistics of the previous iteration read the other frame
+        if (p->blind) {
+          HIPCHK(hipMemcpyAsync(j->psf_bak, j->psf, npsf * 4, hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(j->psf_bak + npsf, j->psf_caller, npsf * 4, hipMemcpyDeviceToDevice, s));
+        }
+      }
+      RC(enqueue_body());
+      HIPCHK(hipEventRecord(j->ev_body[enq & 1], s));
+      HIPCHK(hipStreamWaitEvent(c->stream2, j->ev_body[enq & 1], 0));
+      RC(enqueue_stats(c->stream2, j->h_scal + (enq & 1) * (ICS_SC_COUNT + 4), pr_s2));
+      HIPCHK(hipEventRecord(j->ev_stats[enq & 1], c->stream2));
+      ev_mark[enq & 1] = j->ev_used;
+      ++enq;
+      if (enq >= 2) {                                         // the scalars of the iteration BEFORE the one just queued
+        HIPCHK(hipEventSynchronize(j->ev_stats[(enq - 2) & 1]));
+        RC(pr.collect_range(ms, launches, ev_done, ev_mark[(enq - 2) & 1]));
+        consume(j->h_scal + ((enq - 2) & 1) * (ICS_SC_COUNT + 4));
+        if (stop) RC(undo());
+      }
+    }
+    if (!stop && enq > it) {                                  // the last iteration's scalars (nothing is ahead of it)
+      HIPCHK(hipEventSynchronize(j->ev_stats[(enq - 1) & 1]));
+      consume(j->h_scal + ((enq - 1) & 1) * (ICS_SC_COUNT + 4));
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipStreamSynchronize(c->stream2));
+    RC(pr.collect_range(ms, launches, ev_done, j->ev_used));
+    j->ev_used = 0;
+    j->par = 0;
+  } else
   while (it < p->iterations && !stop) {                       // pyx:460
-    if (it == 0 || j->win_empty) {   // later outer iterations: re-armed on the device by the kernel that writes the scalars (ics_stats.hip)
+    if (j->win_empty && it > 0) {   // (no statistics kernel re-arms them for an empty window)
       HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
       RC(reset_dofkeys(j));
     }
@@ -1152,26 +1293,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     //  same iteration time, 0.8178 vs 0.8185 ms at 4096^2 and 0.1573 vs 0.1562 at 2048^2 non-blind)
     HIPCHK(hipStreamSynchronize(s));
     RC(pr.collect(ms, launches));
-    if (it > 0) M_r_prev = M_r;                               // pyx:623-624
-    M_r = p->stop_test ? j->h_scal[ICS_SC_MR] : nanf("");
-    Hu = j->h_scal[ICS_SC_HU]; varu = j->h_scal[ICS_SC_VARU];
-    dmin = j->h_scal[ICS_SC_DOFMIN]; dmax = j->h_scal[ICS_SC_DOFMAX];
-    if (it < st->trace_cap) {
-      if (st->trace_M_r) st->trace_M_r[it] = M_r;
-      if (st->trace_Hu) st->trace_Hu[it] = Hu;
-      if (st->trace_varu) st->trace_varu[it] = varu;
-      if (st->trace_dof_min) st->trace_dof_min[it] = dmin;
-      if (st->trace_dof_max) st->trace_dof_max[it] = dmax;
-      st->trace_len = it + 1;
-    }
-    if (it > 1 && p->stop_test == 1) {                        // pyx:643-654 (stop_test 2: evaluate only)
-      if (p->blind) { if (M_r > M_r_prev) stop = 1; }
-      else { if ((M_r - M_r_prev) / (M_r + M_r_prev) > p->tau) stop = 1; }
-    }
-    ++it;
-    // pyx:593,648,658-659: where the reference prints.  A non-zero return leaves the loop with the state of this outer iteration
-    // (deconvolve.py:338-342 keeps the partial result of an interrupted run)
-    if (p->progress && p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu) != 0 && !stop) stop = 2;
+    consume(j->h_scal);
   }
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));
@@ -1192,6 +1314,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
 
 extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   RC(check_params(j, p));
+  j->par = 0;
   HIPCHK(hipSetDevice(j->ctx->device));
   hipStream_t s = j->ctx->stream;
   Prof pr{j, false};

@@ -151,3 +151,52 @@ def test_job_describe_equals_shape_describe():
             assert [getattr(a, f) for f, _ in nv.RLRoute._fields_] == [getattr(b, f) for f, _ in nv.RLRoute._fields_]
         finally:
             job.close()
+
+
+@pytest.mark.parametrize("name,iters", [("nb_97x97_k5_tau", 40), ("bl_129x129_k15", 5), ("bl_65x65_k7_corr", 3), ("nb_129x129_k15", 20), ("bl_65x49_k9", 10)])
+def test_statistics_overlapped_with_the_next_iteration_change_nothing(golden_dir, debug_switch, name, iters):
+    """ics_rl_run queues outer iteration i + 1 before the stop-test scalars of iteration i are on the host (second stream; residual
+    frame, reduction slots and DoF keys in two sets) and, when the stop test fires at i, drops iteration i + 1 again (u from the
+    majoriser frame, PSF from its copy).  Against the loop that drains at every outer boundary (debug switch overlap = 0): same
+    iterations done, same stop flag, u / PSF / every trace bit for bit -- on goldens that stop early (tau = 0 after 3 ... 40 iterations,
+    blind M_r > M_r_prev), that run to the end, and with the correlation quirk (the caller's PSF frozen after the first step)."""
+    z, meta = load_golden(golden_dir, name)
+    res = {}
+    for ov in (0, 2):
+        debug_switch("overlap", ov)
+        u, psf, log, st = _run(z, meta, iters)
+        res[ov] = (u, psf, log, st.iterations_done, st.stopped, st.inner_iterations, np.array(st.trace_M_r[:st.trace_len]), np.array(st.trace_Hu[:st.trace_len]),
+                   np.array(st.trace_varu[:st.trace_len]), np.array(st.trace_dof_min[:st.trace_len]), np.array(st.trace_dof_max[:st.trace_len]), st.M_r, st.Hu, st.varu)
+    a, b = res[0], res[2]
+    print("%s: %d of %d outer iterations, stopped = %d" % (name, a[3], iters, a[4]))
+    assert a[3:6] == b[3:6] and a[5] == 5 * a[3]
+    assert a[2] == b[2]                                                  # the printed lines
+    for x, y in zip(a[:2] + a[6:11], b[:2] + b[6:11]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert a[11:] == b[11:] or all(np.isnan(v) for v in a[11:] + b[11:])
+
+
+def test_abort_under_overlap_drops_the_iteration_that_was_ahead(debug_switch):
+    """the callback asks to stop at outer iteration 4 of 30 while iteration 5 is already queued: u and PSF must be those of a 4-iteration run"""
+    from lib import _native as nv
+    M, N, MK = 120, 100, 9
+    case = orc.synth_case(M, N, MK, seed=11, blind=True)
+    win = orc.default_window(M, N, MK)
+    out = {}
+    for mode in ("ref4", "abort"):
+        job = nv.RLJob(M, N, MK)
+        try:
+            job.upload(case["image"], case["u0"], case["psf0"])
+            if mode == "ref4":
+                debug_switch("overlap", 0)
+                st = job.run(job.params(*win, 1e9, 4, 1e-3, 1e4, True, stop_test=2))
+            else:
+                debug_switch("overlap", 1)
+                st = job.run(job.params(*win, 1e9, 30, 1e-3, 1e4, True, stop_test=2), progress=lambda it, *a: it == 4)
+                assert st.stopped == 2
+            assert st.iterations_done == 4 and st.inner_iterations == 20
+            out[mode] = job.download()
+        finally:
+            job.close()
+    for x, y in zip(out["ref4"], out["abort"]):
+        assert np.array_equal(x, y)
