@@ -200,3 +200,26 @@ def test_abort_under_overlap_drops_the_iteration_that_was_ahead(debug_switch):
             job.close()
     for x, y in zip(out["ref4"], out["abort"]):
         assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("blind,tv_mode", [(False, 0), (True, 0), (True, 3)])
+def test_long_overlapped_run_equals_the_drained_one(debug_switch, blind, tv_mode):
+    """150 outer iterations (750 inner) with the statistics one iteration behind the kernels, against the drained loop: the two sets of
+    reduction slots / DoF keys and the residual ping-pong are each used 75 times, the frame rotation 50 times"""
+    from lib import _native as nv
+    M, N, MK = 140, 123, 11
+    case = orc.synth_case(M, N, MK, seed=5, blind=blind)
+    win = orc.default_window(M, N, MK)
+    out = {}
+    for ov in (0, 2):
+        debug_switch("overlap", ov)
+        job = nv.RLJob(M, N, MK)
+        try:
+            job.upload(case["image"], case["u0"], case["psf0"])
+            st = job.run(job.params(*win, 1e9, 150, 1e-4, 1e4, blind, tv_mode=tv_mode, stop_test=2))
+            assert st.iterations_done == 150 and st.inner_iterations == 750
+            out[ov] = job.download() + (np.array(st.trace_M_r[:150]), np.array(st.trace_dof_max[:150]), np.array(st.trace_varu[:150]))
+        finally:
+            job.close()
+    for x, y in zip(out[0], out[2]):
+        assert np.array_equal(x, y, equal_nan=True)
