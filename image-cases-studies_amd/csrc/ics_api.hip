@@ -936,8 +936,11 @@ static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof
   a.wy0 = p->top + j->g.pad; a.wy1 = p->bottom + j->g.pad; a.wx0 = p->left + j->g.pad; a.wx1 = p->right + j->g.pad;
   a.store_all = store_all;
   // tile height: 32-row tiles with three workgroups per CU, or 64-row tiles with two (ics_synth_gradk_mfma.hip); debug switch fused_rs
+  // Measured on MI355X (blind, ms per inner iteration, 64-row -> 32-row form): 255^2 (deblur_module's blind window: 16 tiles of 64 x 64 on
+  // 256 CUs) 0.1095 -> 0.0985, 1024^2 0.1415 -> 0.1316, 2048^2 0.275 -> 0.266; 4096^2 level.  Hence 32-row tiles up to
+  // 2500 tiles of 64 x 64 (~3200^2), 64-row tiles above.
   const int frs = ics_debug().fused_rs.load(std::memory_order_relaxed);
-  a.rs = frs == 2 || frs == 4 ? frs : ICS_FUSED_DEFAULT_RS;
+  a.rs = frs == 2 || frs == 4 ? frs : ((long)j->g.tiles_x * j->g.tiles_y <= 2500 ? 2 : ICS_FUSED_DEFAULT_RS);
   a.facc = nullptr;
   if (use_image_acc(p)) { RC(ensure_image_acc(j, a.rs)); a.facc = j->facc[a.rs == 2 ? 0 : 1]; }
   int nblocks = j->gradk_blocks;

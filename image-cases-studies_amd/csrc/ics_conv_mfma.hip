@@ -256,6 +256,16 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   int* lds_next = reinterpret_cast<int*>(fscr + 8);   // two slots, by tile parity: a fast wave may claim for tile i + 1 before a slow one has read the claim of tile i
   int parity = 0;
 
+  // The first tile's rows are requested before anything else: on small frames (one tile per workgroup: the 255-px windows of
+  // deblur_module's blind phase, 512^2) the kernel is a chain of dependent round trips, and the weight rows' trip to the LDS below
+  // used to sit in front of this one.
+  // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
+  f32x4u raw[C::NIT][3];
+  if (tile < band1) {
+    const int tyi = tile / tpr, txi = tile - tyi * tpr;
+    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
+  }
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
   // weight rows -> LDS once per workgroup (the global table is the LDS image)
@@ -303,17 +313,11 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   float mu[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
   uint32_t rflags = 0u;   // bit 6: any element reduced
 
-  // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
-  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
   // epilogue operands and output through buffer addressing as well (frame origins; offsets are >= 0 there)
   const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
   const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.out);
-  f32x4u raw[C::NIT][3];
-  if (tile < band1) {
-    const int tyi = tile / tpr, txi = tile - tyi * tpr;
-    load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
-  }
+  // (the first tile's rows were requested at the top of the kernel, ahead of the weight rows)
 
   ICS_TICK_INIT;
   int next_tile = 0;

@@ -405,14 +405,16 @@ def test_fused_synth_gradk_32_row_form(M, N, MK, debug_switch):
     assert rel_err(out[2][1], out[4][1]) < 1e-5
 
 
-def test_blind_run_with_the_32_row_fused_kernel_matches_the_reference_golden(golden_dir, debug_switch):
-    """the 129 x 129 blind golden of the compiled reference with fused_rs = 2 (and few workgroups, so that each walks several tiles)"""
+@pytest.mark.parametrize("rs", [2, 4])
+def test_blind_run_with_either_form_of_the_fused_kernel_matches_the_reference_golden(golden_dir, debug_switch, rs):
+    """the 129 x 129 blind golden of the compiled reference with the 32-row and with the 64-row form of the fused A11 + A13 kernel forced
+    (the launcher picks 32-row tiles up to ~3200^2 since round 4, 64-row tiles above) and few workgroups, so that each walks several tiles"""
     import contextlib
     import io
     from helpers import load_golden
     from lib import deconvolution as dc
     z, meta = load_golden(golden_dir, "bl_129x129_k15")
-    debug_switch("fused_rs", 2)
+    debug_switch("fused_rs", rs)
     debug_switch("max_wgs", 3)
     dc._drop_jobs()
     n = meta["snaps"][1]
