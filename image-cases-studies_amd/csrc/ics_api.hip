@@ -1209,7 +1209,11 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     // iteration i + 1 is undone: its u is dropped for the majoriser frame (= u(i)), the PSF comes back from the copy taken when i + 1
     // started.  At most one outer iteration is ever ahead, and only the run's last decision costs a wasted one.
     ics_ctx* c = j->ctx;
-    if (!c->stream2) HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (!c->stream2) {   // lowest priority: the statistics take what the iteration's kernels leave free
+      int lo = 0, hi = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIPCHK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    }
     if (!j->ev_body[0])
       for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&j->ev_body[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&j->ev_stats[i], hipEventDisableTiming)); }
     if (!j->e2) RC(dalloc(c, &j->e2, j->frame_floats));
