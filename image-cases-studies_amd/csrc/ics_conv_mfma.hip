@@ -80,6 +80,9 @@
 #ifndef ICS_MFMA_WSPLIT
 #define ICS_MFMA_WSPLIT 1   /* see MCfg::WSPLIT */
 #endif
+#ifndef ICS_MFMA_NO_RS1
+#define ICS_MFMA_NO_RS1 0
+#endif
 #ifndef ICS_MFMA_ALL_RS
 #define ICS_MFMA_ALL_RS 0  /* tools/: build both tile heights for every PSF size (ICS_TEST_CONV_RS=2|4 then picks one) */
 #endif
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
     // of the next tile's rows (loads return in order), and is there when the matrix phase ends
     constexpr bool EARLY = ICS_EPI_EARLY && MODE == 0 && RS == 2 && NH == 1;
     u4 fpre[3][C::RS];
-    const float* faccp0 = MODE == 0 ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
+    const float* faccp0 = (MODE == 0 && C::RS != 1) ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
     if (EARLY && faccp0 != nullptr && x0 + 16 * cb < xend) {
       const __amdgpu_buffer_rsrc_t rs_a0 = make_rsrc(faccp0);
       const int lv = 16 * (opaque(tid) & 63), sb0 = (tile * 4 + cb) * (3 * C::RS * 1024);
@@ -867,7 +870,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       // TVOP (extended modes): the T frame is a third operand, requested like the others (as per-element scalar loads it
       // cost the back-projection +40 %)
       const __amdgpu_buffer_rsrc_t rs_tv = make_rsrc(a.tv);
-      const float* faccp = MODE == 0 ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
+      const float* faccp = (MODE == 0 && C::RS != 1) ? a.facc[C::RS == 2 ? 0 : 1] : nullptr;
       const bool use_acc = MODE == 0 && NH == 1 && faccp != nullptr;           // uniform
       const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(faccp);
       const int acc_voff = 16 * (tide & 63);
@@ -1057,9 +1060,26 @@ hipError_t launch_one(const IcsConvArgs& a, hipStream_t s) {
 template <int K> struct TileRs {
   static constexpr bool has2 = ICS_MFMA_ALL_RS || K <= 21 || K >= 39;   // 39 .. 49: the planes of a 64-row tile do not fit the LDS
   static constexpr bool has4 = ICS_MFMA_ALL_RS || K <= 13 || (K >= 23 && K <= 37);
+  // 16-row tiles (fragment rows 1 apart, one accumulator set; round 4) for frames that do not give every CU a 32-row tile: the 255-px
+  // windows of deblur_module's blind phase (45 tiles of 32 x 64 on 256 CUs) and 512^2 (128).  A fragment read then feeds 3 MFMAs only --
+  // irrelevant where a kernel is one chain of dependent round trips per workgroup; what counts is that the chain is half as long.
+  static constexpr bool has1 = !ICS_MFMA_NO_RS1 && K <= 15;
 };
+// does this frame take the 16-row tiles?  (fewer 32-row tiles than compute units)
+template <int K>
+static bool small_frame_rs1(int mode, const IcsGeom& g) {
+  if (!TileRs<K>::has1) return false;
+  const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
+  if (frs == 1) return true;
+  if (frs == 2 || frs == 4) return false;
+  const long t32 = mode == 0 ? (long)((g.N + 63) / 64) * ((g.M + 31) / 32) : (long)g.tiles_x * ((g.uM + 31) / 32);
+  return t32 < (long)ics_device_cus(ics_current_device());
+}
 template <int K>
 hipError_t launch_k(int mode, const IcsConvArgs& a, hipStream_t s) {
+  if constexpr (TileRs<K>::has1) {
+    if (small_frame_rs1<K>(mode, a.g)) return mode == 0 ? launch_one<K, 0, 1>(a, s) : launch_one<K, 1, 1>(a, s);
+  }
   bool rs2 = K >= 39 || (K <= 21 && (K >= 15 || (long)a.g.tiles_x * a.g.tiles_y <= 3000));
   if (TileRs<K>::has2 && TileRs<K>::has4) {   // test / harness hook: force a tile height where both are built
     const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
@@ -1152,6 +1172,11 @@ bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K); }
 // kernels (K >= 23): the caller prepares the accumulator-order image (ics_image_acc.h) of that layout for mode 0.
 int ics_conv_mfma_rs(int K, const IcsGeom& g) {
   if (K >= 23) return 0;
+  if (K <= 15) {   // 16-row tiles on small frames (TileRs::has1): no accumulator-order image for them
+    const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
+    const long t32 = (long)((g.N + 63) / 64) * ((g.M + 31) / 32);
+    if (!ICS_MFMA_NO_RS1 && (frs == 1 || (frs == 0 && t32 < (long)ics_device_cus(ics_current_device())))) return 0;
+  }
   bool rs2 = K <= 21 && (K >= 15 || (long)g.tiles_x * g.tiles_y <= 3000);
   if (K <= 13) {   // both heights are built
     const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
