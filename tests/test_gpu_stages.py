@@ -60,10 +60,11 @@ def test_synth_residual_and_backprojection_all_psf_sizes(MK, conv):
 
 
 @pytest.mark.parametrize("MK", [3, 9, 13])
-@pytest.mark.parametrize("rs", ["2", "4"])
+@pytest.mark.parametrize("rs", ["2", "4", "1"])
 def test_matrix_core_convolution_both_tile_heights(MK, rs, debug_switch):
     """ics_conv_mfma.hip builds 64-row and 32-row tiles for K <= 13 and picks by frame size (32-row up to 3000 tiles of
-    64 x 64): the debug switch conv_rs forces either, on a frame several tiles high and wide with ragged edges."""
+    64 x 64; round 4: 16-row tiles, K <= 15, where the frame has fewer 32-row tiles than compute units): the debug switch conv_rs forces
+    any of them, on a frame several tiles high and wide with ragged edges."""
     from lib import _native as nv
     debug_switch("conv_rs", int(rs))
     M, N = 203, 277
@@ -82,7 +83,7 @@ def test_matrix_core_convolution_both_tile_heights(MK, rs, debug_switch):
     red = job.red_keys()
     job.close()
     # the step-size reductions of the back-projection do not depend on the tiling (maxima)
-    debug_switch("conv_rs", 4 if rs == "2" else 2)
+    debug_switch("conv_rs", 4 if rs in ("2", "1") else 2)
     job2, _, _ = make_job(M, N, MK, seed=MK + 40)
     job2.write(nv.BUF_U, u)
     job2.write(nv.BUF_UT, case["u0"])
