@@ -62,6 +62,12 @@ __device__ unsigned long long ics_fused_ticks[17];
                                 32 no funnel shifts (operands taken unshifted), 64 no MFMAs (operands kept alive), 128 no workgroup barriers */
 #endif
 
+#ifndef ICS_FUSED_WSPLIT
+#define ICS_FUSED_WSPLIT 0   /* measured: stand-alone harness 0.2749 -> 0.2622 ms (-4.6 %), inside the iteration 0.2739 -> 0.2767 (same box, two
+                                libraries alternating): the restaging of a channel's rows from the global table sits on the critical path between the
+                                two barriers there.  Built, correct (every fused-kernel test with the 64-row form forced), default off. */
+#endif
+
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -109,7 +115,14 @@ struct FCfg {
   static constexpr int WZERO = (K + 7) / 2;
   static constexpr int WLDS = 3 * K * 2 * WROWB;
   static constexpr int WOFF = SCR + 256;
-  static constexpr size_t LDS_BYTES = WOFF + WLDS;
+  // ICS_FUSED_WSPLIT (round 4): the weight rows of ONE channel at a time, as four plain rows per kernel row -- hi, lo, hi moved up one
+  // half, lo moved up one half -- so that a lane finds its 8 halves dword-aligned in the copy of its parity and reads them with two
+  // ds_read2_b32 per split term straight into the operand registers: 4 LDS instructions and no funnel shift per B fragment instead of
+  // 5 + 8 (ics_conv_mfma.hip, MCfg::WSPLIT).  All three channels in that form would need 11.5 KB where 5.8 KB are free; one channel
+  // (3.8 KB) is restaged from the global table between the two barriers every channel already has.
+  static constexpr bool WSPLIT = ICS_FUSED_WSPLIT != 0;
+  static constexpr int WLDS_USED = WSPLIT ? K * 4 * WROWB : WLDS;
+  static constexpr size_t LDS_BYTES = WOFF + WLDS_USED;
   static constexpr int NQ = K + 3;
   static constexpr int XG = LCOLS / 4;
   static constexpr int NTASK = LROWS * XG;
@@ -223,11 +236,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   {
     u4* z = reinterpret_cast<u4*>(lds);
     for (int i = tid; i < C::WOFF / 16; i += C::NT) z[i] = (u4){0u, 0u, 0u, 0u};
-    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
-    const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
-    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+    if (!C::WSPLIT) {
+      uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
+      const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
+      for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+    }
   }
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
+  // WSPLIT: the weight rows of channel `ch` from the global table (hi dword d at 2d, lo at 2d + 1 of a (c, a) block) into the four plain
+  // rows; one dword position per thread (K * WROWB / 4 <= 256), requested (wq_issue) ahead of the work it hides behind, stored (wq_store)
+  // before the barrier that precedes the convolution of that channel
+  typedef uint32_t wq2 __attribute__((ext_vector_type(2)));
+  wq2 wq_a = {0u, 0u}, wq_b = {0u, 0u};
+  auto wq_issue = [&](int ch) {
+    if (!C::WSPLIT) return;
+    constexpr int RD = C::WROWB / 4;
+    static_assert(!C::WSPLIT || K * RD <= C::NT, "one dword position per thread");
+    const int t0 = opaque(tid);
+    const int i = t0 < K * RD ? t0 : K * RD - 1;
+    const int ar = i / RD, d = i - ar * RD;
+    const wq2* src = reinterpret_cast<const wq2*>(reinterpret_cast<const uint32_t*>(a.bt) + (ch * K + ar) * 2 * RD) + d;
+    wq_a = src[0];
+    wq_b = d + 1 < RD ? src[1] : (wq2){0u, 0u};
+  };
+  auto wq_store = [&]() {
+    if (!C::WSPLIT) return;
+    constexpr int RD = C::WROWB / 4;
+    const int i = opaque(tid);
+    if (i < K * RD) {
+      const int ar = i / RD, d = i - ar * RD;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(lds + C::WOFF) + ar * 4 * RD + d;
+      dst[0] = wq_a.x; dst[RD] = wq_a.y;
+      dst[2 * RD] = __builtin_amdgcn_alignbit(wq_b.x, wq_a.x, 16); dst[3 * RD] = __builtin_amdgcn_alignbit(wq_b.y, wq_a.y, 16);
+    }
+  };
+  wq_issue(0);
+  wq_store();
 
   // ---- lane constants --------------------------------------------------------------------------------------------
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
@@ -238,7 +282,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int bo = 8 * lg - li + 15;
     const bool bzero = bo < 8 || bo > K + 14;
     wsh = bzero ? 0u : (uint32_t)(bo & 1) * 16u;
-    wa0 = lds0 + (uint32_t)C::WOFF + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
+    if (C::WSPLIT) wa0 = lds0 + (uint32_t)C::WOFF + 4u * (uint32_t)(bzero ? C::WZERO : ((bo & 1) * 2 * (C::WROWB / 4) + ((bo - 8 - (bo & 1)) >> 1)));
+    else wa0 = lds0 + (uint32_t)C::WOFF + 8u * (uint32_t)(bzero ? C::WZERO : ((bo - 8) >> 1));
     asm volatile("" : "+v"(wa0));
   }
   // convolution, A operand: lane row li of column block wv, 8 halves at 16 wv + 8 lg
@@ -397,11 +442,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       h8 Bh[K], Bl[K];
       u2 rawB[5];
       auto issueB = [&](int ka) {
+        if constexpr (C::WSPLIT) {   // (inline asm: as C++ loads the pairs are merged into ds_read2_b64 at 4-byte alignment, which gfx950 executes very slowly)
+          const uint32_t ad = wb + (uint32_t)(ka * 4 * C::WROWB);
+          constexpr int RD = C::WROWB / 4;
+          u2 h01, h23, l01, l23;
+          asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(h01) : "v"(ad));
+          asm volatile("ds_read2_b32 %0, %1 offset0:2 offset1:3" : "=v"(h23) : "v"(ad));
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(l01) : "v"(ad), "n"(RD), "n"(RD + 1));
+          asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(l23) : "v"(ad), "n"(RD + 2), "n"(RD + 3));
+          Bh[ka] = __builtin_bit_cast(h8, (u4){h01.x, h01.y, h23.x, h23.y});
+          Bl[ka] = __builtin_bit_cast(h8, (u4){l01.x, l01.y, l23.x, l23.y});
+          return;
+        }
         const lds_vu2p r = reinterpret_cast<lds_vu2p>(wb + (uint32_t)((ch * K + ka) * 2 * C::WROWB));
 #pragma unroll
         for (int d = 0; d < 5; ++d) rawB[d] = r[d];
       };
       auto finishB = [&](int ka) {
+        if constexpr (C::WSPLIT) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }   // (asm results are not tracked by the compiler's s_waitcnt insertion)
         const u2* d = rawB;
         const u4 wh = {f_align(d[1].x, d[0].x, wsh), f_align(d[2].x, d[1].x, wsh),
                        f_align(d[3].x, d[2].x, wsh), f_align(d[4].x, d[3].x, wsh)};
@@ -439,8 +497,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
           for (int t = 0; t < 4; ++t) nt += (q - t >= 0 && q - t < K) ? 1 : 0;
           const int nm = 3 * nt;
-          const int nr = ((q + 1 < C::NQ) ? 2 : 0) + ((q + 1 < K) ? 5 : 0);
-          const int nv = (q + 1 < K) ? 8 : 0;
+          const int nr = ((q + 1 < C::NQ) ? 2 : 0) + ((q + 1 < K) ? (C::WSPLIT ? 4 : 5) : 0);
+          const int nv = (q + 1 < K && !C::WSPLIT) ? 8 : 0;
           const int tail = nv ? (nm > 4 ? 4 : nm) : 0;
           const int head = nm - tail;
 #pragma unroll
@@ -653,9 +711,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(3);                                                                                                           \
     lds_barrier();     /* tile maximum; every wave is past the previous gradient phase: e' planes and u buffer free */  \
     FTICK(4);                                                                                                           \
+    wq_issue(((CH) + 1) % 3);   /* every wave is past conv(CH): the weight rows of the next channel may take its place */          \
     me = __builtin_fmaxf(__builtin_fmaxf(fscr[8 + 4 * (CH)], fscr[9 + 4 * (CH)]), __builtin_fmaxf(fscr[10 + 4 * (CH)], fscr[11 + 4 * (CH)])); \
     pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, me))), s_e, inv_e);      \
-    write_e(s_e);
+    write_e(s_e);                                                                                                       \
+    wq_store();
 
     ICS_FUSED_CHANNEL(0)
     if (!(ICS_FUSED_ABLATE & 8)) convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
