@@ -700,7 +700,6 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         u2 rawB[3][5];
         h8 Bn[3][2];                                           // (WSPLIT) the fragments just requested
         h8 Bs[2][3][2];                                        // [item & 1][window][hi, lo]
-        typedef const __attribute__((address_space(3), aligned(4))) u2* lds_u2a4p;   // 8 bytes at 4-byte alignment: ds_read2_b32
         auto issueB = [&](int item) {
           const int a = 2 * item;
           const int kinds[3] = {0, item < NP ? 3 : 1, 2};
