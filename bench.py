@@ -67,7 +67,20 @@ def gaussian_1d(MK):
     return (w / w.sum()).astype(np.float32)
 
 
+_FRAME_CACHE = {}
+
+
 def synth_frame(M, N, MK, seed):
+    """the last frame built is kept: the secondary configurations reuse one size several times, and host-side frame synthesis was most of
+    the wall time of a default run (the GPU idled through it)"""
+    key = (M, N, MK, seed)
+    if key not in _FRAME_CACHE:
+        _FRAME_CACHE.clear()
+        _FRAME_CACHE[key] = _synth_frame(M, N, MK, seed)
+    return _FRAME_CACHE[key]
+
+
+def _synth_frame(M, N, MK, seed):
     """Synthetic problem of SURVEY.md 8d at full size, cheap enough for a benchmark prologue: smooth
     random scene on the padded frame, blurred by the separable Gaussian PSF (sigma = MK/6), + noise."""
     rng = np.random.default_rng(seed)
