@@ -159,9 +159,10 @@ def mfma_counters(kernel, M, MK):
     """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/r04_mfma_counters.json, written by
     scripts/make_mfma_json.py from rocprofv3 --pmc runs): static, NOT measured in this run -- like `traffic`."""
     try:
-        mj = json.load(open(os.path.join(ROOT, "profiles", "r04_mfma_counters.json")))
-        if mj["workload"] == {"size": M, "psf": MK} and kernel in mj["kernels"]:
-            return dict(mj["kernels"][kernel], source="profiles/r04_mfma_counters.json (static: rocprofv3 SQ passes of an earlier run of this command)")
+        for name in ("r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
+            mj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if mj["workload"] == {"size": M, "psf": MK} and kernel in mj["kernels"]:
+                return dict(mj["kernels"][kernel], source="profiles/%s (static: rocprofv3 SQ passes of an earlier run of this command)" % name)
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -423,12 +424,14 @@ def main():
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
         traffic, traffic_file = None, "profiles/r04_hbm_traffic.json"
-        try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
-            tj = json.load(open(os.path.join(ROOT, traffic_file)))
-            if tj["workload"] == {"size": M, "psf": MK}:
-                traffic = tj[lab["traffic_key"]]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+        for tf in ("profiles/r04_hbm_traffic.json", "profiles/r04_6144_31_hbm_traffic.json"):
+            try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
+                tj = json.load(open(os.path.join(ROOT, tf)))
+                if tj["workload"] == {"size": M, "psf": MK}:
+                    traffic, traffic_file = tj[lab["traffic_key"]], tf
+                    break
+            except (OSError, ValueError, KeyError):
+                traffic = None
         if kern:
             dom = max((k for k in kern if k in BYTES_PER_PX), key=lambda k: kern[k]["ms"] * kern[k]["launches"])
             bytes_launch = BYTES_PER_PX[dom] * M * N
