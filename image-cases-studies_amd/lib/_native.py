@@ -416,8 +416,13 @@ class RLJob:
         _check(load().ics_rl_download(self._h, None, None, _ptr(psf_caller)))
         return psf_caller
 
-    def download(self):
-        u = np.empty((self.uM, self.uN, 3), np.float32)
+    def download(self, u_out=None):
+        """(u, psf_local, psf_caller).  `u_out`: a C-contiguous float32 array of u's shape to download into (the caller's own `u`: saves a
+        frame-sized host copy, 10 ms at 4096^2); anything else gets a fresh array."""
+        if u_out is not None and isinstance(u_out, np.ndarray) and u_out.dtype == np.float32 and u_out.shape == (self.uM, self.uN, 3) and u_out.flags["C_CONTIGUOUS"] and u_out.flags["WRITEABLE"]:
+            u = u_out
+        else:
+            u = np.empty((self.uM, self.uN, 3), np.float32)
         psf_local = np.empty((self.MK, self.MK, 3), np.float32)
         psf_caller = np.empty((self.MK, self.MK, 3), np.float32)
         _check(load().ics_rl_download(self._h, _ptr(u), _ptr(psf_local), _ptr(psf_caller)))

@@ -191,8 +191,9 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,
                         tv_mode=tv_mode, conv=conv, flags=flags)
     st, interrupt = _run_interruptible(job, params)
-    u_new, _psf_local, psf_caller = job.download()
-    u[...] = u_new                                                             # in place, any strides
+    u_new, _psf_local, psf_caller = job.download(u)                            # straight into the caller's u when it is contiguous ...
+    if u_new is not u:
+        u[...] = u_new                                                         # ... else in place through a copy, any strides
     if blind:
         psf[...] = psf_caller
     if tv_mode == 1:
