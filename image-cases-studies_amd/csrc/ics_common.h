@@ -152,6 +152,16 @@ __device__ __forceinline__ float ics_dof_ratio(float g, float f) {
   return (g == 0.f && f == 0.f) ? 1.0f : d;
 }
 
+// Persistent tile walks (ics_conv_mfma.hip, ics_synth_gradk_mfma.hip): workgroup b runs on XCD b % nb and walks the band of tiles
+// [ics_band_begin(x), ics_band_begin(x + 1)) of its XCD x.  A band's share of the tiles follows the number of workgroups that walk it
+// (grid / nb, or one more for the first grid % nb XCDs).  With equal shares, 85 tiles dealt to 85 workgroups gave two XCDs 11 tiles
+// and 10 workgroups: one workgroup walked two tiles and a 255^2 back-projection took 16 us instead of 10 (phase timeline,
+// tools/bench_conv_mfma.hip -DICS_MFMA_TRACE).
+__host__ __device__ inline int ics_band_begin(int ntiles, int grid, int nb, int x) {
+  const int q = grid / nb, r = grid - q * nb;
+  return (int)((long)ntiles * (q * x + (x < r ? x : r)) / grid);
+}
+
 // Wave-wide maximum (all 64 lanes receive it) without ds_bpermute: four DPP steps inside each row of 16 lanes, then the four
 // row results through v_readlane.  The shuffle form (__shfl_xor = ds_bpermute) needs one address register per step; inside a
 // persistent tile loop the compiler hoisted those addresses above the loop and, in the 256-register kernels, spilled one of

@@ -69,6 +69,9 @@
 #ifndef ICS_EPI_TB
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
 #endif
+#ifndef ICS_EPI_EARLY1
+#define ICS_EPI_EARLY1 1      /* 16-row tiles (small frames, one tile per workgroup): the epilogue operands are requested with the tile's rows, at the top of the kernel */
+#endif
 #ifndef ICS_EPI_EARLY
 #define ICS_EPI_EARLY 1       /* mode 0, 32-row tiles, accumulator-order image: request the image operand BEFORE the matrix phase (130 of 168 VGPRs in use: room for its 24) */
 #endif
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   const int cb = wv & 3, half = wv >> 2;                      // column block of this wave; which kernel rows it takes (NH = 2)
   const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
   const int pitch = a.g.pitch;
+  ICS_TICK_INIT;
 
   // persistent tile walk: workgroup b runs on XCD b % 8 (observed dispatch); every XCD owns one contiguous
   // band of tiles so that the halos shared by neighbouring tiles hit in that XCD's L2
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;         // bands (= XCDs when the grid covers them all)
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
   const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;            // workgroups walking this band
-  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  const int band0 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd), band1 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd + 1);
   // Tile walk inside a band.  Static: workgroup kx takes tiles band0 + kx, + nx, ...  Dynamic (a.sched): the first tile is the
   // static one, every further tile is claimed from the band's counter when the current one starts (early enough for the
   // register prefetch) -- the back-projection's 65 x 65 tiles of a 4096^2 frame are 8.25 per workgroup and the edge tiles
@@ -264,11 +268,46 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   // used to sit in front of this one.
   // frame allocation start = origin - (ay rows + ax pixels); tile offsets are then non-negative
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in - ((ptrdiff_t)a.g.ay * pitch + 3 * a.g.ax));
+  // (and the weight rows ahead of those: loads return in order, so the rows' trip to the LDS below waits for nothing but itself while the
+  //  tile rows are still in flight -- as a load / store loop behind them it was a second round trip in series: 2.7 us of the 8.5 us a
+  //  255^2 synthesis takes were spent before the first conversion)
+  constexpr int WPT = C::WSPLIT ? 1 : (C::WLDS / 4 + C::NT - 1) / C::NT;
+  uint32_t wreg[WPT];
+  if constexpr (!C::WSPLIT) {
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) { const int i = tid + k * C::NT; wreg[k] = i < C::WLDS / 4 ? tab[i] : 0u; }
+  }
   f32x4u raw[C::NIT][3];
   if (tile < band1) {
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
+  // 16-row tiles are what frames with fewer tiles than compute units get: every workgroup runs ONE tile and the kernel's time is its chain
+  // of dependent round trips, so the epilogue operands (image; u and the majoriser) travel with the rows instead of behind the matrix phase
+  // (on frames that fill the device the same move measured nothing: other workgroups cover the latency there).
+  constexpr bool EARLY1 = ICS_EPI_EARLY1 != 0 && RS == 1 && NH == 1 && (MODE == 0 || ICS_EPI_EARLY1 >= 3);
+  constexpr int EOPS1 = (MODE == 0) ? 1 : 2;
+  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
+  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
+  u3 pre1[EOPS1][4];
+  auto request1 = [&](int tl) {
+    const int tyi = tl / tpr, txi = tl - tyi * tpr;
+    const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
+    if (x0 + 16 * cb < xend) {
+      const int tide = opaque(tid);
+      const int voff = 4 * (4 * C::RS * ((tide >> 4) & 3) * pitch + 3 * (tide & 15)), sb = 4 * (y0 * pitch + 3 * (x0 + 16 * cb));
+      const bool maj = MODE == 1 && a.tv_kind < 2;   // (the PAM kinds have no majoriser term)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int so = sb + 4 * C::RS * r * pitch;
+        pre1[0][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
+        if (maj) pre1[EOPS1 - 1][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
+      }
+    }
+  };
+  bool first1 = true;
+  if (EARLY1 && ICS_EPI_EARLY1 != 2 && tile < band1) request1(tile);
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
   // weight rows -> LDS once per workgroup (the global table is the LDS image)
@@ -288,9 +327,12 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
         dst[2 * RD] = __builtin_amdgcn_alignbit(h1, h0, 16); dst[3 * RD] = __builtin_amdgcn_alignbit(l1, l0, 16);
       }
     } else {
-      for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+#pragma unroll
+      for (int k = 0; k < WPT; ++k) { const int i = tid + k * C::NT; if (i < C::WLDS / 4) ldsW[i] = wreg[k]; }
     }
   }
+  ICS_TICK(8);
+  if (EARLY1 && ICS_EPI_EARLY1 == 2 && tile < band1) request1(tile);
   // lane constants of the B operand: in window h this lane's 8 consecutive halves start at half
   // bo = 32h + 8*lg - li + 15 of the zero-padded row; it reads the five dwords that contain them and funnel-shifts
   // by the parity (v_alignbit).  (Gathering them from a row image with ds_bpermute cost ~5 LDS cycles per bpermute.)
@@ -317,12 +359,9 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
   uint32_t rflags = 0u;   // bit 6: any element reduced
 
   // epilogue operands and output through buffer addressing as well (frame origins; offsets are >= 0 there)
-  const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
-  const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
   const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(a.out);
   // (the first tile's rows were requested at the top of the kernel, ahead of the weight rows)
 
-  ICS_TICK_INIT;
   int next_tile = 0;
 #pragma unroll 1
   for (; tile < band1; tile = next_tile) {
@@ -395,6 +434,8 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
 #pragma unroll
         for (int t = 0; t < C::RS; ++t) fpre[c][t] = __builtin_amdgcn_raw_buffer_load_b128(rs_a0, lv, sb0 + (c * C::RS + t) * 1024, ICS_EPI_LOAD_AUX0);
     }
+    if (EARLY1 && !first1) request1(tile);   // (a workgroup's further tiles, if any: ahead of the matrix phase)
+    first1 = false;
     next_tile = a.sched ? __builtin_amdgcn_readfirstlane(lds_next[parity]) : tile + nx;
     parity ^= 1;
     if (next_tile < band1) {
@@ -894,6 +935,12 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           const int so = sb + 4 * (t + C::RS * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           if (MODE == 0 && use_acc) continue;   // requested below, per (channel, t)
+          if (EARLY1) {
+            eop[0][t][r] = pre1[0][r];
+            if (MODE == 1 && !pam) eop[EOPS - 1][t][r] = pre1[EOPS1 - 1][r];
+            if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
+            continue;
+          }
           eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
           if (MODE == 1 && !pam) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);   // (PAM has no majoriser term)
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
@@ -981,7 +1028,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
     //  before the next conversion overwrites the planes)
   }
 
-  ICS_TICK_FLUSH;
+  ICS_TICK(6);
   if (a.sched && tid == 0) {   // the last workgroup out re-arms the counters for the next launch
     if (atomicAdd(a.sched + 8, 1u) == gridDim.x - 1) {
 #pragma unroll
@@ -1014,6 +1061,8 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
       if (m > a.red[slot]) atomicMax(a.red + slot, m);
     }
   }
+  ICS_TICK(9);
+  ICS_TICK_FLUSH;
 }
 
 template <int K, int MODE, int RS, int NH = 1>

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
   const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;
-  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  const int band0 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd), band1 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd + 1);
   int tile = band0 + kx;
 
   f4 tot[3];
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int nb = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
   const int xcd = blockIdx.x % nb, kx = blockIdx.x / nb;
   const int nx = ((int)gridDim.x + nb - 1 - xcd) / nb;
-  const int band0 = (int)((long)ntiles * xcd / nb), band1 = (int)((long)ntiles * (xcd + 1) / nb);
+  const int band0 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd), band1 = ics_band_begin(ntiles, (int)gridDim.x, nb, xcd + 1);
   int tile = band0 + kx;
 
   f4 tot[3];
@@ -1216,6 +1216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       dst[(c * 16 + ta) * 16 + tb] = s;
     }
   }
+
 }
 
 template <int K>

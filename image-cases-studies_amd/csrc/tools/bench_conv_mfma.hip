@@ -1,7 +1,15 @@
 // bench_conv_mfma.hip -- stand-alone timing harness for the matrix-core convolution (ics_conv_mfma.hip) at
 // 4096^2 x 3, 15x15 PSF; built in variants (-DICS_MFMA_ABLATE=mask) to see which phase bounds the kernel.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I.. [-DICS_MFMA_ABLATE=m] bench_conv_mfma.hip -o bench_conv_mfma
+#ifdef ICS_BENCH_SMALL_K   /* K <= 17 only (seconds to build): the other parts' entry points are stubs */
+#define ICS_MFMA_PART 0
+#endif
 #include "../ics_conv_mfma.hip"
+#ifdef ICS_BENCH_SMALL_K
+hipError_t ics_launch_conv_mfma_part1(int, const IcsConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t ics_launch_conv_mfma_part2(int, const IcsConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t ics_launch_conv_mfma_part3(int, const IcsConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-NAMES = {15: 'start', 0: 'convert', 7: 'prefetch', 1: 'mfma', 3: 'epi-issue', 5: 'epilogue'}
+NAMES = {15: 'start', 8: 'weights', 0: 'convert', 7: 'prefetch', 1: 'mfma', 3: 'epi-issue', 5: 'epilogue', 6: 'loop-exit', 9: 'reductions'}
 
 
 def load(path):
@@ -42,7 +42,8 @@ def main(path):
             for i in range(ia, ib + 1):
                 occ[m][i] += (min(b, i + 1) - max(a, i))
             prev = t
-    for m in (0, 7, 1, 3, 5):
+    for m in (8, 0, 7, 1, 3, 5, 6, 9):
+        if not dur[m]: continue
         x = np.array(dur[m])
         print('%-10s n=%5d mean %.2f us  p10 %.2f p50 %.2f p90 %.2f' % (NAMES[m], len(x), x.mean(), *np.percentile(x, [10, 50, 90])))
     print('waves per phase over time (1-us bins): t, convert, prefetch, mfma, epi-issue, epilogue')
