@@ -900,14 +900,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int c = 0; c < 3; ++c) tot[c] = (f4){0.f, 0.f, 0.f, 0.f};
 
+  // Prologue: the weight rows (the global table is the LDS image) are requested first, into registers, then the first tile's rows; the
+  // LDS is zeroed and the weight rows stored while the tile rows are in flight.  (As zero-fill, a load / store loop for the weights and
+  // then the tile rows these were three round trips in series -- what a frame of one tile per workgroup, e.g. deblur_module's 255-px
+  // blind windows, spends its time on; as in ics_conv_mfma.hip.)
+  constexpr int WPT = (C::WLDS / 4 + C::NT - 1) / C::NT;
+  uint32_t wreg[WPT];
   {
-    u4* z = reinterpret_cast<u4*>(lds);
-    for (int i = tid; i < C::WOFF / 16; i += C::NT) z[i] = (u4){0u, 0u, 0u, 0u};
-    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
     const uint32_t* tab = reinterpret_cast<const uint32_t*>(a.bt);
-    for (int i = tid; i < C::WLDS / 4; i += C::NT) ldsW[i] = tab[i];
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) { const int i = tid + k * C::NT; wreg[k] = i < C::WLDS / 4 ? tab[i] : 0u; }
   }
-  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
   typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32p)(lds);
@@ -922,6 +925,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int tyi = tile / tpr, txi = tile - tyi * tpr;
     load_raw2<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
+  {
+    u4* z = reinterpret_cast<u4*>(lds);
+    for (int i = tid; i < C::WOFF / 16; i += C::NT) z[i] = (u4){0u, 0u, 0u, 0u};
+    uint32_t* ldsW = reinterpret_cast<uint32_t*>(lds + C::WOFF);
+#pragma unroll
+    for (int k = 0; k < WPT; ++k) { const int i = tid + k * C::NT; if (i < C::WLDS / 4) ldsW[i] = wreg[k]; }
+  }
+  const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
   __syncthreads();   // LDS initialised
 
 #pragma unroll 1
