@@ -176,8 +176,12 @@ struct ics_rl {
   int graph_epoch;                      // ... and the state of the debug switches they were captured under
   // profiling
   std::vector<hipEvent_t> ev;
-  std::vector<int> ev_class;
+  struct EvPair { int b, e, cls; };     // a bracketed launch group: events ev[b] .. ev[e]
+  std::vector<EvPair> ev_pairs;
   size_t ev_used;
+  int ev_open = -1, ev_open_cls = 0;    // begin() without its end() yet
+  int ev_chain = -1;                    // the event the last end() recorded, while nothing else has been queued behind it (Prof::begin)
+  hipStream_t ev_chain_stream = nullptr;
   hipEvent_t ev_begin, ev_end;
 };
 
@@ -653,44 +657,58 @@ static int ensure_window(ics_rl* j, const ics_rl_params* p) {
 }
 
 // ---- launch helpers with optional event bracketing -----------------------------------------------
+#define RC0(x) do { int rc0_ = (x); if (rc0_ != ICS_OK) return rc0_; } while (0)
 struct Prof {
   ics_rl* j; bool on;
   hipStream_t s = nullptr;              // nullptr: the job's stream
   hipStream_t st() const { return s ? s : j->ctx->stream; }
-  int begin(int cls) {
-    if (!on) return ICS_OK;
-    if (j->ev_used + 2 > j->ev.size()) {
+  int grow() {
+    if (j->ev_used + 1 > j->ev.size()) {
       for (int i = 0; i < 64; ++i) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); j->ev.push_back(e); }
     }
-    j->ev_class.resize(j->ev.size());
-    j->ev_class[j->ev_used] = cls;
-    HIPCHK(hipEventRecord(j->ev[j->ev_used], st()));
+    return ICS_OK;
+  }
+  // Consecutive brackets on one stream share an event: the end of one is the begin of the next (an event record between two dependent
+  // kernels is a bubble of a few microseconds on the device; 10 per bracketed blind iteration were 2 % of bench.py's timed region).
+  // Anything queued outside a bracket breaks the chain: unbracketed launches come through a disabled Prof, other sites call unchain().
+  int begin(int cls) {
+    if (!on) { j->ev_chain = -1; return ICS_OK; }
+    if (j->ev_chain >= 0 && j->ev_chain_stream == st()) j->ev_open = j->ev_chain;
+    else {
+      RC0(grow());
+      HIPCHK(hipEventRecord(j->ev[j->ev_used], st()));
+      j->ev_open = (int)j->ev_used++;
+    }
+    j->ev_open_cls = cls;
+    j->ev_chain = -1;
     return ICS_OK;
   }
   int end() {
     if (!on) return ICS_OK;
-    HIPCHK(hipEventRecord(j->ev[j->ev_used + 1], st()));
-    j->ev_used += 2;
+    RC0(grow());
+    HIPCHK(hipEventRecord(j->ev[j->ev_used], st()));
+    j->ev_pairs.push_back({j->ev_open, (int)j->ev_used, j->ev_open_cls});
+    j->ev_chain = (int)j->ev_used++; j->ev_chain_stream = st();
+    j->ev_open = -1;
     return ICS_OK;
   }
+  void unchain() { j->ev_chain = -1; }
   // call after a stream synchronisation
   int collect(double* ms, int* launches) {
     if (!on) return ICS_OK;
-    for (size_t i = 0; i + 1 < j->ev_used; i += 2) {
-      float t = 0.f;
-      HIPCHK(hipEventElapsedTime(&t, j->ev[i], j->ev[i + 1]));
-      ms[j->ev_class[i]] += t; launches[j->ev_class[i]] += 1;
-    }
-    j->ev_used = 0;
+    size_t done = 0;
+    RC0(collect_range(ms, launches, done, j->ev_pairs.size()));
+    j->ev_used = 0; j->ev_pairs.clear(); j->ev_chain = -1;
     return ICS_OK;
   }
-  // overlapped runs: the events [done, upto) are known to be complete; nothing is recycled until the run ends
+  // overlapped runs: the pairs [done, upto) are known to be complete; nothing is recycled until the run ends
   int collect_range(double* ms, int* launches, size_t& done, size_t upto) {
     if (!on) return ICS_OK;
-    for (size_t i = done; i + 1 < upto; i += 2) {
+    for (size_t i = done; i < upto; ++i) {
+      const ics_rl::EvPair& q = j->ev_pairs[i];
       float t = 0.f;
-      HIPCHK(hipEventElapsedTime(&t, j->ev[i], j->ev[i + 1]));
-      ms[j->ev_class[i]] += t; launches[j->ev_class[i]] += 1;
+      HIPCHK(hipEventElapsedTime(&t, j->ev[q.b], j->ev[q.e]));
+      ms[q.cls] += t; launches[q.cls] += 1;
     }
     done = upto;
     return ICS_OK;
@@ -1098,7 +1116,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   Prof pr_on{j, p->profile != 0};       // (per-outer kernels are always bracketed when profiling)
   Prof pr_off{j, false};
   Prof& pr = pr_on;
-  j->ev_used = 0;
+  j->ev_used = 0; j->ev_pairs.clear(); j->ev_chain = -1;
   double ms[ICS_KERNEL_COUNT] = {0};
   int launches[ICS_KERNEL_COUNT] = {0};
   const int INNER = 5;  // pyx:375
@@ -1114,6 +1132,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   HIPCHK(hipEventRecord(j->ev_begin, s));
   // the launches of one outer iteration (pyx:462-591) ...
   auto enqueue_body = [&]() -> int {
+    j->ev_chain = -1;
     if (p->fuse) RC(do_majorize(j, pr));                      // pyx:462 (explicit copy only for the fused path)
     else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
     const bool fuse = p->fuse != 0;
@@ -1249,7 +1268,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       HIPCHK(hipStreamWaitEvent(c->stream2, j->ev_body[enq & 1], 0));
       RC(enqueue_stats(c->stream2, j->h_scal + (enq & 1) * (ICS_SC_COUNT + 4), pr_s2));
       HIPCHK(hipEventRecord(j->ev_stats[enq & 1], c->stream2));
-      ev_mark[enq & 1] = j->ev_used;
+      ev_mark[enq & 1] = j->ev_pairs.size();
+      j->ev_chain = -1;
       ++enq;
       if (enq >= 2) {                                         // the scalars of the iteration BEFORE the one just queued
         HIPCHK(hipEventSynchronize(j->ev_stats[(enq - 2) & 1]));
@@ -1264,8 +1284,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     }
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipStreamSynchronize(c->stream2));
-    RC(pr.collect_range(ms, launches, ev_done, j->ev_used));
-    j->ev_used = 0;
+    RC(pr.collect_range(ms, launches, ev_done, j->ev_pairs.size()));
+    j->ev_used = 0; j->ev_pairs.clear(); j->ev_chain = -1;
     j->par = 0;
   } else
   while (it < p->iterations && !stop) {                       // pyx:460
