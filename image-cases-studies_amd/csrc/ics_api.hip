@@ -309,6 +309,31 @@ static int dalloc(ics_ctx* c, T** p, size_t count, bool zero = true) {
   return ICS_OK;
 }
 
+// ... or collected in `zl` and zero-filled by ONE launch (flush_zero): a new job's ~24 buffers as 24 memsets cost the host ~35 us each
+// (deblur_module creates a job per pyramid level and phase: 8 % of a resident 2048^2 run were the gaps in front of those fills)
+struct ZeroList { std::vector<std::pair<void*, size_t>> items; };
+template <typename T>
+static int dalloc(ics_ctx* c, T** p, size_t count, ZeroList* zl) {
+  const int rc = dalloc(c, p, count, false);
+  if (rc == ICS_OK) zl->items.emplace_back((void*)*p, count * sizeof(T));
+  return rc;
+}
+static int flush_zero(ics_ctx* c, ZeroList& zl) {
+  size_t i = 0;
+  while (i < zl.items.size()) {
+    IcsZeroArgs a{};
+    unsigned long long run = 0;
+    for (; a.count < ICS_ZERO_MAX && i < zl.items.size(); ++i) {
+      a.p[a.count] = zl.items[i].first;
+      run += (zl.items[i].second + 15) / 16;        // (pool blocks are multiples of 8 KiB: the rounding stays inside the block)
+      a.end16[a.count++] = run;
+    }
+    HIPCHK(ics_launch_zero_many(a, c->stream));
+  }
+  zl.items.clear();
+  return ICS_OK;
+}
+
 extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
@@ -352,23 +377,25 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   int rc;
 #define TRY(x) if ((rc = (x)) != ICS_OK) { ics_rl_destroy(j); return rc; }
   hipStream_t s = c->stream;
-  TRY(dalloc(c, &j->u, j->frame_floats)); TRY(dalloc(c, &j->u2, j->frame_floats)); TRY(dalloc(c, &j->ut, j->frame_floats)); TRY(dalloc(c, &j->gr, j->frame_floats));
-  TRY(dalloc(c, &j->f, j->frame_floats)); TRY(dalloc(c, &j->e, j->frame_floats));
-  TRY(dalloc(c, &j->psf, n)); TRY(dalloc(c, &j->gradk, n)); TRY(dalloc(c, &j->psf_caller, n));
-  if (ics_big_supported(MK)) TRY(dalloc(c, &j->psf_work, n));
+  ZeroList zl;
+  TRY(dalloc(c, &j->u, j->frame_floats, &zl)); TRY(dalloc(c, &j->u2, j->frame_floats, &zl)); TRY(dalloc(c, &j->ut, j->frame_floats, &zl)); TRY(dalloc(c, &j->gr, j->frame_floats, &zl));
+  TRY(dalloc(c, &j->f, j->frame_floats, &zl)); TRY(dalloc(c, &j->e, j->frame_floats, &zl));
+  TRY(dalloc(c, &j->psf, n, &zl)); TRY(dalloc(c, &j->gradk, n, &zl)); TRY(dalloc(c, &j->psf_caller, n, &zl));
+  if (ics_big_supported(MK)) TRY(dalloc(c, &j->psf_work, n, &zl));
   if (MK >= 51) {   // tap blocks: the fewest blocks of a size the matrix-core convolution is built for (odd, <= 33)
     j->blk_n = (MK + 32) / 33;
     j->blk_kb = ((MK + j->blk_n - 1) / j->blk_n) | 1;
     const size_t tf = ics_conv_mfma_table_floats(j->blk_kb);
-    TRY(dalloc(c, &j->blk_conv, tf * j->blk_n * j->blk_n)); TRY(dalloc(c, &j->blk_corr, tf * j->blk_n * j->blk_n));
-    TRY(dalloc(c, &j->blk_scr, j->frame_floats)); TRY(dalloc(c, &j->blk_zero, j->frame_floats));
-    TRY(dalloc(c, &j->blk_red, (size_t)ICS_RED_STRIDE));
+    TRY(dalloc(c, &j->blk_conv, tf * j->blk_n * j->blk_n, &zl)); TRY(dalloc(c, &j->blk_corr, tf * j->blk_n * j->blk_n, &zl));
+    TRY(dalloc(c, &j->blk_scr, j->frame_floats, &zl)); TRY(dalloc(c, &j->blk_zero, j->frame_floats, &zl));
+    TRY(dalloc(c, &j->blk_red, (size_t)ICS_RED_STRIDE, &zl));
   }
-  TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow));
-  if (ics_conv_mfma_supported(MK)) { TRY(dalloc(c, &j->bt_conv, ics_conv_mfma_table_floats(MK))); TRY(dalloc(c, &j->bt_corr, ics_conv_mfma_table_floats(MK))); }
-  TRY(dalloc(c, &j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt));
-  TRY(dalloc(c, &j->red, (size_t)2 * 8 * ICS_RED_STRIDE)); TRY(dalloc(c, &j->dofkeys, (size_t)2 * 4)); TRY(dalloc(c, &j->sched, (size_t)16));   // (two sets: ics_rl::par)
-  TRY(dalloc(c, &j->scal, (size_t)ICS_SC_COUNT)); TRY(dalloc(c, &j->dacc, (size_t)8)); TRY(dalloc(c, &j->ukey, (size_t)2)); TRY(dalloc(c, &j->flags, (size_t)4));
+  TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow, &zl)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow, &zl));
+  if (ics_conv_mfma_supported(MK)) { TRY(dalloc(c, &j->bt_conv, ics_conv_mfma_table_floats(MK), &zl)); TRY(dalloc(c, &j->bt_corr, ics_conv_mfma_table_floats(MK), &zl)); }
+  TRY(dalloc(c, &j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, &zl));
+  TRY(dalloc(c, &j->red, (size_t)2 * 8 * ICS_RED_STRIDE, &zl)); TRY(dalloc(c, &j->dofkeys, (size_t)2 * 4, &zl)); TRY(dalloc(c, &j->sched, (size_t)16, &zl));   // (two sets: ics_rl::par)
+  TRY(dalloc(c, &j->scal, (size_t)ICS_SC_COUNT, &zl)); TRY(dalloc(c, &j->dacc, (size_t)8, &zl)); TRY(dalloc(c, &j->ukey, (size_t)2, &zl)); TRY(dalloc(c, &j->flags, (size_t)4, &zl));
+  TRY(flush_zero(c, zl));
 #undef TRY
   hipError_t e = hipHostMalloc((void**)&j->h_scal, 2 * (ICS_SC_COUNT + 4) * sizeof(float), hipHostMallocDefault);   // (one mirror per set)
   if (e != hipSuccess) { ics_rl_destroy(j); return fail(ICS_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e)); }
@@ -1122,10 +1149,13 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   const int INNER = 5;  // pyx:375
   int it = 0, stop = 0, inner_done = 0;
   float M_r = 0.f, M_r_prev = 0.f, Hu = 0.f, varu = 0.f, dmin = 0.f, dmax = 0.f;
-  HIPCHK(hipMemsetAsync(j->flags, 0, 4 * sizeof(int), s));
-  HIPCHK(hipMemsetAsync(j->sched, 0, 16 * sizeof(uint32_t), s));   // (the kernels re-arm them; an aborted launch must not leak a count)
-  HIPCHK(hipMemsetAsync(j->dacc, 0, 8 * sizeof(double), s));       // accumulators of the window statistics: likewise re-armed by their last kernel
-  HIPCHK(hipMemsetAsync(j->ukey, 0, 2 * sizeof(uint32_t), s));
+  {   // the job's small state in one launch: flags, the tile counters (the kernels re-arm them; an aborted launch must not leak a count), the
+      // accumulators of the window statistics (likewise re-armed by their last kernel), both sets of reduction slots and DoF keys (later
+      // outer iterations: re-armed on the device by the kernel that writes the scalars)
+    IcsRunResetArgs ra;
+    ra.flags = j->flags; ra.sched = j->sched; ra.dacc = j->dacc; ra.ukey = j->ukey; ra.red = j->red; ra.nred = 2 * 8 * ICS_RED_STRIDE; ra.dofkeys = j->dofkeys;
+    HIPCHK(ics_launch_run_reset(ra, s));
+  }
   // the caller's psf array is the local psf when the call starts (pyx:341)
   HIPCHK(hipMemcpyAsync(j->psf_caller, j->psf, (size_t)3 * j->g.K * j->g.K * 4, hipMemcpyDeviceToDevice, s));
   RC(pack_weights(j, 0, 0.f, 0, s));
@@ -1216,8 +1246,6 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     if (p->progress && p->progress(p->progress_user, it, stop, dmin, dmax, M_r, Hu, varu) != 0 && !stop) stop = 2;
   };
   j->par = 0;
-  HIPCHK(hipMemsetAsync(j->red, 0, 2 * 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));   // both sets; later outer iterations: re-armed on the
-  RC(reset_dofkeys(j));                                                               // device by the kernel that writes the scalars
   if (use_overlap(j, p) && !graphs_on) {
     // ---- statistics of iteration i on a second stream, iteration i + 1 already running on the job's stream (round 4) -------------------
     // The stop decision of iteration i needs M_r(i) on the host, so until round 3 the device drained at every outer boundary: five

@@ -71,6 +71,27 @@ hipError_t ics_launch_gradk_reduce_block(const float* partial, int nblocks, floa
 hipError_t ics_launch_band_reduce(const float* gr, const float* u, const float* ut, const IcsGeom& g, float lambd, int r0, int r1, uint32_t* red, hipStream_t s);
 hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hipStream_t s);
 
+// ---- zero-fill of up to ICS_ZERO_MAX device blocks in one launch (the ~24 buffers of a new job: one launch instead of 24 memsets) ----
+#define ICS_ZERO_MAX 32
+struct IcsZeroArgs {
+  void* p[ICS_ZERO_MAX];                 // 16-byte aligned
+  unsigned long long end16[ICS_ZERO_MAX]; // running total of 16-byte units up to and including block i
+  int count;
+};
+hipError_t ics_launch_zero_many(const IcsZeroArgs& a, hipStream_t s);
+
+// the small device state of a job at the start of ics_rl_run, in one launch (was five memsets and two host -> device copies)
+struct IcsRunResetArgs {
+  int* flags;          // [4]  := 0
+  uint32_t* sched;     // [16] := 0
+  double* dacc;        // [8]  := 0
+  uint32_t* ukey;      // [2]  := 0
+  uint32_t* red;       // [nred] := 0
+  int nred;
+  uint32_t* dofkeys;   // [8] := {0xFFFFFFFF, 0, 0, 0} x 2
+};
+hipError_t ics_launch_run_reset(const IcsRunResetArgs& a, hipStream_t s);
+
 // ---- A14-A17 (pyx:574-589) + weight packing ---------------------------------------------------
 struct IcsPsfArgs {
   float* psf;          // [K][K][3] local psf (pyx: the name `psf` inside the function)

@@ -1102,6 +1102,46 @@ hipError_t ics_launch_gradk_reduce_block(const float* partial, int nblocks, floa
   return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_zero_many(IcsZeroArgs a) {
+  const unsigned long long total = a.end16[a.count - 1];
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  int e = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    while (i >= a.end16[e]) ++e;                                   // (i only grows)
+    const unsigned long long first = e ? a.end16[e - 1] : 0ull;
+    reinterpret_cast<uint4*>(a.p[e])[i - first] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+}  // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void k_run_reset(IcsRunResetArgs a) {
+  const int t = threadIdx.x;
+  if (t < 4) a.flags[t] = 0;
+  if (t < 16) a.sched[t] = 0u;
+  if (t < 8) a.dacc[t] = 0.0;
+  if (t < 2) a.ukey[t] = 0u;
+  if (t < 8) a.dofkeys[t] = (t & 3) == 0 ? 0xFFFFFFFFu : 0u;
+  for (int i = t; i < a.nred; i += 256) a.red[i] = 0u;
+}
+}  // namespace
+hipError_t ics_launch_run_reset(const IcsRunResetArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_run_reset, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t ics_launch_zero_many(const IcsZeroArgs& a, hipStream_t s) {
+  if (a.count <= 0) return hipSuccess;
+  const unsigned long long total = a.end16[a.count - 1];
+  if (!total) return hipSuccess;
+  unsigned long long blocks = (total + 256 * 8 - 1) / (256 * 8);
+  const unsigned long long cap = (unsigned long long)ics_device_cus(ics_current_device()) * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_zero_many, dim3((unsigned)blocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t ics_launch_psf(const IcsPsfArgs& a, hipStream_t s) {
   if (a.K > 63) {
     if (!a.work) return hipErrorInvalidValue;

@@ -45,7 +45,11 @@ def _check_buffer(name, arr):
         raise ValueError("Buffer dtype mismatch, expected 'DTYPE_t' but got '%s'" % cname)
 
 
-_JOB_CACHE_MAX = 4   # deblur_module alternates between the pyramid levels' window and full-frame sizes
+# deblur_module calls the solver at 2 x (pyramid levels) problem sizes per picture -- 10 for a 15-px blur -- and batch runs repeat them per
+# picture: with 4 cached jobs every call built a new one (24 buffers, a pinned mirror, events; ~1 ms).  Least recently used out, by count
+# and by device bytes (a job holds 7-8 frames of its size).
+_JOB_CACHE_MAX = 16
+_JOB_CACHE_MAX_BYTES = 32 << 30
 
 
 def _get_job(M, N, MK):
@@ -55,11 +59,17 @@ def _get_job(M, N, MK):
     key = (int(M), int(N), int(MK), _native.default_device())
     job = _job_cache.pop(key, None)
     if job is None:
-        while len(_job_cache) >= _JOB_CACHE_MAX:
+        need = _job_bytes(key)
+        while _job_cache and (len(_job_cache) >= _JOB_CACHE_MAX or need + sum(_job_bytes(k) for k in _job_cache) > _JOB_CACHE_MAX_BYTES):
             _job_cache.pop(next(iter(_job_cache))).close()
         job = _native.RLJob(M, N, MK)
     _job_cache[key] = job            # (re)inserted last = most recently used
     return job
+
+
+def _job_bytes(key):
+    M, N, MK = key[:3]
+    return 8 * (M + 2 * MK) * (N + 2 * MK) * 12
 
 
 def _drop_jobs():
