@@ -162,6 +162,17 @@ __host__ __device__ inline int ics_band_begin(int ntiles, int grid, int nb, int 
   return (int)((long)ntiles * (q * x + (x < r ? x : r)) / grid);
 }
 
+// Fair shares for the workgroups that share a CU under a STATIC tile walk (ics_synth_gradk_mfma.hip, ics_gradk_mfma.hip; the walks are
+// static because a workgroup's partial sums must not depend on timing).  The CU's arbiter serves the oldest wave first: of the two
+// workgroups of a CU (blocks b and b + CUs of a grid of 2 x CUs) the first-dispatched one walked its tiles a quarter faster and left its
+// mate alone on a half-empty CU for the last fifth of the kernel.  Priority alternates between the mates in slices of 2^slice ticks of the
+// 100 MHz wall clock; `team` = which mate (blockIdx / (grid / mates)).  Scheduling only -- results do not change.
+__device__ __forceinline__ void ics_prio_turn(int slice, int team, int nteams) {
+  if (slice <= 0) return;
+  const unsigned turn = (unsigned)(wall_clock64() >> slice) % (unsigned)nteams;
+  if (turn == (unsigned)team) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+}
+
 // Wave-wide maximum (all 64 lanes receive it) without ds_bpermute: four DPP steps inside each row of 16 lanes, then the four
 // row results through v_readlane.  The shuffle form (__shfl_xor = ds_bpermute) needs one address register per step; inside a
 // persistent tile loop the compiler hoisted those addresses above the loop and, in the 256-register kernels, spilled one of

@@ -43,6 +43,9 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+#ifndef ICS_GRADK_SLICE
+#define ICS_GRADK_SLICE 12   /* priority slices between the two workgroups of a CU, 2^12 x 10 ns (ics_prio_turn, ics_common.h); 0: off.  6144^2 / 31x31: 0.782 (off) -> 0.755 (2^10) -> 0.747 ms (2^12); 4096^2 / 23x23 0.359 -> 0.342 */
+#endif
 template <int NB>
 struct GCfg {
   static constexpr int TW = 64, NT = 16 * NB;        // U columns per tile; taps per axis (padded to 16 NB)
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
       for (int jb = 0; jb < NB; ++jb) tot[c][ia][jb] = (f4){0.f, 0.f, 0.f, 0.f};
 
+  const int team = (int)gridDim.x >= C::WGS ? (int)blockIdx.x / ((int)gridDim.x / C::WGS) % C::WGS : 0;   // which of the CU's workgroups (ics_prio_turn)
   // this workgroup's run of tiles, column-major: [t0, t1)
   const int t0 = (int)((long)ntiles * blockIdx.x / gridDim.x), t1 = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
   f32x4u pu[C::UIT][3], pe[C::EIT][3];
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
         for (int e = 0; e < 4; ++e) me = __builtin_fmaxf(me, __builtin_fabsf(pe[k][h][e]));
     __syncthreads();                       // previous tile's planes fully consumed (and fscr free)
+    ics_prio_turn(ICS_GRADK_SLICE, team, C::WGS);
     wg_max3<C::NW>(mu, me, mc, fscr, wave, lane);
     float s_u, inv_u, s_e, inv_e;
     pow2_scale(mu, s_u, inv_u);

@@ -43,6 +43,14 @@ __device__ unsigned long long ics_fused_ticks[17];
 #define FTICK_INIT unsigned long long tk_prev = __builtin_readcyclecounter(), tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define FTICK(i) do { const unsigned long long tk_now = __builtin_readcyclecounter(); tk_acc[i] += tk_now - tk_prev; tk_prev = tk_now; } while (0)
 #define FTICK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 16; ++i) atomicAdd(&ics_fused_ticks[i], tk_acc[i]); atomicAdd(&ics_fused_ticks[16], 1ull); } } while (0)
+#elif defined(ICS_FUSED_TRACE)
+// phase timeline (tools/bench_synth_gradk.hip -DICS_FUSED_TRACE; format of ics_conv_mfma.hip's ICS_MFMA_TRACE, scripts/trace_conv_mfma.py):
+// lane 0 of every wave records (100 MHz wall clock << 8 | mark) at each mark; entry 0 = HW_ID | XCC_ID << 32.  1024 entries per wave.
+__device__ unsigned long long* ics_fused_trace_buf;
+#define FTICK_INIT unsigned long long* tr_ = ics_fused_trace_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 1024; int tri_ = 0; \
+  if ((threadIdx.x & 63) == 0) { tr_[tri_++] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); tr_[tri_++] = (wall_clock64() << 8) | 15; }
+#define FTICK(i) do { if ((threadIdx.x & 63) == 0 && tri_ < 1023) tr_[tri_++] = (wall_clock64() << 8) | (i); } while (0)
+#define FTICK_FLUSH do { if ((threadIdx.x & 63) == 0) tr_[tri_] = 0; } while (0)
 #else
 #define FTICK_INIT
 #define FTICK(i)
@@ -51,6 +59,21 @@ __device__ unsigned long long ics_fused_ticks[17];
 #ifndef ICS_FUSED_GK_INTERLEAVE
 #define ICS_FUSED_GK_INTERLEAVE 1
 #endif
+// Fair shares for the workgroups of one CU.  The walk is static (the partial sums of a workgroup must not depend on timing), every
+// workgroup has the same number of tiles, and the CU's arbiter serves the OLDEST wave first: of the two workgroups that share a CU (blocks b
+// and b + CUs) the first-dispatched one walked its 8 tiles of a 4096^2 frame in 199 us, the other needed 256 -- 37 us per tile beside its
+// mate, 20 alone on a half-empty CU for the last 57 us (phase timeline, tools/bench_synth_gradk.hip -DICS_FUSED_TRACE,
+// scripts/dbg/trace_teams.py).  Priority now alternates between the mates in slices of 2^ICS_FUSED_SLICE ticks of the 100 MHz wall clock
+// (ics_prio_turn, ics_common.h: s_setprio behind the barriers of the tile).  Scheduling only: results are bit-identical.
+// 4096^2, 15x15, 64-row form (tools/bench_synth_gradk.hip, sustained): 0.2744 -> 0.2616 ms with slices of 2^10 ticks (2^7: 0.262, 2^12: 0.262,
+// 2^14: 0.266; the younger mate always first: 0.275); the mates now end at 219 / 233 us instead of 199 / 256.
+#ifndef ICS_FUSED_SLICE
+#define ICS_FUSED_SLICE 10   /* 0: off */
+#endif
+#ifndef ICS_FUSED_SLICE2
+#define ICS_FUSED_SLICE2 0   /* the 32-row form, three mates: every slice length measured slower than none (0.2646 -> 0.267 ... 0.273 ms) */
+#endif
+#define ICS_FUSED_TURN(team, nteams) ics_prio_turn((nteams) == 2 ? ICS_FUSED_SLICE : ICS_FUSED_SLICE2, team, nteams)
 #ifndef ICS_FUSED_PRIO
 #define ICS_FUSED_PRIO 0
 #endif
@@ -335,6 +358,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();   // LDS initialised
   FTICK_INIT;
+  constexpr int MATES = 2;                                                      // workgroups per CU
+  const int team = (int)gridDim.x >= MATES ? (int)blockIdx.x / ((int)gridDim.x / MATES) % MATES : 0;
 
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       m = ics_wave_max_f32(m);
       if (lane == 0) fscr[wv] = m;
       lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
+      ICS_FUSED_TURN(team, MATES);
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
       pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
@@ -722,6 +748,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(5);
     lds_barrier();                                                     // e'(0) and planes(1) visible
     FTICK(6);
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
     FTICK(7);
     if (use_acc) load_acc(1); else if (ICS_FUSED_F01) take_f1(); else load_f(1);
@@ -733,6 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(5);
     lds_barrier();                                                     // e'(1) and planes(2) visible
     FTICK(6);
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
     FTICK(7);
     if (use_acc) load_acc(2); else load_f(2);
@@ -753,6 +781,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(5);
     lds_barrier();                                                     // e'(2) visible
     FTICK(6);
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
     FTICK(7);
 #undef ICS_FUSED_CHANNEL
@@ -934,6 +963,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
   __syncthreads();   // LDS initialised
+  constexpr int MATES = 3;                                                      // workgroups per CU (see ICS_FUSED_TURN)
+  const int team = (int)gridDim.x >= MATES ? (int)blockIdx.x / ((int)gridDim.x / MATES) % MATES : 0;
 
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -954,6 +985,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       m = ics_wave_max_f32(m);
       if (lane == 0) fscr[wv] = m;
       lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
+      ICS_FUSED_TURN(team, MATES);
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
       pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
@@ -1176,6 +1208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(0)
     convert_channel2<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
     lds_barrier();                                                     // e'(0) and planes(1) visible
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
     load_img(1);
     conv_phase(std::integral_constant<int, 1>{});
@@ -1183,6 +1216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(1)
     convert_channel2<C, 2>(raw, s_x, up, opaque(tid));
     lds_barrier();                                                     // e'(1) and planes(2) visible
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
     load_img(2);
     auto prefetch = [&]() {
@@ -1198,6 +1232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(2)
     lds_barrier();                                                     // e'(2) visible
     if (ICS_FUSED2_PREFETCH == 1) prefetch();                          // ... during gradk(2) only
+    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
     if (ICS_FUSED2_PREFETCH == 0) prefetch();                          // ... not at all: the other two workgroups of the CU cover the latency
 #undef ICS_FUSED2_CHANNEL

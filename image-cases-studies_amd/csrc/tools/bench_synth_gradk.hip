@@ -44,6 +44,11 @@ int main(int argc, char** argv) {
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_synth_gradk2<15, true>, 256, FCfg2<15>::LDS_BYTES);
     printf("occupancy (workgroups per CU) K=15: 64-row %d (LDS %zu B), 32-row %d (LDS %zu B)\n", nb0, (size_t)FCfg<15>::LDS_BYTES, nb2, (size_t)FCfg2<15>::LDS_BYTES);
   }
+#ifdef ICS_FUSED_TRACE
+  unsigned long long* trace; const size_t trace_n = (size_t)1024 * 4 * 1024;   // up to 1024 workgroups
+  hipMalloc(&trace, trace_n * 8); hipMemset(trace, 0, trace_n * 8);
+  hipMemcpyToSymbol(HIP_SYMBOL(ics_fused_trace_buf), &trace, sizeof trace);
+#endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 200; ++i) if (ics_launch_synth_gradk(a, nblocks, 0) != hipSuccess) { printf("launch failed\n"); return 1; }
   hipDeviceSynchronize();
@@ -56,6 +61,24 @@ int main(int argc, char** argv) {
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("synth_gradk %dx%d K=%d, %d workgroups: %.4f ms\n", M, N, K, nblocks, ms / reps);
+#ifdef ICS_FUSED_TRACE
+  {  // one more launch, traced (scripts/trace_conv_mfma.py, scripts/dbg/trace_tail.py)
+    hipMemset(trace, 0, trace_n * 8);
+    ics_launch_synth_gradk(a, nblocks, 0); hipDeviceSynchronize();
+    std::vector<unsigned long long> ht(trace_n);
+    hipMemcpy(ht.data(), trace, trace_n * 8, hipMemcpyDeviceToHost);
+    char nm[256]; snprintf(nm, sizeof nm, "%s/trace_fused.bin", getenv("ICS_TRACE_DIR") ? getenv("ICS_TRACE_DIR") : ".");
+    FILE* fp = fopen(nm, "wb");
+    if (fp) {
+      for (size_t w = 0; w < trace_n / 1024; ++w) {
+        const unsigned long long* t = ht.data() + w * 1024; int n = 0; while (n < 1024 && t[n]) ++n;
+        if (!n) continue;
+        unsigned long long hdr[2] = {w, (unsigned long long)n}; fwrite(hdr, 8, 2, fp); fwrite(t, 8, n, fp);
+      }
+      fclose(fp);
+    }
+  }
+#endif
 #ifdef ICS_FUSED_TIMING
   {
     unsigned long long t[17]; hipMemcpyFromSymbol(t, HIP_SYMBOL(ics_fused_ticks), sizeof t);
