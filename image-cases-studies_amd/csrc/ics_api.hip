@@ -1079,11 +1079,17 @@ static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
 // Measured (MI355X, ms per inner iteration, drained -> overlapped): non-blind 512^2 / 9x9 0.044 -> 0.040 (0.060 -> 0.040 after a long run of
 // small launches, when the device has clocked down), non-blind 2048^2 / 15x15 0.160 -> 0.152; blind 4096^2 / 15x15 0.808 -> 0.804 without
 // and 0.810 -> 0.821 with event brackets in the timed region: on frames that fill the device the statistics' small kernels only compete
-// with the persistent workgroups of the convolutions.  Hence by default up to 9 Mpx (switch = 1), everywhere with switch = 2.
+// with the persistent workgroups of the convolutions.
+// Re-measured at the end of round 4 on two boxes, drained -> overlapped: non-blind 512^2 0.045 -> 0.040, 1024^2 0.080 -> 0.073, 1448^2 0.103 -> 0.096,
+// 2048^2 level, 2560^2 0.218 -> 0.223, 2900^2 0.270 -> 0.277, 3072^2 0.320 -> 0.333; blind 255^2 0.066 -> 0.066 ... 0.070 (the copies of the PSF
+// and the event bubble of an outer boundary weigh as much as the drain they replace), 512^2 0.073 -> 0.077, 1024^2 0.114 -> 0.111, 1536^2
+// level, 2048^2 0.227 -> 0.232, 2560^2 0.333 -> 0.341.  Hence by default (switch = 1): non-blind up to 4.5 Mpx, blind between 0.6 and 2.5 Mpx;
+// everywhere with switch = 2.
 static bool use_overlap(const ics_rl* j, const ics_rl_params* p) {
   if (p->fuse || p->tv_mode == ICS_TV_MM_ACTIVE || j->win_empty || p->iterations < 2) return false;
   const int sw = ics_debug().overlap.load(std::memory_order_relaxed);
-  return sw == 2 || (sw == 1 && (long)j->g.uM * j->g.uN <= 9000000L);
+  const long px = (long)j->g.uM * j->g.uN;
+  return sw == 2 || (sw == 1 && (p->blind ? (px >= 600000L && px <= 2500000L) : px <= 4500000L));
 }
 
 // ics_rl_describe / ics_describe: the routing predicates above, as the launches below evaluate them

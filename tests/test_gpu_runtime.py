@@ -191,7 +191,7 @@ def test_abort_under_overlap_drops_the_iteration_that_was_ahead(debug_switch):
                 debug_switch("overlap", 0)
                 st = job.run(job.params(*win, 1e9, 4, 1e-3, 1e4, True, stop_test=2))
             else:
-                debug_switch("overlap", 1)
+                debug_switch("overlap", 2)
                 st = job.run(job.params(*win, 1e9, 30, 1e-3, 1e4, True, stop_test=2), progress=lambda it, *a: it == 4)
                 assert st.stopped == 2
             assert st.iterations_done == 4 and st.inner_iterations == 20
