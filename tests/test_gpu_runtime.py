@@ -162,18 +162,19 @@ def test_statistics_overlapped_with_the_next_iteration_change_nothing(golden_dir
     blind M_r > M_r_prev), that run to the end, and with the correlation quirk (the caller's PSF frozen after the first step)."""
     z, meta = load_golden(golden_dir, name)
     res = {}
-    for ov in (0, 2):
+    for ov in (0, 2, 3):
         debug_switch("overlap", ov)
         u, psf, log, st = _run(z, meta, iters)
         res[ov] = (u, psf, log, st.iterations_done, st.stopped, st.inner_iterations, np.array(st.trace_M_r[:st.trace_len]), np.array(st.trace_Hu[:st.trace_len]),
                    np.array(st.trace_varu[:st.trace_len]), np.array(st.trace_dof_min[:st.trace_len]), np.array(st.trace_dof_max[:st.trace_len]), st.M_r, st.Hu, st.varu)
-    a, b = res[0], res[2]
+    a = res[0]
     print("%s: %d of %d outer iterations, stopped = %d" % (name, a[3], iters, a[4]))
-    assert a[3:6] == b[3:6] and a[5] == 5 * a[3]
-    assert a[2] == b[2]                                                  # the printed lines
-    for x, y in zip(a[:2] + a[6:11], b[:2] + b[6:11]):
-        assert np.array_equal(x, y, equal_nan=True)
-    assert a[11:] == b[11:] or all(np.isnan(v) for v in a[11:] + b[11:])
+    for b in (res[2], res[3]):       # 2: statistics on the second stream; 3: look-ahead on the job's own stream
+        assert a[3:6] == b[3:6] and a[5] == 5 * a[3]
+        assert a[2] == b[2]                                                  # the printed lines
+        for x, y in zip(a[:2] + a[6:11], b[:2] + b[6:11]):
+            assert np.array_equal(x, y, equal_nan=True)
+        assert a[11:] == b[11:] or all(np.isnan(v) for v in a[11:] + b[11:])
 
 
 def test_abort_under_overlap_drops_the_iteration_that_was_ahead(debug_switch):
@@ -211,7 +212,7 @@ def test_long_overlapped_run_equals_the_drained_one(debug_switch, blind, tv_mode
     case = orc.synth_case(M, N, MK, seed=5, blind=blind)
     win = orc.default_window(M, N, MK)
     out = {}
-    for ov in (0, 2):
+    for ov in (0, 2, 3):
         debug_switch("overlap", ov)
         job = nv.RLJob(M, N, MK)
         try:
@@ -221,5 +222,6 @@ def test_long_overlapped_run_equals_the_drained_one(debug_switch, blind, tv_mode
             out[ov] = job.download() + (np.array(st.trace_M_r[:150]), np.array(st.trace_dof_max[:150]), np.array(st.trace_varu[:150]))
         finally:
             job.close()
-    for x, y in zip(out[0], out[2]):
-        assert np.array_equal(x, y, equal_nan=True)
+    for ov in (2, 3):
+        for x, y in zip(out[0], out[ov]):
+            assert np.array_equal(x, y, equal_nan=True)
