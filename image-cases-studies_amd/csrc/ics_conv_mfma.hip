@@ -70,7 +70,7 @@
 #define ICS_EPI_TB(mode) ((mode) == 0 ? 4 : 2)   /* mode 1 carries two operand frames: two batches keep it spill-free */
 #endif
 #ifndef ICS_EPI_EARLY1
-#define ICS_EPI_EARLY1 1      /* 16-row tiles (small frames, one tile per workgroup): the epilogue operands are requested with the tile's rows, at the top of the kernel */
+#define ICS_EPI_EARLY1 1      /* 16-row tiles (small frames, one tile per workgroup), mode 0: the image operand of the residual is requested with the tile's rows, at the top of the kernel (-0.2 us of 6.9).  The same for mode 1's u / majoriser operands measured +0.7 ... 1.5 us -- more requests in front of the rows the kernel waits for -- and is not built */
 #endif
 #ifndef ICS_EPI_EARLY
 #define ICS_EPI_EARLY 1       /* mode 0, 32-row tiles, accumulator-order image: request the image operand BEFORE the matrix phase (130 of 168 VGPRs in use: room for its 24) */
@@ -284,30 +284,24 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
     load_raw<C>(raw, rs_in, 4 * ((a.g.ay + TORG + tyi * C::TH - C::PAD) * pitch + 3 * (a.g.ax + TORG + txi * C::TW - C::PAD)), tid, pitch);
   }
   // 16-row tiles are what frames with fewer tiles than compute units get: every workgroup runs ONE tile and the kernel's time is its chain
-  // of dependent round trips, so the epilogue operands (image; u and the majoriser) travel with the rows instead of behind the matrix phase
-  // (on frames that fill the device the same move measured nothing: other workgroups cover the latency there).
-  constexpr bool EARLY1 = ICS_EPI_EARLY1 != 0 && RS == 1 && NH == 1 && (MODE == 0 || ICS_EPI_EARLY1 >= 3);
-  constexpr int EOPS1 = (MODE == 0) ? 1 : 2;
+  // of dependent round trips, so the synthesis' image operand travels with the rows instead of behind the matrix phase (on frames that fill
+  // the device the same move measured nothing: other workgroups cover the latency there; ICS_EPI_EARLY1 above for the back-projection).
+  constexpr bool EARLY1 = ICS_EPI_EARLY1 != 0 && RS == 1 && NH == 1 && MODE == 0;
   const __amdgpu_buffer_rsrc_t rs_f = make_rsrc(MODE == 0 ? a.f : a.u);
   const __amdgpu_buffer_rsrc_t rs_t = make_rsrc(MODE == 0 ? a.f : a.ut);
-  u3 pre1[EOPS1][4];
+  u3 pre1[4];
   auto request1 = [&](int tl) {
     const int tyi = tl / tpr, txi = tl - tyi * tpr;
     const int x0 = TORG + txi * C::TW, y0 = TORG + tyi * C::TH;
     if (x0 + 16 * cb < xend) {
       const int tide = opaque(tid);
       const int voff = 4 * (4 * C::RS * ((tide >> 4) & 3) * pitch + 3 * (tide & 15)), sb = 4 * (y0 * pitch + 3 * (x0 + 16 * cb));
-      const bool maj = MODE == 1 && a.tv_kind < 2;   // (the PAM kinds have no majoriser term)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int so = sb + 4 * C::RS * r * pitch;
-        pre1[0][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
-        if (maj) pre1[EOPS1 - 1][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);
-      }
+      for (int r = 0; r < 4; ++r) pre1[r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, sb + 4 * C::RS * r * pitch, ICS_EPI_LOAD_AUX0);
     }
   };
   bool first1 = true;
-  if (EARLY1 && ICS_EPI_EARLY1 != 2 && tile < band1) request1(tile);
+  if (EARLY1 && tile < band1) request1(tile);
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
 
   // weight rows -> LDS once per workgroup (the global table is the LDS image)
@@ -332,7 +326,6 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
     }
   }
   ICS_TICK(8);
-  if (EARLY1 && ICS_EPI_EARLY1 == 2 && tile < band1) request1(tile);
   // lane constants of the B operand: in window h this lane's 8 consecutive halves start at half
   // bo = 32h + 8*lg - li + 15 of the zero-padded row; it reads the five dwords that contain them and funnel-shifts
   // by the parity (v_alignbit).  (Gathering them from a row image with ds_bpermute cost ~5 LDS cycles per bpermute.)
@@ -935,12 +928,7 @@ __global__ __launch_bounds__(256 * NH) __attribute__((amdgpu_waves_per_eu(MCfg<K
           const int so = sb + 4 * (t + C::RS * r) * pitch;
           if (ICS_MFMA_ABLATE & 8) { eop[0][t][r] = (u3){0u, 0u, 0u}; eop[EOPS - 1][t][r] = (u3){0u, 0u, 0u}; continue; }
           if (MODE == 0 && use_acc) continue;   // requested below, per (channel, t)
-          if (EARLY1) {
-            eop[0][t][r] = pre1[0][r];
-            if (MODE == 1 && !pam) eop[EOPS - 1][t][r] = pre1[EOPS1 - 1][r];
-            if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
-            continue;
-          }
+          if (EARLY1) { eop[0][t][r] = pre1[r]; continue; }
           eop[0][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_f, voff, so, (MODE == 0 ? ICS_EPI_LOAD_AUX0 : ICS_EPI_LOAD_AUX));
           if (MODE == 1 && !pam) eop[EOPS - 1][t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_t, voff, so, ICS_EPI_LOAD_AUX);   // (PAM has no majoriser term)
           if (MODE == 1 && TVOP) eopT[t][r] = __builtin_amdgcn_raw_buffer_load_b96(rs_tv, voff, so, ICS_EPI_LOAD_AUX);
