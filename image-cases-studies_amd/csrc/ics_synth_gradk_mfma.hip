@@ -70,10 +70,8 @@ __device__ unsigned long long* ics_fused_trace_buf;
 #ifndef ICS_FUSED_SLICE
 #define ICS_FUSED_SLICE 10   /* 0: off */
 #endif
-#ifndef ICS_FUSED_SLICE2
-#define ICS_FUSED_SLICE2 0   /* the 32-row form, three mates: every slice length measured slower than none (0.2646 -> 0.267 ... 0.273 ms) */
-#endif
-#define ICS_FUSED_TURN(team, nteams) ics_prio_turn((nteams) == 2 ? ICS_FUSED_SLICE : ICS_FUSED_SLICE2, team, nteams)
+// (the 32-row form, three mates: every slice length measured slower than none, 0.2646 -> 0.267 ... 0.273 ms; it keeps the arbiter's order)
+#define ICS_FUSED_TURN(team, nteams) ics_prio_turn(ICS_FUSED_SLICE, team, nteams)
 #ifndef ICS_FUSED_PRIO
 #define ICS_FUSED_PRIO 0
 #endif
@@ -963,8 +961,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   const float inv_w = *reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.bt) + C::WLDS);
   __syncthreads();   // LDS initialised
-  constexpr int MATES = 3;                                                      // workgroups per CU (see ICS_FUSED_TURN)
-  const int team = (int)gridDim.x >= MATES ? (int)blockIdx.x / ((int)gridDim.x / MATES) % MATES : 0;
+  // (no priority slices here: with three workgroups per CU every slice length, and a rotation in which one mate steps back, measured slower
+  //  than the arbiter's own order -- ICS_FUSED_TURN above)
 
 #pragma unroll 1
   for (; tile < band1; tile += nx) {
@@ -985,7 +983,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       m = ics_wave_max_f32(m);
       if (lane == 0) fscr[wv] = m;
       lds_barrier();     // S0: also orders the previous tile's last gradient phase before the planes are rewritten
-      ICS_FUSED_TURN(team, MATES);
 #pragma unroll
       for (int w = 0; w < C::NW; ++w) m = __builtin_fmaxf(m, fscr[w]);
       pow2_scale(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m))), s_x, inv_x);
@@ -1208,7 +1205,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(0)
     convert_channel2<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
     lds_barrier();                                                     // e'(0) and planes(1) visible
-    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 0>{}, inv_x * inv_e);
     load_img(1);
     conv_phase(std::integral_constant<int, 1>{});
@@ -1216,7 +1212,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(1)
     convert_channel2<C, 2>(raw, s_x, up, opaque(tid));
     lds_barrier();                                                     // e'(1) and planes(2) visible
-    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 1>{}, inv_x * inv_e);
     load_img(2);
     auto prefetch = [&]() {
@@ -1232,7 +1227,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     ICS_FUSED2_CHANNEL(2)
     lds_barrier();                                                     // e'(2) visible
     if (ICS_FUSED2_PREFETCH == 1) prefetch();                          // ... during gradk(2) only
-    ICS_FUSED_TURN(team, MATES);
     gradk_phase(std::integral_constant<int, 2>{}, inv_x * inv_e);
     if (ICS_FUSED2_PREFETCH == 0) prefetch();                          // ... not at all: the other two workgroups of the CU cover the latency
 #undef ICS_FUSED2_CHANNEL
