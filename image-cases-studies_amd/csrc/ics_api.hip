@@ -1674,6 +1674,21 @@ extern "C" int ics_img_upload(ics_img* m, const float* host) {
   HIPCHK(hipStreamSynchronize(m->ctx->stream));   // the host buffer may be released by the caller
   return ICS_OK;
 }
+extern "C" int ics_img_upload_int(ics_img* m, const void* host, int bytes_per_value) {
+  if (!m || !host) return fail(ICS_EINVAL, "NULL argument");
+  if (bytes_per_value != 1 && bytes_per_value != 2) return fail(ICS_EINVAL, "bytes_per_value = %d (1: uint8, 2: uint16)", bytes_per_value);
+  ics_ctx* c = m->ctx;
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = (size_t)m->H * m->W * 3;
+  void* raw = nullptr;
+  if (hipError_t e = c->pool.alloc(&raw, n * bytes_per_value); e != hipSuccess) return fail(ICS_ENOMEM, "img_upload_int: %s", hipGetErrorString(e));
+  hipError_t e = hipMemcpyAsync(raw, host, n * bytes_per_value, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = ics_launch_int_to_f32(raw, bytes_per_value, m->d, (long)n, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);   // the host buffer may be released by the caller
+  c->pool.release(raw);                                       // (everything of a context runs on its one stream: a recycled block needs no more)
+  if (e != hipSuccess) return fail(ICS_EHIP, "img_upload_int: %s", hipGetErrorString(e));
+  return ICS_OK;
+}
 extern "C" int ics_img_download(const ics_img* m, float* host) {
   if (!m || !host) return fail(ICS_EINVAL, "NULL argument");
   HIPCHK(hipSetDevice(m->ctx->device));

@@ -35,6 +35,11 @@ __global__ __launch_bounds__(256) void k_f64_to_f32(const double* __restrict__ i
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (float)in[i];
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void k_int_to_f32(const T* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = (float)in[i];
+}
+
 inline unsigned grid_for(long n) { long b = (n + 255) / 256; return (unsigned)(b > 65536 ? 65536 : (b < 1 ? 1 : b)); }
 
 }  // namespace
@@ -54,5 +59,11 @@ hipError_t ics_launch_f32_to_f64(const float* in, double* out, long n, hipStream
 }
 hipError_t ics_launch_f64_to_f32(const double* in, float* out, long n, hipStream_t s) {
   hipLaunchKernelGGL(k_f64_to_f32, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+hipError_t ics_launch_int_to_f32(const void* in, int bytes_per_value, float* out, long n, hipStream_t s) {
+  if (bytes_per_value == 1) hipLaunchKernelGGL(k_int_to_f32<unsigned char>, dim3(grid_for(n)), dim3(256), 0, s, (const unsigned char*)in, out, n);
+  else if (bytes_per_value == 2) hipLaunchKernelGGL(k_int_to_f32<unsigned short>, dim3(grid_for(n)), dim3(256), 0, s, (const unsigned short*)in, out, n);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -156,4 +156,5 @@ hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy,
 hipError_t ics_launch_img_pad_edge(const float* in, int H, int W, float* out, int top, int bottom, int left, int right, hipStream_t s);
 hipError_t ics_launch_img_gamma(float* a, long n, float div, float exponent, float mul, int clip01, hipStream_t s);
 hipError_t ics_launch_f32_to_f64(const float* in, double* out, long n, hipStream_t s);
+hipError_t ics_launch_int_to_f32(const void* in, int bytes_per_value, float* out, long n, hipStream_t s);   // uint8 / uint16 -> float32
 hipError_t ics_launch_f64_to_f32(const double* in, float* out, long n, hipStream_t s);

@@ -242,7 +242,7 @@ def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, 
         raise ValueError("The blur width should be at least 3 pixels.")
     elif blur_width % 2 == 0:
         raise ValueError("The blur width should be odd. You can use %i." % (blur_width + 1))
-    raw = DeviceImage.from_host(np.ascontiguousarray(pic, dtype=np.float32))
+    raw = DeviceImage.from_host(pic)              # (uint8 / uint16 pictures cross PCIe as they are and become float32 on the device)
     pic_d = raw.pad_edge(1, 1, 1, 1)                                        # :94
     raw.close()
     pic_d.gamma(2 ** bits - 1, 1 / 2.2)                                     # :97-103

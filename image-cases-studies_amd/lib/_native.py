@@ -137,6 +137,7 @@ def load():
     lib.ics_img_destroy.argtypes = [vp]; lib.ics_img_destroy.restype = None
     lib.ics_img_shape.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     lib.ics_img_upload.argtypes = [vp, vp]
+    lib.ics_img_upload_int.argtypes = [vp, vp, ci]
     lib.ics_img_download.argtypes = [vp, vp]
     lib.ics_img_pad_edge.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
     lib.ics_img_crop.argtypes = [vp, ci, ci, ci, ci, C.POINTER(vp)]
@@ -163,7 +164,7 @@ def load():
     for name in ("ics_device_count", "ics_ctx_create", "ics_ctx_synchronize", "ics_ctx_info", "ics_rl_create", "ics_rl_upload",
                  "ics_rl_download", "ics_rl_run", "ics_rl_stage", "ics_rl_read", "ics_rl_write", "ics_rl_read_rows", "ics_rl_write_rows", "ics_rl_copy_rows", "ics_normalize_kernel",
                  "ics_tv", "ics_conv2d_symm", "ics_usm", "ics_bilateral", "ics_resize_bicubic", "ics_img_create", "ics_img_shape",
-                 "ics_img_upload", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
+                 "ics_img_upload", "ics_img_upload_int", "ics_img_download", "ics_img_pad_edge", "ics_img_crop", "ics_img_paste", "ics_img_gamma", "ics_img_resize",
                  "ics_rl_upload_img", "ics_rl_download_img", "ics_group_create", "ics_group_info", "ics_group_barrier",
                  "ics_group_allreduce_max", "ics_group_allreduce_sum", "ics_group_describe", "ics_group_allgather"):
         getattr(lib, name).restype = ci
@@ -305,13 +306,18 @@ class DeviceImage:
     @classmethod
     def from_host(cls, arr, ctx=None):
         ctx = ctx or Context.get()
-        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        arr = np.asarray(arr)
+        as_int = arr.dtype in (np.uint8, np.uint16)      # pixels as read from a file: converted on the device (exact), 1 / 2 bytes per value over PCIe
+        arr = np.ascontiguousarray(arr) if as_int else np.ascontiguousarray(arr, dtype=np.float32)
         if arr.ndim != 3 or arr.shape[2] != 3:
             raise ValueError("DeviceImage needs an H x W x 3 array")
         h = C.c_void_p()
         _check(load().ics_img_create(ctx._h, arr.shape[0], arr.shape[1], C.byref(h)))
         img = cls(h, ctx)
-        _check(load().ics_img_upload(img._h, _ptr(arr)))
+        if as_int:
+            _check(load().ics_img_upload_int(img._h, arr.ctypes.data_as(C.c_void_p), arr.dtype.itemsize))
+        else:
+            _check(load().ics_img_upload(img._h, _ptr(arr)))
         return img
 
     @property

@@ -307,6 +307,10 @@ int ics_img_create(ics_ctx *ctx, int H, int W, ics_img **out);
 void ics_img_destroy(ics_img *img);
 int ics_img_shape(const ics_img *img, int *H, int *W);
 int ics_img_upload(ics_img *img, const float *host);        /* H*W*3 floats */
+/* the same from 8- or 16-bit pixels (what deconvolve.py:357-368 reads from its files): bytes_per_value = 1 (uint8) or 2 (uint16); the
+ * values cross PCIe as they are and become float32 on the device (exact: np.float32(v)) -- a quarter / half of the float transfer and
+ * no host-side conversion pass */
+int ics_img_upload_int(ics_img *img, const void *host, int bytes_per_value);
 int ics_img_download(const ics_img *img, float *host);
 /* deconvolve.py:24-37 pad_image (np.pad mode="edge" on the two spatial axes) */
 int ics_img_pad_edge(const ics_img *src, int top, int bottom, int left, int right, ics_img **out);

@@ -160,3 +160,10 @@ def test_device_image_operations_match_numpy():
     assert np.abs(r - ro.resize_scipy(a, (27, 31)).astype(np.float32)).max() < 1e-6
     with pytest.raises(_native.NativeError):
         d.crop(0, 38, 0, 45)
+    # 8- and 16-bit pictures are converted on the device: exactly np.float32(v)
+    for dt, top in ((np.uint8, 255), (np.uint16, 65535)):
+        px = rng.integers(0, top + 1, size=(37, 45, 3)).astype(dt)
+        px[0, 0] = top
+        di = _native.DeviceImage.from_host(px)
+        assert np.array_equal(di.to_host(), px.astype(np.float32))
+        di.close()
