@@ -5,17 +5,17 @@
 
 namespace {
 
-// np.pad(mode="edge") on the two spatial axes (deconvolve.py:24-37)
+// np.pad(mode="edge") on the two spatial axes (deconvolve.py:24-37); one output row per blockIdx.y
 __global__ __launch_bounds__(256) void k_img_pad_edge(const float* __restrict__ in, int H, int W, float* __restrict__ out, int top, int left,
                                                       int OH, int OW) {
-  const long n = (long)OH * OW * 3;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % 3);
-    const long p = i / 3;
-    int x = (int)(p % OW) - left, y = (int)(p / OW) - top;
+  int y = (int)blockIdx.y - top;
+  y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
+  const int rowl = 3 * OW;
+  for (int xc = blockIdx.x * 256 + threadIdx.x; xc < rowl; xc += gridDim.x * 256) {
+    const int xq = xc / 3, c = xc - 3 * xq;
+    int x = xq - left;
     x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-    y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-    out[i] = in[((long)y * W + x) * 3 + c];
+    out[(long)blockIdx.y * rowl + xc] = in[((long)y * W + x) * 3 + c];
   }
 }
 
@@ -46,7 +46,8 @@ inline unsigned grid_for(long n) { long b = (n + 255) / 256; return (unsigned)(b
 
 hipError_t ics_launch_img_pad_edge(const float* in, int H, int W, float* out, int top, int bottom, int left, int right, hipStream_t s) {
   const int OH = H + top + bottom, OW = W + left + right;
-  hipLaunchKernelGGL(k_img_pad_edge, dim3(grid_for((long)OH * OW * 3)), dim3(256), 0, s, in, H, W, out, top, left, OH, OW);
+  const unsigned gx = (unsigned)((3 * OW + 255) / 256);
+  hipLaunchKernelGGL(k_img_pad_edge, dim3(gx > 64 ? 64 : gx, (unsigned)OH), dim3(256), 0, s, in, H, W, out, top, left, OH, OW);
   return hipGetLastError();
 }
 hipError_t ics_launch_img_gamma(float* a, long n, float div, float exponent, float mul, int clip01, hipStream_t s) {
