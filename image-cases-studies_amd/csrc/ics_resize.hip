@@ -117,10 +117,13 @@ __global__ __launch_bounds__(256) void k_rs_pad(const double* __restrict__ in, d
 // results agree to the last bit wherever the discarded history is below half an ulp, i.e. everywhere but on rounding ties
 // (tests/test_resize.py pins the whole resize within 1e-12 of scipy.ndimage).  The mirror sum of the first sample runs over 120
 // terms (|z|^120 = 1e-69) instead of until z^i underflows (~540): same double for any data whose dynamic range is below 1e50.
-constexpr int RS_SEG = 32, RS_WARM = 40, RS_HORIZON = 120;
+constexpr int RS_WARM = 40, RS_HORIZON = 120;
+// samples a thread owns: 32 on short lines (parallelism), more on long ones (the 40 warm-up samples are re-read per segment: 2.25 reads per
+// sample at 32, 1.3 at 128)
+static inline int rs_seg(int n) { return n >= 4096 ? 128 : (n >= 1024 ? 64 : 32); }
 constexpr double RS_Z = -0.26794919243112270647;   // sqrt(3) - 2
 
-__global__ __launch_bounds__(256) void k_rs_prefilter_fwd(const double* __restrict__ in, double* __restrict__ out, int n, long L) {
+__global__ __launch_bounds__(256) void k_rs_prefilter_fwd(const double* __restrict__ in, double* __restrict__ out, int n, long L, int RS_SEG) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int nseg = (n + RS_SEG - 1) / RS_SEG;
   if (t >= L * nseg) return;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void k_rs_prefilter_fwd(const double* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void k_rs_prefilter_bwd(const double* __restrict__ cp, double* __restrict__ out, int n, long L) {
+__global__ __launch_bounds__(256) void k_rs_prefilter_bwd(const double* __restrict__ cp, double* __restrict__ out, int n, long L, int RS_SEG) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   const int nseg = (n + RS_SEG - 1) / RS_SEG;
   if (t >= L * nseg) return;
@@ -320,14 +323,14 @@ hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy,
   // pad into the buffer that does not hold `cur`; from there the two buffers alternate (the prefilter passes are out of place)
   double* P = (cur == A) ? B : A;
   double* T = (P == A) ? B : A;
-  auto pf_grid = [](int n, long L) { return dim3((unsigned)((L * ((n + RS_SEG - 1) / RS_SEG) + 255) / 256)); };
+  auto pf_grid = [](int n, long L) { const int sg = rs_seg(n); return dim3((unsigned)((L * ((n + sg - 1) / sg) + 255) / 256)); };
   hipLaunchKernelGGL(k_rs_pad, dim3((unsigned)((Wp * C + 255) / 256 > 64 ? 64 : (Wp * C + 255) / 256), (unsigned)Hp), dim3(256), 0, s, cur, P, H, W, C);
-  hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, P, T, Hp, (long)Wp * C);
-  hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, T, P, Hp, (long)Wp * C);
+  hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, P, T, Hp, (long)Wp * C, rs_seg(Hp));
+  hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, T, P, Hp, (long)Wp * C, rs_seg(Hp));
   if (C == 3) hipLaunchKernelGGL(k_rs_transpose3, dim3((Wp + 31) / 32, (Hp + 31) / 32), dim3(256), 0, s, P, T, Hp, Wp);
   else hipLaunchKernelGGL(k_rs_transpose, dim3((Wp + 31) / 32, (Hp + 31) / 32, C), dim3(256), 0, s, P, T, Hp, Wp, C);
-  hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, T, P, Wp, (long)Hp * C);
-  hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, P, T, Wp, (long)Hp * C);
+  hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, T, P, Wp, (long)Hp * C, rs_seg(Wp));
+  hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, P, T, Wp, (long)Hp * C, rs_seg(Wp));
   hipLaunchKernelGGL(k_rs_eval, dim3((OW + 31) / 32, (OH + 31) / 32), dim3(256), 0, s, T, Hp, Wp, C, (double)H / (double)OH, (double)W / (double)OW, out, OH, OW);
   return hipGetLastError();
 }
