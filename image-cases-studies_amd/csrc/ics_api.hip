@@ -1740,7 +1740,6 @@ extern "C" int ics_img_resize(const ics_img* src, int OH, int OW, ics_img** out)
   const int H = src->H, W = src->W;
   if (H == OH && W == OW) return ics_img_crop(src, 0, 0, H, W, out);
   RC(img_new(c, OH, OW, out));
-  const size_t n = (size_t)H * W * 3, no = (size_t)OH * OW * 3;
   auto weights = [](double sigma, std::vector<double>& w) {
     const int r = (int)(4.0 * sigma + 0.5);
     w.resize(2 * r + 1);
@@ -1754,10 +1753,8 @@ extern "C" int ics_img_resize(const ics_img* src, int OH, int OW, ics_img** out)
   int ry = 0, rx = 0;
   if (sy > 1e-15) ry = weights(sy, hwy);
   if (sx > 1e-15) rx = weights(sx, hwx);
-  double *ds = nullptr, *scr = nullptr, *dout = nullptr, *dw = nullptr;
-  hipError_t e = c->pool.alloc((void**)&ds, n * 8);
-  if (e == hipSuccess) e = c->pool.alloc((void**)&scr, ics_resize_scratch_doubles(H, W, 3) * 8);
-  if (e == hipSuccess) e = c->pool.alloc((void**)&dout, no * 8);
+  double *scr = nullptr, *dw = nullptr;          // (the float32 frames are read and written by the float64 pipeline's first and last pass)
+  hipError_t e = c->pool.alloc((void**)&scr, ics_resize_scratch_doubles(H, W, 3) * 8);
   if (e == hipSuccess) e = c->pool.alloc((void**)&dw, (hwy.size() + hwx.size() + 1) * 8);
   const size_t nw = hwy.size() + hwx.size();
   bool staged = false;
@@ -1777,11 +1774,9 @@ extern "C" int ics_img_resize(const ics_img* src, int OH, int OW, ics_img** out)
       if (e == hipSuccess && !hwx.empty()) e = hipMemcpyAsync(dw + hwy.size(), hwx.data(), hwx.size() * 8, hipMemcpyHostToDevice, s);
     }
   }
-  if (e == hipSuccess) e = ics_launch_f32_to_f64(src->d, ds, (long)n, s);
-  if (e == hipSuccess) e = ics_launch_resize(ds, H, W, 3, hwy.empty() ? nullptr : dw, ry, hwx.empty() ? nullptr : dw + hwy.size(), rx, scr, dout, OH, OW, s);
-  if (e == hipSuccess) e = ics_launch_f64_to_f32(dout, (*out)->d, (long)no, s);
+  if (e == hipSuccess) e = ics_launch_resize_f32(src->d, H, W, 3, hwy.empty() ? nullptr : dw, ry, hwx.empty() ? nullptr : dw + hwy.size(), rx, scr, (*out)->d, OH, OW, s);
   if (e == hipSuccess && nw && !staged) e = hipStreamSynchronize(s);   // pageable host vectors are released below
-  c->pool.release(ds); c->pool.release(scr); c->pool.release(dout); c->pool.release(dw);
+  c->pool.release(scr); c->pool.release(dw);
   if (e != hipSuccess) { ics_img_destroy(*out); *out = nullptr; return fail(e == hipErrorOutOfMemory ? ICS_ENOMEM : ICS_EHIP, "img_resize: %s", hipGetErrorString(e)); }
   return ICS_OK;
 }

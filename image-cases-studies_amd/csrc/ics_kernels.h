@@ -151,6 +151,8 @@ hipError_t ics_launch_bilateral(const double* src, int H, int W, int radius, dou
 size_t ics_resize_scratch_doubles(int H, int W, int C);
 hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
                              double* out, int OH, int OW, hipStream_t s);
+hipError_t ics_launch_resize_f32(const float* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
+                                 float* out, int OH, int OW, hipStream_t s);   // float32 in / out, float64 inside
 
 // ---- device-resident images (ics_img.hip; deconvolve.py:24-37, :100-103, :346-352) ----------------------
 hipError_t ics_launch_img_pad_edge(const float* in, int H, int W, float* out, int top, int bottom, int left, int right, hipStream_t s);

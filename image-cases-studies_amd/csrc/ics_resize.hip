@@ -20,7 +20,8 @@ constexpr int NPAD = 12;
 // in LDS; along y a thread keeps RS_GY consecutive rows of one column in flight and loads every input once for all of them
 // (RS_GY + 2 r loads for RS_GY values); along x a workgroup stages its run of the row (+ r pixels either side) in LDS.
 constexpr int RS_GY = 8, RS_GTAPS = 64;
-__global__ __launch_bounds__(256) void k_rs_gauss_y(const double* __restrict__ in, double* __restrict__ out, int H, int W, int C,
+template <typename InT>
+__global__ __launch_bounds__(256) void k_rs_gauss_y(const InT* __restrict__ in, double* __restrict__ out, int H, int W, int C,
                                                     const double* __restrict__ w, int r) {
   __shared__ double sw[RS_GTAPS];
   for (int k = threadIdx.x; k < 2 * r + 1; k += 256) sw[k] = w[k];
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void k_rs_gauss_y(const double* __restrict__ i
     for (int j = 0; j < RS_GY; ++j) acc[j] = 0.0;
     for (int t = y0 - r; t < y0 + RS_GY + r; ++t) {          // unclamped row index: an edge row counts once per tap that lands on it
       const int yy = t < 0 ? 0 : (t > H - 1 ? H - 1 : t);
-      const double v = in[(long)yy * rowl + xc];
+      const double v = (double)in[(long)yy * rowl + xc];
 #pragma unroll
       for (int j = 0; j < RS_GY; ++j) {
         const int k = t - (y0 + j) + r;                        // tap of output row y0 + j that reads row t
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(256) void k_rs_gauss_y(const double* __restrict__ i
       if (y0 + j < H) out[(long)(y0 + j) * rowl + xc] = acc[j];
   }
 }
-__global__ __launch_bounds__(256) void k_rs_gauss_x(const double* __restrict__ in, double* __restrict__ out, int H, int W, int C,
+template <typename InT>
+__global__ __launch_bounds__(256) void k_rs_gauss_x(const InT* __restrict__ in, double* __restrict__ out, int H, int W, int C,
                                                     const double* __restrict__ w, int r) {
   extern __shared__ double sm[];                 // [RS_GTAPS] weights, then the staged run: (256 + 2 r C) values
   double* sw = sm;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_rs_gauss_x(const double* __restrict__ i
   for (int k = threadIdx.x; k < 2 * r + 1; k += 256) sw[k] = w[k];
   const int rowl = W * C;
   const int y = blockIdx.y;
-  const double* row = in + (long)y * rowl;
+  const InT* row = in + (long)y * rowl;
   for (int x0c = blockIdx.x * 256; x0c < rowl; x0c += gridDim.x * 256) {
     __syncthreads();
     // values x0c - r C .. x0c + 255 + r C of the row, clamped per PIXEL (channel kept)
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void k_rs_gauss_x(const double* __restrict__ i
       const int c = ((f % C) + C) % C;
       int x = (f - c) / C;
       x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-      run[e] = row[x * C + c];
+      run[e] = (double)row[x * C + c];
     }
     __syncthreads();
     const int xc = x0c + threadIdx.x;
@@ -74,8 +76,8 @@ __global__ __launch_bounds__(256) void k_rs_gauss_x(const double* __restrict__ i
   }
 }
 // (radii beyond the LDS table: the flat form)
-template <int AXIS>
-__global__ __launch_bounds__(256) void k_rs_gauss(const double* __restrict__ in, double* __restrict__ out, int H, int W, int C,
+template <int AXIS, typename InT>
+__global__ __launch_bounds__(256) void k_rs_gauss(const InT* __restrict__ in, double* __restrict__ out, int H, int W, int C,
                                                   const double* __restrict__ w, int r) {
   const int rowl = W * C;
   const int y = blockIdx.y;
@@ -86,14 +88,15 @@ __global__ __launch_bounds__(256) void k_rs_gauss(const double* __restrict__ in,
       int yy = y, xx = x;
       if (AXIS == 0) { yy = y + k; yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy); }
       else { xx = x + k; xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx); }
-      s += w[k + r] * in[(long)yy * rowl + xx * C + c];
+      s += w[k + r] * (double)in[(long)yy * rowl + xx * C + c];
     }
     out[(long)y * rowl + xc] = s;
   }
 }
 
 // edge padding by NPAD on both spatial axes (one padded row per blockIdx.y)
-__global__ __launch_bounds__(256) void k_rs_pad(const double* __restrict__ in, double* __restrict__ out, int H, int W, int C) {
+template <typename InT>
+__global__ __launch_bounds__(256) void k_rs_pad(const InT* __restrict__ in, double* __restrict__ out, int H, int W, int C) {
   const int Wp = W + 2 * NPAD, rowl = Wp * C;
   int y = (int)blockIdx.y - NPAD;
   y = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void k_rs_pad(const double* __restrict__ in, d
     const int xq = xc / C, c = xc - xq * C;
     int x = xq - NPAD;
     x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-    out[(long)blockIdx.y * rowl + xc] = in[((long)y * W + x) * C + c];
+    out[(long)blockIdx.y * rowl + xc] = (double)in[((long)y * W + x) * C + c];
   }
 }
 
@@ -228,8 +231,9 @@ __device__ __forceinline__ void bspline3(double t, double (&w)[4]) {
 // output ROWS i (and channels) first, which is the fast axis of the transposed coefficients, and the results leave through LDS as runs of
 // 96 consecutive doubles.  (The first version ran the lanes along j: 16 gathered reads per value at a stride of a whole coefficient line,
 // and two 64-bit divisions -- 0.37 ms for a 4096^2 frame.)  The sum of a value is formed in the same order as before.
+template <typename OutT>
 __global__ __launch_bounds__(256) void k_rs_eval(const double* __restrict__ coefT, int Hp, int Wp, int C, double fy, double fx,
-                                                 double* __restrict__ out, int OH, int OW) {
+                                                 OutT* __restrict__ out, int OH, int OW) {
   __shared__ double res[32][97];
   const int j0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
   const bool tiled = C == 3;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void k_rs_eval(const double* __restrict__ coef
     const int nj = OW - j0 < 32 ? OW - j0 : 32;
     for (int e = threadIdx.x; e < 32 * 96; e += 256) {
       const int il = e / 96, col = e - il * 96;
-      if (i0 + il < OH && col < 3 * nj) out[((long)(i0 + il) * OW + j0) * 3 + col] = res[il][col];
+      if (i0 + il < OH && col < 3 * nj) out[((long)(i0 + il) * OW + j0) * 3 + col] = (OutT)res[il][col];
     }
     return;
   }
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256) void k_rs_eval(const double* __restrict__ coef
         s += (wy[a] * wx[b]) * coefT[((long)xx * Hp + yy) * C + c];
       }
     }
-    out[((long)oi * OW + oj) * C + c] = s;
+    out[((long)oi * OW + oj) * C + c] = (OutT)s;
   }
 }
 
@@ -301,36 +305,56 @@ size_t ics_resize_scratch_doubles(int H, int W, int C) {   // two padded buffers
 
 // src: H x W x C on the device (overwritten by the Gaussian when shrinking); wy / wx: Gaussian weights on the device (radius ry / rx,
 // NULL = no smoothing along that axis); scratch: ics_resize_scratch_doubles(); out: OH x OW x C
-hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
-                             double* out, int OH, int OW, hipStream_t s) {
+template <typename InT, typename OutT>
+static hipError_t launch_resize_t(const InT* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
+                                  OutT* out, int OH, int OW, hipStream_t s) {
   const int Hp = H + 2 * NPAD, Wp = W + 2 * NPAD;
   double* A = scratch;
   double* B = scratch + (size_t)Hp * Wp * C;
-  double* cur = src;
+  // the first pass reads the source in its own type (float32 images: no conversion pass in front), everything behind it is float64
   const unsigned gx = (unsigned)((W * C + 255) / 256 > 64 ? 64 : (W * C + 255) / 256);
-  const dim3 g_rows(gx, (unsigned)H);
+  const dim3 g_rows(gx, (unsigned)H), g_y(gx, (unsigned)((H + RS_GY - 1) / RS_GY));
+  const size_t lds_x = (size_t)(RS_GTAPS + 256 + 2 * rx * C) * sizeof(double);
+  double* cur = nullptr;                         // nullptr: still the source
   if (wy) {
-    if (2 * ry + 1 <= RS_GTAPS) hipLaunchKernelGGL(k_rs_gauss_y, dim3(gx, (unsigned)((H + RS_GY - 1) / RS_GY)), dim3(256), 0, s, cur, A, H, W, C, wy, ry);
-    else hipLaunchKernelGGL(k_rs_gauss<0>, g_rows, dim3(256), 0, s, cur, A, H, W, C, wy, ry);
+    if (2 * ry + 1 <= RS_GTAPS) hipLaunchKernelGGL(k_rs_gauss_y<InT>, g_y, dim3(256), 0, s, src, A, H, W, C, wy, ry);
+    else hipLaunchKernelGGL((k_rs_gauss<0, InT>), g_rows, dim3(256), 0, s, src, A, H, W, C, wy, ry);
     cur = A;
   }
   if (wx) {
     double* dst = (cur == A) ? B : A;
-    if (2 * rx + 1 <= RS_GTAPS) hipLaunchKernelGGL(k_rs_gauss_x, g_rows, dim3(256), (size_t)(RS_GTAPS + 256 + 2 * rx * C) * sizeof(double), s, cur, dst, H, W, C, wx, rx);
-    else hipLaunchKernelGGL(k_rs_gauss<1>, g_rows, dim3(256), 0, s, cur, dst, H, W, C, wx, rx);
+    if (cur) {
+      if (2 * rx + 1 <= RS_GTAPS) hipLaunchKernelGGL(k_rs_gauss_x<double>, g_rows, dim3(256), lds_x, s, (const double*)cur, dst, H, W, C, wx, rx);
+      else hipLaunchKernelGGL((k_rs_gauss<1, double>), g_rows, dim3(256), 0, s, (const double*)cur, dst, H, W, C, wx, rx);
+    } else {
+      if (2 * rx + 1 <= RS_GTAPS) hipLaunchKernelGGL(k_rs_gauss_x<InT>, g_rows, dim3(256), lds_x, s, src, dst, H, W, C, wx, rx);
+      else hipLaunchKernelGGL((k_rs_gauss<1, InT>), g_rows, dim3(256), 0, s, src, dst, H, W, C, wx, rx);
+    }
     cur = dst;
   }
   // pad into the buffer that does not hold `cur`; from there the two buffers alternate (the prefilter passes are out of place)
   double* P = (cur == A) ? B : A;
   double* T = (P == A) ? B : A;
   auto pf_grid = [](int n, long L) { const int sg = rs_seg(n); return dim3((unsigned)((L * ((n + sg - 1) / sg) + 255) / 256)); };
-  hipLaunchKernelGGL(k_rs_pad, dim3((unsigned)((Wp * C + 255) / 256 > 64 ? 64 : (Wp * C + 255) / 256), (unsigned)Hp), dim3(256), 0, s, cur, P, H, W, C);
+  const dim3 g_pad((unsigned)((Wp * C + 255) / 256 > 64 ? 64 : (Wp * C + 255) / 256), (unsigned)Hp);
+  if (cur) hipLaunchKernelGGL(k_rs_pad<double>, g_pad, dim3(256), 0, s, (const double*)cur, P, H, W, C);
+  else hipLaunchKernelGGL(k_rs_pad<InT>, g_pad, dim3(256), 0, s, src, P, H, W, C);
   hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, P, T, Hp, (long)Wp * C, rs_seg(Hp));
   hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Hp, (long)Wp * C), dim3(256), 0, s, T, P, Hp, (long)Wp * C, rs_seg(Hp));
   if (C == 3) hipLaunchKernelGGL(k_rs_transpose3, dim3((Wp + 31) / 32, (Hp + 31) / 32), dim3(256), 0, s, P, T, Hp, Wp);
   else hipLaunchKernelGGL(k_rs_transpose, dim3((Wp + 31) / 32, (Hp + 31) / 32, C), dim3(256), 0, s, P, T, Hp, Wp, C);
   hipLaunchKernelGGL(k_rs_prefilter_fwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, T, P, Wp, (long)Hp * C, rs_seg(Wp));
   hipLaunchKernelGGL(k_rs_prefilter_bwd, pf_grid(Wp, (long)Hp * C), dim3(256), 0, s, P, T, Wp, (long)Hp * C, rs_seg(Wp));
-  hipLaunchKernelGGL(k_rs_eval, dim3((OW + 31) / 32, (OH + 31) / 32), dim3(256), 0, s, T, Hp, Wp, C, (double)H / (double)OH, (double)W / (double)OW, out, OH, OW);
+  hipLaunchKernelGGL(k_rs_eval<OutT>, dim3((OW + 31) / 32, (OH + 31) / 32), dim3(256), 0, s, T, Hp, Wp, C, (double)H / (double)OH, (double)W / (double)OW, out, OH, OW);
   return hipGetLastError();
+}
+
+hipError_t ics_launch_resize(double* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
+                             double* out, int OH, int OW, hipStream_t s) {
+  return launch_resize_t<double, double>(src, H, W, C, wy, ry, wx, rx, scratch, out, OH, OW, s);
+}
+// float32 images (ics_img_resize): read and written in place of the float32 <-> float64 conversion passes around the float64 pipeline
+hipError_t ics_launch_resize_f32(const float* src, int H, int W, int C, const double* wy, int ry, const double* wx, int rx, double* scratch,
+                                 float* out, int OH, int OW, hipStream_t s) {
+  return launch_resize_t<float, float>(src, H, W, C, wy, ry, wx, rx, scratch, out, OH, OW, s);
 }
