@@ -473,7 +473,7 @@ def main():
             # secondary lines (never `value`): the other BASELINE.json configurations and the build-defined TV variants they name
             out["conv_rel_err_vs_f64"] = conv_rel_err(ctx, MK)
             oc = {}
-            oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 100, 10)
+            oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)
             oc["configs[1] non-blind 2048^2 15x15 + active MM-TV (tv_mode 1, build-defined)"] = timed_run(ctx, 2048, 15, False, 1, conv, 50, 5)
             oc["configs[1] non-blind 2048^2 15x15 + PAM isotropic TV (tv_mode 2, build-defined)"] = timed_run(ctx, 2048, 15, False, 2, conv, 50, 5)
