@@ -138,6 +138,7 @@ struct ics_rl {
   float* facc[2];                       // the image in accumulator order for 32-row / 64-row tiles (ics_image_acc.h), allocated on first use
   bool facc_valid[2];                   // ... and whether it still mirrors the image frame
   float *psf, *gradk, *wconv, *wcorr, *psf_caller, *partial;
+  size_t partial_floats;                // size of `partial`
   float* psf_work;                      // PSF sizes above 63: working copy of k_psf (3*K*K floats), else NULL
   // overlap of the statistics with the next outer iteration: the reduction slots / DoF keys of outer iteration i are the set i & 1
   // (`par`; the stage API always uses set 0), the residual frame ping-pongs with e2, the PSF of the last finished iteration is kept
@@ -298,6 +299,12 @@ extern "C" int ics_ctx_info(ics_ctx* c, char* name, size_t name_len, int* cus, u
 }
 
 // -------------------------------------------------------------------------------------------------
+// PSF sizes 129 ... ICS_PSF_MAX: only as tap blocks on the matrix cores -- convolutions as blocks of <= 33 x 33 taps (do_conv_blocks), the
+// gradient as blocks of <= 31 x 31 (do_gradk_split); the run-time-sized fp32 kernels of ics_big.hip (ICS_CONV_VECTOR) stop at 127.
+#define ICS_PSF_MAX 255
+static bool psf_blocks_only(int K) { return K > 127 && K <= ICS_PSF_MAX && (K & 1); }
+static bool psf_supported(int K) { return ics_conv_supported(K) || ics_big_supported(K) || psf_blocks_only(K); }
+
 // Device allocation, zero-filled ON THE GIVEN STREAM: the job's stream is non-blocking, so a
 // null-stream hipMemset would not be ordered with the uploads/kernels that follow on it.
 template <typename T>
@@ -356,7 +363,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   *out = nullptr;
   if (M < 1 || N < 1) return fail(ICS_EINVAL, "image size %dx%d", M, N);
   if (MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "MK must be odd and >= 3 (got %d)", MK);
-  if (!ics_conv_supported(MK) && !ics_big_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..127)", MK);
+  if (!psf_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..%d)", MK, ICS_PSF_MAX);
   HIPCHK(hipSetDevice(c->device));
   ics_rl* j = new ics_rl();  // value-initialised: every pointer/flag starts at 0
   j->ctx = c;
@@ -381,7 +388,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   TRY(dalloc(c, &j->u, j->frame_floats, &zl)); TRY(dalloc(c, &j->u2, j->frame_floats, &zl)); TRY(dalloc(c, &j->ut, j->frame_floats, &zl)); TRY(dalloc(c, &j->gr, j->frame_floats, &zl));
   TRY(dalloc(c, &j->f, j->frame_floats, &zl)); TRY(dalloc(c, &j->e, j->frame_floats, &zl));
   TRY(dalloc(c, &j->psf, n, &zl)); TRY(dalloc(c, &j->gradk, n, &zl)); TRY(dalloc(c, &j->psf_caller, n, &zl));
-  if (ics_big_supported(MK)) TRY(dalloc(c, &j->psf_work, n, &zl));
+  if (MK > 63) TRY(dalloc(c, &j->psf_work, n, &zl));   // (k_psf<BIG>)
   if (MK >= 51) {   // tap blocks: the fewest blocks of a size the matrix-core convolution is built for (odd, <= 33)
     j->blk_n = (MK + 32) / 33;
     j->blk_kb = ((MK + j->blk_n - 1) / j->blk_n) | 1;
@@ -392,7 +399,10 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   }
   TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow, &zl)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow, &zl));
   if (ics_conv_mfma_supported(MK)) { TRY(dalloc(c, &j->bt_conv, ics_conv_mfma_table_floats(MK), &zl)); TRY(dalloc(c, &j->bt_corr, ics_conv_mfma_table_floats(MK), &zl)); }
-  TRY(dalloc(c, &j->partial, (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt, &zl));
+  // (129 ...: the gradient only ever runs as 31 x 31 blocks -- 2 * CUs workgroups of 3 x 32 x 32 partial sums each, do_gradk_split)
+  j->partial_floats = psf_blocks_only(MK) ? (size_t)2 * c->cus * 3 * 32 * 32
+                                          : (size_t)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt * nt;
+  TRY(dalloc(c, &j->partial, j->partial_floats, &zl));
   TRY(dalloc(c, &j->red, (size_t)2 * 8 * ICS_RED_STRIDE, &zl)); TRY(dalloc(c, &j->dofkeys, (size_t)2 * 4, &zl)); TRY(dalloc(c, &j->sched, (size_t)16, &zl));   // (two sets: ics_rl::par)
   TRY(dalloc(c, &j->scal, (size_t)ICS_SC_COUNT, &zl)); TRY(dalloc(c, &j->dacc, (size_t)8, &zl)); TRY(dalloc(c, &j->ukey, (size_t)2, &zl)); TRY(dalloc(c, &j->flags, (size_t)4, &zl));
   TRY(flush_zero(c, zl));
@@ -804,6 +814,7 @@ static bool use_big_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
 // k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see DESIGN.md 4c.
 static bool use_block_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
   if (!j->blk_conv || mode == 2 || p->tv_mode != ICS_TV_SHIPPED || p->conv == ICS_CONV_VECTOR) return false;
+  if (psf_blocks_only(j->g.K)) return true;   // (no other path: ICS_CONV_PATH does not apply)
   return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
@@ -923,6 +934,7 @@ static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
 static bool use_split_gradk(const ics_rl* j, const ics_rl_params* p) {
   const int K = j->g.K;
   if (K < 33 || p->conv == ICS_CONV_VECTOR) return false;
+  if (psf_blocks_only(K)) return true;
   return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
@@ -942,8 +954,7 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
       // as many persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
       int nblocks = 2 * j->ctx->cus;                        // (GCfg::WGS of ics_gradk_mfma.hip)
       if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && nblocks > mw) nblocks = mw;
-      const int nt_full = 16 * ((K + 15) / 16);
-      const long cap = (long)(j->gradk_blocks > j->fused2_blocks ? j->gradk_blocks : j->fused2_blocks) * 3 * nt_full * nt_full / (3L * nt * nt);
+      const long cap = (long)(j->partial_floats / (3UL * nt * nt));
       if (nblocks > cap) nblocks = (int)cap;
       HIPCHK(ics_launch_gradk_mfma(a, nblocks, j->ctx->stream));
       HIPCHK(ics_launch_gradk_reduce_block(j->partial, nblocks, j->gradk, nt, La, Lb, K, a0, b0, j->ctx->stream));
@@ -1054,8 +1065,10 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && !j->blk_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX: no matrix-core path for this PSF size");
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && p->tv_mode != ICS_TV_SHIPPED)   // (the tap-block path has no TV epilogue; never run the fp32 kernels under an explicit MATRIX request)
     return fail(ICS_ENOSUP, "ICS_CONV_MATRIX with tv_mode %d: PSF sizes above 49 run on the matrix cores as tap blocks, which exist for the shipped loop only", p->tv_mode);
+  if (p->conv == ICS_CONV_VECTOR && psf_blocks_only(j->g.K))
+    return fail(ICS_ENOSUP, "ICS_CONV_VECTOR: PSF sizes above 127 only run as tap blocks on the matrix cores (ICS_CONV_AUTO / ICS_CONV_MATRIX)");
   if (p->fuse && j->g.K > 31) return fail(ICS_ENOSUP, "fuse = 1 is only built for PSF sizes <= 31");
-  if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 127)", p->tv_mode);
+  if (p->tv_mode != ICS_TV_SHIPPED && j->g.K > 63) return fail(ICS_ENOSUP, "tv_mode %d is only built for PSF sizes <= 63 (the shipped loop runs to 255)", p->tv_mode);
   if (p->blind && p->channels != 3) return fail(ICS_ENOSUP, "blind deconvolution requires C == 3 (pyx:557,570 leave gradk undefined otherwise)");
   return ICS_OK;
 }
@@ -1130,7 +1143,7 @@ extern "C" int ics_rl_describe(ics_rl* j, const ics_rl_params* p, ics_rl_route* 
 // the same for a shape alone: no device, no job (the predicates read the geometry and which weight tables a job of this PSF size owns)
 extern "C" int ics_describe(int M, int N, int MK, const ics_rl_params* p, ics_rl_route* r) {
   if (M < 1 || N < 1 || MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "bad shape: M=%d N=%d MK=%d (MK odd >= 3)", M, N, MK);
-  if (!ics_conv_supported(MK) && !ics_big_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..127)", MK);
+  if (!psf_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..%d)", MK, ICS_PSF_MAX);
   ics_rl shell{};
   shell.g = ics_make_geom(M, N, MK);
   float dummy = 0.f;                                               // non-NULL markers only: nothing is dereferenced

@@ -50,7 +50,7 @@ extern "C" {
 #define ICS_EHIP (-3)    /* a HIP runtime call failed (see ics_last_error)       */
 #define ICS_ENOMEM (-4)  /* device or host allocation failed                     */
 #define ICS_ESTATE (-5)  /* call sequence error (e.g. run before upload)         */
-#define ICS_ENOSUP (-6)  /* unsupported size: PSF > 127, stats window > 4096 px, frame > 2 GiB */
+#define ICS_ENOSUP (-6)  /* unsupported size: PSF > 255, stats window > 4096 px, frame > 2 GiB */
 
 typedef struct ics_ctx ics_ctx; /* one per (process, device): stream, events, scratch   */
 typedef struct ics_rl ics_rl;   /* one deconvolution job: device-resident frames        */
@@ -188,10 +188,10 @@ typedef struct ics_rl_stats {
 } ics_rl_stats;
 size_t ics_rl_stats_size(void);
 
-/* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 127):
+/* Allocates the device frames for an M x N x 3 image and MK x MK x 3 PSF (MK odd, 3 <= MK <= 255):
  * u is (M+2*(MK/2)) x (N+2*(MK/2)) x 3 as in pyx:372-376.  All sizes run on the matrix cores (to 49 directly, above as tap
- * blocks; 65 ... 127: shipped loop only, tv_mode 0, fuse 0); fp32-product kernels behind ICS_CONV_VECTOR.  Limits (the reference has none; each
- * fails with ICS_ENOSUP and a message, never silently): PSF sizes above 127 (the reference's own examples go to 45,
+ * blocks; 65 ... 255: shipped loop only, tv_mode 0, fuse 0); fp32-product kernels behind ICS_CONV_VECTOR (to 127).  Limits (the reference has none; each
+ * fails with ICS_ENOSUP and a message, never silently): PSF sizes above 255 (the reference's own examples go to 45,
  * deconvolve.py:409), stats windows
  * wider or higher than 4096 px (ics_rl_run; 8192-point transforms in 128 KB of LDS), frames of 2 GiB and more (32-bit
  * buffer offsets: about 13000 x 13000 px). */

@@ -46,8 +46,13 @@ def test_route_switches():
     with pytest.raises(nv.NativeError) as ei:      # an explicit MATRIX request is never served by fp32 kernels
         _route(512, 55, True, conv=nv.CONV_MATRIX, tv_mode=2)
     assert ei.value.code == nv.ICS_ENOSUP
+    big = _route(512, 129, True)                   # 129 ... 255: tap blocks on the matrix cores and nothing else
+    assert (big.conv_family, big.conv_fp16_split, big.gradk_family) == (2, 1, 3)
+    with pytest.raises(nv.NativeError) as ei:
+        _route(512, 129, True, conv=nv.CONV_VECTOR)
+    assert ei.value.code == nv.ICS_ENOSUP
     with pytest.raises(nv.NativeError):
-        _route(512, 129, True)
+        _route(512, 257, True)
 
 
 def test_bench_help_and_docs_do_not_restate_a_size_rule():
