@@ -82,7 +82,7 @@ def test_repeated_calls_reuse_the_cached_job_and_stay_deterministic():
 def test_unsupported_sizes_fail_loudly():
     from lib import _native as nv
     with pytest.raises(nv.NativeError) as ei:
-        nv.RLJob(32, 32, 129)            # (65 ... 127: run-time-sized kernels since round 3, tests/test_gpu_bigpsf.py)
+        nv.RLJob(32, 32, 257)            # (65 ... 255: tests/test_gpu_bigpsf.py)
     assert ei.value.code == nv.ICS_ENOSUP
     with pytest.raises(nv.NativeError) as ei:
         nv.RLJob(32, 32, 4)
