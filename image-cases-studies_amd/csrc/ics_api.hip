@@ -147,10 +147,11 @@ struct ics_rl {
   float* e2;                            // second residual frame (first overlapped run)
   float* psf_bak;                       // psf + psf_caller as they were when the running outer iteration started (blind, overlapped)
   double* gradk64;                      // row bands over several ranks: the gradient sums as float64 for the cross-rank all-reduce (first use)
-  // PSF sizes 51 ... 127 on the matrix cores as nblk x nblk tap blocks of Kb x Kb (do_conv_blocks): weight tables of both
-  // orientations, a scratch frame for the block results, a frame of zeros (the image operand of the blocks after the first)
+  // PSF sizes 51 ... 255 on the matrix cores as nblk x nblk tap blocks of Kb x Kb (do_conv_blocks): weight tables of both
+  // orientations, a scratch frame for the block results
   int blk_n, blk_kb;
-  float *blk_conv, *blk_corr, *blk_scr, *blk_zero;
+  float *blk_conv, *blk_corr, *blk_scr, *blk_negf;   // blk_negf: -image (even block counts only: the chain of do_conv_blocks starts from it)
+  bool negf_valid;
   uint32_t* blk_red;                    // reduction slots the block passes may scribble on (the maxima are taken over the sum)
   float *bt_conv, *bt_corr;  // Toeplitz fragment tables of the matrix-core convolution (MK <= 37), else NULL
   int gradk_blocks;
@@ -345,7 +346,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (!j) return;
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
-  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_zero, j->blk_red,
+  void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_negf, j->blk_red,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64, j->e2, j->psf_bak};
   for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
@@ -394,7 +395,8 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
     j->blk_kb = ((MK + j->blk_n - 1) / j->blk_n) | 1;
     const size_t tf = ics_conv_mfma_table_floats(j->blk_kb);
     TRY(dalloc(c, &j->blk_conv, tf * j->blk_n * j->blk_n, &zl)); TRY(dalloc(c, &j->blk_corr, tf * j->blk_n * j->blk_n, &zl));
-    TRY(dalloc(c, &j->blk_scr, j->frame_floats, &zl)); TRY(dalloc(c, &j->blk_zero, j->frame_floats, &zl));
+    TRY(dalloc(c, &j->blk_scr, j->frame_floats, &zl));
+    if (!(j->blk_n & 1)) TRY(dalloc(c, &j->blk_negf, j->frame_floats, &zl));
     TRY(dalloc(c, &j->blk_red, (size_t)ICS_RED_STRIDE, &zl));
   }
   TRY(dalloc(c, &j->wconv, (size_t)(MK + 1) * j->g.wrow, &zl)); TRY(dalloc(c, &j->wcorr, (size_t)(MK + 1) * j->g.wrow, &zl));
@@ -430,7 +432,7 @@ static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px,
 }
 
 // the accumulator-order copies of the image follow the image frame: every writer of j->f calls this
-static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; }
+static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; j->negf_valid = false; }
 
 // (re)build the accumulator-order image for tile height 16 * RS if it is missing or stale; queued on the job's stream
 static int ensure_image_acc(ics_rl* j, int RS) {
@@ -825,15 +827,33 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
   float* out = org(j, mode == 1 ? j->gr : j->e);
   const float* in = org(j, mode == 1 ? j->e : j->u);
   const ptrdiff_t oshift = mode == 0 ? (ptrdiff_t)(pad - padb) * (G.pitch + 3) : 0;   // mode 0: the kernel's tile origin (padb, padb) = the image origin
+  // Mode 0 (residual = synthesis - image): the blocks form a CHAIN through the kernel's own "- image" operand instead of being added by
+  // passes of their own.  With S_q = C_0 + ... + C_q - image, block q stores T_q = s_q S_q = conv(s_q W_q) - T_{q-1}, signs alternating
+  // (s_q = -s_{q-1}: the weight tables of the conv orientation carry them, k_pack_blocks) and ending on s_{n-1} = +1; the chain starts from
+  // T_{-1} = s_0 * image: the image itself for an odd number of blocks, a negated copy of it (blk_negf) for an even one.  T_q alternates
+  // between the result frame and the scratch frame so that the last one lands in the result.  Same sums in the same order as adding the
+  // blocks one by one (IEEE negation is exact and rounding is symmetric), one launch and 36 B/px less per block after the first, and no
+  // frame of zeros read as the image operand.  (255 x 255 at 2048^2: synthesis 8.8 -> see DESIGN.md 4d.)
+  const int nq = nb * nb;
+  if (mode == 0 && !(nq & 1) && !j->negf_valid) {
+    HIPCHK(ics_launch_frame_neg(j->blk_negf, j->f, j->frame_floats, j->ctx->stream));
+    j->negf_valid = true;
+  }
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
-  for (int q = 0; q < nb * nb; ++q) {
+  for (int q = 0; q < nq; ++q) {
     const int qa = q / nb, qb = q - qa * nb;
     IcsConvArgs a;
     a.g = G; a.g.K = Kb; a.g.pad = padb;
     a.lambd = p->lambd; a.w = nullptr;
     a.in = in + oshift + (ptrdiff_t)(qa * Kb + padb - pad) * G.pitch + 3 * (qb * Kb + padb - pad);
-    a.out = (q == 0 ? out : org(j, j->blk_scr)) + oshift;
-    a.f = (q == 0 ? org(j, j->f) : org(j, j->blk_zero)) + oshift;
+    if (mode == 0) {
+      float* const fr[2] = {out, org(j, j->blk_scr)};            // T_q -> fr[(nq - 1 - q) & 1], read from the other one
+      a.out = fr[(nq - 1 - q) & 1] + oshift;
+      a.f = (q == 0 ? ((nq & 1) ? org(j, j->f) : org(j, j->blk_negf)) : fr[(nq - q) & 1]) + oshift;
+    } else {
+      a.out = (q == 0 ? out : org(j, j->blk_scr));
+      a.f = org(j, j->f);                                       // (mode 1 reads no image operand)
+    }
     a.u = org(j, j->u); a.ut = org(j, ut_of(j));
     a.red = j->blk_red;                                   // (per-block maxima mean nothing)
     a.gr = nullptr; a.u_out = nullptr; a.scal = j->scal; a.dofkeys = dof_of(j);
@@ -842,10 +862,7 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
     a.facc[0] = a.facc[1] = nullptr;
     a.sched = j->sched;
     HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
-    if (q > 0) {
-      if (mode == 0) HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, pad, pad + G.M, 3 * pad, 3 * (pad + G.N), j->ctx->stream));
-      else HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, 0, G.uM, 0, 3 * G.uN, j->ctx->stream));
-    }
+    if (q > 0 && mode == 1) HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, 0, G.uM, 0, 3 * G.uN, j->ctx->stream));
   }
   if (mode == 1) HIPCHK(ics_launch_band_reduce(out, org(j, j->u), org(j, ut_of(j)), G, p->lambd, 0, G.uM, red_of(j) + slot * ICS_RED_STRIDE, j->ctx->stream));
   RC(pr.end());

@@ -252,6 +252,8 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ p
   uint32_t sb = 127u;
   if (m > 0.f && e != 255u) { sb = 268u - e; sb = sb > 240u ? 240u : sb; }
   const float s_w = __uint_as_float(sb << 23), inv_w = __uint_as_float((254u - sb) << 23);
+  // the residual's blocks are chained with alternating signs, the last one positive (ics_api.hip, do_conv_blocks)
+  const float s_wc = ((nblk * nblk - 1 - (int)blockIdx.x) & 1) ? -s_w : s_w;
   _Float16* tc = reinterpret_cast<_Float16*>(reinterpret_cast<float*>(tconv) + (size_t)blockIdx.x * table_floats);
   _Float16* tr = reinterpret_cast<_Float16*>(reinterpret_cast<float*>(tcorr) + (size_t)blockIdx.x * table_floats);
   const int rh = ((2 * (Kb + 17) + 3) & ~3) / 2;      // halves per row (MCfg::WROWB / 2)
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void k_pack_blocks(const float* __restrict__ p
     float w1 = 0.f, w2 = 0.f;
     if (b >= 0 && b < Kb && A < K && B < K) {
       w1 = psf[(A * K + B) * 3 + c] * s_w;                              // correlation orientation (A3): W = psf
-      w2 = psf[((K - 1 - A) * K + (K - 1 - B)) * 3 + c] * s_w;          // convolution orientation (A1): W = rot180(psf)
+      w2 = psf[((K - 1 - A) * K + (K - 1 - B)) * 3 + c] * s_wc;         // convolution orientation (A1): W = rot180(psf), with the block's sign
     }
     const _Float16 h1 = (_Float16)w1, h2 = (_Float16)w2;
     const int o = ca * 2 * rh + 4 * (hh >> 1) + 2 * sp + (hh & 1);
@@ -287,8 +289,16 @@ __global__ __launch_bounds__(256) void k_frame_add(float* __restrict__ out, cons
   }
 }
 
+__global__ __launch_bounds__(256) void k_frame_neg(float* __restrict__ out, const float* __restrict__ in, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) out[i] = -in[i];
+}
+
 }  // namespace
 
+hipError_t ics_launch_frame_neg(float* out, const float* in, size_t count, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_neg, dim3(2048), dim3(256), 0, s, out, in, count);
+  return hipGetLastError();
+}
 hipError_t ics_launch_pack_blocks(const float* psf, int K, int Kb, int nblk, void* tconv, void* tcorr, size_t table_floats, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_blocks, dim3(nblk * nblk), dim3(256), 0, s, psf, K, Kb, nblk, tconv, tcorr, table_floats);
   return hipGetLastError();

@@ -117,6 +117,7 @@ hipError_t ics_launch_gradk_big(const IcsGradkArgs& a, int nblocks, hipStream_t 
 // tap blocks on the matrix cores (PSF sizes 51 ... 127, ics_big.hip): nblk x nblk weight tables of Kb x Kb taps, and the frame sum
 hipError_t ics_launch_pack_blocks(const float* psf, int K, int Kb, int nblk, void* tconv, void* tcorr, size_t table_floats, hipStream_t s);
 hipError_t ics_launch_frame_add(float* out, const float* add, int pitch, int y0, int y1, int f0, int f1, hipStream_t s);
+hipError_t ics_launch_frame_neg(float* out, const float* in, size_t count, hipStream_t s);   // out = -in over a whole frame buffer
 
 // ---- A18/A19 (pyx:593-638): window statistics and residual-whiteness metric -------------------
 struct IcsStatsArgs {
