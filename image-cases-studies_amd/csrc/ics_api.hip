@@ -844,25 +844,29 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
     const int qa = q / nb, qb = q - qa * nb;
     IcsConvArgs a;
     a.g = G; a.g.K = Kb; a.g.pad = padb;
-    a.lambd = p->lambd; a.w = nullptr;
+    a.lambd = p->lambd; a.w = nullptr; a.tv = nullptr; a.tv_kind = 0;
     a.in = in + oshift + (ptrdiff_t)(qa * Kb + padb - pad) * G.pitch + 3 * (qb * Kb + padb - pad);
     if (mode == 0) {
       float* const fr[2] = {out, org(j, j->blk_scr)};            // T_q -> fr[(nq - 1 - q) & 1], read from the other one
       a.out = fr[(nq - 1 - q) & 1] + oshift;
       a.f = (q == 0 ? ((nq & 1) ? org(j, j->f) : org(j, j->blk_negf)) : fr[(nq - q) & 1]) + oshift;
     } else {
-      a.out = (q == 0 ? out : org(j, j->blk_scr));
+      // Mode 1 chains through the epilogue the PAM kinds use: with tv_kind = 2 the kernel stores fl32(double(T) + double(lambd * sums)) for
+      // an operand frame T -- lambd = 1 and T = the blocks so far make that T_q = T_{q-1} + C_q, the sum the adding pass formed.  The
+      // first block stores its raw sums as before; the maxima of A7 are taken over the finished frame by k_band_reduce below.
+      float* const fr[2] = {out, org(j, j->blk_scr)};
+      a.out = fr[(nq - 1 - q) & 1];
       a.f = org(j, j->f);                                       // (mode 1 reads no image operand)
+      if (q > 0) { a.tv = fr[(nq - q) & 1]; a.tv_kind = ICS_TV_PAM_ISO; a.lambd = 1.0f; }
     }
     a.u = org(j, j->u); a.ut = org(j, ut_of(j));
     a.red = j->blk_red;                                   // (per-block maxima mean nothing)
     a.gr = nullptr; a.u_out = nullptr; a.scal = j->scal; a.dofkeys = dof_of(j);
-    a.tv = nullptr; a.tv_kind = 0; a.step = p->step_factor; a.blind = p->blind; a.want_dof = 0;
+    a.step = p->step_factor; a.blind = p->blind; a.want_dof = 0;
     a.bt = (mode == 1 ? j->blk_corr : j->blk_conv) + (size_t)q * tf;
     a.facc[0] = a.facc[1] = nullptr;
     a.sched = j->sched;
     HIPCHK(ics_launch_conv_mfma(mode, a, j->ctx->stream));
-    if (q > 0 && mode == 1) HIPCHK(ics_launch_frame_add(out, org(j, j->blk_scr), G.pitch, 0, G.uM, 0, 3 * G.uN, j->ctx->stream));
   }
   if (mode == 1) HIPCHK(ics_launch_band_reduce(out, org(j, j->u), org(j, ut_of(j)), G, p->lambd, 0, G.uM, red_of(j) + slot * ICS_RED_STRIDE, j->ctx->stream));
   RC(pr.end());
