@@ -811,9 +811,9 @@ static bool use_big_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
 // the K x K PSF is cut into blk_n x blk_n blocks of Kb x Kb taps (Kb odd, <= 33: sizes k_conv_mfma is built for); block (qa, qb) is
 //     out_q[y][x] = sum_{a',b' < Kb} W[qa Kb + a'][qb Kb + b'] * in'[y + a' - Kb/2][x + b' - Kb/2],   in' = in shifted by (qa Kb + Kb/2 - pad, ...)
 // i.e. the Kb x Kb kernel on a shifted pointer with a geometry that differs in K and pad only (mode 0 tiles start at the kernel's
-// own pad: all three pointers move by pad - Kb/2 so that this is the image origin).  The first block writes the result frame
-// (mode 0: minus the image), the others a scratch frame that is added to it; the maxima of A7 are taken over the sum by
-// k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see DESIGN.md 4c.
+// own pad: all three pointers move by pad - Kb/2 so that this is the image origin).  The blocks are summed as a chain through the
+// kernels' own operand frames, alternating between the result frame and a scratch frame (do_conv_blocks); the maxima of A7 are taken
+// over the sum by k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see DESIGN.md 4c.
 static bool use_block_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
   if (!j->blk_conv || mode == 2 || p->tv_mode != ICS_TV_SHIPPED || p->conv == ICS_CONV_VECTOR) return false;
   if (psf_blocks_only(j->g.K)) return true;   // (no other path: ICS_CONV_PATH does not apply)
