@@ -74,6 +74,21 @@ def test_blind_bands_match_one_job(bands, conv):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("MK,M,N", [(65, 330, 150), (99, 420, 140), (129, 500, 150)])
+def test_blind_bands_with_tap_block_psf_sizes_match_one_job(MK, M, N):
+    """PSF sizes that run as tap blocks (csrc/ics_api.hip do_conv_blocks: 4, 9 and 16 blocks -- the chain of the residual's blocks starts
+    from the negated image of EACH band job for the even counts), two bands against the single job."""
+    case = orc.synth_case(M, N, MK, seed=MK, blind=True)
+    win = (M // 2 - 40, M // 2 + 41, 20, N - 20)
+    u1, p1, _, st1 = run_single(case, M, N, MK, win, 0.0, 2, True, 0, flags=1)
+    u2, p2, _, st2 = run_banded(case, M, N, MK, win, 0.0, 2, True, 0, 2)
+    eu, ep = rel_err(u2, u1), rel_err(p2, p1)
+    print("blind 2 bands MK=%d: rel err u %.2e psf %.2e" % (MK, eu, ep))
+    assert st1.iterations_done == st2.iterations_done
+    assert eu < 2e-5 and ep < 2e-5
+
+
+@pytest.mark.gpu
 def test_banded_run_against_the_reference_golden(golden_dir):
     """the 129 x 129 blind golden from the compiled reference, deconvolved as 3 bands"""
     from helpers import load_golden
