@@ -1,0 +1,224 @@
+// bench_conv_fft.hip -- stand-alone harness for the overlap-save FFT convolution (ics_conv_fft.hip).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -I.. -I../../../include bench_conv_fft.hip -o bench_conv_fft
+//   ./bench_conv_fft emulate [M K N]     CPU emulation of the kernel's stages (host pass of the same functions, "threads" run one after
+//                                        the other per stage) against float64 direct sums over the whole output: no GPU needed
+//   ./bench_conv_fft M K [N] [reps]      GPU: both modes checked against float64 direct sums on sampled rows, then timed
+#include "../ics_conv_fft.hip"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+namespace {
+
+struct Host {
+  IcsGeom g;
+  size_t nf, org;
+  std::vector<float> u, e, f, ut, psf;   // frames (u-frame geometry) and the K x K x 3 PSF
+};
+
+Host make_host(int M, int N, int K) {
+  Host h;
+  h.g = ics_make_geom(M, N, K);
+  h.nf = ics_frame_floats(h.g); h.org = ics_origin_offset(h.g);
+  h.u.assign(h.nf, 0.f); h.e.assign(h.nf, 0.f); h.f.assign(h.nf, 0.f); h.ut.assign(h.nf, 0.f);
+  srand(7);
+  const IcsGeom& g = h.g;
+  for (int y = 0; y < g.uM; ++y)
+    for (int x = 0; x < g.uN; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = h.org + (size_t)y * g.pitch + 3 * x + c;
+        h.u[o] = 0.1f + 0.8f * (float)rand() / RAND_MAX;
+        h.ut[o] = h.u[o] + 1e-3f * ((float)rand() / RAND_MAX - 0.5f);
+        const bool in = y >= g.pad && y < g.pad + M && x >= g.pad && x < g.pad + N;
+        h.e[o] = in ? 2e-3f * ((float)rand() / RAND_MAX - 0.5f) : 0.f;
+        h.f[o] = in ? 0.1f + 0.8f * (float)rand() / RAND_MAX : 0.f;
+      }
+  h.psf.resize((size_t)K * K * 3);
+  double sum[3] = {0, 0, 0};
+  for (int a = 0; a < K; ++a)
+    for (int b = 0; b < K; ++b)
+      for (int c = 0; c < 3; ++c) {
+        const double s = K / 6.0 * (1.0 + 0.1 * c), dy = a - K / 2 + 0.3, dx = b - K / 2 - 0.2 * c;   // not symmetric: orientation errors show
+        const double v = exp(-(dy * dy + dx * dx) / (2 * s * s)) * (1.0 + 0.05 * ((a * 7 + b * 3) % 5));
+        h.psf[((size_t)a * K + b) * 3 + c] = (float)v; sum[c] += v;
+      }
+  for (size_t i = 0; i < h.psf.size(); ++i) h.psf[i] = (float)(h.psf[i] / sum[i % 3]);
+  return h;
+}
+
+// float64 direct sum of one output value in u-frame coordinates
+double direct(const Host& h, int mode, int y, int x, int c) {
+  const IcsGeom& g = h.g;
+  const std::vector<float>& in = mode == 0 ? h.u : h.e;
+  double s = 0.0;
+  for (int a = 0; a < g.K; ++a)
+    for (int b = 0; b < g.K; ++b) {
+      const double w = mode == 0 ? h.psf[((size_t)(g.K - 1 - a) * g.K + (g.K - 1 - b)) * 3 + c] : h.psf[((size_t)a * g.K + b) * 3 + c];
+      const ptrdiff_t o = (ptrdiff_t)h.org + (ptrdiff_t)(y + a - g.pad) * g.pitch + 3 * (x + b - g.pad) + c;
+      s += w * (double)in[o];
+    }
+  return s;
+}
+
+void host_spectrum(const Host& h, int o, std::vector<v2f>& spec) {
+  const int K = h.g.K;
+  spec.assign((size_t)3 * 128 * 128, (v2f){0.f, 0.f});
+  std::vector<double> G((size_t)K * 128 * 2);
+  for (int c = 0; c < 3; ++c) {
+    for (int a = 0; a < K; ++a)
+      for (int kx = 0; kx < 128; ++kx) {
+        double re = 0, im = 0;
+        for (int b = 0; b < K; ++b) {
+          const double w = o == 0 ? h.psf[((size_t)(K - 1 - a) * K + (K - 1 - b)) * 3 + c] : h.psf[((size_t)a * K + b) * 3 + c];
+          const double ph = -2.0 * M_PI * ((b * kx) & 127) / 128.0;
+          re += w * cos(ph); im += w * sin(ph);
+        }
+        G[((size_t)a * 128 + kx) * 2] = re; G[((size_t)a * 128 + kx) * 2 + 1] = im;
+      }
+    for (int ky = 0; ky < 128; ++ky)
+      for (int kx = 0; kx < 128; ++kx) {
+        double re = 0, im = 0;
+        for (int a = 0; a < K; ++a) {
+          const double ph = -2.0 * M_PI * ((a * ky) & 127) / 128.0, wr = cos(ph), wi = sin(ph);
+          const double gr = G[((size_t)a * 128 + kx) * 2], gi = G[((size_t)a * 128 + kx) * 2 + 1];
+          re += gr * wr - gi * wi; im += gr * wi + gi * wr;
+        }
+        spec[((size_t)c * 128 + ky) * 128 + kx] = (v2f){(float)(re / 16384.0), (float)(-im / 16384.0)};
+      }
+  }
+}
+
+IcsConvArgs conv_args(const Host& h, int mode, const float* in, float* out, const float* f, const float* u, const float* ut, uint32_t* red) {
+  IcsConvArgs a = {};
+  a.in = in + h.org; a.out = out + h.org; a.f = f + h.org; a.u = u + h.org; a.ut = ut + h.org; a.red = red; a.lambd = 10000.f; a.g = h.g;
+  a.tv = nullptr; a.tv_kind = 0;
+  return a;
+}
+
+double check(const Host& h, int mode, const std::vector<float>& out, int row_step, double* worst_abs) {
+  const IcsGeom& g = h.g;
+  double worst = 0, ref_max = 0;
+  const int y0 = mode == 0 ? g.pad : 0, y1 = mode == 0 ? g.pad + g.M : g.uM, x0 = mode == 0 ? g.pad : 0, x1 = mode == 0 ? g.pad + g.N : g.uN;
+  for (int y = y0; y < y1; y += (y < y0 + 3 || y >= y1 - 3) ? 1 : row_step)
+    for (int x = x0; x < x1; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = h.org + (size_t)y * g.pitch + 3 * x + c;
+        double r = direct(h, mode, y, x, c);
+        ref_max = fmax(ref_max, fabs(r));
+        if (mode == 0) r -= (double)h.f[o];
+        worst = fmax(worst, fabs(r - (double)out[o]));
+      }
+  *worst_abs = worst;
+  return worst / ref_max;   // relative to the largest convolution value (the stage gate of tests/test_gpu_stages.py)
+}
+
+int emulate(int M, int K, int N) {
+  Host h = make_host(M, N, K);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128);
+  int rc = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    std::vector<v2f> spec;
+    host_spectrum(h, mode, spec);
+    std::vector<float> out(h.nf, 0.f);
+    uint32_t red[16] = {0};
+    IcsFftArgs a;
+    ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.u.data() : h.e.data(), out.data(), h.f.data(), h.u.data(), h.ut.data(), red), (const float*)spec.data(), &a);
+    printf("mode %d: V %d, tiles %d (x %d), units %d\n", mode, a.V, a.ntiles, a.tiles_x, a.nunits);
+    const icsfft::Mem mem = icsfft::make_mem(a);
+    std::vector<v2f> twl(128);
+    for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
+    for (int n = 0; n < a.nunits; ++n) {
+      const icsfft::Unit u = icsfft::decode_unit(a, n);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(a, mem, u, lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+      // C, D, E exchange inside a wave that runs in lock step (reads of all lanes before the writes): C and E read a snapshot here
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_d(mem, u.c, lds.data(), t);
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) {
+        v2f v[16];
+        icsfft::stage_g(lds.data(), t, v);
+        float mg = 0, mu = 0; bool ng = false, nu = false, any = false;
+        if (mode == 0) icsfft::epilogue<0>(a, mem, u, t, v, mg, mu, ng, nu, any);
+        else icsfft::epilogue<1>(a, mem, u, t, v, mg, mu, ng, nu, any);
+      }
+    }
+    double wa;
+    const double rel = check(h, mode, out, 1, &wa);
+    printf("emulation %d x %d, K = %d, mode %d: max |d| = %.3e, relative to max |conv| = %.3e  %s\n", M, N, K, mode, wa, rel, rel < 5e-6 ? "OK" : "FAIL");
+    if (!(rel < 5e-6)) rc = 1;
+  }
+  return rc;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+int gpu(int M, int K, int N, int reps) {
+  Host h = make_host(M, N, K);
+  float *du, *de, *df, *dut, *dout, *dpsf, *dspec0, *dspec1; uint32_t* dred;
+  for (float** p : {&du, &de, &df, &dut, &dout}) CK(hipMalloc(p, h.nf * 4));
+  CK(hipMalloc(&dpsf, h.psf.size() * 4)); CK(hipMalloc(&dred, 1024)); CK(hipMemset(dred, 0, 1024));
+  const size_t sf = ics_conv_fft_spectrum_floats();
+  CK(hipMalloc(&dspec0, sf * 4)); CK(hipMalloc(&dspec1, sf * 4));
+  CK(hipMemcpy(du, h.u.data(), h.nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(de, h.e.data(), h.nf * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(df, h.f.data(), h.nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dut, h.ut.data(), h.nf * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dpsf, h.psf.data(), h.psf.size() * 4, hipMemcpyHostToDevice));
+  CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
+  CK(hipDeviceSynchronize());
+  {   // spectrum against the host's float64 evaluation
+    std::vector<v2f> hs, ds(sf / 2);
+    for (int o = 0; o < 2; ++o) {
+      host_spectrum(h, o, hs);
+      CK(hipMemcpy(ds.data(), o ? dspec1 : dspec0, sf * 4, hipMemcpyDeviceToHost));
+      double w = 0, m = 0;
+      for (size_t i = 0; i < hs.size(); ++i) { w = fmax(w, fmax(fabs(hs[i].x - ds[i].x), fabs(hs[i].y - ds[i].y))); m = fmax(m, fabs(hs[i].x)); }
+      printf("spectrum %d: max |d| = %.3e of %.3e\n", o, w, m);
+    }
+  }
+  int rc = 0;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int mode = 0; mode < 2; ++mode) {
+    CK(hipMemset(dout, 0, h.nf * 4));
+    IcsConvArgs a = conv_args(h, mode, mode == 0 ? du : de, dout, df, du, dut, dred);
+    CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> out(h.nf);
+    CK(hipMemcpy(out.data(), dout, h.nf * 4, hipMemcpyDeviceToHost));
+    double wa;
+    const int step = (M <= 600) ? 1 : (M / 24) | 1;
+    const double rel = check(h, mode, out, step, &wa);
+    printf("GPU %d x %d, K = %d, mode %d: max |d| = %.3e, relative to max |conv| = %.3e  %s\n", M, N, K, mode, wa, rel, rel < 5e-6 ? "OK" : "FAIL");
+    if (!(rel < 5e-6)) rc = 1;
+    if (mode == 1) {
+      uint32_t red[16];
+      CK(hipMemcpy(red, dred, 64, hipMemcpyDeviceToHost));
+      printf("  maxima keys -> max|g| %.6g %.6g %.6g   max u %.6g %.6g %.6g\n", ics_key2f(red[0]), ics_key2f(red[1]), ics_key2f(red[2]), ics_key2f(red[3]), ics_key2f(red[4]), ics_key2f(red[5]));
+    }
+    for (int i = 0; i < 5; ++i) CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    IcsFftArgs fa; ics_conv_fft_fill_args(mode, a, dspec0, &fa);
+    printf("  mode %d: %.4f ms per launch (%d launches), %d units, %.2f us per unit and CU\n", mode, ms / reps, reps, fa.nunits, 1e3 * ms / reps / ((fa.nunits + 255) / 256));
+  }
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < 20; ++i) CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("  spectrum kernel: %.4f ms\n", ms / 20);
+  return rc;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "emulate")) {
+    const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
+    return emulate(M, K, N);
+  }
+  const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
+  return gpu(M, K, N, reps);
+}
