@@ -46,7 +46,11 @@ def labels(route, fuse=False):
     gradk_f = _native.RLRoute.GRADK_FAMILIES[route.gradk_family]
     split_conv = bool(route.conv_fp16_split) and not fuse
     split_gradk = bool(route.gradk_fp16_split)
-    if split_conv:
+    if route.conv_family == 5 and not fuse:
+        dtype = "f32" if not split_gradk else "f32 (fp32 transform-tile convolutions; fp16x2-split MFMA PSF gradient, fp32 accumulate)"
+        note = ("fp32 throughout in the two PSF convolutions: 128 x 128 overlap-save FFT tiles held in LDS, on channel-planar mirrors of the frames "
+                "(ics_conv_fft.hip)%s" % ("; the PSF gradient on the matrix cores with fp16x2-split operands" if split_gradk else ""))
+    elif split_conv:
         dtype = "f32 (fp16x2-split MFMA convolutions, fp32 accumulate)"
         note = ("frames, sums and every elementwise step in fp32; the two PSF convolutions%s run on the matrix cores%s with each fp32 operand split into "
                 "two fp16 terms (22 significand bits), three fp16 MFMAs per product, fp32 accumulation; `--conv vector` runs fp32 products throughout"
@@ -58,7 +62,7 @@ def labels(route, fuse=False):
         dtype = "f32"
         note = "fp32 throughout (packed-fp32 vector convolutions%s)" % (", fp32-MFMA PSF gradient" if route.gradk_family else "")
     return {"matrix": split_conv, "dtype": dtype, "dtype_note": note, "conv": conv_f if not fuse else "vector (fused update + convolution)", "gradk": gradk_f,
-            "traffic_key": "kernels_matrix" if split_conv else "kernels_vector"}
+            "traffic_key": "kernels_fft" if (route.conv_family == 5 and not fuse) else ("kernels_matrix" if split_conv else "kernels_vector")}
 
 
 def gaussian_1d(MK):
@@ -246,7 +250,7 @@ def bench_bands(args, grp):
     MK = args.psf
     blind = args.mode == "blind"
     steps, warm = ((args.steps + 4) // 5) * 5, ((args.warmup + 4) // 5) * 5
-    conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
+    conv = {"auto": 0, "vector": 1, "matrix": 2, "fft": 3}[args.conv]
     pad = MK // 2
     win = (M // 2 - 127, M // 2 + 128, N // 2 - 127, N // 2 + 128)      # 255-px window at the centre: straddles the bands for even N
     image, u0, psf_true, psf_uniform = synth_frame(M, N, MK, seed=0)   # (every rank builds the same frame and takes its rows)
@@ -286,7 +290,7 @@ def bench_bands(args, grp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--conv", choices=["auto", "vector", "matrix"], default="auto",
+    ap.add_argument("--conv", choices=["auto", "vector", "matrix", "fft"], default="auto",
                     help="convolution kernels: auto = matrix cores (fp16-split MFMA) at every PSF size (whole PSF to 49 x 49, tap blocks above); "
                          "vector = fp32 products everywhere; the JSON's dtype / config.conv come from the library's own routing (ics_rl_describe)")
     ap.add_argument("--steps", type=int, default=200)
@@ -323,7 +327,7 @@ def main():
     steps = ((args.steps + 4) // 5) * 5
     warm = ((args.warmup + 4) // 5) * 5
     blind = args.mode == "blind"
-    conv = {"auto": 0, "vector": 1, "matrix": 2}[args.conv]
+    conv = {"auto": 0, "vector": 1, "matrix": 2, "fft": 3}[args.conv]
     if conv == 0 and os.environ.get("ICS_CONV_PATH", "")[:1] == "v":
         conv = 1
 

@@ -45,6 +45,8 @@ int ics_set_error(int code, const char* fmt, ...) {
                   hipGetErrorString(e_), __FILE__, __LINE__);                                    \
   } while (0)
 
+#define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
+
 // Device memory of a context is recycled, not returned (round 4).  deblur_module creates a job and a handful of images per pyramid
 // level and phase (deconvolve.py:204-313); hipMalloc / hipFree cost 0.1 ... 0.7 ms each and hipFree synchronises the device: the
 // rocprof timeline of a device-resident 2048^2 run showed 42 % of its 0.19 s idle, most of it in front of the first kernel that
@@ -185,9 +187,25 @@ struct ics_rl {
   int ev_chain = -1;                    // the event the last end() recorded, while nothing else has been queued behind it (Prof::begin)
   hipStream_t ev_chain_stream = nullptr;
   hipEvent_t ev_begin, ev_end;
+  // FFT-tile pipeline (round 5; ics_conv_fft.hip, ics_planar.hip): channel-planar mirrors of the frames (ics_common.h), allocated by the
+  // first run that uses it.  A mirror belongs to a BUFFER, not to a role: u / ut / u2 and e / e2 rotate as pointers, the table is looked
+  // up by the HWC pointer's value.  fft_on = a run / stage on the pipeline is in progress: the do_* helpers work on the mirrors and
+  // pack_weights also builds the two spectra.
+  struct Twin { float* hwc; float* pl; };
+  Twin twins[8];
+  int ntwins;
+  float *spec_conv, *spec_corr;
+  bool fft_on;
+  bool plf_valid;                       // the mirror of the image frame still mirrors it (every writer of j->f calls image_changed)
 };
 
 static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
+static inline float* pl_of(ics_rl* j, const float* hwc) {
+  for (int i = 0; i < j->ntwins; ++i) if (j->twins[i].hwc == hwc) return j->twins[i].pl;
+  return nullptr;
+}
+// origin of the planar mirror of an HWC frame buffer
+static inline float* porg(ics_rl* j, const float* hwc) { float* p = pl_of(j, hwc); return p ? p + ics_planar_origin(j->g) : nullptr; }
 // majoriser frame: pyx:462 `ut = u.copy()` is realised without a copy -- until the first update of the outer
 // iteration ut IS u; that update writes out of place and the old u frame becomes ut (buffer rotation)
 static inline float* ut_of(ics_rl* j) { return j->ut_is_u ? j->u : j->ut; }
@@ -348,9 +366,12 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_negf, j->blk_red,
                   j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64, j->e2, j->psf_bak};
+  if (j->ctx->stream2) hipStreamSynchronize(j->ctx->stream2);   // (the statistics' stream uses the job's buffers as well: drain it before they are recycled)
   for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
+  for (int i = 0; i < j->ntwins; ++i) if (j->twins[i].pl) j->ctx->pool.release(j->twins[i].pl);
+  if (j->spec_conv) j->ctx->pool.release(j->spec_conv);
+  if (j->spec_corr) j->ctx->pool.release(j->spec_corr);
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
-  if (j->ctx->stream2) hipStreamSynchronize(j->ctx->stream2);
   for (int i = 0; i < 2; ++i) { if (j->ev_body[i]) hipEventDestroy(j->ev_body[i]); if (j->ev_stats[i]) hipEventDestroy(j->ev_stats[i]); }
   if (j->h_scal) hipHostFree(j->h_scal);
   for (hipEvent_t e : j->ev) hipEventDestroy(e);
@@ -432,7 +453,7 @@ static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px,
 }
 
 // the accumulator-order copies of the image follow the image frame: every writer of j->f calls this
-static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; j->negf_valid = false; }
+static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; j->negf_valid = false; j->plf_valid = false; }
 
 // (re)build the accumulator-order image for tile height 16 * RS if it is missing or stale; queued on the job's stream
 static int ensure_image_acc(ics_rl* j, int RS) {
@@ -457,8 +478,39 @@ static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hip
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
   if (j->blk_conv) HIPCHK(ics_launch_pack_blocks(j->psf, j->g.K, j->blk_kb, j->blk_n, j->blk_conv, j->blk_corr, ics_conv_mfma_table_floats(j->blk_kb), s));
+  if (j->fft_on) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s));   // conj(DFT2(W)) / 128^2 of both orientations
   return ICS_OK;
 }
+
+// ---- FFT-tile pipeline: mirrors ---------------------------------------------------------------------------------------------------------
+// every HWC frame buffer the pipeline touches gets a planar mirror (zero-filled: the aprons of a mirror are never written either)
+static int ensure_planar(ics_rl* j) {
+  float* want[] = {j->u, j->u2, j->ut, j->gr, j->f, j->e, j->e2};
+  for (float* h : want) {
+    if (!h || pl_of(j, h)) continue;
+    if (j->ntwins >= 8) return fail(ICS_ESTATE, "planar mirror table full");
+    float* pl = nullptr;
+    RC(dalloc(j->ctx, &pl, ics_planar_floats(j->g)));
+    j->twins[j->ntwins].hwc = h; j->twins[j->ntwins].pl = pl; ++j->ntwins;
+    if (h == j->f) j->plf_valid = false;
+  }
+  if (!j->spec_conv) RC(dalloc(j->ctx, &j->spec_conv, ics_conv_fft_spectrum_floats()));
+  if (!j->spec_corr) RC(dalloc(j->ctx, &j->spec_corr, ics_conv_fft_spectrum_floats()));
+  return ICS_OK;
+}
+// whole-buffer copies HWC -> mirror / mirror -> HWC (run and stage boundaries), and the stop-test window mirror -> HWC
+static int to_planar(ics_rl* j, float* hwc, hipStream_t s) {
+  HIPCHK(ics_launch_planar_convert(true, hwc, pl_of(j, hwc), j->g, true, 0, 0, 0, 0, s));
+  return ICS_OK;
+}
+static int from_planar(ics_rl* j, float* hwc, hipStream_t s) {   // the u-frame only: the aprons of both stay zero
+  HIPCHK(ics_launch_planar_convert(false, pl_of(j, hwc), hwc, j->g, false, 0, j->g.uM, 0, j->g.uN, s));
+  return ICS_OK;
+}
+struct FftScope {   // fft_on for the duration of a run / stage, whatever path leaves it
+  ics_rl* j;
+  ~FftScope() { if (j) j->fft_on = false; }
+};
 
 extern "C" int ics_rl_upload(ics_rl* j, const float* image, const float* u, const float* psf) {
   if (!j) return fail(ICS_EINVAL, "job is NULL");
@@ -754,7 +806,6 @@ struct Prof {
   }
 };
 
-#define RC(x) do { int rc_ = (x); if (rc_ != ICS_OK) return rc_; } while (0)
 
 // ---- row bands over several ranks: the two per-iteration reductions, in place on the device (lib/banded.py rank mode) -----------
 int ics_group_allreduce_device(ics_group* g, void* buf, size_t count, int kind, hipStream_t stream);   // ics_group.hip
@@ -787,6 +838,24 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
   if (p->conv == ICS_CONV_MATRIX) return true;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
   return env == 2 || (env == 0 && ics_conv_mfma_preferred(j->g.K));
+}
+
+// The FFT-tile pipeline (ics_conv_fft.hip; round 5): A1 / A3 / A11 as LDS-resident 128 x 128 overlap-save transforms on planar mirrors,
+// fp32 throughout, with the update pass and the matrix-core PSF gradient on the mirrors as well.  Shipped loop only (tv_mode 0, fuse 0),
+// PSF sizes 3 ... 65.  Explicit: conv = ICS_CONV_FFT (also through the stage API); under ICS_CONV_AUTO inside ics_rl_run where it measured
+// ahead of the matrix-core kernels (fft_preferred); ICS_CONV_PATH=fft|matrix|vector overrides AUTO.
+static bool fft_preferred(const IcsGeom& g) {
+  // measured on MI355X: per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
+  // the Toeplitz matrix-core kernels pay K^2: the tiles win from the two-window sizes (K >= 17) on, on frames that fill the device
+  return g.K >= 17 && (long)g.uM * g.uN >= 1500000L;
+}
+static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
+  if (!ics_conv_fft_supported(j->g.K) || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
+  if (p->conv == ICS_CONV_FFT) return true;
+  if (p->conv != ICS_CONV_AUTO || !in_run) return false;
+  const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
+  if (env == 3) return true;
+  return env == 0 && fft_preferred(j->g);
 }
 
 // tv_mode 1 rewrites the image in every inner iteration (pyx:547-549 live): a copy would have to be rebuilt each time
@@ -873,7 +942,24 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
   return ICS_OK;
 }
 
+static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Prof& pr) {
+  IcsConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.g = j->g; a.lambd = p->lambd;
+  if (mode == 1) { a.in = porg(j, j->e); a.out = porg(j, j->gr); }
+  else { a.in = porg(j, j->u); a.out = porg(j, j->e); }
+  a.f = porg(j, j->f); a.u = porg(j, j->u); a.ut = porg(j, ut_of(j));
+  a.red = red_of(j) + slot * ICS_RED_STRIDE;
+  a.step = p->step_factor; a.blind = p->blind;
+  if (!a.in || !a.out || !a.f || !a.u || !a.ut) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
+  HIPCHK(ics_launch_conv_fft(mode, a, mode == 1 ? j->spec_corr : j->spec_conv, ICS_FFT_PL_ALL, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
+  if (j->fft_on && mode != 2) return do_conv_fft(j, mode, p, slot, pr);
   if (use_block_conv(j, p, mode)) return do_conv_blocks(j, mode, p, slot, pr);
   IcsConvArgs a;
   a.g = j->g; a.lambd = p->lambd;
@@ -912,6 +998,12 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
   a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.want_dof = want_dof; a.geo = j->g;
   if (a.tv_kind == ICS_TV_MM_ACTIVE) image_changed(j);          // pyx:547-549: this update also steps the image
   RC(pr.begin(ICS_K_UPDATE));
+  if (j->fft_on) {   // the same pass on the planar mirrors (bit-identical arithmetic, ics_planar.hip)
+    a.u = porg(j, j->u); a.ut = porg(j, ut_of(j)); a.g = porg(j, j->gr); a.f = porg(j, j->f);
+    a.u_out = porg(j, j->ut_is_u ? j->u2 : j->u); a.f_rw = nullptr;
+    if (!a.u || !a.ut || !a.g || !a.f || !a.u_out) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+    HIPCHK(ics_launch_update_planar(a, j->ctx->stream));
+  } else
   HIPCHK(ics_launch_update(a, j->ctx->stream));
   RC(pr.end());
   if (j->ut_is_u) {  // rotate: the untouched old u is the majoriser now, the stale ut frame becomes the spare
@@ -942,7 +1034,7 @@ static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
 // where AUTO keeps the packed-fp32 convolutions, 0.35 vs 0.97 ms at 4096^2)
 static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
   if (!ics_gradk_mfma_supported(j->g.K) || p->conv == ICS_CONV_VECTOR) return false;
-  if (p->conv == ICS_CONV_MATRIX) return true;
+  if (p->conv == ICS_CONV_MATRIX || j->fft_on) return true;   // (the FFT pipeline's gradient reads the mirrors: matrix-core kernel only)
   return ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
@@ -955,7 +1047,7 @@ static bool use_matrix_gradk(const ics_rl* j, const ics_rl_params* p) {
 static bool use_split_gradk(const ics_rl* j, const ics_rl_params* p) {
   const int K = j->g.K;
   if (K < 33 || p->conv == ICS_CONV_VECTOR) return false;
-  if (psf_blocks_only(K)) return true;
+  if (psf_blocks_only(K) || j->fft_on) return true;
   return p->conv == ICS_CONV_MATRIX || ics_debug().conv_path.load(std::memory_order_relaxed) != 1;
 }
 
@@ -969,8 +1061,9 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
       const int Ks = (La <= 15 && Lb <= 15) ? 15 : 31, pads = Ks / 2, nt = Ks == 15 ? 16 : 32;
       IcsGradkArgs a;
       a.geo = j->g; a.geo.K = Ks; a.geo.pad = pads;
-      a.e = org(j, j->e);
-      a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads);
+      a.planar = j->fft_on ? 1 : 0;
+      if (a.planar) { a.e = porg(j, j->e); a.u = porg(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * ics_ppitch(j->g) + (pad - b0 - pads); }
+      else { a.e = org(j, j->e); a.u = org(j, j->u) + (ptrdiff_t)(pad - a0 - pads) * j->g.pitch + 3 * (pad - b0 - pads); }
       a.partial = j->partial;
       // as many persistent workgroups per CU as for the sizes the kernel was built for, within what the partial buffer (sized for K) holds
       int nblocks = 2 * j->ctx->cus;                        // (GCfg::WGS of ics_gradk_mfma.hip)
@@ -987,9 +1080,10 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   if (use_split_gradk(j, p)) return do_gradk_split(j, pr);
   IcsGradkArgs a;
-  a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g;
+  a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g; a.planar = 0;
+  if (j->fft_on) { a.e = porg(j, j->e); a.u = porg(j, j->u); a.planar = 1; }
   RC(pr.begin(ICS_K_PSF_GRADIENT));
-  if (ics_big_supported(j->g.K)) HIPCHK(ics_launch_gradk_big(a, j->gradk_blocks, j->ctx->stream));
+  if (ics_big_supported(j->g.K) && !j->fft_on) HIPCHK(ics_launch_gradk_big(a, j->gradk_blocks, j->ctx->stream));
   else if (use_matrix_gradk(j, p)) HIPCHK(ics_launch_gradk_mfma(a, j->gradk_blocks, j->ctx->stream));
   else HIPCHK(ics_launch_gradk(a, j->gradk_blocks, j->ctx->stream));
   HIPCHK(ics_launch_gradk_reduce(j->partial, j->gradk_blocks, j->gradk, j->g, j->ctx->stream));
@@ -1002,7 +1096,7 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
 #endif
 // A11 + A13 in one kernel where it exists (matrix-core path, MK <= 15): ics_synth_gradk_mfma.hip
 static bool use_fused_gradk(const ics_rl* j, const ics_rl_params* p) {
-  if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return false;
+  if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv || j->fft_on) return false;
   if (p->flags & ICS_FLAG_NO_FUSED_GRADK) return false;
   return ics_debug().fused_gradk.load(std::memory_order_relaxed) != 0 && use_matrix_conv(j, p) && use_matrix_gradk(j, p);
 }
@@ -1054,6 +1148,11 @@ static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr, int rearm = 0, 
     HIPCHK(hipMemcpyAsync(j->scal + ICS_SC_MR, nan3, sizeof nan3, hipMemcpyHostToDevice, j->ctx->stream));
     return ICS_OK;
   }
+  if (j->fft_on) {   // A18 / A19 read HWC frames: bring the window of e and u over from the mirrors (u-frame rows [top, bottom + 2 pad))
+    const int pad2 = 2 * j->g.pad;
+    HIPCHK(ics_launch_planar_convert(false, pl_of(j, j->e), j->e, j->g, false, p->top, p->bottom + pad2, p->left, p->right + pad2, st));
+    HIPCHK(ics_launch_planar_convert(false, pl_of(j, j->u), j->u, j->g, false, p->top, p->bottom + pad2, p->left, p->right + pad2, st));
+  }
   IcsStatsArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = dof_of(j); a.dacc = j->dacc; a.ukey = j->ukey;
   a.z = j->z; a.tw = j->tw; a.weights = j->weights;
@@ -1082,7 +1181,9 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->tv_mode < ICS_TV_SHIPPED || p->tv_mode > ICS_TV_PAM_COLLAB)
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
-  if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_MATRIX) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
+  if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_FFT) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
+  if (p->conv == ICS_CONV_FFT && (!ics_conv_fft_supported(j->g.K) || p->tv_mode != ICS_TV_SHIPPED || p->fuse))
+    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 65 and the shipped loop (tv_mode 0, fuse 0)");
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && !j->blk_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX: no matrix-core path for this PSF size");
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && p->tv_mode != ICS_TV_SHIPPED)   // (the tap-block path has no TV epilogue; never run the fp32 kernels under an explicit MATRIX request)
     return fail(ICS_ENOSUP, "ICS_CONV_MATRIX with tv_mode %d: PSF sizes above 49 run on the matrix cores as tap blocks, which exist for the shipped loop only", p->tv_mode);
@@ -1101,7 +1202,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
 // with hipGraphLaunch.  Not with profiling (events between the kernels), not with the opt-in fused update + convolution (its own
 // ping-pong), not with an empty window (host-side NaN upload).  Default: frames up to 1.2 Mpx; debug switch `graph` = 0 / 1 forces.
 static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
-  if (p->profile || p->fuse || j->win_empty) return false;
+  if (p->profile || p->fuse || j->win_empty || use_fft_pipeline(j, p, true)) return false;
   const int g = ics_debug().graph.load(std::memory_order_relaxed);
   if (g >= 0) return g != 0;
   return (long)j->g.uM * j->g.uN <= 1200000L;
@@ -1145,8 +1246,11 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
   RC(check_params(j, p));
   memset(r, 0, sizeof *r);
   r->struct_size = sizeof(ics_rl_route);
-  const bool blocks = use_block_conv(j, p, 0), matrix = !blocks && use_matrix_conv(j, p);
-  r->conv_family = blocks ? 2 : (matrix ? 1 : (use_big_conv(j, p, 0) ? 4 : 3));
+  const bool fft = use_fft_pipeline(j, p, true);
+  struct Flag { ics_rl* j; bool was; ~Flag() { j->fft_on = was; } } flag{j, j->fft_on};   // (the gradient's predicates read it)
+  j->fft_on = fft;
+  const bool blocks = !fft && use_block_conv(j, p, 0), matrix = !fft && !blocks && use_matrix_conv(j, p);
+  r->conv_family = fft ? 5 : (blocks ? 2 : (matrix ? 1 : (use_big_conv(j, p, 0) ? 4 : 3)));
   r->conv_fp16_split = blocks || matrix;
   if (p->blind) {
     const bool fused = !p->fuse && use_fused_gradk(j, p);
@@ -1185,6 +1289,16 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   RC(ensure_window(j, p));
   const bool tv = p->tv_mode != ICS_TV_SHIPPED;
   if (tv) RC(ensure_tv(j));
+  // whatever path leaves this function: the statistics' stream is drained before the caller can release or reuse the job's buffers (an
+  // error return inside the overlapped loop used to skip the drain), and the FFT pipeline's flag is cleared
+  struct Drain { ics_ctx* c; ~Drain() { if (c->stream2) (void)hipStreamSynchronize(c->stream2); } } drain{j->ctx};
+  FftScope fft_scope{j};
+  if (use_fft_pipeline(j, p, true)) {   // the frames live as channel-planar mirrors for the duration of the run (ics_planar.hip)
+    j->fft_on = true;
+    RC(ensure_planar(j));
+    RC(to_planar(j, j->u, s));
+    if (!j->plf_valid) { RC(to_planar(j, j->f, s)); j->plf_valid = true; }
+  }
   {  // everything but the caller's in-fields is overwritten
     ics_rl_stats in = *st;
     memset(st, 0, sizeof *st);
@@ -1317,6 +1431,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     if (!j->ev_body[0])
       for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&j->ev_body[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&j->ev_stats[i], hipEventDisableTiming)); }
     if (!j->e2) RC(dalloc(c, &j->e2, j->frame_floats));
+    if (j->fft_on) RC(ensure_planar(j));                     // (a mirror for e2 as well)
     const size_t npsf = (size_t)3 * j->g.K * j->g.K;
     if (p->blind && !j->psf_bak) RC(dalloc(c, &j->psf_bak, 2 * npsf, false));
     const hipStream_t st2 = ovl == 1 ? c->stream2 : s;      // where the statistics run
@@ -1406,6 +1521,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     RC(pr.collect(ms, launches));
     consume(j->h_scal);
   }
+  if (j->fft_on) { RC(from_planar(j, j->u, s)); RC(from_planar(j, j->e, s)); }   // the HWC frames are the job's state between calls
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));
   int hflags[4] = {0, 0, 0, 0};
@@ -1430,6 +1546,21 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   hipStream_t s = j->ctx->stream;
   Prof pr{j, false};
   HIPCHK(hipMemsetAsync(j->sched, 0, 16 * sizeof(uint32_t), s));
+  // conv = ICS_CONV_FFT through the stage API (tests): the stage runs on the mirrors, every frame is copied over before and the frames a
+  // stage writes are copied back after -- slow and simple; ics_rl_run converts at its boundaries only
+  FftScope fft_scope{j};
+  const bool fft_stage = use_fft_pipeline(j, p, false) && (stage == ICS_STAGE_SYNTH_RESIDUAL || stage == ICS_STAGE_BACKPROJECT || stage == ICS_STAGE_UPDATE ||
+                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE);
+  if (fft_stage) {
+    j->fft_on = true;
+    RC(ensure_planar(j));
+    for (float* h : {j->u, j->ut, j->gr, j->f, j->e}) RC(to_planar(j, h, s));
+    j->plf_valid = true;
+  }
+  struct StageBack {   // (runs before fft_scope clears the flag: declared after it)
+    ics_rl* j; bool on; hipStream_t s;
+    ~StageBack() { if (on) { for (float* h : {j->u, j->gr, j->e}) (void)from_planar(j, h, s); (void)hipStreamSynchronize(s); } }
+  } stage_back{j, fft_stage, s};
   switch (stage) {
     case ICS_STAGE_SYNTH_RESIDUAL:
       RC(pack_weights(j, 0, 0.f, 0, s));

@@ -55,6 +55,14 @@ static inline IcsGeom ics_make_geom(int M, int N, int K) {
   return g;
 }
 static inline size_t ics_frame_floats(const IcsGeom& g) { return (size_t)g.rows * g.pitch; }
+// Channel-planar mirror of a frame (operands of the FFT convolutions, ics_conv_fft.hip): three planes of g.rows rows, one float per pixel,
+// same aprons and tile slack as the HWC frame; plane row = the HWC row's pixel count rounded up to 64 floats (never more than a third of the
+// HWC pitch rounded up: a planar mirror fits the HWC frame's allocation + 3 * 64 * rows floats).  Pixel (y, x, c) of the u-frame sits at
+// plane_origin + c * plane_floats + y * ppitch + x.
+__host__ __device__ static inline int ics_ppitch(const IcsGeom& g) { return (g.ax + g.tiles_x * ICS_TILE + g.ax + 63) / 64 * 64; }
+__host__ __device__ static inline size_t ics_plane_floats(const IcsGeom& g) { return (size_t)g.rows * ics_ppitch(g); }
+__host__ __device__ static inline size_t ics_planar_floats(const IcsGeom& g) { return 3 * ics_plane_floats(g); }
+__host__ __device__ static inline size_t ics_planar_origin(const IcsGeom& g) { return (size_t)g.ay * ics_ppitch(g) + g.ax; }
 static inline size_t ics_origin_offset(const IcsGeom& g) { return (size_t)g.ay * g.pitch + 3 * (size_t)g.ax; }
 
 // ---- per-device launcher state ----------------------------------------------------------------------------------------
@@ -93,7 +101,7 @@ struct IcsDebug {
   std::atomic<int> dynamic_tiles;     // ICS_DYNAMIC_TILES     -1 launcher decides, 0 static walk, 1 dynamic tile claiming
   std::atomic<int> conv_rs;           // ICS_TEST_CONV_RS      0 launcher decides, 2 / 4 = force 32- / 64-row tiles where both are built
   std::atomic<int> conv_nh;           // ICS_TEST_CONV_NH      harness builds only: 1 = 4-wave form of the K >= 23 kernels
-  std::atomic<int> conv_path;         // ICS_CONV_PATH         what ICS_CONV_AUTO resolves to: 0 default, 1 vector, 2 matrix
+  std::atomic<int> conv_path;         // ICS_CONV_PATH         what ICS_CONV_AUTO resolves to: 0 default, 1 vector, 2 matrix, 3 fft (transform tiles, ics_conv_fft.hip)
   std::atomic<int> fused_gradk;       // ICS_FUSED_GRADK       0 = two-kernel A11 + A13 (like ICS_FLAG_NO_FUSED_GRADK)
   std::atomic<int> update_wg_per_cu;  // ICS_UPDATE_WG_PER_CU  0 launcher decides
   std::atomic<int> update_kernel;     // ICS_UPDATE_KERNEL     0 = the pixel-group kernel everywhere
@@ -111,7 +119,7 @@ struct IcsDebug {
     conv_rs = env_int("ICS_TEST_CONV_RS", 0);
     conv_nh = env_int("ICS_TEST_CONV_NH", 0);
     const char* cp = getenv("ICS_CONV_PATH");
-    conv_path = !cp ? 0 : (cp[0] == 'v' ? 1 : (cp[0] == 'm' ? 2 : 0));
+    conv_path = !cp ? 0 : (cp[0] == 'v' ? 1 : (cp[0] == 'm' ? 2 : (cp[0] == 'f' ? 3 : 0)));
     fused_gradk = env_int("ICS_FUSED_GRADK", 1);
     update_wg_per_cu = env_int("ICS_UPDATE_WG_PER_CU", 0);
     update_kernel = env_int("ICS_UPDATE_KERNEL", 1);

@@ -69,6 +69,9 @@ namespace icsfft {
 // buffer (origin offset added: the apron in front of the origin has negative coordinates).  The host pass (CPU emulation) indexes pointers.
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t gbuf;
+// (index -1 = "no access": the byte offset 0xFFFFFFFC lies beyond num_records, the hardware returns 0 for the load and drops the store --
+//  every access is issued unconditionally, so the number of memory operations in flight is static and the compiler's s_waitcnt vmcnt(n)
+//  for the register prefetch of the next unit does not degrade to vmcnt(0) behind the epilogue's stores)
 __device__ __forceinline__ gbuf make_gbuf(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); }
 __device__ __forceinline__ float ld_f32(gbuf b, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * i, 0, 0)); }
 __device__ __forceinline__ void st_f32(gbuf b, int i, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * i, 0, 0); }
@@ -76,18 +79,23 @@ __device__ __forceinline__ v2f ld_v2f(gbuf b, int i) { return __builtin_bit_cast
 #else
 typedef const void* gbuf;
 static inline gbuf make_gbuf(const void* p) { return p; }
-static inline float ld_f32(gbuf b, int i) { return static_cast<const float*>(b)[i]; }
-static inline void st_f32(gbuf b, int i, float v) { const_cast<float*>(static_cast<const float*>(b))[i] = v; }
+static inline float ld_f32(gbuf b, int i) { return i < 0 ? 0.f : static_cast<const float*>(b)[i]; }
+static inline void st_f32(gbuf b, int i, float v) { if (i >= 0) const_cast<float*>(static_cast<const float*>(b))[i] = v; }
 static inline v2f ld_v2f(gbuf b, int i) { return static_cast<const v2f*>(b)[i]; }
 #endif
+// where pixel (Y, X, c) of a frame lives: index = org + Y * pitch + X * xmul + c * cmul  (HWC: xmul 3, cmul 1; planar mirror: xmul 1, cmul plane)
+struct Lay { int org, pitch, xmul, cmul; };
 struct Mem {
   gbuf in, out, f, u, ut, tv, spec;
-  int org;   // floats from the start of a frame buffer to its origin
+  Lay lin, lout, lf, lu, lut, ltv;
 };
 
 // exp(-2 pi i t / 128): device copy (scalar / vector loads through the caches) and host copy (CPU emulation in tools/bench_conv_fft.hip)
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __constant__ const float d_tw128[128][2] = {ICS_TW128_VALUES};
+#else
 static const float h_tw128[128][2] = {ICS_TW128_VALUES};
+#endif
 
 ICS_FFT_HD v2f tw128(int t) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -168,6 +176,9 @@ struct IcsFftArgs {
   int V;                // valid output pixels per tile edge = 128 - K + 1
   int tiles_x, ntiles, nunits;
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
+  int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
+  int ablate;               // harness only: 1 window loads, 2 operand loads, 4 stores, 8 spectrum loads become dropped accesses (index -1)
+  long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][10] shader-clock stamps of wave 0, else unused
 };
 
 namespace icsfft {
@@ -192,11 +203,22 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
   return u;
 }
 
-ICS_FFT_HD Mem make_mem(const IcsFftArgs& a) {
+ICS_FFT_HD Lay make_lay(const IcsGeom& g, bool planar) {
+  Lay l;
+  if (planar) { l.pitch = ics_ppitch(g); l.org = g.ay * l.pitch + g.ax; l.xmul = 1; l.cmul = g.rows * l.pitch; }
+  else { l.pitch = g.pitch; l.org = g.ay * g.pitch + 3 * g.ax; l.xmul = 3; l.cmul = 1; }
+  return l;
+}
+// (mode = 0 / 1: only the frames that mode touches get a resource of their own -- scalar registers are short in this kernel; -1: all)
+ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   Mem m;
-  m.org = a.c.g.ay * a.c.g.pitch + 3 * a.c.g.ax;   // ics_origin_offset()
-  m.in = make_gbuf(a.c.in - m.org); m.out = make_gbuf(a.c.out - m.org); m.f = make_gbuf(a.c.f - m.org);
-  m.u = make_gbuf(a.c.u - m.org); m.ut = make_gbuf(a.c.ut - m.org); m.tv = make_gbuf(a.c.tv ? a.c.tv - m.org : a.c.u - m.org);
+  const IcsGeom& g = a.c.g;
+  m.lin = make_lay(g, a.planar & ICS_FFT_PL_IN); m.lout = make_lay(g, a.planar & ICS_FFT_PL_OUT); m.lf = make_lay(g, a.planar & ICS_FFT_PL_F);
+  m.lu = make_lay(g, a.planar & ICS_FFT_PL_U); m.lut = make_lay(g, a.planar & ICS_FFT_PL_UT); m.ltv = make_lay(g, a.planar & ICS_FFT_PL_TV);
+  m.in = make_gbuf(a.c.in - m.lin.org); m.out = make_gbuf(a.c.out - m.lout.org);
+  m.f = mode == 1 ? m.in : make_gbuf(a.c.f - m.lf.org);
+  m.u = mode == 0 ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
+  m.tv = (a.c.tv && mode != 0) ? make_gbuf(a.c.tv - m.ltv.org) : m.in;
   m.spec = make_gbuf(a.spec);
   return m;
 }
@@ -205,26 +227,29 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a) {
 // row-owner mapping (stages C, D, E): wave w -> rows 8 w + (lane >> 3), selector lane & 7
 #define ICS_FFT_AT(row, col) lds[(row) * ICS_FFT_PITCH + (col)]
 
-// A: the window's column x, rows j + 8 m of both tiles -> radix-16 over m -> twiddle -> rows 16 j + k1
-// (loads from clamped addresses, values selected: no divergent or conditional loads; offsets are 32-bit -- frames stay below 2 GiB)
-ICS_FFT_HD void stage_a(const IcsFftArgs& a, const Mem& mem, const Unit& u, v2f* lds, int tid) {
+// A, first half: the loads of a unit's window -- column x, rows j + 8 m of both tiles (0 outside the frame's value range or beyond the last unit)
+ICS_FFT_HD void load_a(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, float (&p)[2][16]) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const int pad = a.c.g.pad, pitch = a.c.g.pitch, ylast = a.c.g.uM + pad - 1;
-  v2f v[16];
+  const int pad = a.c.g.pad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int X = u.ox[t] - pad + x;
     const bool xin = u.has[t] && X < a.c.g.uN + pad;         // (X >= -pad by construction)
-    const int xo = mem.org + 3 * (xin ? X : 0) + u.c;
+    const int xo = mem.lin.org + mem.lin.xmul * X + mem.lin.cmul * u.c;
     const int Y0 = u.oy[t] - pad + j;                        // >= -pad by construction
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int Y = Y0 + 8 * m;
-      const float val = ld_f32(mem.in, (Y < ylast ? Y : ylast) * pitch + xo);
-      const float sel = (xin && Y <= ylast) ? val : 0.f;
-      if (t == 0) v[m].x = sel; else v[m].y = sel;
+      p[t][m] = ld_f32(mem.in, (xin && Y <= ylast && !(a.ablate & 1)) ? Y * pitch + xo : -1);
     }
   }
+}
+// A, second half: radix-16 over m -> twiddle -> rows 16 j + k1
+ICS_FFT_HD void stage_a(const float (&p)[2][16], v2f* lds, int tid) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
+  v2f v[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) v[m] = (v2f){p[0][m], p[1][m]};
   fft16<1>(v);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) {
@@ -273,14 +298,14 @@ ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
 }
 
 // D: radix-8 over j -> kx = k1 + 16 k2, multiply by the spectrum, inverse radix-8 over k2 -> j, same slots
-ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid) {
+ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid, int ablate = 0) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), q = lane & 7;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int k1 = q + 8 * s;
     v2f v[8], sp[8];
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sp[k2] = ld_v2f(mem.spec, (c * ICS_FFT_P + ky) * ICS_FFT_P + k1 + 16 * k2);
+    for (int k2 = 0; k2 < 8; ++k2) sp[k2] = ld_v2f(mem.spec, (ablate & 8) ? -1 : (c * ICS_FFT_P + ky) * ICS_FFT_P + k1 + 16 * k2);
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = ICS_FFT_AT(ky, skew_col(j, k1));
     fft8<1>(v);
@@ -320,56 +345,60 @@ ICS_FFT_HD void stage_g(const v2f* lds, int tid, v2f (&v)[16]) {
 // canonical positive NaN so that a NaN propagates through the integer max like np.amax does (ics_conv.hip)
 ICS_FFT_HD uint32_t key_of(float f) { return (f != f) ? 0xFFC00000u : ics_f2key(f); }
 
-// G, second half: the epilogue of ics_conv.hip on the thread's 16 + 16 values (rows j + 8 m of column x; j is wave-uniform, so the
-// row count is a scalar).  Accumulates the thread's maxima (mode 1).
-template <int MODE>
-ICS_FFT_HD void epilogue(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, const v2f (&v)[16], float& mg, float& mu, bool& nan_g, bool& nan_u, bool& any) {
+// G, second half: the epilogue of ics_conv.hip on the thread's 16 + 16 values (rows j + 8 m of column x), in eight chunks k = 4 t + h
+// (tile t, rows m = 4 h .. 4 h + 3): the operands of chunk k + 1 are requested before chunk k is finished, those of chunk 0 before stage F.
+#define ICS_FFT_CH 4
+struct Ops { float a[ICS_FFT_CH], b[ICS_FFT_CH], tv[ICS_FFT_CH]; };   // mode 0: a = image; mode 1: a = u, b = ut, tv = T frame (TV kinds)
+struct Maxima { float mg, mu; bool nan_g, nan_u, any; };
+
+ICS_FFT_HD int epi_index(const IcsFftArgs& a, const Unit& u, const Lay& L, int tid, int k, int i) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const int pitch = a.c.g.pitch, c = u.c, dstep = 8 * pitch;
+  const int t = k >> 2, m = ICS_FFT_CH * (k & 3) + i, y = j + 8 * m;
+  const int X = u.ox[t] + x, Y = u.oy[t] + y;
+  const bool ok = u.has[t] && x < a.V && X < a.ox1 && y < a.V && Y < a.oy1;
+  return ok ? L.org + Y * L.pitch + X * L.xmul + u.c * L.cmul : -1;
+}
+
+template <int MODE, bool TV>
+ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, Ops& o) {
+#pragma unroll
+  for (int i = 0; i < ICS_FFT_CH; ++i) {
+    const bool ab = a.ablate & 2;
+    if (MODE == 0) o.a[i] = ld_f32(mem.f, ab ? -1 : epi_index(a, u, mem.lf, tid, k, i));
+    else {
+      o.a[i] = ld_f32(mem.u, ab ? -1 : epi_index(a, u, mem.lu, tid, k, i));
+      o.b[i] = ld_f32(mem.ut, ab ? -1 : epi_index(a, u, mem.lut, tid, k, i));
+      if (TV) o.tv[i] = ld_f32(mem.tv, ab ? -1 : epi_index(a, u, mem.ltv, tid, k, i));
+    }
+  }
+}
+
+template <int MODE, bool TV>
+ICS_FFT_HD void finish_chunk(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, const v2f (&v)[16], const Ops& o, Maxima& mx) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
+  const int t = k >> 2;
   const float lambd = a.c.lambd;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int X = u.ox[t] + x;
-    const bool xok = u.has[t] && x < a.V && X < a.ox1;
-    const int rows = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;   // output rows of this tile
-    const int mcount = (rows - j + 7) >> 3;                            // of them, this wave's: y = j + 8 m < rows
-    if (!xok || mcount <= 0) continue;
-    const int o0 = mem.org + (u.oy[t] + j) * pitch + 3 * X + c;
-    if (MODE == 0) {
-      float f[16];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) if (m < mcount) f[m] = ld_f32(mem.f, o0 + m * dstep);
-#pragma unroll
-      for (int m = 0; m < 16; ++m) if (m < mcount) st_f32(mem.out, o0 + m * dstep, ICS_FSUB(t ? v[m].y : v[m].x, f[m]));
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float uu[8], tt[8], tv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int m = 8 * h + i;
-          if (m < mcount) { uu[i] = ld_f32(mem.u, o0 + m * dstep); tt[i] = ld_f32(mem.ut, o0 + m * dstep); tv[i] = a.c.tv_kind ? ld_f32(mem.tv, o0 + m * dstep) : 0.f; }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int m = 8 * h + i;
-          if (m < mcount) {
-            const int Y = u.oy[t] + j + 8 * m;
-            const float r = t ? v[m].y : v[m].x;
-            float g, st = r;
-            if (a.c.tv_kind >= 2) { g = (float)((double)tv[i] + (double)ICS_FMUL(lambd, r)); st = g; }          // PAM: G = T + lambd*gradu, stored
-            else if (a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)             // active MM-TV, pyx:517
-              g = (float)(((double)tv[i] + (double)ICS_FMUL(lambd, r)) + (double)ICS_FSUB(uu[i], tt[i]) / 4.0);
-            else
-              g = ICS_FADD(ICS_FMUL(lambd, r), ICS_FMUL(ICS_FSUB(uu[i], tt[i]), 0.5f));                           // pyx:519
-            mg = __builtin_fmaxf(mg, __builtin_fabsf(g));
-            mu = __builtin_fmaxf(mu, uu[i]);
-            nan_g |= (g != g); nan_u |= (uu[i] != uu[i]);
-            any = true;
-            st_f32(mem.out, o0 + m * dstep, st);
-          }
-        }
+  for (int i = 0; i < ICS_FFT_CH; ++i) {
+    const int m = ICS_FFT_CH * (k & 3) + i;
+    const int idx = (a.ablate & 4) ? -1 : epi_index(a, u, mem.lout, tid, k, i);
+    const float r = t ? v[m].y : v[m].x;
+    if (MODE == 0) st_f32(mem.out, idx, ICS_FSUB(r, o.a[i]));
+    else {
+      const int Y = u.oy[t] + j + 8 * m, X = u.ox[t] + x;
+      float g, st = r;
+      if (TV && a.c.tv_kind >= 2) { g = (float)((double)o.tv[i] + (double)ICS_FMUL(lambd, r)); st = g; }            // PAM: G = T + lambd*gradu, stored
+      else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)                // active MM-TV, pyx:517
+        g = (float)(((double)o.tv[i] + (double)ICS_FMUL(lambd, r)) + (double)ICS_FSUB(o.a[i], o.b[i]) / 4.0);
+      else
+        g = ICS_FADD(ICS_FMUL(lambd, r), ICS_FMUL(ICS_FSUB(o.a[i], o.b[i]), 0.5f));                            // pyx:519
+      if (idx >= 0) {
+        mx.mg = __builtin_fmaxf(mx.mg, __builtin_fabsf(g));
+        mx.mu = __builtin_fmaxf(mx.mu, o.a[i]);
+        mx.nan_g |= (g != g); mx.nan_u |= (o.a[i] != o.a[i]);
+        mx.any = true;
       }
+      st_f32(mem.out, idx, st);
     }
   }
 }
@@ -387,47 +416,90 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// a copy of `x` the optimiser cannot trace back: lane constants derived from it (LDS addresses, frame offsets) are recomputed in the stage that
+// uses them instead of being hoisted out of the unit loop and kept alive -- and spilled -- across it (as in ics_conv_mfma.hip)
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+
 // workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also waits for the global loads and stores in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MODE>
+template <int MODE, bool TV>
 __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   extern __shared__ __attribute__((aligned(16))) v2f lds[];
   v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
   const int tid = threadIdx.x;
   const int G = gridDim.x;
   if (tid < 128) twl[tid] = tw128(tid);
-  const Mem mem = make_mem(a);
+  const Mem mem = make_mem(a, MODE);
   // workgroup b runs on XCD b % 8 (observed dispatch): consecutive unit slots q go to one XCD, so the three channel units of a tile pair
   // (n = 3 pair + c) share that XCD's L2.  Affects speed only.
   const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+#ifdef ICS_FFT_TRACE
+  int round = 0;
+#define ICS_FFT_STAMP(i) do { if (tid == 0 && round < 16 && a.trace) a.trace[((size_t)blockIdx.x * 16 + round) * 10 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ICS_FFT_STAMP(i) do { } while (0)
+#endif
+  uint32_t accg[3] = {0u, 0u, 0u}, accu[3] = {0u, 0u, 0u};   // the workgroup's maxima as order-preserving keys (0 = nothing seen, NaN = largest)
+  float pa[2][16];                        // the window of the unit about to start, requested one unit ahead
+  load_a(a, mem, decode_unit(a, q), opaque(tid), pa);
   for (int n = q; n < a.nunits; n += G) {
     const Unit u = decode_unit(a, n);
-    stage_a(a, mem, u, lds, tid);
+    ICS_FFT_STAMP(0);
+    stage_a(pa, lds, opaque(tid));
+    load_a(a, mem, decode_unit(a, n + G), opaque(tid), pa);   // (beyond the last unit: no tile, every access a dropped one)
+    ICS_FFT_STAMP(1);
     lds_barrier();
-    stage_b<1>(lds, tid);
+    ICS_FFT_STAMP(2);
+    stage_b<1>(lds, opaque(tid));
     lds_barrier();
-    stage_c(lds, lds, twl, tid);
+    ICS_FFT_STAMP(3);
+    stage_c(lds, lds, twl, opaque(tid));
     wave_sync();
-    stage_d(mem, u.c, lds, tid);
+    ICS_FFT_STAMP(4);
+    stage_d(mem, u.c, lds, opaque(tid), a.ablate);
     wave_sync();
-    stage_e(lds, lds, twl, tid);
+    ICS_FFT_STAMP(5);
+    stage_e(lds, lds, twl, opaque(tid));
+    Ops o0, o1;
+    load_ops<MODE, TV>(a, mem, u, opaque(tid), 0, o0);
     lds_barrier();
-    stage_b<-1>(lds, tid);
+    ICS_FFT_STAMP(6);
+    stage_b<-1>(lds, opaque(tid));
     lds_barrier();
+    ICS_FFT_STAMP(7);
     v2f v[16];
-    stage_g(lds, tid, v);
-    float mg = 0.f, mu = -__builtin_inff();
-    bool nan_g = false, nan_u = false, any = false;
-    epilogue<MODE>(a, mem, u, tid, v, mg, mu, nan_g, nan_u, any);
-    if (MODE == 1) {
-      // wave maxima -> one conditional atomic per wave and value (the running maximum only grows: a stale read lets most skip the atomic)
-      uint32_t kg = nan_g ? 0xFFC00000u : (any ? ics_f2key(mg) : 0u);
-      uint32_t ku = nan_u ? 0xFFC00000u : (any ? ics_f2key(mu) : 0u);
-      kg = ics_wave_max_u32(kg); ku = ics_wave_max_u32(ku);
+    stage_g(lds, opaque(tid), v);
+    ICS_FFT_STAMP(8);
+    Maxima mx; mx.mg = 0.f; mx.mu = -__builtin_inff(); mx.nan_g = mx.nan_u = mx.any = false;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      load_ops<MODE, TV>(a, mem, u, opaque(tid), k + 1, o1);
+      finish_chunk<MODE, TV>(a, mem, u, opaque(tid), k, v, o0, mx);
+      if (k + 2 < 8) load_ops<MODE, TV>(a, mem, u, opaque(tid), k + 2, o0);
+      finish_chunk<MODE, TV>(a, mem, u, opaque(tid), k + 1, v, o1, mx);
+    }
+    ICS_FFT_STAMP(9);
+#ifdef ICS_FFT_TRACE
+    ++round;
+#endif
+    if (MODE == 1) {   // (u.c is uniform)
+      const uint32_t kg = mx.nan_g ? 0xFFC00000u : (mx.any ? ics_f2key(mx.mg) : 0u);   // NaN propagates like np.amax
+      const uint32_t ku = mx.nan_u ? 0xFFC00000u : (mx.any ? ics_f2key(mx.mu) : 0u);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (u.c == c) { accg[c] = accg[c] > kg ? accg[c] : kg; accu[c] = accu[c] > ku ? accu[c] : ku; }
+    }
+  }
+  if (MODE == 1) {
+    // the workgroup's maxima: wave maxima -> one conditional atomic per wave, channel and value at the END of the kernel (inside the loop
+    // the read of the running maximum waited for every store in flight)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t kg = ics_wave_max_u32(accg[c]), ku = ics_wave_max_u32(accu[c]);
       if ((tid & 63) == 0) {
-        if (kg > a.c.red[ICS_RED_MAXG + u.c]) atomicMax(a.c.red + ICS_RED_MAXG + u.c, kg);
-        if (ku > a.c.red[ICS_RED_MAXU + u.c]) atomicMax(a.c.red + ICS_RED_MAXU + u.c, ku);
+        if (kg > a.c.red[ICS_RED_MAXG + c]) atomicMax(a.c.red + ICS_RED_MAXG + c, kg);
+        if (ku > a.c.red[ICS_RED_MAXU + c]) atomicMax(a.c.red + ICS_RED_MAXU + c, ku);
       }
     }
   }
@@ -489,6 +561,9 @@ hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, fl
 
 void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, IcsFftArgs* a) {
   a->c = c;
+  a->trace = nullptr;
+  a->planar = 0;
+  a->ablate = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->V = ICS_FFT_P - g.K + 1;
@@ -500,22 +575,29 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->nunits = 3 * ((a->ntiles + 1) / 2);
 }
 
-hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, hipStream_t s) {
+hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s);
+hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, int planar, hipStream_t s) {
   if (mode != 0 && mode != 1) return hipErrorInvalidValue;
   IcsFftArgs a;
   ics_conv_fft_fill_args(mode, c, spec, &a);
-  static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
+  a.planar = planar;
+  return ics_launch_conv_fft_args(mode, a, s);
+}
+hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s) {
+  static std::atomic<bool> configured[3][ICS_MAX_DEVICES];
   const int dev = ics_current_device();
   int grid = ics_device_cus(dev);
   if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
   if (grid > a.nunits) grid = a.nunits;
-  if (mode == 0) {
-    if (hipError_t e = ics_configure_lds(configured[0], dev, icsfft::k_conv_fft<0>, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(icsfft::k_conv_fft<0>, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
-  } else {
-    if (hipError_t e = ics_configure_lds(configured[1], dev, icsfft::k_conv_fft<1>, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL(icsfft::k_conv_fft<1>, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
-  }
+  // (the epilogue carries the TV kinds of ics_conv.hip behind a template flag; the library routes only the shipped loop here and does not
+  //  instantiate that form: with the T operand the kernel does not fit 128 registers)
+  if (a.c.tv && a.c.tv_kind) return hipErrorInvalidValue;
+  auto k0 = icsfft::k_conv_fft<0, false>;
+  auto k1 = icsfft::k_conv_fft<1, false>;
+  auto kern = mode == 0 ? k0 : k1;
+  const int slot = mode == 0 ? 0 : 1;
+  if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 #endif

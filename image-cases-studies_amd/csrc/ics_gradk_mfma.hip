@@ -156,37 +156,51 @@ __device__ __forceinline__ void split_store_interleaved(const f32x4u (&v)[3], fl
 // [x0 - 8 NB, x0 + 64 + 8 NB), one 4-pixel group (three dwordx4) per task
 // `t` is a column-major tile index (strip = t / nty, row block = t % nty).  carry: the first NT - 1 rows of the U block are
 // already in LDS (from the tile above): only rows NT - 1 .. UROWS - 1 are requested, as tasks 0 .. TH * UXG - 1.
-template <int NB>
+// PL (round 5): both frames are channel-planar mirrors (ics_common.h; the FFT-tile pipeline keeps u and e that way): a 4-pixel group is one
+// dwordx4 per plane, rearranged into the HWC order the split expects (register renaming)
+template <bool PL, int aux>
+__device__ __forceinline__ void load_group(f32x4u (&v)[3], __amdgpu_buffer_rsrc_t rs, int voff, int soff, int plane_bytes) {
+  if (!PL) {
+#pragma unroll
+    for (int h = 0; h < 3; ++h) v[h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * h, soff, aux));
+  } else {
+    f32x4u p[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff + c * plane_bytes, aux));
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i >> 2][i & 3] = p[i % 3][i / 3];   // HWC float i = pixel i / 3, channel i % 3
+  }
+}
+
+template <int NB, bool PL>
 __device__ __forceinline__ void load_tile(f32x4u (&pu)[GCfg<NB>::UIT][3], f32x4u (&pe)[GCfg<NB>::EIT][3], __amdgpu_buffer_rsrc_t rs_u,
                                           __amdgpu_buffer_rsrc_t rs_e, const IcsGeom& G, int nty, int t, bool carry, int tid) {
   using C = GCfg<NB>;
-  const int x0 = (t / nty) * C::TW, y0 = (t % nty) * C::TH, pitch = G.pitch;
+  const int x0 = (t / nty) * C::TW, y0 = (t % nty) * C::TH, pitch = PL ? ics_ppitch(G) : G.pitch;
+  constexpr int XM = PL ? 1 : 3;                       // floats per pixel step
+  const int plane_bytes = PL ? 4 * G.rows * pitch : 0;
   const int r0 = carry ? C::NT - 1 : 0;
   const int ntask = (C::UROWS - r0) * C::UXG;
-  const int su = 4 * ((G.ay + y0 + G.pad - (C::NT - 1) + r0) * pitch + 3 * (G.ax + x0));
+  const int su = 4 * ((G.ay + y0 + G.pad - (C::NT - 1) + r0) * pitch + XM * (G.ax + x0));
 #pragma unroll
   for (int k = 0; k < C::UIT; ++k) {
     if (k * C::NTH >= ntask) break;                       // wave-uniform
     int v = tid + k * C::NTH; v = v < ntask ? v : ntask - 1;
     const int row = v / C::UXG, xg = v - row * C::UXG;
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-      pu[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_u, 4 * (row * pitch + 12 * xg) + 16 * h, su, ICS_GRADK_U_AUX));
+    load_group<PL, ICS_GRADK_U_AUX>(pu[k], rs_u, 4 * (row * pitch + 4 * XM * xg), su, plane_bytes);
   }
-  const int se = 4 * ((G.ay + y0) * pitch + 3 * (G.ax + x0 - 8 * NB));
+  const int se = 4 * ((G.ay + y0) * pitch + XM * (G.ax + x0 - 8 * NB));
 #pragma unroll
   for (int k = 0; k < C::EIT; ++k) {
     int v = tid + k * C::NTH; v = v < C::ETASK ? v : C::ETASK - 1;
     const int row = v / C::EXG, xg = v - row * C::EXG;
-#pragma unroll
-    for (int h = 0; h < 3; ++h)
-      pe[k][h] = __builtin_bit_cast(f32x4u, __builtin_amdgcn_raw_buffer_load_b128(rs_e, 4 * (row * pitch + 12 * xg) + 16 * h, se, ICS_GRADK_E_AUX));
+    load_group<PL, ICS_GRADK_E_AUX>(pe[k], rs_e, 4 * (row * pitch + 4 * XM * xg), se, plane_bytes);
   }
 }
 
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 
-template <int NB>
+template <int NB, bool PL>
 __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gradk_mfma(IcsGradkArgs a) {
   using C = GCfg<NB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
   const int ntiles = ntx * nty;
 
   // frames addressed from their allocation start (offsets are then non-negative)
-  const ptrdiff_t org = (ptrdiff_t)G.ay * pitch + 3 * G.ax;
+  const ptrdiff_t org = PL ? (ptrdiff_t)G.ay * ics_ppitch(G) + G.ax : (ptrdiff_t)G.ay * pitch + 3 * G.ax;
   const __amdgpu_buffer_rsrc_t rs_u = make_rsrc(a.u - org), rs_e = make_rsrc(a.e - org);
 
   // lane constants of the B operand: for tap block jb this lane's 8 halves start at half bo of the row segment that
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
   // this workgroup's run of tiles, column-major: [t0, t1)
   const int t0 = (int)((long)ntiles * blockIdx.x / gridDim.x), t1 = (int)((long)ntiles * (blockIdx.x + 1) / gridDim.x);
   f32x4u pu[C::UIT][3], pe[C::EIT][3];
-  if (t0 < t1) load_tile<NB>(pu, pe, rs_u, rs_e, G, nty, t0, false, tid);
+  if (t0 < t1) load_tile<NB, PL>(pu, pe, rs_u, rs_e, G, nty, t0, false, tid);
   float mu_prev = 0.f, mc_last = 0.f, s_prev = 1.f;
 #pragma unroll 1
   for (int t = t0; t < t1; ++t) {
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
     __syncthreads();
 
     // next tile's rows: in flight during the whole MFMA phase (which issues no vector-memory load)
-    if (t + 1 < t1) load_tile<NB>(pu, pe, rs_u, rs_e, G, nty, t + 1, ((t + 1) % nty) != 0, opaque(tid));
+    if (t + 1 < t1) load_tile<NB, PL>(pu, pe, rs_u, rs_e, G, nty, t + 1, ((t + 1) % nty) != 0, opaque(tid));
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- MFMA phase: wave w owns TH/4 consecutive residual rows ------------------------------------------------
@@ -480,12 +494,12 @@ __global__ __launch_bounds__(GCfg<NB>::NTH) __attribute__((amdgpu_waves_per_eu(2
   }
 }
 
-template <int NB>
+template <int NB, bool PL>
 hipError_t launch_nb(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
   using C = GCfg<NB>;
   static std::atomic<bool> configured[ICS_MAX_DEVICES];
   const int dev = ics_current_device();
-  auto kern = k_gradk_mfma<NB>;
+  auto kern = k_gradk_mfma<NB, PL>;
   if (hipError_t e = ics_configure_lds(configured, dev, kern, C::LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(nblocks), dim3(C::NTH), C::LDS_BYTES, s, a);
   return hipGetLastError();
@@ -496,5 +510,6 @@ hipError_t launch_nb(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
 bool ics_gradk_mfma_supported(int K) { return K >= 3 && K <= 31 && (K & 1); }
 
 hipError_t ics_launch_gradk_mfma(const IcsGradkArgs& a, int nblocks, hipStream_t s) {
-  return a.geo.K <= 15 ? launch_nb<1>(a, nblocks, s) : launch_nb<2>(a, nblocks, s);
+  if (a.planar) return a.geo.K <= 15 ? launch_nb<1, true>(a, nblocks, s) : launch_nb<2, true>(a, nblocks, s);
+  return a.geo.K <= 15 ? launch_nb<1, false>(a, nblocks, s) : launch_nb<2, false>(a, nblocks, s);
 }

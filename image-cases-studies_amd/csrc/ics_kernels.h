@@ -41,6 +41,7 @@ struct IcsGradkArgs {
   const float* u;   // u frame origin
   float* partial;   // [nblocks][3][16nb][16nb] per-workgroup partial sums
   IcsGeom geo;
+  int planar;       // matrix-core kernel only: e and u are ORIGINS of channel-planar mirrors (ics_common.h, the FFT-tile pipeline)
 };
 int ics_gradk_blocks(const IcsGeom& g, int cus);  // grid size (persistent workgroups)
 hipError_t ics_launch_gradk(const IcsGradkArgs& a, int nblocks, hipStream_t s);
@@ -70,6 +71,23 @@ hipError_t ics_launch_gradk_reduce_block(const float* partial, int nblocks, floa
 // ---- row bands: see include/ics_hip.h ICS_STAGE_BAND_* ----------------------------------------------
 hipError_t ics_launch_band_reduce(const float* gr, const float* u, const float* ut, const IcsGeom& g, float lambd, int r0, int r1, uint32_t* red, hipStream_t s);
 hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hipStream_t s);
+
+// ---- channel-planar mirrors (ics_planar.hip) and the FFT-tile convolution (ics_conv_fft.hip) --------------------------------------------
+// src / dst: buffer STARTS; rows [y0, y1), pixels [x0, x1) in u-frame coordinates (widened to 4-pixel groups), or the whole buffer
+hipError_t ics_launch_planar_convert(bool to_planar, const float* src, float* dst, const IcsGeom& g, bool whole, int y0, int y1, int x0, int x1, hipStream_t s);
+hipError_t ics_launch_update_planar(const IcsUpdateArgs& a, hipStream_t s);   // frame pointers = origins of planar mirrors
+bool ics_conv_fft_supported(int K);
+size_t ics_conv_fft_spectrum_floats();                                        // per orientation
+hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s);
+// modes 0 and 1 of ics_launch_conv; `planar` = bit mask of the frames of `a` that are origins of planar mirrors (ICS_FFT_PL_*)
+#define ICS_FFT_PL_IN 1
+#define ICS_FFT_PL_OUT 2
+#define ICS_FFT_PL_F 4
+#define ICS_FFT_PL_U 8
+#define ICS_FFT_PL_UT 16
+#define ICS_FFT_PL_TV 32
+#define ICS_FFT_PL_ALL 63
+hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& a, const float* spec, int planar, hipStream_t s);
 
 // ---- zero-fill of up to ICS_ZERO_MAX device blocks in one launch (the ~24 buffers of a new job: one launch instead of 24 memsets) ----
 #define ICS_ZERO_MAX 32

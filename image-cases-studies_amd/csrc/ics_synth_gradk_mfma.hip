@@ -910,7 +910,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   float* fscr = reinterpret_cast<float*>(lds + C::SCR);
   const int tid = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lane = tid & 63, li = lane & 15, lg = lane >> 4;
+  const int lane = tid & 63;
   const int pitch = a.g.pitch;
 
   constexpr int TORG = C::PAD;

@@ -11,11 +11,31 @@
 
 namespace {
 
+int g_planar = 0;   // ICS_FFT_PLANAR=1: every frame the kernel touches is a channel-planar mirror (ics_common.h)
+
 struct Host {
   IcsGeom g;
   size_t nf, org;
   std::vector<float> u, e, f, ut, psf;   // frames (u-frame geometry) and the K x K x 3 PSF
+  std::vector<float> pu, pe, pf, put;    // their planar mirrors
+  size_t pnf, porg;
 };
+
+void to_planar(const Host& h, const std::vector<float>& src, std::vector<float>& dst) {
+  const IcsGeom& g = h.g; const int pp = ics_ppitch(g); const size_t pl = ics_plane_floats(g);
+  dst.assign(h.pnf, 0.f);
+  for (int y = -g.ay; y < g.rows - g.ay; ++y)
+    for (int x = -g.ax; x < pp - g.ax && 3 * (x + g.ax) + 2 < g.pitch; ++x)
+      for (int c = 0; c < 3; ++c)
+        dst[c * pl + (size_t)(y + g.ay) * pp + x + g.ax] = src[(size_t)(y + g.ay) * g.pitch + 3 * (x + g.ax) + c];
+}
+void from_planar(const Host& h, const std::vector<float>& src, std::vector<float>& dst) {
+  const IcsGeom& g = h.g; const int pp = ics_ppitch(g); const size_t pl = ics_plane_floats(g);
+  for (int y = 0; y < g.uM; ++y)
+    for (int x = 0; x < g.uN; ++x)
+      for (int c = 0; c < 3; ++c)
+        dst[h.org + (size_t)y * g.pitch + 3 * x + c] = src[c * pl + h.porg + (size_t)y * pp + x];
+}
 
 Host make_host(int M, int N, int K) {
   Host h;
@@ -44,6 +64,8 @@ Host make_host(int M, int N, int K) {
         h.psf[((size_t)a * K + b) * 3 + c] = (float)v; sum[c] += v;
       }
   for (size_t i = 0; i < h.psf.size(); ++i) h.psf[i] = (float)(h.psf[i] / sum[i % 3]);
+  h.pnf = ics_planar_floats(h.g); h.porg = ics_planar_origin(h.g);
+  to_planar(h, h.u, h.pu); to_planar(h, h.e, h.pe); to_planar(h, h.f, h.pf); to_planar(h, h.ut, h.put);
   return h;
 }
 
@@ -91,7 +113,8 @@ void host_spectrum(const Host& h, int o, std::vector<v2f>& spec) {
 
 IcsConvArgs conv_args(const Host& h, int mode, const float* in, float* out, const float* f, const float* u, const float* ut, uint32_t* red) {
   IcsConvArgs a = {};
-  a.in = in + h.org; a.out = out + h.org; a.f = f + h.org; a.u = u + h.org; a.ut = ut + h.org; a.red = red; a.lambd = 10000.f; a.g = h.g;
+  const size_t org = g_planar ? h.porg : h.org;
+  a.in = in + org; a.out = out + org; a.f = f + org; a.u = u + org; a.ut = ut + org; a.red = red; a.lambd = 10000.f; a.g = h.g;
   a.tv = nullptr; a.tv_kind = 0;
   return a;
 }
@@ -120,17 +143,19 @@ int emulate(int M, int K, int N) {
   for (int mode = 0; mode < 2; ++mode) {
     std::vector<v2f> spec;
     host_spectrum(h, mode, spec);
-    std::vector<float> out(h.nf, 0.f);
+    std::vector<float> out(h.nf, 0.f), pout(g_planar ? h.pnf : 0, 0.f);
     uint32_t red[16] = {0};
     IcsFftArgs a;
-    ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.u.data() : h.e.data(), out.data(), h.f.data(), h.u.data(), h.ut.data(), red), (const float*)spec.data(), &a);
+    if (g_planar) ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.pu.data() : h.pe.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec.data(), &a);
+    else ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.u.data() : h.e.data(), out.data(), h.f.data(), h.u.data(), h.ut.data(), red), (const float*)spec.data(), &a);
+    if (g_planar) a.planar = 63;
     printf("mode %d: V %d, tiles %d (x %d), units %d\n", mode, a.V, a.ntiles, a.tiles_x, a.nunits);
     const icsfft::Mem mem = icsfft::make_mem(a);
     std::vector<v2f> twl(128);
     for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
     for (int n = 0; n < a.nunits; ++n) {
       const icsfft::Unit u = icsfft::decode_unit(a, n);
-      for (int t = 0; t < 1024; ++t) icsfft::stage_a(a, mem, u, lds.data(), t);
+      for (int t = 0; t < 1024; ++t) { float pa[2][16]; icsfft::load_a(a, mem, u, t, pa); icsfft::stage_a(pa, lds.data(), t); }
       for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
       // C, D, E exchange inside a wave that runs in lock step (reads of all lanes before the writes): C and E read a snapshot here
       { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
@@ -140,11 +165,15 @@ int emulate(int M, int K, int N) {
       for (int t = 0; t < 1024; ++t) {
         v2f v[16];
         icsfft::stage_g(lds.data(), t, v);
-        float mg = 0, mu = 0; bool ng = false, nu = false, any = false;
-        if (mode == 0) icsfft::epilogue<0>(a, mem, u, t, v, mg, mu, ng, nu, any);
-        else icsfft::epilogue<1>(a, mem, u, t, v, mg, mu, ng, nu, any);
+        icsfft::Maxima mx = {0.f, 0.f, false, false, false};
+        for (int k = 0; k < 8; ++k) {
+          icsfft::Ops o;
+          if (mode == 0) { icsfft::load_ops<0, false>(a, mem, u, t, k, o); icsfft::finish_chunk<0, false>(a, mem, u, t, k, v, o, mx); }
+          else { icsfft::load_ops<1, true>(a, mem, u, t, k, o); icsfft::finish_chunk<1, true>(a, mem, u, t, k, v, o, mx); }
+        }
       }
     }
+    if (g_planar) from_planar(h, pout, out);
     double wa;
     const double rel = check(h, mode, out, 1, &wa);
     printf("emulation %d x %d, K = %d, mode %d: max |d| = %.3e, relative to max |conv| = %.3e  %s\n", M, N, K, mode, wa, rel, rel < 5e-6 ? "OK" : "FAIL");
@@ -158,12 +187,13 @@ int emulate(int M, int K, int N) {
 int gpu(int M, int K, int N, int reps) {
   Host h = make_host(M, N, K);
   float *du, *de, *df, *dut, *dout, *dpsf, *dspec0, *dspec1; uint32_t* dred;
-  for (float** p : {&du, &de, &df, &dut, &dout}) CK(hipMalloc(p, h.nf * 4));
+  const size_t fb = (g_planar ? h.pnf : h.nf) * 4;
+  for (float** p : {&du, &de, &df, &dut, &dout}) CK(hipMalloc(p, fb));
   CK(hipMalloc(&dpsf, h.psf.size() * 4)); CK(hipMalloc(&dred, 1024)); CK(hipMemset(dred, 0, 1024));
   const size_t sf = ics_conv_fft_spectrum_floats();
   CK(hipMalloc(&dspec0, sf * 4)); CK(hipMalloc(&dspec1, sf * 4));
-  CK(hipMemcpy(du, h.u.data(), h.nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(de, h.e.data(), h.nf * 4, hipMemcpyHostToDevice));
-  CK(hipMemcpy(df, h.f.data(), h.nf * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dut, h.ut.data(), h.nf * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(du, (g_planar ? h.pu : h.u).data(), fb, hipMemcpyHostToDevice)); CK(hipMemcpy(de, (g_planar ? h.pe : h.e).data(), fb, hipMemcpyHostToDevice));
+  CK(hipMemcpy(df, (g_planar ? h.pf : h.f).data(), fb, hipMemcpyHostToDevice)); CK(hipMemcpy(dut, (g_planar ? h.put : h.ut).data(), fb, hipMemcpyHostToDevice));
   CK(hipMemcpy(dpsf, h.psf.data(), h.psf.size() * 4, hipMemcpyHostToDevice));
   CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
   CK(hipDeviceSynchronize());
@@ -180,12 +210,15 @@ int gpu(int M, int K, int N, int reps) {
   int rc = 0;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int mode = 0; mode < 2; ++mode) {
-    CK(hipMemset(dout, 0, h.nf * 4));
+    CK(hipMemset(dout, 0, fb));
     IcsConvArgs a = conv_args(h, mode, mode == 0 ? du : de, dout, df, du, dut, dred);
-    CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    IcsFftArgs fa; ics_conv_fft_fill_args(mode, a, mode == 0 ? dspec0 : dspec1, &fa);
+    if (g_planar) fa.planar = 63;
+    CK(ics_launch_conv_fft_args(mode, fa, 0));
     CK(hipDeviceSynchronize());
-    std::vector<float> out(h.nf);
-    CK(hipMemcpy(out.data(), dout, h.nf * 4, hipMemcpyDeviceToHost));
+    std::vector<float> out(h.nf, 0.f);
+    if (g_planar) { std::vector<float> po(h.pnf); CK(hipMemcpy(po.data(), dout, fb, hipMemcpyDeviceToHost)); from_planar(h, po, out); }
+    else CK(hipMemcpy(out.data(), dout, h.nf * 4, hipMemcpyDeviceToHost));
     double wa;
     const int step = (M <= 600) ? 1 : (M / 24) | 1;
     const double rel = check(h, mode, out, step, &wa);
@@ -196,12 +229,37 @@ int gpu(int M, int K, int N, int reps) {
       CK(hipMemcpy(red, dred, 64, hipMemcpyDeviceToHost));
       printf("  maxima keys -> max|g| %.6g %.6g %.6g   max u %.6g %.6g %.6g\n", ics_key2f(red[0]), ics_key2f(red[1]), ics_key2f(red[2]), ics_key2f(red[3]), ics_key2f(red[4]), ics_key2f(red[5]));
     }
-    for (int i = 0; i < 5; ++i) CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    if (const char* e = getenv("ICS_FFT_ABLATE")) fa.ablate = atoi(e);
+    for (int i = 0; i < 5; ++i) CK(ics_launch_conv_fft_args(mode, fa, 0));
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) CK(ics_launch_conv_fft(mode, a, mode == 0 ? dspec0 : dspec1, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_conv_fft_args(mode, fa, 0));
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    IcsFftArgs fa; ics_conv_fft_fill_args(mode, a, dspec0, &fa);
+#ifdef ICS_FFT_TRACE
+    {
+      long long* dtr; const size_t nt = (size_t)256 * 16 * 10;
+      CK(hipMalloc(&dtr, nt * 8)); CK(hipMemset(dtr, 0, nt * 8));
+      fa.trace = dtr;
+      CK(ics_launch_conv_fft_args(mode, fa, 0)); CK(hipDeviceSynchronize());
+      std::vector<long long> tr(nt);
+      CK(hipMemcpy(tr.data(), dtr, nt * 8, hipMemcpyDeviceToHost));
+      static const char* nm[9] = {"A load+fft16", "barrier", "B", "C", "D spec", "E", "F", "G fft", "epilogue"};
+      double sum[10] = {0}; int cnt = 0;
+      for (int b = 0; b < 256; b += 5)
+        for (int r = 1; r < 8; ++r) {   // rounds 1..7 of every fifth workgroup
+          const long long* t = &tr[((size_t)b * 16 + r) * 10];
+          if (!t[9] || !t[0]) continue;
+          for (int i = 0; i < 9; ++i) sum[i] += (double)(t[i + 1] - t[i]);
+          sum[9] += (double)(t[0] - tr[((size_t)b * 16 + r - 1) * 10 + 9]);
+          ++cnt;
+        }
+      printf("  phase timeline of wave 0 (shader clocks, mean of %d units):", cnt);
+      double tot = 0; for (int i = 0; i < 10; ++i) tot += sum[i] / cnt;
+      for (int i = 0; i < 9; ++i) printf("  %s %.0f", nm[i], sum[i] / cnt);
+      printf("  loop %.0f  | total %.0f\n", sum[9] / cnt, tot);
+      fa.trace = nullptr; hipFree(dtr);
+    }
+#endif
     printf("  mode %d: %.4f ms per launch (%d launches), %d units, %.2f us per unit and CU\n", mode, ms / reps, reps, fa.nunits, 1e3 * ms / reps / ((fa.nunits + 255) / 256));
   }
   CK(hipEventRecord(e0, 0));
@@ -215,6 +273,7 @@ int gpu(int M, int K, int N, int reps) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  if (const char* e = getenv("ICS_FFT_PLANAR")) g_planar = atoi(e);
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
     return emulate(M, K, N);

@@ -26,7 +26,7 @@ ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0
 STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK, STAGE_BAND_REDUCE, STAGE_BAND_MASK_E = range(1, 13)
 FLAG_NO_FUSED_GRADK = 1   # ics_rl_params.flags (include/ics_hip.h ICS_FLAG_*)
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV, BUF_RED = range(10)
-CONV_AUTO, CONV_VECTOR, CONV_MATRIX = range(3)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
+CONV_AUTO, CONV_VECTOR, CONV_MATRIX, CONV_FFT = range(4)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",
                 "dof_min", "dof_max", "_")
 
@@ -71,7 +71,7 @@ class RLRoute(C.Structure):
     """struct ics_rl_route (ics_rl_describe): which kernel families a run with these parameters launches."""
     _fields_ = [("struct_size", C.c_uint32), ("conv_family", C.c_int), ("conv_fp16_split", C.c_int), ("gradk_family", C.c_int),
                 ("gradk_fp16_split", C.c_int), ("image_in_accumulator_order", C.c_int), ("graph", C.c_int)]
-    CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big"}
+    CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big", 5: "fft-tiles"}
     GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big"}
 
 

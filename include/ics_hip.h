@@ -130,6 +130,13 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 49, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
+#define ICS_CONV_FFT 3    /* transform tiles (ics_conv_fft.hip, round 5; MK <= 65, shipped loop): A1 / A3 / A11 as 128 x 128 overlap-save
+                             FFTs held in LDS, fp32 throughout -- the reference's own method (scipy's complex64 FFT over the frame,
+                             lib/deconvolution.pyx:478,491), tile by tile; against float64 direct sums 2 - 5e-7 of the largest
+                             convolution value.  The frames live as channel-planar mirrors for the duration of a run; the PSF gradient
+                             stays on the matrix cores.  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 17 on for frames
+                             >= 1.5 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.  Where image and u are exactly 0 the
+                             transforms return rounding noise instead of exact zeros, like the reference's (see "DoF ratio" below) */
 
 /* Accuracy of the matrix-core path (tests/test_gpu_precision.py drives it with adversarial inputs).  Every fp32 operand x of a
  * 78 x 80-pixel tile is scaled by a power of two s (tile maximum m -> [2^14, 2^15)) and split, x s = hi + lo + r, hi and lo
@@ -209,7 +216,8 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 /* Which kernels ics_rl_run / ics_rl_stage will launch for this job and these parameters (PSF size, params.conv, tv_mode, fuse,
  * flags, the ICS_CONV_PATH override): the library's own routing predicates, so that a benchmark labels its precision and traffic
  * figures from what actually runs.  Families:  convolutions A1/A3 -- 1 fp16-split matrix cores (whole PSF), 2 the same as tap blocks
- * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip);  PSF gradient A13 -- 1 fused with
+ * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip), 5 fp32 transform tiles on planar
+ * mirrors (ics_conv_fft.hip);  PSF gradient A13 -- 1 fused with
  * A11 (k_synth_gradk, MK <= 15), 2 fp16-split matrix cores (k_gradk_mfma), 3 the same as tap blocks (MK >= 33), 4 fp32 MFMA
  * (k_gradk), 5 run-time-sized fp32 (k_gradk_big); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
  * stage are formed from two fp16 terms per operand (22 significand bits, fp32 accumulation), 0 = fp32 products. */

@@ -1,0 +1,131 @@
+"""The transform-tile pipeline (csrc/ics_conv_fft.hip, ics_planar.hip; conv = ICS_CONV_FFT): A1 / A3 / A11 as LDS-resident 128 x 128
+overlap-save FFTs on channel-planar mirrors of the frames, the update pass and the matrix-core PSF gradient on the mirrors as well.
+
+  * the two convolutions against float64 direct sums at the gate of every other convolution path (5e-6 of the largest convolution
+    value; measured 2 - 5e-7), PSF sizes 3 ... 65, frames of one tile and of several ragged ones;
+  * the update pass on planes bit-identical to the HWC pass, the planar PSF gradient bit-identical to the HWC one (same kernels'
+    arithmetic, other loads);
+  * whole runs: every reference golden of tests/test_gpu_rl.py and the deep goldens at BASELINE sizes run with conv = 3 there;
+    here the routing (ICS_CONV_AUTO picks the tiles for wide PSFs on big frames, describe says so) and the step-size maxima.
+"""
+import numpy as np
+import pytest
+
+import rl_mm_oracle as orc
+from helpers import conv_valid64, corr_full64, gradk64, rel_err, update_f32
+
+pytestmark = pytest.mark.gpu
+
+CONV_TOL = 5e-6
+FFT = 3
+
+
+def make_job(M, N, MK, seed=0, blind=False):
+    from lib import _native
+    case = orc.synth_case(M, N, MK, seed=seed, blind=blind, per_channel_psf=True)
+    rng = np.random.default_rng(seed + 1)
+    psf = (case["psf0"] * (0.5 + rng.random(case["psf0"].shape, dtype=np.float32))).astype(np.float32)   # no symmetry: flips show
+    orc.normalize_kernel(psf, MK)
+    job = _native.RLJob(M, N, MK)
+    job.upload(case["image"], case["u0"], psf)
+    return job, case, psf
+
+
+@pytest.mark.parametrize("M,N,MK", [(40, 50, 3), (70, 131, 9), (90, 100, 15), (114, 114, 15), (115, 229, 15), (150, 260, 17), (99, 197, 31),
+                                    (200, 120, 31), (84, 169, 45), (130, 70, 63), (64, 129, 65), (300, 310, 23)])
+def test_fft_convolutions_against_float64(M, N, MK):
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=MK + M)
+    rng = np.random.default_rng(7)
+    u = (case["u0"] + 0.05 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False, conv=FFT)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    full = conv_valid64(u, psf)
+    err_e = np.max(np.abs(e - (full - case["image"]))) / np.max(np.abs(full))
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    g_ref = corr_full64(e.astype(np.float64), psf)
+    err_g = rel_err(g, g_ref)
+    print("%dx%d K=%d: residual %.2e back-projection %.2e" % (M, N, MK, err_e, err_g))
+    assert err_e < CONV_TOL and err_g < CONV_TOL
+    # the step-size maxima of A7 (pyx:523-524) over the finished back-projection
+    red = job.red_keys()
+    gg = (np.float32(10000.0) * g + (u - case["u0"]) * np.float32(0.5)).astype(np.float32)
+    def key_to_float(k):   # ics_key2f (csrc/ics_common.h)
+        k = int(k)
+        return np.array([(k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)], np.uint32).view(np.float32)[0]
+    for c in range(3):
+        assert key_to_float(red[c]) == np.max(np.abs(gg[..., c]))
+        assert key_to_float(red[3 + c]) == np.max(u[..., c])
+    # the residual frame outside the image stays zero; u untouched
+    assert np.array_equal(job.read(nv.BUF_U), u)
+    job.close()
+
+
+@pytest.mark.parametrize("M,N,MK,blind", [(130, 67, 9, True), (257, 300, 15, True), (100, 90, 31, False), (97, 133, 45, True)])
+def test_planar_update_and_gradient_equal_the_hwc_passes(M, N, MK, blind):
+    from lib import _native as nv
+    out = {}
+    for conv in (2, FFT):
+        job, case, psf = make_job(M, N, MK, seed=M + N, blind=blind)
+        rng = np.random.default_rng(3)
+        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+        e = np.zeros_like(case["image"]); e[...] = (0.01 * rng.standard_normal(e.shape)).astype(np.float32)
+        g = (1e-4 * rng.standard_normal(u.shape)).astype(np.float32)
+        job.write(nv.BUF_U, u); job.write(nv.BUF_UT, case["u0"]); job.write(nv.BUF_ERROR, e); job.write(nv.BUF_GRADU, g)
+        p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=blind, conv=conv)
+        # the maxima the update reads: taken by the back-projection stage normally; here by the row-band reduction over all rows
+        pb = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=blind, conv=0, band_rows=(0, u.shape[0]))
+        job.stage(nv.STAGE_BAND_REDUCE, pb)
+        job.stage(nv.STAGE_PSF_GRADIENT, p)
+        gk = job.read(nv.BUF_GRADK)
+        job.stage(nv.STAGE_UPDATE, p)
+        out[conv] = (job.read(nv.BUF_U), gk, job.red_keys())
+        job.close()
+    assert np.array_equal(out[2][0], out[FFT][0], equal_nan=True)      # A5-A10: bit-identical
+    assert np.array_equal(out[2][1], out[FFT][1])                      # A13: bit-identical
+    assert np.array_equal(out[2][2], out[FFT][2])
+
+
+def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
+    from lib import _native as nv
+
+    def describe(M, N, MK, **kw):
+        return nv.describe(M, N, MK, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True, **kw))
+    r = describe(2048, 2048, 31)
+    assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 2
+    r = describe(2048, 2048, 15)
+    assert r.conv_family == 1 and r.gradk_family == 1
+    r = describe(300, 300, 31)
+    assert r.conv_family == 1
+    r = describe(2048, 2048, 45, conv=FFT)
+    assert r.conv_family == 5 and r.gradk_family == 3
+    r = describe(2048, 2048, 31, tv_mode=2)
+    assert r.conv_family == 1
+
+
+@pytest.mark.parametrize("blind", [False, True])
+def test_whole_run_on_the_tiles_equals_the_matrix_core_run(blind):
+    """a 1400 x 1100 frame, 31 x 31: AUTO takes the tiles; against the matrix-core run of the same call (both within 1e-5 of each other
+    after two outer iterations: two correct evaluations of the same sums) and with the same stop-test scalars."""
+    from lib import deconvolution as dc
+    M, N, MK = 1100, 1400, 31
+    case = orc.synth_case_large(M, N, MK, seed=5, blind=blind)
+    res = {}
+    for conv in (0, 2):
+        u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 2, 1e-3, 10000.0, blind=blind, conv=conv)
+        st = dc.richardson_lucy_MM.last
+        res[conv] = (u, psf, st)
+        assert st.iterations_done == 2 and not st.has_nan
+    eu, ep = rel_err(res[0][0], res[2][0]), rel_err(res[0][1], res[2][1])
+    print("tiles vs matrix cores, blind=%s: u %.2e psf %.2e" % (blind, eu, ep))
+    assert eu < 1e-5 and ep < 1e-5
+    for a, b in ((res[0][2].trace_M_r, res[2][2].trace_M_r), (res[0][2].trace_Hu, res[2][2].trace_Hu), (res[0][2].trace_varu, res[2][2].trace_varu)):
+        np.testing.assert_allclose(np.array(a[:2]), np.array(b[:2]), rtol=2e-3)
+    dc._drop_jobs()

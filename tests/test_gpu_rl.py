@@ -71,7 +71,7 @@ def _ref_iterations(ref_log):
     return int([w for w in line.replace(".", " ").split() if w.isdigit()][0]), line.startswith("Convergence"), line
 
 
-@pytest.mark.parametrize("conv", [0, 1], ids=["auto", "fp32"])   # 0: matrix-core kernels (MK <= 15), 1: fp32 products
+@pytest.mark.parametrize("conv", [0, 1, 3], ids=["auto", "fp32", "fft"])   # 0: matrix-core kernels (MK <= 15), 1: fp32 products, 3: transform tiles on planar mirrors
 @pytest.mark.parametrize("name", CASES)
 def test_trajectory_matches_reference_golden(golden_dir, name, conv):
     """Every snapshot: same stop decision, u / psf within the gate, and the per-outer-iteration scalars of the run equal to
@@ -108,13 +108,14 @@ def test_trajectory_matches_reference_golden(golden_dir, name, conv):
             np.testing.assert_allclose(np.array(st.trace_dof_max[:k]), z["dof_max"][:k], rtol=5e-3, atol=1e-12)
 
 
-def test_blind_chain_of_calls_100_inner_iterations(golden_dir):
+@pytest.mark.parametrize("conv", [0, 3], ids=["auto", "fft"])
+def test_blind_chain_of_calls_100_inner_iterations(golden_dir, conv):
     """10 calls x 2 outer iterations (pyx:643 `it > 1` never holds -> no stop decision): a 100-inner-
     iteration blind trajectory, PSF refined from the uniform kernel, against the reference chain."""
     z, meta = load_golden(golden_dir, "bl_101x101_k11_chain")
     u, psf = z["u0"], z["psf0"]
     for k in range(1, meta["chain"] + 1):
-        u, psf, _, st = run_gpu(z, meta, 2, u_start=u, psf_start=psf)
+        u, psf, _, st = run_gpu(z, meta, 2, u_start=u, psf_start=psf, conv=conv)
         assert st.iterations_done == 2 and not st.stopped
         key = "u_2" if k == 1 else "u_chain_%d" % k
         if key in z.files:
