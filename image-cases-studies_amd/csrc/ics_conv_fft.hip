@@ -64,24 +64,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 namespace icsfft {
 
-// Global memory goes through buffer addressing on the device (SGPR resource + 32-bit lane offset): with flat 64-bit pointers the compiler
-// keeps one 64-bit VGPR address per access alive across the unit loop and spills them.  Indices count floats from the START of the frame
-// buffer (origin offset added: the apron in front of the origin has negative coordinates).  The host pass (CPU emulation) indexes pointers.
+// Global memory goes through buffer addressing on the device (SGPR resource + 32-bit lane offset + SGPR offset): with flat 64-bit pointers
+// the compiler keeps one 64-bit VGPR address per access alive across the unit loop and spills them, and every access costs vector
+// instructions for its address.  Here an access is  base + 4 * (lane index) + 4 * (wave-uniform index)  with the uniform part in a scalar
+// register: the row walk of a tile costs no vector instruction at all.  Indices count floats from the START of the frame buffer (origin
+// offset added: the apron in front of the origin has negative coordinates).
+// Lane index ICS_FFT_NONE = "no access": its byte offset 2^31 lies beyond num_records, the hardware returns 0 for the load and drops the
+// store.  Every access is issued unconditionally, so the number of memory operations in flight is static and the compiler's
+// s_waitcnt vmcnt(n) for the register prefetch of the next unit does not degrade to vmcnt(0) behind the epilogue's stores.
+// The host pass (CPU emulation, tools/bench_conv_fft.hip) indexes pointers.
+#define ICS_FFT_NONE 0x20000000
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t gbuf;
-// (index -1 = "no access": the byte offset 0xFFFFFFFC lies beyond num_records, the hardware returns 0 for the load and drops the store --
-//  every access is issued unconditionally, so the number of memory operations in flight is static and the compiler's s_waitcnt vmcnt(n)
-//  for the register prefetch of the next unit does not degrade to vmcnt(0) behind the epilogue's stores)
 __device__ __forceinline__ gbuf make_gbuf(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); }
-__device__ __forceinline__ float ld_f32(gbuf b, int i) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * i, 0, 0)); }
-__device__ __forceinline__ void st_f32(gbuf b, int i, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * i, 0, 0); }
-__device__ __forceinline__ v2f ld_v2f(gbuf b, int i) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, 8 * i, 0, 0)); }
+__device__ __forceinline__ float ld_f32(gbuf b, int vi, int si) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * vi, 4 * si, 0)); }
+__device__ __forceinline__ void st_f32(gbuf b, int vi, int si, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * vi, 4 * si, 0); }
+__device__ __forceinline__ v2f ld_v2f(gbuf b, int vi, int si) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, 8 * vi, 8 * si, 0)); }
 #else
 typedef const void* gbuf;
 static inline gbuf make_gbuf(const void* p) { return p; }
-static inline float ld_f32(gbuf b, int i) { return i < 0 ? 0.f : static_cast<const float*>(b)[i]; }
-static inline void st_f32(gbuf b, int i, float v) { if (i >= 0) const_cast<float*>(static_cast<const float*>(b))[i] = v; }
-static inline v2f ld_v2f(gbuf b, int i) { return static_cast<const v2f*>(b)[i]; }
+static inline float ld_f32(gbuf b, int vi, int si) { return vi >= ICS_FFT_NONE ? 0.f : static_cast<const float*>(b)[vi + si]; }
+static inline void st_f32(gbuf b, int vi, int si, float v) { if (vi < ICS_FFT_NONE) const_cast<float*>(static_cast<const float*>(b))[vi + si] = v; }
+static inline v2f ld_v2f(gbuf b, int vi, int si) { return static_cast<const v2f*>(b)[vi + si]; }
 #endif
 // where pixel (Y, X, c) of a frame lives: index = org + Y * pitch + X * xmul + c * cmul  (HWC: xmul 3, cmul 1; planar mirror: xmul 1, cmul plane)
 struct Lay { int org, pitch, xmul, cmul; };
@@ -105,17 +109,62 @@ ICS_FFT_HD v2f tw128(int t) {
 #endif
 }
 
-// a * b and a * conj(b): one packed multiply + one packed fma
-ICS_FFT_HD v2f cmul(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
-ICS_FFT_HD v2f cmulc(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){b.y, b.x}, (v2f){a.x, a.x} * (v2f){b.x, -b.y}); }
+// a * b and a * conj(b): one packed multiply + one packed fma.  On the device the operand swaps and sign flips ride on the VOP3P modifiers
+// (op_sel / neg): as vector shuffles the compiler spent a v_mov + v_xor on every product with a register operand.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                                   // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));      // + (-a.y b.y, a.y b.x)
+  return r;
+}
+__device__ __forceinline__ v2f cmulc(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));                       // (a.x b.x, -a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(t));                    // + (a.y b.y, a.y b.x)
+  return r;
+}
+// the same with the second factor in a scalar register pair (wave-uniform twiddles of stages A and G: one scalar operand per instruction)
+__device__ __forceinline__ v2f cmul_s(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f cmulc_s(v2f a, v2f b) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+  return r;
+}
+// a + b * (-i) = a + (b.y, -b.x)   and   a + b * (+i) = a + (-b.y, b.x): one instruction each
+__device__ __forceinline__ v2f add_mi(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ v2f add_pi(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#else
+static inline v2f cmul(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
+static inline v2f cmulc(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){b.y, b.x}, (v2f){a.x, a.x} * (v2f){b.x, -b.y}); }
+static inline v2f cmul_s(v2f a, v2f b) { return cmul(a, b); }
+static inline v2f cmulc_s(v2f a, v2f b) { return cmulc(a, b); }
+static inline v2f add_mi(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
+static inline v2f add_pi(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
+#endif
+// products with COMPILE-TIME constants stay in C++: the compiler folds the swapped / negated constant and reads it from scalar registers
+ICS_FFT_HD v2f cmulk(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
+ICS_FFT_HD v2f cmulck(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){b.y, b.x}, (v2f){a.x, a.x} * (v2f){b.x, -b.y}); }
 // forward twiddles are exp(-i phi): DIR = +1 multiplies by b, DIR = -1 by conj(b)
-template <int DIR> ICS_FFT_HD v2f cmuld(v2f a, v2f b) { return DIR > 0 ? cmul(a, b) : cmulc(a, b); }
-// a * (-i) forward, a * (+i) inverse
-template <int DIR> ICS_FFT_HD v2f rot90(v2f a) { return DIR > 0 ? (v2f){a.y, -a.x} : (v2f){-a.y, a.x}; }
+template <int DIR> ICS_FFT_HD v2f cmuld(v2f a, v2f b) { return DIR > 0 ? cmulk(a, b) : cmulck(a, b); }
+// a + b * (-i)^DIR and a - b * (-i)^DIR
+template <int DIR> ICS_FFT_HD v2f add_rot(v2f a, v2f b) { return DIR > 0 ? add_mi(a, b) : add_pi(a, b); }
+template <int DIR> ICS_FFT_HD v2f sub_rot(v2f a, v2f b) { return DIR > 0 ? add_pi(a, b) : add_mi(a, b); }
 
 template <int DIR> ICS_FFT_HD void fft4(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
-  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = rot90<DIR>(a1 - a3);
-  a0 = t0 + t2; a2 = t0 - t2; a1 = t1 + t3; a3 = t1 - t3;
+  const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
+  a0 = t0 + t2; a2 = t0 - t2; a1 = add_rot<DIR>(t1, d); a3 = sub_rot<DIR>(t1, d);
+}
+// the same with input 2 still to be multiplied by (-i)^DIR (w16^4 of the 16-point transform)
+template <int DIR> ICS_FFT_HD void fft4_r2(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
+  const v2f t0 = add_rot<DIR>(a0, a2), t1 = sub_rot<DIR>(a0, a2), t2 = a1 + a3, d = a1 - a3;
+  a0 = t0 + t2; a2 = t0 - t2; a1 = add_rot<DIR>(t1, d); a3 = sub_rot<DIR>(t1, d);
 }
 
 // 8 points, natural order in, natural order out.  n = 2 n1 + n2, k = k1 + 4 k2.
@@ -124,19 +173,12 @@ template <int DIR> ICS_FFT_HD void fft8(v2f (&v)[8]) {
   v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
   fft4<DIR>(e0, e1, e2, e3);
   fft4<DIR>(o0, o1, o2, o3);
-  // o[k1] *= w8^(k1):  w8 = (1 - i)/sqrt2 forward, (1 + i)/sqrt2 inverse
-  if (DIR > 0) {
-    o1 = (v2f){o1.x + o1.y, o1.y - o1.x} * R;
-    o2 = (v2f){o2.y, -o2.x};
-    o3 = (v2f){o3.y - o3.x, -o3.x - o3.y} * R;
-  } else {
-    o1 = (v2f){o1.x - o1.y, o1.x + o1.y} * R;
-    o2 = (v2f){-o2.y, o2.x};
-    o3 = (v2f){-o3.x - o3.y, o3.x - o3.y} * R;
-  }
+  // o[k1] *= w8^(k1):  w8 = (1 - i)/sqrt2 forward, (1 + i)/sqrt2 inverse;  w8^2 = -+i rides on the last butterfly;  w8^3 = -(1 + i)/sqrt2 / -(1 - i)/sqrt2
+  o1 = add_rot<DIR>(o1, o1) * R;
+  o3 = sub_rot<DIR>(o3, o3) * -R;
   v[0] = e0 + o0; v[4] = e0 - o0;
   v[1] = e1 + o1; v[5] = e1 - o1;
-  v[2] = e2 + o2; v[6] = e2 - o2;
+  v[2] = add_rot<DIR>(e2, o2); v[6] = sub_rot<DIR>(e2, o2);
   v[3] = e3 + o3; v[7] = e3 - o3;
 }
 
@@ -149,19 +191,19 @@ template <int DIR> ICS_FFT_HD void fft16(v2f (&v)[16]) {
     a[n2][0] = v[n2]; a[n2][1] = v[4 + n2]; a[n2][2] = v[8 + n2]; a[n2][3] = v[12 + n2];
     fft4<DIR>(a[n2][0], a[n2][1], a[n2][2], a[n2][3]);
   }
-  // a[n2][k1] *= w16^(n2 k1), w16^t = (cos(pi t / 8), -sin(pi t / 8)) forward
+  // a[n2][k1] *= w16^(n2 k1), w16^t = (cos(pi t / 8), -sin(pi t / 8)) forward  (w16^4 = -+i: inside fft4_r2)
   a[1][1] = cmuld<DIR>(a[1][1], (v2f){C1, -S1});
   a[1][2] = cmuld<DIR>(a[1][2], (v2f){R, -R});
   a[1][3] = cmuld<DIR>(a[1][3], (v2f){S1, -C1});
   a[2][1] = cmuld<DIR>(a[2][1], (v2f){R, -R});
-  a[2][2] = rot90<DIR>(a[2][2]);
   a[2][3] = cmuld<DIR>(a[2][3], (v2f){-R, -R});
   a[3][1] = cmuld<DIR>(a[3][1], (v2f){S1, -C1});
   a[3][2] = cmuld<DIR>(a[3][2], (v2f){-R, -R});
   a[3][3] = cmuld<DIR>(a[3][3], (v2f){-C1, S1});
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) {
-    fft4<DIR>(a[0][k1], a[1][k1], a[2][k1], a[3][k1]);   // -> k2 = 0..3
+    if (k1 == 2) fft4_r2<DIR>(a[0][k1], a[1][k1], a[2][k1], a[3][k1]);
+    else fft4<DIR>(a[0][k1], a[1][k1], a[2][k1], a[3][k1]);   // -> k2 = 0..3
 #pragma unroll
     for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = a[k2][k1];
   }
@@ -177,7 +219,6 @@ struct IcsFftArgs {
   int tiles_x, ntiles, nunits;
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
-  int ablate;               // harness only: 1 window loads, 2 operand loads, 4 stores, 8 spectrum loads become dropped accesses (index -1)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][10] shader-clock stamps of wave 0, else unused
 };
 
@@ -223,39 +264,50 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   return m;
 }
 
+// LDS reads are volatile: left alone, the compiler pairs them into ds_read2_b64 / ds_read2st64_b64, which take 8 LDS cycles per wave
+// instruction where two ds_read_b64 take 2 + 2 (MI355X_MICROARCH: 128 vs 256 B/clk)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ v2f lds_ld(const v2f* p) {   // (the low half of a generic address inside the LDS aperture is the LDS address)
+  typedef const volatile __attribute__((address_space(3))) v2f* lds_vp;
+  return *(lds_vp)(uint32_t)(uintptr_t)p;
+}
+#else
+static inline v2f lds_ld(const v2f* p) { return *p; }
+#endif
+
 // x-major mapping (stages A, B, F, G): wave w -> selector w & 7 and columns 64 (w >> 3) + lane
 // row-owner mapping (stages C, D, E): wave w -> rows 8 w + (lane >> 3), selector lane & 7
 #define ICS_FFT_AT(row, col) lds[(row) * ICS_FFT_PITCH + (col)]
 
-// A, first half: the loads of a unit's window -- column x, rows j + 8 m of both tiles (0 outside the frame's value range or beyond the last unit)
+// A, first half: the loads of a unit's window -- column x, rows j + 8 m of both tiles.  The lane part of the address (column, channel, "no
+// such tile") is one register per tile, the row part a scalar: rows and columns beyond the frame's value range are clamped INTO the apron,
+// whose zeros are the values wanted there (ics_common.h: aprons are never written).
 ICS_FFT_HD void load_a(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, float (&p)[2][16]) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const int pad = a.c.g.pad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1;
+  const int pad = a.c.g.pad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int X = u.ox[t] - pad + x;
-    const bool xin = u.has[t] && X < a.c.g.uN + pad;         // (X >= -pad by construction)
-    const int xo = mem.lin.org + mem.lin.xmul * X + mem.lin.cmul * u.c;
+    int X = u.ox[t] - pad + x;                               // >= -pad by construction
+    X = X < xlast ? X : xlast;
+    const int vo = u.has[t] ? mem.lin.org + mem.lin.xmul * X + mem.lin.cmul * u.c : ICS_FFT_NONE;
     const int Y0 = u.oy[t] - pad + j;                        // >= -pad by construction
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int Y = Y0 + 8 * m;
-      p[t][m] = ld_f32(mem.in, (xin && Y <= ylast && !(a.ablate & 1)) ? Y * pitch + xo : -1);
+      p[t][m] = ld_f32(mem.in, vo, (Y < ylast ? Y : ylast) * pitch);
     }
   }
 }
-// A, second half: radix-16 over m -> twiddle -> rows 16 j + k1
+// A, second half: radix-16 over m -> twiddle (wave-uniform: scalar registers) -> rows 16 j + k1
 ICS_FFT_HD void stage_a(const float (&p)[2][16], v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
   v2f v[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) v[m] = (v2f){p[0][m], p[1][m]};
   fft16<1>(v);
+  v2f* wp = lds + (16 * j) * ICS_FFT_PITCH + x;
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    const v2f r = k1 ? cmul(v[k1], tw128(j * k1)) : v[k1];
-    ICS_FFT_AT(16 * j + k1, x) = r;
-  }
+  for (int k1 = 0; k1 < 16; ++k1) wp[k1 * ICS_FFT_PITCH] = k1 ? cmul_s(v[k1], tw128(j * k1)) : v[k1];
 }
 
 // B: radix-8 over j at fixed k1 -> rows ky = k1 + 16 k2  (the same eight slots)
@@ -263,21 +315,13 @@ template <int DIR> ICS_FFT_HD void stage_b(v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, x = 64 * (w >> 3) + lane;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int k1 = (w & 7) + 8 * s;
+    v2f* bp = lds + ((w & 7) + 8 * s) * ICS_FFT_PITCH + x;     // row k1; rows 16 j + k1 and k1 + 16 k2 are the same eight
     v2f v[8];
-    if (DIR > 0) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = ICS_FFT_AT(16 * j + k1, x);
-      fft8<1>(v);
+    for (int i = 0; i < 8; ++i) v[i] = lds_ld(bp + 16 * i * ICS_FFT_PITCH);
+    if (DIR > 0) fft8<1>(v); else fft8<-1>(v);                 // (F: inverse radix-8 over k2 -> rows 16 j + k1)
 #pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) ICS_FFT_AT(k1 + 16 * k2, x) = v[k2];
-    } else {   // F: inverse radix-8 over k2 -> rows 16 j + k1
-#pragma unroll
-      for (int k2 = 0; k2 < 8; ++k2) v[k2] = ICS_FFT_AT(k1 + 16 * k2, x);
-      fft8<-1>(v);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ICS_FFT_AT(16 * j + k1, x) = v[j];
-    }
+    for (int i = 0; i < 8; ++i) bp[16 * i * ICS_FFT_PITCH] = v[i];
   }
 }
 
@@ -286,119 +330,156 @@ ICS_FFT_HD int skew_col(int j, int k1) { return 8 * k1 + ((j + k1) & 7); }
 // C: row ky, x = j + 8 m -> radix-16 over m -> twiddle -> column 8 k1 + (j + k1) % 8
 // (`rd` = `lds` on the device -- the lanes of a wave run in lock step, every read is back before the first write; the CPU emulation, which
 //  runs the threads one after the other, passes a snapshot)
-// (`twl` = the 128 twiddles in LDS behind the tile: the lane-dependent ones of C and E are read from there)
+// (`twl` = the 128 twiddles in LDS behind the tile: the lane-dependent ones of C and E are read from there, all fifteen requested ahead of
+//  the transform; the skewed columns are eight base addresses (j + s) % 8, s = k1 % 8, plus compile-time offsets)
 ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16];
+  v2f v[16], tw[16];
+  const v2f* rp = rd + ky * ICS_FFT_PITCH + j;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = rd[ky * ICS_FFT_PITCH + j + 8 * m];
+  for (int m = 0; m < 16; ++m) v[m] = lds_ld(rp + 8 * m);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
   fft16<1>(v);
+  v2f* cb[8];
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) ICS_FFT_AT(ky, skew_col(j, k1)) = k1 ? cmul(v[k1], twl[(j * k1) & 127]) : v[k1];
+  for (int s = 0; s < 8; ++s) cb[s] = lds + ky * ICS_FFT_PITCH + ((j + s) & 7);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) cb[k1 & 7][8 * k1] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
 }
 
 // D: radix-8 over j -> kx = k1 + 16 k2, multiply by the spectrum, inverse radix-8 over k2 -> j, same slots
-ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid, int ablate = 0) {
+ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), q = lane & 7;
+  v2f* db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) db[j] = lds + ky * ICS_FFT_PITCH + 8 * q + ((j + q) & 7);   // column 8 k1 + (j + k1) % 8 with k1 = q + 8 s: + 64 s
+  const int so = c * ICS_FFT_P * ICS_FFT_P, vo = ky * ICS_FFT_P + q;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const int k1 = q + 8 * s;
     v2f v[8], sp[8];
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sp[k2] = ld_v2f(mem.spec, (ablate & 8) ? -1 : (c * ICS_FFT_P + ky) * ICS_FFT_P + k1 + 16 * k2);
+    for (int k2 = 0; k2 < 8; ++k2) sp[k2] = ld_v2f(mem.spec, vo, so + 8 * s + 16 * k2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ICS_FFT_AT(ky, skew_col(j, k1));
+    for (int j = 0; j < 8; ++j) v[j] = lds_ld(db[j] + 64 * s);
     fft8<1>(v);
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) v[k2] = cmul(v[k2], sp[k2]);
     fft8<-1>(v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ICS_FFT_AT(ky, skew_col(j, k1)) = v[j];
+    for (int j = 0; j < 8; ++j) db[j][64 * s] = v[j];
   }
 }
 
 // E: conj twiddle, inverse radix-16 over k1 -> x = j + 8 m
 ICS_FFT_HD void stage_e(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16];
+  v2f v[16], tw[16];
+  const v2f* cb[8];
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    const v2f r = rd[ky * ICS_FFT_PITCH + skew_col(j, k1)];
-    v[k1] = k1 ? cmulc(r, twl[(j * k1) & 127]) : r;
-  }
+  for (int s = 0; s < 8; ++s) cb[s] = rd + ky * ICS_FFT_PITCH + ((j + s) & 7);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(cb[k1 & 7] + 8 * k1);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulc(v[k1], tw[k1]);
   fft16<-1>(v);
+  v2f* wp = lds + ky * ICS_FFT_PITCH + j;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) ICS_FFT_AT(ky, j + 8 * m) = v[m];
+  for (int m = 0; m < 16; ++m) wp[8 * m] = v[m];
 }
 
 // G, first half: conj twiddle, inverse radix-16 over k1 -> rows y = j + 8 m of column x (tile 0 in .x, tile 1 in .y)
 ICS_FFT_HD void stage_g(const v2f* lds, int tid, v2f (&v)[16]) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
+  const v2f* rp = lds + (16 * j) * ICS_FFT_PITCH + x;
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) {
-    const v2f r = ICS_FFT_AT(16 * j + k1, x);
-    v[k1] = k1 ? cmulc(r, tw128(j * k1)) : r;
-  }
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(rp + k1 * ICS_FFT_PITCH);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulc_s(v[k1], tw128(j * k1));
   fft16<-1>(v);
 }
 
-// canonical positive NaN so that a NaN propagates through the integer max like np.amax does (ics_conv.hip)
-ICS_FFT_HD uint32_t key_of(float f) { return (f != f) ? 0xFFC00000u : ics_f2key(f); }
-
-// G, second half: the epilogue of ics_conv.hip on the thread's 16 + 16 values (rows j + 8 m of column x), in eight chunks k = 4 t + h
-// (tile t, rows m = 4 h .. 4 h + 3): the operands of chunk k + 1 are requested before chunk k is finished, those of chunk 0 before stage F.
-#define ICS_FFT_CH 4
-struct Ops { float a[ICS_FFT_CH], b[ICS_FFT_CH], tv[ICS_FFT_CH]; };   // mode 0: a = image; mode 1: a = u, b = ut, tv = T frame (TV kinds)
+// G, second half: the epilogue of ics_conv.hip on the thread's 16 + 16 values (rows j + 8 m of column x).  On gfx9 vmcnt counts loads
+// and stores alike and retires them in order: a load issued behind a store waits out the store's round trip to L2.  So within a unit every
+// operand load is issued before the first store: mode 0 requests the image values of both tiles before stage F and subtracts in place;
+// mode 1 walks its operands (u, ut[, T]) in four chunks of eight rows, chunk c + 1 requested before the maxima of chunk c are taken, and
+// stores the finished values at the end.  Addresses as in load_a: one lane register per tile and frame (column, channel, or "nothing of
+// this tile is mine"), the row a scalar; operand rows beyond the tile's are clamped (values unused), stores beyond it are dropped ones.
+struct Ops { float a[8], b[8], tv[8]; };   // mode 1: a = u, b = ut, tv = T frame (TV kinds)
 struct Maxima { float mg, mu; bool nan_g, nan_u, any; };
+struct EpiTile { int mcount; bool lane_ok; int Yj, X; };              // rows of this wave in the tile (uniform), this lane's column valid
 
-ICS_FFT_HD int epi_index(const IcsFftArgs& a, const Unit& u, const Lay& L, int tid, int k, int i) {
+ICS_FFT_HD EpiTile epi_tile(const IcsFftArgs& a, const Unit& u, int tid, int t) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const int t = k >> 2, m = ICS_FFT_CH * (k & 3) + i, y = j + 8 * m;
-  const int X = u.ox[t] + x, Y = u.oy[t] + y;
-  const bool ok = u.has[t] && x < a.V && X < a.ox1 && y < a.V && Y < a.oy1;
-  return ok ? L.org + Y * L.pitch + X * L.xmul + u.c * L.cmul : -1;
+  EpiTile e;
+  const int rows = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;      // output rows of this tile
+  e.mcount = u.has[t] ? (rows - j + 7) >> 3 : 0;                       // of them this wave's: y = j + 8 m < rows
+  e.X = u.ox[t] + x; e.Yj = u.oy[t] + j;
+  e.lane_ok = e.mcount > 0 && x < a.V && e.X < a.ox1;
+  return e;
 }
+ICS_FFT_HD int epi_lane(const EpiTile& e, const Lay& L, int c) { return e.lane_ok ? L.org + e.Yj * L.pitch + e.X * L.xmul + c * L.cmul : ICS_FFT_NONE; }
 
-template <int MODE, bool TV>
-ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, Ops& o) {
+// mode 0: the image values under both tiles
+ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, float (&f)[2][16]) {
 #pragma unroll
-  for (int i = 0; i < ICS_FFT_CH; ++i) {
-    const bool ab = a.ablate & 2;
-    if (MODE == 0) o.a[i] = ld_f32(mem.f, ab ? -1 : epi_index(a, u, mem.lf, tid, k, i));
-    else {
-      o.a[i] = ld_f32(mem.u, ab ? -1 : epi_index(a, u, mem.lu, tid, k, i));
-      o.b[i] = ld_f32(mem.ut, ab ? -1 : epi_index(a, u, mem.lut, tid, k, i));
-      if (TV) o.tv[i] = ld_f32(mem.tv, ab ? -1 : epi_index(a, u, mem.ltv, tid, k, i));
-    }
+  for (int t = 0; t < 2; ++t) {
+    const EpiTile e = epi_tile(a, u, tid, t);
+    const int last = e.mcount > 0 ? e.mcount - 1 : 0, vo = epi_lane(e, mem.lf, u.c);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) f[t][m] = ld_f32(mem.f, vo, 8 * (m < last ? m : last) * mem.lf.pitch);
   }
 }
-
-template <int MODE, bool TV>
-ICS_FFT_HD void finish_chunk(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, const v2f (&v)[16], const Ops& o, Maxima& mx) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const int t = k >> 2;
+// the finished values leave: rows beyond the tile's become dropped stores
+ICS_FFT_HD void store_tiles(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, const v2f (&v)[16]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const EpiTile e = epi_tile(a, u, tid, t);
+    const int vo = epi_lane(e, mem.lout, u.c);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) st_f32(mem.out, m < e.mcount ? vo : ICS_FFT_NONE, 8 * m * mem.lout.pitch, t ? v[m].y : v[m].x);
+  }
+}
+// mode 1, chunk k = 2 t + h: operands of rows m = 8 h .. 8 h + 7 of tile t
+template <bool TV>
+ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, Ops& o) {
+  const EpiTile e = epi_tile(a, u, tid, k >> 1);
+  const int last = e.mcount > 0 ? e.mcount - 1 : 0;
+  const int va = epi_lane(e, mem.lu, u.c), vb = epi_lane(e, mem.lut, u.c), vt = TV ? epi_lane(e, mem.ltv, u.c) : 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = 8 * (k & 1) + i, mc = m < last ? m : last;
+    o.a[i] = ld_f32(mem.u, va, 8 * mc * mem.lu.pitch);
+    o.b[i] = ld_f32(mem.ut, vb, 8 * mc * mem.lut.pitch);
+    if (TV) o.tv[i] = ld_f32(mem.tv, vt, 8 * mc * mem.ltv.pitch);
+  }
+}
+// ... and their use: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7; the PAM kinds replace the stored value by G
+template <bool TV>
+ICS_FFT_HD void finish_chunk(const IcsFftArgs& a, const Unit& u, int tid, int k, v2f (&v)[16], const Ops& o, Maxima& mx) {
+  const int t = k >> 1;
+  const EpiTile e = epi_tile(a, u, tid, t);
   const float lambd = a.c.lambd;
 #pragma unroll
-  for (int i = 0; i < ICS_FFT_CH; ++i) {
-    const int m = ICS_FFT_CH * (k & 3) + i;
-    const int idx = (a.ablate & 4) ? -1 : epi_index(a, u, mem.lout, tid, k, i);
+  for (int i = 0; i < 8; ++i) {
+    const int m = 8 * (k & 1) + i;
     const float r = t ? v[m].y : v[m].x;
-    if (MODE == 0) st_f32(mem.out, idx, ICS_FSUB(r, o.a[i]));
-    else {
-      const int Y = u.oy[t] + j + 8 * m, X = u.ox[t] + x;
-      float g, st = r;
-      if (TV && a.c.tv_kind >= 2) { g = (float)((double)o.tv[i] + (double)ICS_FMUL(lambd, r)); st = g; }            // PAM: G = T + lambd*gradu, stored
-      else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)                // active MM-TV, pyx:517
-        g = (float)(((double)o.tv[i] + (double)ICS_FMUL(lambd, r)) + (double)ICS_FSUB(o.a[i], o.b[i]) / 4.0);
-      else
-        g = ICS_FADD(ICS_FMUL(lambd, r), ICS_FMUL(ICS_FSUB(o.a[i], o.b[i]), 0.5f));                            // pyx:519
-      if (idx >= 0) {
-        mx.mg = __builtin_fmaxf(mx.mg, __builtin_fabsf(g));
-        mx.mu = __builtin_fmaxf(mx.mu, o.a[i]);
-        mx.nan_g |= (g != g); mx.nan_u |= (o.a[i] != o.a[i]);
-        mx.any = true;
-      }
-      st_f32(mem.out, idx, st);
+    const int Y = e.Yj + 8 * m, X = e.X;
+    float g;
+    if (TV && a.c.tv_kind >= 2) {                                                                                  // PAM: G = T + lambd*gradu, stored
+      g = (float)((double)o.tv[i] + (double)ICS_FMUL(lambd, r));
+      if (t) v[m].y = g; else v[m].x = g;
+    } else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)              // active MM-TV, pyx:517
+      g = (float)(((double)o.tv[i] + (double)ICS_FMUL(lambd, r)) + (double)ICS_FSUB(o.a[i], o.b[i]) / 4.0);
+    else
+      g = ICS_FADD(ICS_FMUL(lambd, r), ICS_FMUL(ICS_FSUB(o.a[i], o.b[i]), 0.5f));                                  // pyx:519
+    if (m < e.mcount && e.lane_ok) {
+      mx.mg = __builtin_fmaxf(mx.mg, __builtin_fabsf(g));
+      mx.mu = __builtin_fmaxf(mx.mu, o.a[i]);
+      mx.nan_g |= (g != g); mx.nan_u |= (o.a[i] != o.a[i]);
+      mx.any = true;
     }
   }
 }
@@ -441,44 +522,62 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
 #define ICS_FFT_STAMP(i) do { } while (0)
 #endif
   uint32_t accg[3] = {0u, 0u, 0u}, accu[3] = {0u, 0u, 0u};   // the workgroup's maxima as order-preserving keys (0 = nothing seen, NaN = largest)
-  float pa[2][16];                        // the window of the unit about to start, requested one unit ahead
-  load_a(a, mem, decode_unit(a, q), opaque(tid), pa);
+  // A unit's window is requested one unit ahead (registers), and its stage A runs at the END of the unit before it, behind that
+  // unit's stores: there the compiler knows exactly what is in flight -- the window loads, then the stores -- and waits with vmcnt(32).
+  // (Consumed at the top of the loop the wait became vmcnt(0): the loop header merges the first entry, where nothing follows the loads.)
+  float pa[2][16];
+#ifdef ICS_FFT_STAGGER
+  // workgroups start a fraction of a unit apart: units take the same time everywhere, so without this every CU is in its load phase at once
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * ICS_FFT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+  if (q < a.nunits) {
+    load_a(a, mem, decode_unit(a, q), opaque(tid), pa);
+    stage_a(pa, lds, opaque(tid));
+  }
   for (int n = q; n < a.nunits; n += G) {
     const Unit u = decode_unit(a, n);
     ICS_FFT_STAMP(0);
-    stage_a(pa, lds, opaque(tid));
-    load_a(a, mem, decode_unit(a, n + G), opaque(tid), pa);   // (beyond the last unit: no tile, every access a dropped one)
-    ICS_FFT_STAMP(1);
     lds_barrier();
-    ICS_FFT_STAMP(2);
+    ICS_FFT_STAMP(1);
     stage_b<1>(lds, opaque(tid));
     lds_barrier();
-    ICS_FFT_STAMP(3);
+    ICS_FFT_STAMP(2);
     stage_c(lds, lds, twl, opaque(tid));
     wave_sync();
-    ICS_FFT_STAMP(4);
-    stage_d(mem, u.c, lds, opaque(tid), a.ablate);
+    ICS_FFT_STAMP(3);
+    stage_d(mem, u.c, lds, opaque(tid));
     wave_sync();
-    ICS_FFT_STAMP(5);
+    ICS_FFT_STAMP(4);
+    load_a(a, mem, decode_unit(a, n + G), opaque(tid), pa);   // (beyond the last unit: no tile, every access a dropped one)
     stage_e(lds, lds, twl, opaque(tid));
+    float fimg[2][16];
     Ops o0, o1;
-    load_ops<MODE, TV>(a, mem, u, opaque(tid), 0, o0);
+    if (MODE == 0) load_image(a, mem, u, opaque(tid), fimg);
+    else load_ops<TV>(a, mem, u, opaque(tid), 0, o0);
     lds_barrier();
-    ICS_FFT_STAMP(6);
+    ICS_FFT_STAMP(5);
     stage_b<-1>(lds, opaque(tid));
     lds_barrier();
-    ICS_FFT_STAMP(7);
+    ICS_FFT_STAMP(6);
     v2f v[16];
     stage_g(lds, opaque(tid), v);
-    ICS_FFT_STAMP(8);
+    ICS_FFT_STAMP(7);
     Maxima mx; mx.mg = 0.f; mx.mu = -__builtin_inff(); mx.nan_g = mx.nan_u = mx.any = false;
+    if (MODE == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      load_ops<MODE, TV>(a, mem, u, opaque(tid), k + 1, o1);
-      finish_chunk<MODE, TV>(a, mem, u, opaque(tid), k, v, o0, mx);
-      if (k + 2 < 8) load_ops<MODE, TV>(a, mem, u, opaque(tid), k + 2, o0);
-      finish_chunk<MODE, TV>(a, mem, u, opaque(tid), k + 1, v, o1, mx);
+      for (int m = 0; m < 16; ++m) v[m] = (v2f){ICS_FSUB(v[m].x, fimg[0][m]), ICS_FSUB(v[m].y, fimg[1][m])};   // pyx:488
+    } else {
+      load_ops<TV>(a, mem, u, opaque(tid), 1, o1);
+      finish_chunk<TV>(a, u, opaque(tid), 0, v, o0, mx);
+      load_ops<TV>(a, mem, u, opaque(tid), 2, o0);
+      finish_chunk<TV>(a, u, opaque(tid), 1, v, o1, mx);
+      load_ops<TV>(a, mem, u, opaque(tid), 3, o1);
+      finish_chunk<TV>(a, u, opaque(tid), 2, v, o0, mx);
+      finish_chunk<TV>(a, u, opaque(tid), 3, v, o1, mx);
     }
+    store_tiles(a, mem, u, opaque(tid), v);
+    ICS_FFT_STAMP(8);
+    if (n + G < a.nunits) stage_a(pa, lds, opaque(tid));
     ICS_FFT_STAMP(9);
 #ifdef ICS_FFT_TRACE
     ++round;
@@ -563,7 +662,6 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->c = c;
   a->trace = nullptr;
   a->planar = 0;
-  a->ablate = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->V = ICS_FFT_P - g.K + 1;

@@ -166,11 +166,14 @@ int emulate(int M, int K, int N) {
         v2f v[16];
         icsfft::stage_g(lds.data(), t, v);
         icsfft::Maxima mx = {0.f, 0.f, false, false, false};
-        for (int k = 0; k < 8; ++k) {
-          icsfft::Ops o;
-          if (mode == 0) { icsfft::load_ops<0, false>(a, mem, u, t, k, o); icsfft::finish_chunk<0, false>(a, mem, u, t, k, v, o, mx); }
-          else { icsfft::load_ops<1, true>(a, mem, u, t, k, o); icsfft::finish_chunk<1, true>(a, mem, u, t, k, v, o, mx); }
+        if (mode == 0) {
+          float fimg[2][16];
+          icsfft::load_image(a, mem, u, t, fimg);
+          for (int m = 0; m < 16; ++m) v[m] = (v2f){v[m].x - fimg[0][m], v[m].y - fimg[1][m]};
+        } else {
+          for (int k = 0; k < 4; ++k) { icsfft::Ops o; icsfft::load_ops<true>(a, mem, u, t, k, o); icsfft::finish_chunk<true>(a, u, t, k, v, o, mx); }
         }
+        icsfft::store_tiles(a, mem, u, t, v);
       }
     }
     if (g_planar) from_planar(h, pout, out);
@@ -229,7 +232,6 @@ int gpu(int M, int K, int N, int reps) {
       CK(hipMemcpy(red, dred, 64, hipMemcpyDeviceToHost));
       printf("  maxima keys -> max|g| %.6g %.6g %.6g   max u %.6g %.6g %.6g\n", ics_key2f(red[0]), ics_key2f(red[1]), ics_key2f(red[2]), ics_key2f(red[3]), ics_key2f(red[4]), ics_key2f(red[5]));
     }
-    if (const char* e = getenv("ICS_FFT_ABLATE")) fa.ablate = atoi(e);
     for (int i = 0; i < 5; ++i) CK(ics_launch_conv_fft_args(mode, fa, 0));
     CK(hipEventRecord(e0, 0));
     for (int i = 0; i < reps; ++i) CK(ics_launch_conv_fft_args(mode, fa, 0));
@@ -243,7 +245,7 @@ int gpu(int M, int K, int N, int reps) {
       CK(ics_launch_conv_fft_args(mode, fa, 0)); CK(hipDeviceSynchronize());
       std::vector<long long> tr(nt);
       CK(hipMemcpy(tr.data(), dtr, nt * 8, hipMemcpyDeviceToHost));
-      static const char* nm[9] = {"A load+fft16", "barrier", "B", "C", "D spec", "E", "F", "G fft", "epilogue"};
+      static const char* nm[9] = {"barrier", "B", "C", "D spec", "E + loads", "F", "G fft", "epilogue", "A of next"};
       double sum[10] = {0}; int cnt = 0;
       for (int b = 0; b < 256; b += 5)
         for (int r = 1; r < 8; ++r) {   // rounds 1..7 of every fifth workgroup
