@@ -45,6 +45,7 @@
 #define ICS_FFT_THREADS 1024
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 #ifndef ICS_FFT_HD
 #define ICS_FFT_HD __host__ __device__ __forceinline__
@@ -80,15 +81,37 @@ __device__ __forceinline__ gbuf make_gbuf(const void* p) { return __builtin_amdg
 __device__ __forceinline__ float ld_f32(gbuf b, int vi, int si) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * vi, 4 * si, 0)); }
 __device__ __forceinline__ void st_f32(gbuf b, int vi, int si, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * vi, 4 * si, 0); }
 __device__ __forceinline__ v2f ld_v2f(gbuf b, int vi, int si) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, 8 * vi, 8 * si, 0)); }
+__device__ __forceinline__ v4f ld_f32x4(gbuf b, int vi, int si) { return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(b, 4 * vi, 4 * si, 0)); }
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+// (the s_nop behind the store, with the data registers as its operands: a buffer store of more than 8 bytes reads its data registers for a
+//  few cycles after it issues, and a vector instruction that rewrites one of them right behind it changes what is stored.  The compiler's
+//  hazard table inserts wait states for that -- except when the store has an SGPR offset, which it takes to be safe.  On MI355X it is
+//  not: `buffer_store_dwordx4 v[50:53], v58, s[20:23], s29 offen` followed by `v_mov_b32 v50, v0` stored the new v50 on some lanes
+//  (tools/bench_conv_fft.hip found it: the first pixel of the quads of lanes 12-15 of every row group but the first).  Keeping the data
+//  alive across two wait states costs nothing here: eight stores per thread and unit)
+__device__ __forceinline__ void st_f32x4(gbuf b, int vi, int si, v4f v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), b, 4 * vi, 4 * si, 0);
+  asm volatile("s_nop 2" :: "v"(v) : "memory");
+}
 #else
 typedef const void* gbuf;
 static inline gbuf make_gbuf(const void* p) { return p; }
 static inline float ld_f32(gbuf b, int vi, int si) { return vi >= ICS_FFT_NONE ? 0.f : static_cast<const float*>(b)[vi + si]; }
 static inline void st_f32(gbuf b, int vi, int si, float v) { if (vi < ICS_FFT_NONE) const_cast<float*>(static_cast<const float*>(b))[vi + si] = v; }
 static inline v2f ld_v2f(gbuf b, int vi, int si) { return static_cast<const v2f*>(b)[vi + si]; }
+static inline v4f ld_f32x4(gbuf b, int vi, int si) {
+  if (vi >= ICS_FFT_NONE) return (v4f){0.f, 0.f, 0.f, 0.f};
+  const float* p = static_cast<const float*>(b) + vi + si;
+  return (v4f){p[0], p[1], p[2], p[3]};
+}
+static inline void st_f32x4(gbuf b, int vi, int si, v4f v) {
+  if (vi >= ICS_FFT_NONE) return;
+  float* p = const_cast<float*>(static_cast<const float*>(b)) + vi + si;
+  p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+}
 #endif
-// where pixel (Y, X, c) of a frame lives: index = org + Y * pitch + X * xmul + c * cmul  (HWC: xmul 3, cmul 1; planar mirror: xmul 1, cmul plane)
-struct Lay { int org, pitch, xmul, cmul; };
+// where pixel (Y, X, c) of a channel-planar frame lives: index = org + Y * pitch + X + c * cmul  (ics_common.h: ics_ppitch, ics_plane_floats)
+struct Lay { int org, pitch, cmul; };
 struct Mem {
   gbuf in, out, f, u, ut, tv, spec;
   Lay lin, lout, lf, lu, lut, ltv;
@@ -218,8 +241,11 @@ struct IcsFftArgs {
   int V;                // valid output pixels per tile edge = 128 - K + 1
   int tiles_x, ntiles, nunits;
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
+  int gx0;                  // first column of the tile grid: ox0 rounded down to a multiple of 4, so that every 16-byte access of a plane row
+                            // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
+                            // some lanes); the pixels in front of ox0 are stored as zeros, like those behind ox1
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
-  long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][10] shader-clock stamps of wave 0, else unused
+  long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
 };
 
 namespace icsfft {
@@ -239,15 +265,14 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
     const int ti = 2 * pair + t;
     u.has[t] = ti < a.ntiles;
     const int ty = ti / a.tiles_x, tx = ti - ty * a.tiles_x;
-    u.oy[t] = a.oy0 + ty * a.V; u.ox[t] = a.ox0 + tx * a.V;
+    u.oy[t] = a.oy0 + ty * a.V; u.ox[t] = a.gx0 + tx * a.V;
   }
   return u;
 }
 
-ICS_FFT_HD Lay make_lay(const IcsGeom& g, bool planar) {
+ICS_FFT_HD Lay make_lay(const IcsGeom& g, bool) {
   Lay l;
-  if (planar) { l.pitch = ics_ppitch(g); l.org = g.ay * l.pitch + g.ax; l.xmul = 1; l.cmul = g.rows * l.pitch; }
-  else { l.pitch = g.pitch; l.org = g.ay * g.pitch + 3 * g.ax; l.xmul = 3; l.cmul = 1; }
+  l.pitch = ics_ppitch(g); l.org = g.ay * l.pitch + g.ax; l.cmul = g.rows * l.pitch;
   return l;
 }
 // (mode = 0 / 1: only the frames that mode touches get a resource of their own -- scalar registers are short in this kernel; -1: all)
@@ -275,96 +300,126 @@ __device__ __forceinline__ v2f lds_ld(const v2f* p) {   // (the low half of a ge
 static inline v2f lds_ld(const v2f* p) { return *p; }
 #endif
 
-// x-major mapping (stages A, B, F, G): wave w -> selector w & 7 and columns 64 (w >> 3) + lane
-// row-owner mapping (stages C, D, E): wave w -> rows 8 w + (lane >> 3), selector lane & 7
+// Thread mappings.  x-major (stages A, B, F, G): wave w -> selector w & 7, columns 64 (w >> 3) + lane.  Row-owner (C, D, E): wave w -> rows
+// 8 w + (lane >> 3), selector lane & 7.  Row-quad (the unit's boundaries, 16-byte global accesses): rows (tid >> 5) + 32 i, i < 4, pixels
+// 4 (tid & 31) .. + 3 -- a half-wave covers one 512-byte row segment.
 #define ICS_FFT_AT(row, col) lds[(row) * ICS_FFT_PITCH + (col)]
 
-// A, first half: the loads of a unit's window -- column x, rows j + 8 m of both tiles.  The lane part of the address (column, channel, "no
-// such tile") is one register per tile, the row part a scalar: rows and columns beyond the frame's value range are clamped INTO the apron,
-// whose zeros are the values wanted there (ics_common.h: aprons are never written).
-ICS_FFT_HD void load_a(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, float (&p)[2][16]) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
+// The window of a unit, requested one unit ahead into registers: tile t, row group i -> 4 consecutive pixels (one dwordx4; a wave64 memory
+// instruction costs the texture addresser ~16 cycles whether it moves 4 or 16 bytes per lane: as single floats the 64 loads per thread of
+// a unit took 20 k of its 37 k shader clocks).  Rows and pixels beyond the frame's value range read as 0: rows as dropped accesses, pixels
+// through the apron's zeros (a quad that starts inside [.., uN + pad) ends inside the apron, ax >= pad + 3; quads beyond it are dropped).
+ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&pw)[2][4], int t0 = 0, int t1 = 2) {
+  const int r0 = tid >> 5, xq = tid & 31;
   const int pad = a.c.g.pad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    int X = u.ox[t] - pad + x;                               // >= -pad by construction
-    X = X < xlast ? X : xlast;
-    const int vo = u.has[t] ? mem.lin.org + mem.lin.xmul * X + mem.lin.cmul * u.c : ICS_FFT_NONE;
-    const int Y0 = u.oy[t] - pad + j;                        // >= -pad by construction
+  for (int t = t0; t < t1; ++t) {
+    const int X = u.ox[t] - pad + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad by construction
+    const int vo = (u.has[t] && X <= xlast) ? mem.lin.org + Y0 * pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int Y = Y0 + 8 * m;
-      p[t][m] = ld_f32(mem.in, vo, (Y < ylast ? Y : ylast) * pitch);
-    }
+    for (int i = 0; i < 4; ++i) pw[t][i] = ld_f32x4(mem.in, (Y0 + 32 * i <= ylast) ? vo : ICS_FFT_NONE, 32 * i * pitch);
   }
 }
-// A, second half: radix-16 over m -> twiddle (wave-uniform: scalar registers) -> rows 16 j + k1
-ICS_FFT_HD void stage_a(const float (&p)[2][16], v2f* lds, int tid) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  v2f v[16];
+// ... and its way into the tile buffer: z = tile 0 + i tile 1, natural [row][pixel] layout (two 16-byte LDS stores per row group)
+ICS_FFT_HD void store_window(const v4f (&pw)[2][4], v2f* lds, int tid) {
+  const int r0 = tid >> 5, xq = tid & 31;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = (v2f){p[0][m], p[1][m]};
-  fft16<1>(v);
-  v2f* wp = lds + (16 * j) * ICS_FFT_PITCH + x;
-#pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) wp[k1 * ICS_FFT_PITCH] = k1 ? cmul_s(v[k1], tw128(j * k1)) : v[k1];
+  for (int i = 0; i < 4; ++i) {
+    v4f* wp = reinterpret_cast<v4f*>(lds + (r0 + 32 * i) * ICS_FFT_PITCH + 4 * xq);
+    wp[0] = (v4f){pw[0][i].x, pw[1][i].x, pw[0][i].y, pw[1][i].y};
+    wp[1] = (v4f){pw[0][i].z, pw[1][i].z, pw[0][i].w, pw[1][i].w};
+  }
 }
 
-// B: radix-8 over j at fixed k1 -> rows ky = k1 + 16 k2  (the same eight slots)
+// A: column x, rows j + 8 m -> radix-16 over m -> twiddle (wave-uniform: scalar registers) -> k1 to row j + 8 k1 (the slots it read)
+ICS_FFT_HD void stage_a(v2f* lds, int tid) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
+  v2f* cp = lds + j * ICS_FFT_PITCH + x;
+  v2f v[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) v[m] = lds_ld(cp + 8 * m * ICS_FFT_PITCH);
+  fft16<1>(v);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) cp[8 * k1 * ICS_FFT_PITCH] = k1 ? cmul_s(v[k1], tw128(j * k1)) : v[k1];
+}
+
+// B: radix-8 over j at fixed k1 (rows j + 8 k1) -> k2 to row 8 k1 + k2: frequency ky = k1 + 16 k2 lives in row 8 k1 + k2 from here on
+// (in place again: the row stages do not care which row holds which ky, stage D asks ky_of_row).  F = the inverse, the same slots.
 template <int DIR> ICS_FFT_HD void stage_b(v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, x = 64 * (w >> 3) + lane;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    v2f* bp = lds + ((w & 7) + 8 * s) * ICS_FFT_PITCH + x;     // row k1; rows 16 j + k1 and k1 + 16 k2 are the same eight
+    v2f* bp = lds + 8 * ((w & 7) + 8 * s) * ICS_FFT_PITCH + x;
     v2f v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = lds_ld(bp + 16 * i * ICS_FFT_PITCH);
-    if (DIR > 0) fft8<1>(v); else fft8<-1>(v);                 // (F: inverse radix-8 over k2 -> rows 16 j + k1)
+    for (int i = 0; i < 8; ++i) v[i] = lds_ld(bp + i * ICS_FFT_PITCH);
+    if (DIR > 0) fft8<1>(v); else fft8<-1>(v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bp[16 * i * ICS_FFT_PITCH] = v[i];
+    for (int i = 0; i < 8; ++i) bp[i * ICS_FFT_PITCH] = v[i];
   }
 }
+ICS_FFT_HD int ky_of_row(int row) { return (row >> 3) + 16 * (row & 7); }
 
 ICS_FFT_HD int skew_col(int j, int k1) { return 8 * k1 + ((j + k1) & 7); }
 
-// C: row ky, x = j + 8 m -> radix-16 over m -> twiddle -> column 8 k1 + (j + k1) % 8
+// C: one row, x = j + 8 m -> radix-16 over m -> twiddle -> column 8 k1 + (j + k1) % 8
 // (`rd` = `lds` on the device -- the lanes of a wave run in lock step, every read is back before the first write; the CPU emulation, which
 //  runs the threads one after the other, passes a snapshot)
 // (`twl` = the 128 twiddles in LDS behind the tile: the lane-dependent ones of C and E are read from there, all fifteen requested ahead of
 //  the transform; the skewed columns are eight base addresses (j + s) % 8, s = k1 % 8, plus compile-time offsets)
 ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16], tw[16];
-  const v2f* rp = rd + ky * ICS_FFT_PITCH + j;
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
+  v2f v[16], tw[8];
+  const v2f* rp = rd + row * ICS_FFT_PITCH + j;
 #pragma unroll
   for (int m = 0; m < 16; ++m) v[m] = lds_ld(rp + 8 * m);
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+  for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));   // (in two halves of eight: registers)
   fft16<1>(v);
   v2f* cb[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) cb[s] = lds + ky * ICS_FFT_PITCH + ((j + s) & 7);
+  for (int s = 0; s < 8; ++s) cb[s] = lds + row * ICS_FFT_PITCH + ((j + s) & 7);
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) cb[k1 & 7][8 * k1] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
+  for (int k1 = 0; k1 < 8; ++k1) cb[k1][8 * k1] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
+#pragma unroll
+  for (int k1 = 8; k1 < 16; ++k1) tw[k1 - 8] = lds_ld(twl + ((j * k1) & 127));
+#pragma unroll
+  for (int k1 = 8; k1 < 16; ++k1) cb[k1 - 8][8 * k1] = cmul(v[k1], tw[k1 - 8]);
 }
 
+// The spectrum values a thread multiplies by in stage D: row -> ky, kx = q + 8 s + 16 k2 (from L2: 384 KB for the three channels).  Requested
+// in front of stage C: requested inside stage D, in two batches of eight with a wait each, the last wave left stage D 17 k shader clocks
+// after the first (per-wave timeline, tools/bench_conv_fft.hip -DICS_FFT_TRACE).  (Requested a whole unit ahead -- in front of the
+// previous unit's stores, which vmcnt makes every later load wait for -- they took stage D to 2 k clocks, but 32 registers alive across
+// stages A-C spilled the window prefetch: measured slower.)
+// Layout (k_fft_spectrum writes it): the sixteen values of a thread as eight 16-byte pairs, [channel][pair l = 4 s + k2 / 2][thread] -- a wave's
+// load is 1 KiB contiguous, eight loads per thread instead of sixteen 8-byte ones (the texture addresser's time goes by instructions).
+ICS_FFT_HD int spec_index(int c, int ky, int kx) {   // position of S_c[ky][kx] in v2f units
+  const int tid = 64 * (ky & 15) + 8 * (ky >> 4) + (kx & 7), s = (kx >> 3) & 1, k2 = kx >> 4;
+  return (((c * 8 + 4 * s + (k2 >> 1)) * ICS_FFT_THREADS + tid) * 2) + (k2 & 1);
+}
+ICS_FFT_HD void load_spectrum(const Mem& mem, int c, int tid, v2f (&sp)[2][8]) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const v4f p = ld_f32x4(mem.spec, 4 * tid, (c * 8 + l) * ICS_FFT_THREADS * 4);
+    sp[l >> 2][2 * (l & 3)] = (v2f){p.x, p.y};
+    sp[l >> 2][2 * (l & 3) + 1] = (v2f){p.z, p.w};
+  }
+}
 // D: radix-8 over j -> kx = k1 + 16 k2, multiply by the spectrum, inverse radix-8 over k2 -> j, same slots
-ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), q = lane & 7;
+ICS_FFT_HD void stage_d(const v2f (&sp)[2][8], v2f* lds, int tid) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
   v2f* db[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) db[j] = lds + ky * ICS_FFT_PITCH + 8 * q + ((j + q) & 7);   // column 8 k1 + (j + k1) % 8 with k1 = q + 8 s: + 64 s
-  const int so = c * ICS_FFT_P * ICS_FFT_P, vo = ky * ICS_FFT_P + q;
+  for (int j = 0; j < 8; ++j) db[j] = lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7);   // column 8 k1 + (j + k1) % 8 with k1 = q + 8 s: + 64 s
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    v2f v[8], sp[8];
-#pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) sp[k2] = ld_v2f(mem.spec, vo, so + 8 * s + 16 * k2);
+    v2f v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = lds_ld(db[j] + 64 * s);
     fft8<1>(v);
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) v[k2] = cmul(v[k2], sp[k2]);
+    for (int k2 = 0; k2 < 8; ++k2) v[k2] = cmul(v[k2], sp[s][k2]);
     fft8<-1>(v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j][64 * s] = v[j];
@@ -373,112 +428,123 @@ ICS_FFT_HD void stage_d(const Mem& mem, int c, v2f* lds, int tid) {
 
 // E: conj twiddle, inverse radix-16 over k1 -> x = j + 8 m
 ICS_FFT_HD void stage_e(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, ky = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16], tw[16];
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
+  v2f v[16], tw[8];
   const v2f* cb[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) cb[s] = rd + ky * ICS_FFT_PITCH + ((j + s) & 7);
+  for (int s = 0; s < 8; ++s) cb[s] = rd + row * ICS_FFT_PITCH + ((j + s) & 7);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(cb[k1 & 7] + 8 * k1);
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+  for (int h = 0; h < 2; ++h) {                                              // (the twiddles in two halves of eight: registers)
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulc(v[k1], tw[k1]);
+    for (int k1 = 8 * h; k1 < 8 * h + 8; ++k1) if (k1) tw[k1 - 8 * h] = lds_ld(twl + ((j * k1) & 127));
+#pragma unroll
+    for (int k1 = 8 * h; k1 < 8 * h + 8; ++k1) if (k1) v[k1] = cmulc(v[k1], tw[k1 - 8 * h]);
+  }
   fft16<-1>(v);
-  v2f* wp = lds + ky * ICS_FFT_PITCH + j;
+  v2f* wp = lds + row * ICS_FFT_PITCH + j;
 #pragma unroll
   for (int m = 0; m < 16; ++m) wp[8 * m] = v[m];
 }
 
-// G, first half: conj twiddle, inverse radix-16 over k1 -> rows y = j + 8 m of column x (tile 0 in .x, tile 1 in .y)
-ICS_FFT_HD void stage_g(const v2f* lds, int tid, v2f (&v)[16]) {
+// G: rows j + 8 k1 of column x -> conj twiddle, inverse radix-16 over k1 -> the finished values of rows j + 8 m, back into the slots they
+// came from: the tile buffer now holds r (tile 0 in .x, tile 1 in .y) in natural [row][pixel] layout for the row-quad epilogue
+ICS_FFT_HD void stage_g(v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  const v2f* rp = lds + (16 * j) * ICS_FFT_PITCH + x;
+  v2f* cp = lds + j * ICS_FFT_PITCH + x;
+  v2f v[16];
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(rp + k1 * ICS_FFT_PITCH);
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(cp + 8 * k1 * ICS_FFT_PITCH);
 #pragma unroll
   for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulc_s(v[k1], tw128(j * k1));
   fft16<-1>(v);
+#pragma unroll
+  for (int m = 0; m < 16; ++m) cp[8 * m * ICS_FFT_PITCH] = v[m];
 }
 
-// G, second half: the epilogue of ics_conv.hip on the thread's 16 + 16 values (rows j + 8 m of column x).  On gfx9 vmcnt counts loads
-// and stores alike and retires them in order: a load issued behind a store waits out the store's round trip to L2.  So within a unit every
-// operand load is issued before the first store: mode 0 requests the image values of both tiles before stage F and subtracts in place;
-// mode 1 walks its operands (u, ut[, T]) in four chunks of eight rows, chunk c + 1 requested before the maxima of chunk c are taken, and
-// stores the finished values at the end.  Addresses as in load_a: one lane register per tile and frame (column, channel, or "nothing of
-// this tile is mine"), the row a scalar; operand rows beyond the tile's are clamped (values unused), stores beyond it are dropped ones.
-struct Ops { float a[8], b[8], tv[8]; };   // mode 1: a = u, b = ut, tv = T frame (TV kinds)
+// canonical positive NaN so that a NaN propagates through the integer max like np.amax does (ics_conv.hip)
+ICS_FFT_HD uint32_t key_of(float f) { return (f != f) ? 0xFFC00000u : ics_f2key(f); }
+
+// Epilogue (row-quad ownership): the arithmetic of ics_conv.hip on 4 consecutive pixels of a row at a time, operands and results as
+// dwordx4.  On gfx9 vmcnt counts loads and stores alike and retires them in order: a load issued behind a store waits out the store's round
+// trip to L2.  So within a unit every operand load is issued before the first store: mode 0 requests the image quads of both tiles before
+// stage F; mode 1 walks its operands (u, ut[, T]) row group by row group, group i + 1 requested before the maxima of group i are taken, and
+// stores the values it kept at the end.  A quad's lane address says "this row group of this tile is mine" or is a dropped access; pixels
+// of a valid quad beyond the output region are stored as zeros (they land in the frame's border ring / slack, which holds zeros).
+struct Ops { v4f a[2][4], b[2][4], tv[2][4]; };   // [tile][row group].  mode 1: a = u, b = ut, tv = T frame (TV kinds)
 struct Maxima { float mg, mu; bool nan_g, nan_u, any; };
-struct EpiTile { int mcount; bool lane_ok; int Yj, X; };              // rows of this wave in the tile (uniform), this lane's column valid
 
-ICS_FFT_HD EpiTile epi_tile(const IcsFftArgs& a, const Unit& u, int tid, int t) {
-  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, j = w & 7, x = 64 * (w >> 3) + lane;
-  EpiTile e;
-  const int rows = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;      // output rows of this tile
-  e.mcount = u.has[t] ? (rows - j + 7) >> 3 : 0;                       // of them this wave's: y = j + 8 m < rows
-  e.X = u.ox[t] + x; e.Yj = u.oy[t] + j;
-  e.lane_ok = e.mcount > 0 && x < a.V && e.X < a.ox1;
-  return e;
+// lane address of row group 0 of tile t in frame layout L, or ICS_FFT_NONE; `rows` = number of this lane's row groups inside the tile (0..4)
+ICS_FFT_HD int quad_lane(const IcsFftArgs& a, const Unit& u, const Lay& L, int tid, int t, int& rows, int& X) {
+  const int r0 = tid >> 5, xq = tid & 31;
+  const int lim = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;      // output rows of this tile
+  X = u.ox[t] + 4 * xq;
+  const bool ok = u.has[t] && 4 * xq < a.V && X < a.ox1 && r0 < lim;
+  rows = ok ? (lim - r0 + 31) >> 5 : 0;                                // row groups i with r0 + 32 i < lim
+  return ok ? L.org + (u.oy[t] + r0) * L.pitch + X + L.cmul * u.c : ICS_FFT_NONE;
 }
-ICS_FFT_HD int epi_lane(const EpiTile& e, const Lay& L, int c) { return e.lane_ok ? L.org + e.Yj * L.pitch + e.X * L.xmul + c * L.cmul : ICS_FFT_NONE; }
 
-// mode 0: the image values under both tiles
-ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, float (&f)[2][16]) {
+ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&f)[2][4], int t0 = 0, int t1 = 2) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const EpiTile e = epi_tile(a, u, tid, t);
-    const int last = e.mcount > 0 ? e.mcount - 1 : 0, vo = epi_lane(e, mem.lf, u.c);
+  for (int t = t0; t < t1; ++t) {
+    int rows, X;
+    const int vo = quad_lane(a, u, mem.lf, tid, t, rows, X);
 #pragma unroll
-    for (int m = 0; m < 16; ++m) f[t][m] = ld_f32(mem.f, vo, 8 * (m < last ? m : last) * mem.lf.pitch);
+    for (int i = 0; i < 4; ++i) f[t][i] = ld_f32x4(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
   }
 }
-// the finished values leave: rows beyond the tile's become dropped stores
-ICS_FFT_HD void store_tiles(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, const v2f (&v)[16]) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const EpiTile e = epi_tile(a, u, tid, t);
-    const int vo = epi_lane(e, mem.lout, u.c);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) st_f32(mem.out, m < e.mcount ? vo : ICS_FFT_NONE, 8 * m * mem.lout.pitch, t ? v[m].y : v[m].x);
-  }
-}
-// mode 1, chunk k = 2 t + h: operands of rows m = 8 h .. 8 h + 7 of tile t
+// mode 1: the operands under tile t
 template <bool TV>
-ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int k, Ops& o) {
-  const EpiTile e = epi_tile(a, u, tid, k >> 1);
-  const int last = e.mcount > 0 ? e.mcount - 1 : 0;
-  const int va = epi_lane(e, mem.lu, u.c), vb = epi_lane(e, mem.lut, u.c), vt = TV ? epi_lane(e, mem.ltv, u.c) : 0;
+ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, Ops& o) {
+  int rows, X;
+  const int va = quad_lane(a, u, mem.lu, tid, t, rows, X);
+  const int vb = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.lut.org;      // (the same geometry: all frames of a job are)
+  const int vt = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.ltv.org;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = 8 * (k & 1) + i, mc = m < last ? m : last;
-    o.a[i] = ld_f32(mem.u, va, 8 * mc * mem.lu.pitch);
-    o.b[i] = ld_f32(mem.ut, vb, 8 * mc * mem.lut.pitch);
-    if (TV) o.tv[i] = ld_f32(mem.tv, vt, 8 * mc * mem.ltv.pitch);
+  for (int i = 0; i < 4; ++i) {
+    o.a[t][i] = ld_f32x4(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
+    o.b[t][i] = ld_f32x4(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+    if (TV) o.tv[t][i] = ld_f32x4(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
   }
 }
-// ... and their use: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7; the PAM kinds replace the stored value by G
+// the finished values of row group i: r[t] = 4 pixels of tile t
+ICS_FFT_HD void read_quads(const v2f* lds, int tid, int i, v4f (&r)[2]) {
+  const int r0 = tid >> 5, xq = tid & 31;
+  const v4f* rp = reinterpret_cast<const v4f*>(lds + (r0 + 32 * i) * ICS_FFT_PITCH + 4 * xq);
+  const v4f z0 = rp[0], z1 = rp[1];
+  r[0] = (v4f){z0.x, z0.z, z1.x, z1.z};
+  r[1] = (v4f){z0.y, z0.w, z1.y, z1.w};
+}
+ICS_FFT_HD void store_quad(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, int i, v4f val) {
+  int rows, X;
+  const int vo = quad_lane(a, u, mem.lout, tid, t, rows, X);
+  // pixels beyond the output region: zeros into the border ring / slack
+  val = (v4f){X >= a.ox0 ? val.x : 0.f, (X + 1 >= a.ox0 && X + 1 < a.ox1) ? val.y : 0.f, (X + 2 >= a.ox0 && X + 2 < a.ox1) ? val.z : 0.f, X + 3 < a.ox1 ? val.w : 0.f};
+  st_f32x4(mem.out, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lout.pitch, val);
+}
+// mode 1: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7 on row group i of tile t; the PAM kinds replace the stored value by G
 template <bool TV>
-ICS_FFT_HD void finish_chunk(const IcsFftArgs& a, const Unit& u, int tid, int k, v2f (&v)[16], const Ops& o, Maxima& mx) {
-  const int t = k >> 1;
-  const EpiTile e = epi_tile(a, u, tid, t);
+ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx) {
+  const int r0 = tid >> 5, xq = tid & 31;
   const float lambd = a.c.lambd;
+  const int lim = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;
+  const int X0 = u.ox[t] + 4 * xq, Y = u.oy[t] + r0 + 32 * i;
+  const bool row_ok = u.has[t] && 4 * xq < a.V && r0 + 32 * i < lim;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = 8 * (k & 1) + i;
-    const float r = t ? v[m].y : v[m].x;
-    const int Y = e.Yj + 8 * m, X = e.X;
+  for (int e = 0; e < 4; ++e) {
+    const float rv = r[e], uv = o.a[t][i][e], tv = o.b[t][i][e];
+    const int X = X0 + e;
     float g;
-    if (TV && a.c.tv_kind >= 2) {                                                                                  // PAM: G = T + lambd*gradu, stored
-      g = (float)((double)o.tv[i] + (double)ICS_FMUL(lambd, r));
-      if (t) v[m].y = g; else v[m].x = g;
-    } else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)              // active MM-TV, pyx:517
-      g = (float)(((double)o.tv[i] + (double)ICS_FMUL(lambd, r)) + (double)ICS_FSUB(o.a[i], o.b[i]) / 4.0);
+    if (TV && a.c.tv_kind >= 2) { g = (float)((double)o.tv[t][i][e] + (double)ICS_FMUL(lambd, rv)); r[e] = g; }     // PAM: G = T + lambd*gradu, stored
+    else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)                  // active MM-TV, pyx:517
+      g = (float)(((double)o.tv[t][i][e] + (double)ICS_FMUL(lambd, rv)) + (double)ICS_FSUB(uv, tv) / 4.0);
     else
-      g = ICS_FADD(ICS_FMUL(lambd, r), ICS_FMUL(ICS_FSUB(o.a[i], o.b[i]), 0.5f));                                  // pyx:519
-    if (m < e.mcount && e.lane_ok) {
+      g = ICS_FADD(ICS_FMUL(lambd, rv), ICS_FMUL(ICS_FSUB(uv, tv), 0.5f));                                          // pyx:519
+    if (row_ok && X >= a.ox0 && X < a.ox1) {
       mx.mg = __builtin_fmaxf(mx.mg, __builtin_fabsf(g));
-      mx.mu = __builtin_fmaxf(mx.mu, o.a[i]);
-      mx.nan_g |= (g != g); mx.nan_u |= (o.a[i] != o.a[i]);
+      mx.mu = __builtin_fmaxf(mx.mu, uv);
+      mx.nan_g |= (g != g); mx.nan_u |= (uv != uv);
       mx.any = true;
     }
   }
@@ -517,22 +583,25 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
 #ifdef ICS_FFT_TRACE
   int round = 0;
-#define ICS_FFT_STAMP(i) do { if (tid == 0 && round < 16 && a.trace) a.trace[((size_t)blockIdx.x * 16 + round) * 10 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define ICS_FFT_STAMP(i) do { if ((tid & 63) == 0 && round < 16 && a.trace) a.trace[(((size_t)blockIdx.x * 16 + round) * 16 + (tid >> 6)) * 10 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define ICS_FFT_STAMP(i) do { } while (0)
 #endif
   uint32_t accg[3] = {0u, 0u, 0u}, accu[3] = {0u, 0u, 0u};   // the workgroup's maxima as order-preserving keys (0 = nothing seen, NaN = largest)
-  // A unit's window is requested one unit ahead (registers), and its stage A runs at the END of the unit before it, behind that
-  // unit's stores: there the compiler knows exactly what is in flight -- the window loads, then the stores -- and waits with vmcnt(32).
-  // (Consumed at the top of the loop the wait became vmcnt(0): the loop header merges the first entry, where nothing follows the loads.)
-  float pa[2][16];
+  // A unit's window is requested one unit ahead (registers).  It enters the tile buffer -- and runs its stage A -- at the END of the unit
+  // before it, behind that unit's stores: there the compiler knows exactly what is in flight (the window loads, then the stores) and waits
+  // with vmcnt(n_stores).  (Consumed at the top of the loop the wait became vmcnt(0): the loop header merges the first entry, where
+  // nothing follows the loads.)
+  v4f pw[2][4];
 #ifdef ICS_FFT_STAGGER
-  // workgroups start a fraction of a unit apart: units take the same time everywhere, so without this every CU is in its load phase at once
+  // workgroups start a fraction of a unit apart (measured: no effect -- what bounds a unit's memory phases is its own CU's texture addresser)
   for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * ICS_FFT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
   if (q < a.nunits) {
-    load_a(a, mem, decode_unit(a, q), opaque(tid), pa);
-    stage_a(pa, lds, opaque(tid));
+    load_window(a, mem, decode_unit(a, q), opaque(tid), pw);
+    store_window(pw, lds, opaque(tid));
+    lds_barrier();
+    stage_a(lds, opaque(tid));
   }
   for (int n = q; n < a.nunits; n += G) {
     const Unit u = decode_unit(a, n);
@@ -542,42 +611,60 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     stage_b<1>(lds, opaque(tid));
     lds_barrier();
     ICS_FFT_STAMP(2);
+    v2f sp[2][8];
+    load_spectrum(mem, u.c, opaque(tid), sp);      // (stage C's arithmetic covers their trip to L2; inside stage D the waves queued up on it)
     stage_c(lds, lds, twl, opaque(tid));
     wave_sync();
     ICS_FFT_STAMP(3);
-    stage_d(mem, u.c, lds, opaque(tid));
+    stage_d(sp, lds, opaque(tid));
     wave_sync();
     ICS_FFT_STAMP(4);
-    load_a(a, mem, decode_unit(a, n + G), opaque(tid), pa);   // (beyond the last unit: no tile, every access a dropped one)
+    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
     stage_e(lds, lds, twl, opaque(tid));
-    float fimg[2][16];
-    Ops o0, o1;
+    v4f fimg[2][4];
+    Ops ops;
     if (MODE == 0) load_image(a, mem, u, opaque(tid), fimg);
-    else load_ops<TV>(a, mem, u, opaque(tid), 0, o0);
+    else load_ops<TV>(a, mem, u, opaque(tid), 0, ops);
     lds_barrier();
     ICS_FFT_STAMP(5);
     stage_b<-1>(lds, opaque(tid));
     lds_barrier();
     ICS_FFT_STAMP(6);
-    v2f v[16];
-    stage_g(lds, opaque(tid), v);
+    stage_g(lds, opaque(tid));
+    lds_barrier();
     ICS_FFT_STAMP(7);
+    // row-quad epilogue, row group by row group (at most one group's raw values alive beside the operands).  Mode 1 has two operand
+    // frames: it requests those of the second tile here and takes its maxima in a second pass, and the second tile of the next unit's
+    // window goes out between the passes (registers: 128 per thread with 1024 of them).
+    if (MODE == 1) load_ops<TV>(a, mem, u, opaque(tid), 1, ops);
     Maxima mx; mx.mg = 0.f; mx.mu = -__builtin_inff(); mx.nan_g = mx.nan_u = mx.any = false;
-    if (MODE == 0) {
+    v4f res[4][2];
 #pragma unroll
-      for (int m = 0; m < 16; ++m) v[m] = (v2f){ICS_FSUB(v[m].x, fimg[0][m]), ICS_FSUB(v[m].y, fimg[1][m])};   // pyx:488
-    } else {
-      load_ops<TV>(a, mem, u, opaque(tid), 1, o1);
-      finish_chunk<TV>(a, u, opaque(tid), 0, v, o0, mx);
-      load_ops<TV>(a, mem, u, opaque(tid), 2, o0);
-      finish_chunk<TV>(a, u, opaque(tid), 1, v, o1, mx);
-      load_ops<TV>(a, mem, u, opaque(tid), 3, o1);
-      finish_chunk<TV>(a, u, opaque(tid), 2, v, o0, mx);
-      finish_chunk<TV>(a, u, opaque(tid), 3, v, o1, mx);
+    for (int i = 0; i < 4; ++i) {
+      read_quads(lds, opaque(tid), i, res[i]);
+      if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
+      } else maxima_quad<TV>(a, u, opaque(tid), 0, i, res[i][0], ops, mx);
+      asm volatile("" ::: "memory");
     }
-    store_tiles(a, mem, u, opaque(tid), v);
+    if (MODE == 1) {
+      load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) maxima_quad<TV>(a, u, opaque(tid), 1, i, res[i][1], ops, mx);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) store_quad(a, mem, u, opaque(tid), t, i, res[i][t]);
     ICS_FFT_STAMP(8);
-    if (n + G < a.nunits) stage_a(pa, lds, opaque(tid));
+    if (n + G < a.nunits) {
+      store_window(pw, lds, opaque(tid));      // (the slots this thread just read)
+      lds_barrier();
+      stage_a(lds, opaque(tid));
+    }
     ICS_FFT_STAMP(9);
 #ifdef ICS_FFT_TRACE
     ++round;
@@ -604,7 +691,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   }
 }
 
-// ---- spectrum: S[o][c][ky][kx] = conj( sum_{a,b} W_o[a][b][c] w^(a ky + b kx) ) / 128^2,  w = exp(-2 pi i / 128) ------------------------------
+// ---- spectrum: S_o,c[ky][kx] = conj( sum_{a,b} W_o[a][b][c] w^(a ky + b kx) ) / 128^2,  w = exp(-2 pi i / 128), stored at spec_index(c, ky, kx) ----
 // W_0 = rot180(psf) (mode 0), W_1 = psf (mode 1).  Double accumulation (a PSF value enters with its float32 value, the twiddles from a
 // double table built on the device); one workgroup per (orientation, channel, 32 columns kx): G[a][kx] = sum_b W[a][b] w^(b kx) in LDS,
 // then S[ky][kx] = conj(sum_a G[a][kx] w^(a ky)).
@@ -631,7 +718,6 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
     Gs[2 * i] = re; Gs[2 * i + 1] = im;
   }
   __syncthreads();
-  v2f* out = (o == 0 ? spec0 : spec1) + (size_t)c * ICS_FFT_P * ICS_FFT_P;
   for (int i = tid; i < 128 * 32; i += 256) {
     const int ky = i >> 5, kxl = i & 31;
     double re = 0.0, im = 0.0;
@@ -642,7 +728,7 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
       re += gr * wr - gi * wi; im += gr * wi + gi * wr;
     }
     const double sc = 1.0 / (128.0 * 128.0);
-    out[ky * ICS_FFT_P + kx0 + kxl] = (v2f){(float)(re * sc), (float)(-im * sc)};
+    (o == 0 ? spec0 : spec1)[spec_index(c, ky, kx0 + kxl)] = (v2f){(float)(re * sc), (float)(-im * sc)};
   }
 }
 
@@ -664,10 +750,11 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->planar = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
-  a->V = ICS_FFT_P - g.K + 1;
+  a->V = (ICS_FFT_P - g.K + 1) & ~3;     // valid pixels per tile edge, whole quads (16-byte stores never straddle two tiles)
   if (mode == 0) { a->oy0 = g.pad; a->ox0 = g.pad; a->oy1 = g.pad + g.M; a->ox1 = g.pad + g.N; }
   else { a->oy0 = 0; a->ox0 = 0; a->oy1 = g.uM; a->ox1 = g.uN; }
-  a->tiles_x = (a->ox1 - a->ox0 + a->V - 1) / a->V;
+  a->gx0 = a->ox0 & ~3;
+  a->tiles_x = (a->ox1 - a->gx0 + a->V - 1) / a->V;
   const int tiles_y = (a->oy1 - a->oy0 + a->V - 1) / a->V;
   a->ntiles = a->tiles_x * tiles_y;
   a->nunits = 3 * ((a->ntiles + 1) / 2);
@@ -676,6 +763,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
 hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s);
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, int planar, hipStream_t s) {
   if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+  if (planar != ICS_FFT_PL_ALL) return hipErrorInvalidValue;   // every frame a channel-planar mirror: the kernel moves 4 pixels of a plane row per access
   IcsFftArgs a;
   ics_conv_fft_fill_args(mode, c, spec, &a);
   a.planar = planar;

@@ -11,7 +11,7 @@
 
 namespace {
 
-int g_planar = 0;   // ICS_FFT_PLANAR=1: every frame the kernel touches is a channel-planar mirror (ics_common.h)
+int g_planar = 1;   // every frame the kernel touches is a channel-planar mirror (ics_common.h); the HWC form of round 5's first versions is gone
 
 struct Host {
   IcsGeom g;
@@ -106,7 +106,7 @@ void host_spectrum(const Host& h, int o, std::vector<v2f>& spec) {
           const double gr = G[((size_t)a * 128 + kx) * 2], gi = G[((size_t)a * 128 + kx) * 2 + 1];
           re += gr * wr - gi * wi; im += gr * wi + gi * wr;
         }
-        spec[((size_t)c * 128 + ky) * 128 + kx] = (v2f){(float)(re / 16384.0), (float)(-im / 16384.0)};
+        spec[icsfft::spec_index(c, ky, kx)] = (v2f){(float)(re / 16384.0), (float)(-im / 16384.0)};
       }
   }
 }
@@ -122,6 +122,7 @@ IcsConvArgs conv_args(const Host& h, int mode, const float* in, float* out, cons
 double check(const Host& h, int mode, const std::vector<float>& out, int row_step, double* worst_abs) {
   const IcsGeom& g = h.g;
   double worst = 0, ref_max = 0;
+  int nbad = 0;
   const int y0 = mode == 0 ? g.pad : 0, y1 = mode == 0 ? g.pad + g.M : g.uM, x0 = mode == 0 ? g.pad : 0, x1 = mode == 0 ? g.pad + g.N : g.uN;
   for (int y = y0; y < y1; y += (y < y0 + 3 || y >= y1 - 3) ? 1 : row_step)
     for (int x = x0; x < x1; ++x)
@@ -129,7 +130,10 @@ double check(const Host& h, int mode, const std::vector<float>& out, int row_ste
         const size_t o = h.org + (size_t)y * g.pitch + 3 * x + c;
         double r = direct(h, mode, y, x, c);
         ref_max = fmax(ref_max, fabs(r));
+        const double conv = r;
         if (mode == 0) r -= (double)h.f[o];
+        if (getenv("ICS_FFT_DEBUG") && fabs(r - (double)out[o]) > 1e-3 && nbad++ < 200000)
+          fprintf(stderr, "%d %d %d %d %.6f %.6f %.6f %.6f\n", mode, y, x, c, out[o], r, conv, h.f[o]);
         worst = fmax(worst, fabs(r - (double)out[o]));
       }
   *worst_abs = worst;
@@ -148,32 +152,35 @@ int emulate(int M, int K, int N) {
     IcsFftArgs a;
     if (g_planar) ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.pu.data() : h.pe.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec.data(), &a);
     else ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.u.data() : h.e.data(), out.data(), h.f.data(), h.u.data(), h.ut.data(), red), (const float*)spec.data(), &a);
-    if (g_planar) a.planar = 63;
+    a.planar = 63;
     printf("mode %d: V %d, tiles %d (x %d), units %d\n", mode, a.V, a.ntiles, a.tiles_x, a.nunits);
     const icsfft::Mem mem = icsfft::make_mem(a);
     std::vector<v2f> twl(128);
     for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
     for (int n = 0; n < a.nunits; ++n) {
       const icsfft::Unit u = icsfft::decode_unit(a, n);
-      for (int t = 0; t < 1024; ++t) { float pa[2][16]; icsfft::load_a(a, mem, u, t, pa); icsfft::stage_a(pa, lds.data(), t); }
+      for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
       for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
       // C, D, E exchange inside a wave that runs in lock step (reads of all lanes before the writes): C and E read a snapshot here
       { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
-      for (int t = 0; t < 1024; ++t) icsfft::stage_d(mem, u.c, lds.data(), t);
+      for (int t = 0; t < 1024; ++t) { v2f sp[2][8]; icsfft::load_spectrum(mem, u.c, t, sp); icsfft::stage_d(sp, lds.data(), t); }
       { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
       for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
       for (int t = 0; t < 1024; ++t) {
-        v2f v[16];
-        icsfft::stage_g(lds.data(), t, v);
         icsfft::Maxima mx = {0.f, 0.f, false, false, false};
-        if (mode == 0) {
-          float fimg[2][16];
-          icsfft::load_image(a, mem, u, t, fimg);
-          for (int m = 0; m < 16; ++m) v[m] = (v2f){v[m].x - fimg[0][m], v[m].y - fimg[1][m]};
-        } else {
-          for (int k = 0; k < 4; ++k) { icsfft::Ops o; icsfft::load_ops<true>(a, mem, u, t, k, o); icsfft::finish_chunk<true>(a, u, t, k, v, o, mx); }
+        v4f fimg[2][4];
+        icsfft::Ops o;
+        if (mode == 0) icsfft::load_image(a, mem, u, t, fimg);
+        else { icsfft::load_ops<true>(a, mem, u, t, 0, o); icsfft::load_ops<true>(a, mem, u, t, 1, o); }
+        for (int i = 0; i < 4; ++i) {
+          v4f r[2];
+          icsfft::read_quads(lds.data(), t, i, r);
+          if (mode == 0) { r[0] -= fimg[0][i]; r[1] -= fimg[1][i]; }
+          else { icsfft::maxima_quad<true>(a, u, t, 0, i, r[0], o, mx); icsfft::maxima_quad<true>(a, u, t, 1, i, r[1], o, mx); }
+          icsfft::store_quad(a, mem, u, t, 0, i, r[0]); icsfft::store_quad(a, mem, u, t, 1, i, r[1]);
         }
-        icsfft::store_tiles(a, mem, u, t, v);
       }
     }
     if (g_planar) from_planar(h, pout, out);
@@ -216,7 +223,7 @@ int gpu(int M, int K, int N, int reps) {
     CK(hipMemset(dout, 0, fb));
     IcsConvArgs a = conv_args(h, mode, mode == 0 ? du : de, dout, df, du, dut, dred);
     IcsFftArgs fa; ics_conv_fft_fill_args(mode, a, mode == 0 ? dspec0 : dspec1, &fa);
-    if (g_planar) fa.planar = 63;
+    fa.planar = 63;
     CK(ics_launch_conv_fft_args(mode, fa, 0));
     CK(hipDeviceSynchronize());
     std::vector<float> out(h.nf, 0.f);
@@ -239,26 +246,31 @@ int gpu(int M, int K, int N, int reps) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 #ifdef ICS_FFT_TRACE
     {
-      long long* dtr; const size_t nt = (size_t)256 * 16 * 10;
+      long long* dtr; const size_t nt = (size_t)256 * 16 * 16 * 10;
       CK(hipMalloc(&dtr, nt * 8)); CK(hipMemset(dtr, 0, nt * 8));
       fa.trace = dtr;
       CK(ics_launch_conv_fft_args(mode, fa, 0)); CK(hipDeviceSynchronize());
       std::vector<long long> tr(nt);
       CK(hipMemcpy(tr.data(), dtr, nt * 8, hipMemcpyDeviceToHost));
-      static const char* nm[9] = {"barrier", "B", "C", "D spec", "E + loads", "F", "G fft", "epilogue", "A of next"};
-      double sum[10] = {0}; int cnt = 0;
+      static const char* nm[9] = {"barrier", "B", "C", "D spec", "E + loads", "F", "G", "epilogue", "A of next"};
+      // per stamp: when the FIRST and the LAST of the 16 waves pass it, relative to the unit's first stamp (mean over units)
+      double first[10] = {0}, last[10] = {0}, own[9] = {0}; int cnt = 0;
       for (int b = 0; b < 256; b += 5)
         for (int r = 1; r < 8; ++r) {   // rounds 1..7 of every fifth workgroup
-          const long long* t = &tr[((size_t)b * 16 + r) * 10];
+          const long long* t = &tr[(((size_t)b * 16 + r) * 16) * 10];
           if (!t[9] || !t[0]) continue;
-          for (int i = 0; i < 9; ++i) sum[i] += (double)(t[i + 1] - t[i]);
-          sum[9] += (double)(t[0] - tr[((size_t)b * 16 + r - 1) * 10 + 9]);
+          long long t0 = t[0];
+          for (int w = 0; w < 16; ++w) t0 = t[w * 10] < t0 ? t[w * 10] : t0;
+          for (int i = 0; i < 10; ++i) {
+            long long f = t[i], l = t[i];
+            for (int w = 0; w < 16; ++w) { f = t[w * 10 + i] < f ? t[w * 10 + i] : f; l = t[w * 10 + i] > l ? t[w * 10 + i] : l; }
+            first[i] += (double)(f - t0); last[i] += (double)(l - t0);
+          }
+          for (int i = 0; i < 9; ++i) { double s = 0; for (int w = 0; w < 16; ++w) s += (double)(t[w * 10 + i + 1] - t[w * 10 + i]); own[i] += s / 16; }
           ++cnt;
         }
-      printf("  phase timeline of wave 0 (shader clocks, mean of %d units):", cnt);
-      double tot = 0; for (int i = 0; i < 10; ++i) tot += sum[i] / cnt;
-      for (int i = 0; i < 9; ++i) printf("  %s %.0f", nm[i], sum[i] / cnt);
-      printf("  loop %.0f  | total %.0f\n", sum[9] / cnt, tot);
+      printf("  phase timeline (shader clocks from the unit's start, mean of %d units; first wave / last wave to pass each mark; mean time a wave spends in the phase):\n", cnt);
+      for (int i = 0; i < 9; ++i) printf("    %-10s ends %6.0f / %6.0f   own %6.0f\n", nm[i], first[i + 1] / cnt, last[i + 1] / cnt, own[i] / cnt);
       fa.trace = nullptr; hipFree(dtr);
     }
 #endif
@@ -275,7 +287,6 @@ int gpu(int M, int K, int N, int reps) {
 }  // namespace
 
 int main(int argc, char** argv) {
-  if (const char* e = getenv("ICS_FFT_PLANAR")) g_planar = atoi(e);
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
     return emulate(M, K, N);
