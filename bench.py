@@ -111,15 +111,8 @@ def _synth_frame(M, N, MK, seed):
     return image, u0, psf_true, psf_uniform
 
 
-def cpu_baseline(mode, MK, M_full, budget_s=20.0):
-    """The oracle (numpy/scipy port of lib/deconvolution.pyx, same FFT call pattern as the reference: scipy.signal.convolve ->
-    pocketfft, which runs on ONE thread whatever the host has) on the host cores, on a bounded sample: 2048 x 2048 frames,
-    as many whole outer iterations as fit the budget.  MPix/s/iter of this loop falls slowly with the frame size
-    (0.86 at 1024^2, 0.68 at 2048^2 for the compiled reference), so the 2048^2 figure is an upper
-    bound for the 4096^2 workload; one blind outer iteration at 4096^2 takes ~25 s."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import rl_mm_oracle as orc  # cpu_baseline leg only
-    S = 2048
+def _port_outer(orc, mode, MK, S, max_outer, budget_s):
+    """whole outer iterations of the numpy / scipy port on an S x S frame: (MPix/s/iter, outer iterations, seconds)"""
     image, u0, psf_true, psf_uniform = synth_frame(S, S, MK, seed=0)
     psf = (psf_uniform if mode == "blind" else psf_true).copy()
     win = (MK // 2 + 1, 255 - MK // 2 - 1, MK // 2 + 1, 255 - MK // 2 - 1)
@@ -130,9 +123,23 @@ def cpu_baseline(mode, MK, M_full, budget_s=20.0):
         orc.richardson_lucy_MM(image, u, psf, *win, 1e9, S, S, 3, MK, 1, 1e-3, 10000.0, blind=(mode == "blind"), quiet=True)
         outer += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s * 0.5 or outer >= 8:
+        if dt > budget_s or outer >= max_outer:
             break
-    inner = 5 * outer
+    return S * S * 5 * outer / dt / 1e6, outer, dt, (image, u0, psf_true, psf_uniform, win)
+
+
+def cpu_baseline(mode, MK, M_full, budget_s=10.0):
+    """The oracle (numpy/scipy port of lib/deconvolution.pyx, same FFT call pattern as the reference: scipy.signal.convolve ->
+    pocketfft, which runs on ONE thread whatever the host has) on the host cores, on a bounded sample of the METRIC's workload:
+    one outer iteration (5 inner) at the frame size of `value` (~25 s blind at 4096^2) -> `value`; beside it the 2048^2 sample of
+    earlier rounds, the same port with scipy's FFT on 8 workers, and -- static, labelled as such -- the compiled reference's own
+    figures from the survey container (it cannot travel to the GPU box)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rl_mm_oracle as orc  # cpu_baseline leg only
+    S = M_full if M_full <= 4096 else 4096
+    v_full, outer, dt, pack = _port_outer(orc, mode, MK, S, 1, budget_s)
+    v_2048, outer2, dt2, pack2 = (v_full, outer, dt, pack) if S == 2048 else _port_outer(orc, mode, MK, 2048, 4, budget_s * 0.5)
+    image, u0, psf_true, psf_uniform, win = pack2
     # beside it (never `value`): the same port with scipy's FFT allowed up to 8 host cores (scipy.fft.set_workers) -- the reference's own
     # FFT calls are single-threaded, its elementwise loops OpenMP over all cores (lib/deconvolution.pyx:16,484); this bounds what more
     # cores could buy the FFT-dominated loop
@@ -143,30 +150,34 @@ def cpu_baseline(mode, MK, M_full, budget_s=20.0):
         u2, psf2 = u0.copy(), (psf_uniform if mode == "blind" else psf_true).copy()
         t1 = time.perf_counter()
         with scipy.fft.set_workers(ncpu):
-            orc.richardson_lucy_MM(image, u2, psf2, *win, 1e9, S, S, 3, MK, 1, 1e-3, 10000.0, blind=(mode == "blind"), quiet=True)
+            orc.richardson_lucy_MM(image, u2, psf2, *win, 1e9, 2048, 2048, 3, MK, 1, 1e-3, 10000.0, blind=(mode == "blind"), quiet=True)
         d2 = time.perf_counter() - t1
-        mt = {"value": round(S * S * 5 / d2 / 1e6, 4), "unit": "MPixels/s/iter", "fft_workers": ncpu, "sample": "1 outer (= 5 inner) iterations, %.1f s" % d2}
+        mt = {"value": round(2048 * 2048 * 5 / d2 / 1e6, 4), "unit": "MPixels/s/iter", "fft_workers": ncpu, "sample": "2048^2, 1 outer (= 5 inner) iterations, %.1f s" % d2}
     except Exception as exc:   # (a baseline detail must not fail the bench line)
         mt = {"error": str(exc)[:200]}
-    return {"value": round(S * S * inner / dt / 1e6, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port", "fft_8_workers": mt,
+    return {"value": round(v_full, 4), "unit": "MPixels/s/iter", "cores": 1, "kind": "port", "fft_8_workers": mt,
             "host_cores_available": os.cpu_count(),
             "threads": "1 (scipy.signal.convolve -> scipy.fft pocketfft with workers=None = single thread, numpy elementwise single thread; "
                        "OMP_NUM_THREADS=%s)" % os.environ.get("OMP_NUM_THREADS", "unset"),
             "sample": "%s, %dx%dx3, %dx%d PSF, %d outer (=%d inner) iterations of oracle/rl_mm_oracle.py "
-                      "(numpy + scipy.signal.convolve FFT, single thread), %.1f s" % (mode, S, S, MK, MK, outer, inner, dt),
-            "extrapolation": "measured at 2048^2, NOT at the %d^2 of `value`: per-pixel cost of the FFT loop grows slowly with size, so this is an upper bound for %d^2" % (M_full, M_full),
-            "static_notes": {"reference_compiled": "BASELINE.md section 2 holds the compiled reference's own figures (survey container, 8 OpenMP threads); "
-                                                   "they are not measured in this run and therefore not repeated here -- the reference cannot travel to the GPU box"}}
+                      "(numpy + scipy.signal.convolve FFT, single thread), %.1f s" % (mode, S, S, MK, MK, outer, 5 * outer, dt),
+            "at_2048": {"value": round(v_2048, 4), "sample": "%d outer iterations at 2048^2, %.1f s (the sample of rounds 1-4)" % (outer2, dt2)},
+            "reference_compiled_static": {"note": "NOT measured in this run: the compiled reference (lib/deconvolution.pyx, Cython -O3 -fopenmp, 8 OpenMP threads, scipy FFT single-threaded) "
+                                                  "in the survey container, BASELINE.md section 2; it cannot travel to the GPU box",
+                                          "MPixels_per_s_per_iter": {"nonblind_2048_k15": 1.80, "blind_2048_k15": 0.68, "blind_1024_k15": 0.86, "nonblind_512_k9": 2.98}}}
 
 
 def mfma_counters(kernel, M, MK):
     """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/r04_mfma_counters.json, written by
     scripts/make_mfma_json.py from rocprofv3 --pmc runs): static, NOT measured in this run -- like `traffic`."""
     try:
-        for name in ("r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
-            mj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        for name in ("r05_mfma_counters.json", "r05_6144_31_mfma_counters.json", "r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
+            fn = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(fn):
+                continue
+            mj = json.load(open(fn))
             if mj["workload"] == {"size": M, "psf": MK} and kernel in mj["kernels"]:
-                return dict(mj["kernels"][kernel], source="profiles/%s (static: rocprofv3 SQ passes of an earlier run of this command)" % name)
+                return dict(mj["kernels"][kernel], source="profiles/%s (static: rocprofv3 SQ passes of a run of this command at commit %s)" % (name, mj.get("commit", "unrecorded")))
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -427,12 +438,12 @@ def main():
         names = _native.KERNEL_NAMES
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
-        traffic, traffic_file = None, "profiles/r04_hbm_traffic.json"
-        for tf in ("profiles/r04_hbm_traffic.json", "profiles/r04_6144_31_hbm_traffic.json"):
+        traffic, traffic_file, traffic_commit = None, "profiles/r05_hbm_traffic.json", "unrecorded"
+        for tf in ("profiles/r05_hbm_traffic.json", "profiles/r05_6144_31_hbm_traffic.json", "profiles/r04_hbm_traffic.json", "profiles/r04_6144_31_hbm_traffic.json"):
             try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
                 tj = json.load(open(os.path.join(ROOT, tf)))
-                if tj["workload"] == {"size": M, "psf": MK}:
-                    traffic, traffic_file = tj[lab["traffic_key"]], tf
+                if tj["workload"] == {"size": M, "psf": MK} and lab["traffic_key"] in tj:
+                    traffic, traffic_file, traffic_commit = tj[lab["traffic_key"]], tf, tj.get("commit", "unrecorded")
                     break
             except (OSError, ValueError, KeyError):
                 traffic = None
@@ -446,7 +457,7 @@ def main():
                     "mfma": mfma_counters(dom, M, MK), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": (traffic[dom]["hbm_bytes"] if traffic and dom in traffic else None),
-                    "traffic_source": "%s (static: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of an earlier run of this command, not measured live)" % traffic_file,
+                    "traffic_source": "%s (static: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE passes of a run of this command at commit %s, not measured live)" % (traffic_file, traffic_commit),
                     "algorithmic_bytes_per_launch": bytes_launch, "avg_launch_ms": kern[dom]["ms"],
                     "per_kernel": {k: {"algorithmic_GBps": round(BYTES_PER_PX[k] * M * N / (kern[k]["ms"] * 1e-3) / 1e9, 1),
                                        "frac": round(BYTES_PER_PX[k] * M * N / (kern[k]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -476,6 +487,10 @@ def main():
         if grp.size == 1 and not args.no_other_configs and args.size == 4096 and args.psf == 15 and args.tv_mode == 0 and not args.fuse:
             # secondary lines (never `value`): the other BASELINE.json configurations and the build-defined TV variants they name
             out["conv_rel_err_vs_f64"] = conv_rel_err(ctx, MK)
+            # the headline's default path forms its products from two fp16 terms per operand (22 significand bits); the same workload with
+            # fp32 products throughout, every round, beside it: packed-fp32 vector convolutions + fp32-MFMA gradient, and the fp32 transform tiles
+            out["fp32_product_paths"] = {"vector (ics_conv.hip + fp32-MFMA PSF gradient)": timed_run(ctx, M, MK, blind, 0, 1, 50, 10),
+                                         "fft tiles (ics_conv_fft.hip; PSF gradient on the matrix cores)": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
             oc = {}
             oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)

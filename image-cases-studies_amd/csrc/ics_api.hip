@@ -810,8 +810,12 @@ struct Prof {
 // ---- row bands over several ranks: the two per-iteration reductions, in place on the device (lib/banded.py rank mode) -----------
 int ics_group_allreduce_device(ics_group* g, void* buf, size_t count, int kind, hipStream_t stream);   // ics_group.hip
 int ics_group_info_local(const ics_group* g);
+int ics_group_device(const ics_group* g);   // ics_group.hip
 extern "C" int ics_rl_allreduce_keys(ics_rl* j, ics_group* g) {
   if (!j || !g) return fail(ICS_EINVAL, "NULL argument");
+  if (!ics_group_info_local(g) && ics_group_device(g) != j->ctx->device)   // (the collective runs on the job's stream with the group's communicator)
+    return fail(ICS_EINVAL, "the job lives on device %d, the group's communicator on device %d", j->ctx->device, ics_group_device(g));
+  if (j->par != 0) return fail(ICS_ESTATE, "ics_rl_allreduce_keys acts on reduction set 0 (stage API); the job is inside an overlapped run");
   HIPCHK(hipSetDevice(j->ctx->device));
   return ics_group_allreduce_device(g, j->red, 6, 0, j->ctx->stream);      // slot 0: [0..2] max|g_k|, [3..5] max u_k
 }
@@ -820,6 +824,8 @@ extern "C" int ics_rl_allreduce_gradk(ics_rl* j, ics_group* g) {
   int rank = 0, world = 1;
   RC(ics_group_info(g, &rank, &world));
   if (world == 1 && ics_group_info_local(g)) return ICS_OK;
+  if (!ics_group_info_local(g) && ics_group_device(g) != j->ctx->device)
+    return fail(ICS_EINVAL, "the job lives on device %d, the group's communicator on device %d", j->ctx->device, ics_group_device(g));
   HIPCHK(hipSetDevice(j->ctx->device));
   const size_t n = (size_t)3 * j->g.K * j->g.K;
   if (!j->gradk64) RC(dalloc(j->ctx, &j->gradk64, n, false));

@@ -246,6 +246,7 @@ int ics_group_allreduce_device(ics_group* g, void* buf, size_t count, int kind, 
 }
 
 int ics_group_info_local(const ics_group* g) { return g && g->local ? 1 : 0; }
+int ics_group_device(const ics_group* g) { return g ? g->device : -1; }
 
 // all ranks have reached this call (an all-reduce of one double)
 extern "C" int ics_group_barrier(ics_group* g) {

@@ -49,7 +49,16 @@ def _check_buffer(name, arr):
 # picture: with 4 cached jobs every call built a new one (24 buffers, a pinned mirror, events; ~1 ms).  Least recently used out, by count
 # and by device bytes (a job holds 7-8 frames of its size).
 _JOB_CACHE_MAX = 16
-_JOB_CACHE_MAX_BYTES = 32 << 30
+_JOB_CACHE_MAX_BYTES = 32 << 30      # (upper bound; the effective limit is a quarter of the device's memory, _cache_limit)
+
+
+def _cache_limit():
+    """bytes of device frames the cache may hold: a quarter of the device's memory (ics_ctx_info), at most _JOB_CACHE_MAX_BYTES --
+    a card smaller than an MI355X, or two processes on one, must not find the cache in the way of an allocation"""
+    try:
+        return min(_JOB_CACHE_MAX_BYTES, _native.Context.get(_native.default_device()).hbm_bytes // 4)
+    except Exception:
+        return _JOB_CACHE_MAX_BYTES
 
 
 def _get_job(M, N, MK):
@@ -59,17 +68,27 @@ def _get_job(M, N, MK):
     key = (int(M), int(N), int(MK), _native.default_device())
     job = _job_cache.pop(key, None)
     if job is None:
-        need = _job_bytes(key)
-        while _job_cache and (len(_job_cache) >= _JOB_CACHE_MAX or need + sum(_job_bytes(k) for k in _job_cache) > _JOB_CACHE_MAX_BYTES):
+        need, limit = _job_bytes(key), _cache_limit()
+        while _job_cache and (len(_job_cache) >= _JOB_CACHE_MAX or need + sum(_job_bytes(k) for k in _job_cache) > limit):
             _job_cache.pop(next(iter(_job_cache))).close()
-        job = _native.RLJob(M, N, MK)
+        try:
+            job = _native.RLJob(M, N, MK)
+        except _native.NativeError as exc:
+            if exc.code != _native.ICS_ENOMEM or not _job_cache:
+                raise
+            _drop_jobs()                       # out of device memory with cached jobs alive: release them and try once more
+            job = _native.RLJob(M, N, MK)
     _job_cache[key] = job            # (re)inserted last = most recently used
     return job
 
 
 def _job_bytes(key):
+    """device bytes a job of this shape can come to hold: 6 frames at creation, the ping-pong residual frame and the image's
+    accumulator-order copies of the overlapped / matrix-core runs (3 more), the 7 channel-planar mirrors of the FFT-tile pipeline
+    from PSF size 17 on, the scratch frames of the tap-block path above 49"""
     M, N, MK = key[:3]
-    return 8 * (M + 2 * MK) * (N + 2 * MK) * 12
+    frames = 9 + (7 if 17 <= MK <= 65 else 0) + (2 if MK >= 51 else 0)
+    return frames * (M + 2 * MK + 128) * (N + 2 * MK + 128) * 12
 
 
 def _drop_jobs():
