@@ -225,7 +225,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -236,7 +236,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -852,8 +852,10 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
 // ahead of the matrix-core kernels (fft_preferred); ICS_CONV_PATH=fft|matrix|vector overrides AUTO.
 static bool fft_preferred(const IcsGeom& g) {
   // measured on MI355X: per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
-  // the Toeplitz matrix-core kernels pay K^2: the tiles win from the two-window sizes (K >= 17) on, on frames that fill the device
-  return g.K >= 17 && (long)g.uM * g.uN >= 1500000L;
+  // the Toeplitz matrix-core kernels pay K^2.  scripts/ab_fft.py, ms per inner iteration, matrix cores -> tiles (non-blind / blind):
+  // 2048^2 17: 0.173 -> 0.200 / 0.317 -> 0.368; 21: 0.271 -> 0.198 / 0.437 -> 0.379; 31: 0.303 -> 0.181 / 0.492 -> 0.383;
+  // 4096^2 17: level / 1.110 -> 1.141; 21: 0.949 -> 0.616 / 1.599 -> 1.135; 1448^2 31: 0.194 -> 0.131 / 0.327 -> 0.274; 1024^2 31: 0.117 -> 0.104 / 0.201 -> 0.215.
+  return g.K >= 19 && (long)g.uM * g.uN >= 1500000L;
 }
 static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (!ics_conv_fft_supported(j->g.K) || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
@@ -1083,7 +1085,16 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
   return ICS_OK;
 }
 
+// the FFT-tile pipeline's own PSF gradient (k_gradk_fft): two forward transforms per tile pair, products added up in the frequency domain
+static bool use_fft_gradk(const ics_rl* j) { return j->fft_on && ics_debug().fft_gradk.load(std::memory_order_relaxed) != 0; }
+
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  if (use_fft_gradk(j)) {
+    RC(pr.begin(ICS_K_PSF_GRADIENT));
+    HIPCHK(ics_launch_gradk_fft(porg(j, j->u), porg(j, j->e), j->g, j->partial, j->gradk, j->ctx->stream));
+    RC(pr.end());
+    return ICS_OK;
+  }
   if (use_split_gradk(j, p)) return do_gradk_split(j, pr);
   IcsGradkArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.partial = j->partial; a.geo = j->g; a.planar = 0;
@@ -1261,6 +1272,7 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
   if (p->blind) {
     const bool fused = !p->fuse && use_fused_gradk(j, p);
     if (fused) r->gradk_family = 1;
+    else if (use_fft_gradk(j)) r->gradk_family = 6;
     else if (use_split_gradk(j, p)) r->gradk_family = 3;
     else if (ics_big_supported(j->g.K)) r->gradk_family = 5;
     else r->gradk_family = use_matrix_gradk(j, p) ? 2 : 4;

@@ -164,12 +164,12 @@ __device__ __forceinline__ v2f cmulc_s(v2f a, v2f b) {
 __device__ __forceinline__ v2f add_mi(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ v2f add_pi(v2f a, v2f b) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
 #else
-static inline v2f cmul(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
-static inline v2f cmulc(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){b.y, b.x}, (v2f){a.x, a.x} * (v2f){b.x, -b.y}); }
-static inline v2f cmul_s(v2f a, v2f b) { return cmul(a, b); }
-static inline v2f cmulc_s(v2f a, v2f b) { return cmulc(a, b); }
-static inline v2f add_mi(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
-static inline v2f add_pi(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
+ICS_FFT_HD v2f cmul(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
+ICS_FFT_HD v2f cmulc(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){b.y, b.x}, (v2f){a.x, a.x} * (v2f){b.x, -b.y}); }
+ICS_FFT_HD v2f cmul_s(v2f a, v2f b) { return cmul(a, b); }
+ICS_FFT_HD v2f cmulc_s(v2f a, v2f b) { return cmulc(a, b); }
+ICS_FFT_HD v2f add_mi(v2f a, v2f b) { return (v2f){a.x + b.y, a.y - b.x}; }
+ICS_FFT_HD v2f add_pi(v2f a, v2f b) { return (v2f){a.x - b.y, a.y + b.x}; }
 #endif
 // products with COMPILE-TIME constants stay in C++: the compiler folds the swapped / negated constant and reads it from scalar registers
 ICS_FFT_HD v2f cmulk(v2f a, v2f b) { return __builtin_elementwise_fma((v2f){a.y, a.y}, (v2f){-b.y, b.x}, (v2f){a.x, a.x} * b); }
@@ -367,24 +367,28 @@ ICS_FFT_HD int skew_col(int j, int k1) { return 8 * k1 + ((j + k1) & 7); }
 //  runs the threads one after the other, passes a snapshot)
 // (`twl` = the 128 twiddles in LDS behind the tile: the lane-dependent ones of C and E are read from there, all fifteen requested ahead of
 //  the transform; the skewed columns are eight base addresses (j + s) % 8, s = k1 % 8, plus compile-time offsets)
+template <int TWB = 8>   // twiddles requested TWB at a time (8: two halves; 4: the PSF-gradient kernel, which holds 64 registers of spectra beside this stage)
 ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16], tw[8];
+  v2f v[16], tw[TWB];
   const v2f* rp = rd + row * ICS_FFT_PITCH + j;
 #pragma unroll
   for (int m = 0; m < 16; ++m) v[m] = lds_ld(rp + 8 * m);
+  if (TWB == 8) {
 #pragma unroll
-  for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));   // (in two halves of eight: registers)
+    for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+  }
   fft16<1>(v);
-  v2f* cb[8];
+  v2f* const rowp = lds + row * ICS_FFT_PITCH;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) cb[s] = lds + row * ICS_FFT_PITCH + ((j + s) & 7);
+  for (int h = 0; h < 16 / TWB; ++h) {
+    if (TWB != 8 || h > 0) {
 #pragma unroll
-  for (int k1 = 0; k1 < 8; ++k1) cb[k1][8 * k1] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
+      for (int k1 = TWB * h; k1 < TWB * h + TWB; ++k1) if (k1) tw[k1 - TWB * h] = lds_ld(twl + ((j * k1) & 127));
+    }
 #pragma unroll
-  for (int k1 = 8; k1 < 16; ++k1) tw[k1 - 8] = lds_ld(twl + ((j * k1) & 127));
-#pragma unroll
-  for (int k1 = 8; k1 < 16; ++k1) cb[k1 - 8][8 * k1] = cmul(v[k1], tw[k1 - 8]);
+    for (int k1 = TWB * h; k1 < TWB * h + TWB; ++k1) rowp[8 * k1 + ((j + k1) & 7)] = k1 ? cmul(v[k1], tw[k1 - TWB * h]) : v[k1];
+  }
 }
 
 // The spectrum values a thread multiplies by in stage D: row -> ky, kx = q + 8 s + 16 k2 (from L2: 384 KB for the three channels).  Requested
@@ -423,6 +427,33 @@ ICS_FFT_HD void stage_d(const v2f (&sp)[2][8], v2f* lds, int tid) {
     fft8<-1>(v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) db[j][64 * s] = v[j];
+  }
+}
+
+// The two halves of stage D on their own (PSF gradient, k_gradk_fft): the 2-D spectrum of the tile in the thread's registers -- sixteen
+// values, the same (ky, kx) in the same slot for every tile -- and the way back from such a set of values.
+ICS_FFT_HD void stage_d_forward(const v2f* lds, int tid, v2f (&z)[2][8]) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    v2f v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = lds_ld(lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s);
+    fft8<1>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) z[s][k2] = v[k2];
+  }
+}
+ICS_FFT_HD void stage_d_inverse(const v2f (&z)[2][8], v2f* lds, int tid) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    v2f v[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) v[k2] = z[s][k2];
+    fft8<-1>(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s] = v[j];
   }
 }
 
@@ -691,6 +722,89 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   }
 }
 
+// ---- A12 + A13 (lib/deconvolution.pyx:567-571): the PSF gradient on the same tiles -----------------------------------------------------------
+//     gradk[a, b, c] = sum_{y,x} e'[y, x, c] u[y + pad - a, x + pad - b, c]            (u-frame coordinates; e' = 0 outside the M x N interior)
+// Per tile of V x V residual pixels with the 128 x 128 window t of u that starts pad pixels up and left of it:
+//     g[a][b] = sum_{v,h<V} e'[v][h] t[v + K-1-a][h + K-1-b] = corr(e' zero-padded, t) at lag (K-1-a, K-1-b) < K  (no wrap-around: v + lag <= 127)
+// and corr = IDFT( conj(DFT e') . DFT t ).  The two tiles of a pair travel as real and imaginary part as in the convolutions:
+// conj(E0 + i E1) (T0 + i T1) = conj(E0) T0 + conj(E1) T1 + i (...), and the transforms of the first two terms are REAL -- the real part of
+// the inverse transform is the sum of both tiles' correlations.  The product is linear: a workgroup keeps ONE channel, adds the products
+// of all its tile pairs up in the frequency domain (sixteen complex values per thread) and transforms back once at the end -- two forward
+// transforms per pair and no inverse; one K x K block per workgroup, added up in double by k_gradk_fft_reduce in a fixed order.
+// fp32 throughout.  Against float64 direct sums on the test frames 1 - 3e-7 of max |gradk| (gate 1e-5); the error scales with
+// |e'| |u| of a tile rather than with the sums themselves, so a residual that is pure noise uncorrelated with u is the worst case (4e-5
+// estimated for sigma 1e-2 at 600 x 700) -- the matrix-core kernel (ics_gradk_mfma.hip) stays behind conv = ICS_CONV_MATRIX.
+template <int DUMMY>
+__global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) v2f lds[];
+  v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
+  const int tid = threadIdx.x;
+  if (tid < 128) twl[tid] = tw128(tid);
+  const Mem mem = make_mem(a, 0);                 // in = u, f = e' (the geometry of mode 0: tiles of the M x N interior)
+  const int c = (int)blockIdx.x % 3, slot = (int)blockIdx.x / 3, nslots = (int)gridDim.x / 3, npairs = (a.ntiles + 1) / 2;
+  v2f acc[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
+  for (int p = slot; p < npairs; p += nslots) {
+    const Unit u = decode_unit(a, 3 * p + c);
+    v4f pe[2][4], pw[2][4];
+    load_image(a, mem, u, opaque(tid), pe);       // the residual tiles, zero beyond V x V and beyond the interior
+    lds_barrier();                                // (the previous pair's stage D has read the tile)
+    store_window(pe, lds, opaque(tid));
+    lds_barrier();
+    stage_a(lds, opaque(tid));
+    load_window(a, mem, u, opaque(tid), pw);      // (behind stage A: registers)
+    lds_barrier();
+    stage_b<1>(lds, opaque(tid));
+    lds_barrier();
+    stage_c<4>(lds, lds, twl, opaque(tid));
+    wave_sync();
+    v2f ze[2][8];
+    stage_d_forward(lds, opaque(tid), ze);
+    lds_barrier();
+    store_window(pw, lds, opaque(tid));
+    lds_barrier();
+    stage_a(lds, opaque(tid));
+    lds_barrier();
+    stage_b<1>(lds, opaque(tid));
+    lds_barrier();
+    stage_c<4>(lds, lds, twl, opaque(tid));
+    wave_sync();
+    v2f zu[2][8];
+    stage_d_forward(lds, opaque(tid), zu);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[s][k] += cmulc(zu[s][k], ze[s][k]);     // += DFT(t) conj(DFT(e'))
+  }
+  lds_barrier();
+  stage_d_inverse(acc, lds, opaque(tid));
+  wave_sync();
+  stage_e(lds, lds, twl, opaque(tid));
+  lds_barrier();
+  stage_b<-1>(lds, opaque(tid));
+  lds_barrier();
+  stage_g(lds, opaque(tid));
+  lds_barrier();
+  const int K = a.c.g.K;
+  for (int i = tid; i < K * K; i += ICS_FFT_THREADS) {
+    const int aa = i / K, bb = i - aa * K;
+    partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
+  }
+}
+
+// gradk[a][b][c] = sum of the blocks of the workgroups that kept channel c (block % 3 == c), in double, in block order
+__global__ __launch_bounds__(256) void k_gradk_fft_reduce(const float* __restrict__ partial, int nblocks, int K, float* __restrict__ gradk) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * K * K) return;
+  const int c = i % 3, ab = i / 3;
+  double s = 0.0;
+  for (int b = c; b < nblocks; b += 3) s += (double)partial[(size_t)b * K * K + ab];
+  gradk[i] = (float)s;
+}
+
 // ---- spectrum: S_o,c[ky][kx] = conj( sum_{a,b} W_o[a][b][c] w^(a ky + b kx) ) / 128^2,  w = exp(-2 pi i / 128), stored at spec_index(c, ky, kx) ----
 // W_0 = rot180(psf) (mode 0), W_1 = psf (mode 1).  Double accumulation (a PSF value enters with its float32 value, the twiddles from a
 // double table built on the device); one workgroup per (orientation, channel, 32 columns kx): G[a][kx] = sum_b W[a][b] w^(b kx) in LDS,
@@ -784,6 +898,30 @@ hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s
   const int slot = mode == 0 ? 0 : 1;
   if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+// A12 + A13 on the transform tiles: u and e = origins of channel-planar mirrors; partial: ics_gradk_fft_blocks() * K * K floats
+int ics_gradk_fft_blocks(int cus) {
+  int grid = (cus / 3) * 3;
+  if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = (mw / 3) * 3;
+  return grid < 3 ? 3 : grid;
+}
+hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g, float* partial, float* gradk, hipStream_t s) {
+  IcsConvArgs c;
+  memset(&c, 0, sizeof c);
+  c.g = g; c.in = u; c.f = e; c.out = const_cast<float*>(e); c.u = u; c.ut = u;
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(0, c, nullptr, &a);
+  a.planar = ICS_FFT_PL_ALL;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  int grid = ics_gradk_fft_blocks(ics_device_cus(dev));
+  const int npairs = (a.ntiles + 1) / 2;
+  if (grid > 3 * npairs) grid = 3 * npairs;
+  auto kern = icsfft::k_gradk_fft<0>;
+  if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
+  hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 255) / 256), dim3(256), 0, s, partial, grid, g.K, gradk);
   return hipGetLastError();
 }
 #endif

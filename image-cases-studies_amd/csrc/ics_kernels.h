@@ -88,6 +88,9 @@ hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, fl
 #define ICS_FFT_PL_TV 32
 #define ICS_FFT_PL_ALL 63
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& a, const float* spec, int planar, hipStream_t s);
+// A12 + A13 on the same tiles (fp32): u, e = origins of planar mirrors; partial = ics_gradk_fft_blocks(cus) * K * K floats of scratch
+int ics_gradk_fft_blocks(int cus);
+hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g, float* partial, float* gradk, hipStream_t s);
 
 // ---- zero-fill of up to ICS_ZERO_MAX device blocks in one launch (the ~24 buffers of a new job: one launch instead of 24 memsets) ----
 #define ICS_ZERO_MAX 32

@@ -192,6 +192,67 @@ int emulate(int M, int K, int N) {
   return rc;
 }
 
+// float64 direct sum of one tap of the PSF gradient: gradk[a][b][c] = sum over the interior of e'[y][x] u[y + pad - a][x + pad - b]
+double direct_gradk(const Host& h, const std::vector<float>& e, int a, int b, int c) {
+  const IcsGeom& g = h.g;
+  double s = 0.0;
+  for (int y = g.pad; y < g.pad + g.M; ++y)
+    for (int x = g.pad; x < g.pad + g.N; ++x)
+      s += (double)e[h.org + (size_t)y * g.pitch + 3 * x + c] * (double)h.u[h.org + (size_t)(y + g.pad - a) * g.pitch + 3 * (x + g.pad - b) + c];
+  return s;
+}
+double check_gradk(const Host& h, const std::vector<float>& e, const std::vector<float>& gk, int stride) {
+  const int K = h.g.K;
+  double worst = 0, m = 0;
+  for (int a = 0; a < K; a += stride)
+    for (int b = 0; b < K; b += (a % 2 ? stride : 1))
+      for (int c = 0; c < 3; ++c) {
+        const double r = direct_gradk(h, e, a, b, c);
+        m = fmax(m, fabs(r)); worst = fmax(worst, fabs(r - (double)gk[((size_t)a * K + b) * 3 + c]));
+      }
+  return worst / m;
+}
+
+int emulate_gradk(int M, int K, int N) {
+  Host h = make_host(M, N, K);
+  // a residual with structure (as in the loop: e' = conv(u) - image), not the harness' white noise alone
+  for (size_t i = 0; i < h.nf; ++i) h.e[i] = h.e[i] + 0.01f * (h.u[i] - 0.5f) * (h.f[i] != 0.f);
+  to_planar(h, h.e, h.pe);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(128);
+  for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
+  IcsConvArgs c = conv_args(h, 0, h.pu.data(), h.pe.data(), h.pe.data(), h.pu.data(), h.pu.data(), nullptr);
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(0, c, nullptr, &a);
+  a.planar = 63;
+  const icsfft::Mem mem = icsfft::make_mem(a);
+  std::vector<float> gk((size_t)K * K * 3, 0.f);
+  const int npairs = (a.ntiles + 1) / 2;
+  for (int ch = 0; ch < 3; ++ch) {           // one "workgroup" per channel
+    std::vector<v2f> acc((size_t)1024 * 16, (v2f){0.f, 0.f});
+    for (int p = 0; p < npairs; ++p) {
+      const icsfft::Unit u = icsfft::decode_unit(a, 3 * p + ch);
+      std::vector<v2f> ze((size_t)1024 * 16), zu((size_t)1024 * 16);
+      for (int pass = 0; pass < 2; ++pass) {
+        for (int t = 0; t < 1024; ++t) { v4f q[2][4]; if (pass == 0) icsfft::load_image(a, mem, u, t, q); else icsfft::load_window(a, mem, u, t, q); icsfft::store_window(q, lds.data(), t); }
+        for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+        for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+        { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+        for (int t = 0; t < 1024; ++t) { v2f z[2][8]; icsfft::stage_d_forward(lds.data(), t, z); for (int i = 0; i < 16; ++i) (pass ? zu : ze)[(size_t)t * 16 + i] = z[i >> 3][i & 7]; }
+      }
+      for (size_t i = 0; i < acc.size(); ++i) acc[i] += icsfft::cmulc(zu[i], ze[i]);
+    }
+    for (int t = 0; t < 1024; ++t) { v2f z[2][8]; for (int i = 0; i < 16; ++i) z[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; icsfft::stage_d_inverse(z, lds.data(), t); }
+    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+    for (int aa = 0; aa < K; ++aa)
+      for (int bb = 0; bb < K; ++bb) gk[((size_t)aa * K + bb) * 3 + ch] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x / 16384.f;
+  }
+  const double rel = check_gradk(h, h.e, gk, 3);
+  printf("emulation %d x %d, K = %d, PSF gradient: relative to max |gradk| = %.3e  %s\n", M, N, K, rel, rel < 1e-5 ? "OK" : "FAIL");
+  return rel < 1e-5 ? 0 : 1;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 int gpu(int M, int K, int N, int reps) {
@@ -276,6 +337,29 @@ int gpu(int M, int K, int N, int reps) {
 #endif
     printf("  mode %d: %.4f ms per launch (%d launches), %d units, %.2f us per unit and CU\n", mode, ms / reps, reps, fa.nunits, 1e3 * ms / reps / ((fa.nunits + 255) / 256));
   }
+  {   // the PSF gradient on the tiles
+    std::vector<float> es = h.e;
+    for (size_t i = 0; i < h.nf; ++i) es[i] = es[i] + 0.01f * (h.u[i] - 0.5f) * (h.f[i] != 0.f);
+    std::vector<float> pes; to_planar(h, es, pes);
+    CK(hipMemcpy(de, pes.data(), fb, hipMemcpyHostToDevice));
+    float *dpart, *dgk;
+    CK(hipMalloc(&dpart, (size_t)768 * K * K * 4)); CK(hipMalloc(&dgk, (size_t)3 * K * K * 4));
+    CK(ics_launch_gradk_fft(du + h.porg, de + h.porg, h.g, dpart, dgk, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> gk((size_t)3 * K * K);
+    CK(hipMemcpy(gk.data(), dgk, gk.size() * 4, hipMemcpyDeviceToHost));
+    if ((long)M * N <= 1200L * 1200L) {
+      const double rel = check_gradk(h, es, gk, M <= 400 ? 2 : 7);
+      printf("GPU %d x %d, K = %d, PSF gradient: relative to max |gradk| = %.3e  %s\n", M, N, K, rel, rel < 1e-5 ? "OK" : "FAIL");
+      if (!(rel < 1e-5)) rc = 1;
+    }
+    for (int i = 0; i < 3; ++i) CK(ics_launch_gradk_fft(du + h.porg, de + h.porg, h.g, dpart, dgk, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_gradk_fft(du + h.porg, de + h.porg, h.g, dpart, dgk, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float msg; CK(hipEventElapsedTime(&msg, e0, e1));
+    printf("  PSF gradient on the tiles: %.4f ms per launch (kernel + reduction)\n", msg / reps);
+  }
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -289,7 +373,7 @@ int gpu(int M, int K, int N, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
-    return emulate(M, K, N);
+    return emulate(M, K, N) | emulate_gradk(M, K, N);
   }
   const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
   return gpu(M, K, N, reps);

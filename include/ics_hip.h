@@ -134,7 +134,8 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                              FFTs held in LDS, fp32 throughout -- the reference's own method (scipy's complex64 FFT over the frame,
                              lib/deconvolution.pyx:478,491), tile by tile; against float64 direct sums 2 - 5e-7 of the largest
                              convolution value.  The frames live as channel-planar mirrors for the duration of a run; the PSF gradient
-                             stays on the matrix cores.  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 17 on for frames
+                             runs on the same tiles (two forward transforms per tile pair, products added up in the frequency domain; env
+                             ICS_FFT_GRADK=0: on the matrix cores).  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 19 on for frames
                              >= 1.5 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.  Where image and u are exactly 0 the
                              transforms return rounding noise instead of exact zeros, like the reference's (see "DoF ratio" below) */
 
@@ -219,7 +220,7 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
  * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip), 5 fp32 transform tiles on planar
  * mirrors (ics_conv_fft.hip);  PSF gradient A13 -- 1 fused with
  * A11 (k_synth_gradk, MK <= 15), 2 fp16-split matrix cores (k_gradk_mfma), 3 the same as tap blocks (MK >= 33), 4 fp32 MFMA
- * (k_gradk), 5 run-time-sized fp32 (k_gradk_big); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
+ * (k_gradk), 5 run-time-sized fp32 (k_gradk_big), 6 fp32 transform tiles (k_gradk_fft, ics_conv_fft.hip); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
  * stage are formed from two fp16 terms per operand (22 significand bits, fp32 accumulation), 0 = fp32 products. */
 typedef struct ics_rl_route {
   uint32_t struct_size; /* in: sizeof(ics_rl_route) */

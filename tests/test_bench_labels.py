@@ -28,9 +28,9 @@ def test_labels_follow_the_library_routing(MK, blind):
         assert lab["matrix"] == bool(r.conv_fp16_split)
         assert lab["traffic_key"] == ("kernels_fft" if r.conv_family == 5 else ("kernels_matrix" if r.conv_fp16_split else "kernels_vector"))
         assert lab["conv"] == nv.RLRoute.CONV_FAMILIES[r.conv_family] and lab["gradk"] == nv.RLRoute.GRADK_FAMILIES[r.gradk_family]
-        if conv == nv.CONV_AUTO and 17 <= MK <= 65:      # round 5: fp32 transform tiles for the two-window sizes on frames >= 1.5 Mpx
-            assert r.conv_fp16_split == 0 and r.conv_family == 5 and "FFT tiles" in lab["dtype_note"]
-            assert r.gradk_family == (0 if not blind else (2 if MK <= 31 else 3))
+        if conv == nv.CONV_AUTO and 19 <= MK <= 65:      # round 5: fp32 transform tiles for wide PSFs on frames >= 1.5 Mpx, the PSF gradient included
+            assert r.conv_fp16_split == 0 and r.conv_family == 5 and "FFT tiles" in lab["dtype_note"] and lab["dtype"] == "f32"
+            assert r.gradk_family == (6 if blind else 0) and r.gradk_fp16_split == 0
             small = _route(512, MK, blind, conv)         # ... and the matrix cores below that
             assert small.conv_fp16_split == 1 and small.conv_family == (1 if MK <= 49 else 2)
         elif conv == nv.CONV_AUTO:    # every PSF size has a matrix-core path since round 3

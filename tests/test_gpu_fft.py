@@ -66,8 +66,9 @@ def test_fft_convolutions_against_float64(M, N, MK):
 
 
 @pytest.mark.parametrize("M,N,MK,blind", [(130, 67, 9, True), (257, 300, 15, True), (100, 90, 31, False), (97, 133, 45, True)])
-def test_planar_update_and_gradient_equal_the_hwc_passes(M, N, MK, blind):
+def test_planar_update_and_gradient_equal_the_hwc_passes(M, N, MK, blind, debug_switch):
     from lib import _native as nv
+    debug_switch("fft_gradk", 0)      # the pipeline's matrix-core gradient on the mirrors (k_gradk_mfma<NB, true>), not the one on the tiles
     out = {}
     for conv in (2, FFT):
         job, case, psf = make_job(M, N, MK, seed=M + N, blind=blind)
@@ -96,13 +97,15 @@ def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
     def describe(M, N, MK, **kw):
         return nv.describe(M, N, MK, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True, **kw))
     r = describe(2048, 2048, 31)
-    assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 2
+    assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 6 and r.gradk_fp16_split == 0
+    r = describe(2048, 2048, 17)
+    assert r.conv_family == 1
     r = describe(2048, 2048, 15)
     assert r.conv_family == 1 and r.gradk_family == 1
     r = describe(300, 300, 31)
     assert r.conv_family == 1
     r = describe(2048, 2048, 45, conv=FFT)
-    assert r.conv_family == 5 and r.gradk_family == 3
+    assert r.conv_family == 5 and r.gradk_family == 6
     r = describe(2048, 2048, 31, tv_mode=2)
     assert r.conv_family == 1
 
@@ -129,3 +132,64 @@ def test_whole_run_on_the_tiles_equals_the_matrix_core_run(blind):
     for a, b in ((res[0][2].trace_M_r, res[2][2].trace_M_r), (res[0][2].trace_Hu, res[2][2].trace_Hu), (res[0][2].trace_varu, res[2][2].trace_varu)):
         np.testing.assert_allclose(np.array(a[:2]), np.array(b[:2]), rtol=2e-3)
     dc._drop_jobs()
+
+
+@pytest.mark.parametrize("blind", [False, True])
+def test_overlapped_statistics_and_dropped_iteration_on_the_tiles(blind, debug_switch):
+    """ics_rl_run queues outer iteration i + 1 before the stop decision of i is known and drops it when the test fires (undo): the mirrors
+    rotate with the frames they belong to (a mirror is looked up by its frame buffer), the residual's mirror ping-pongs with e / e2, the
+    spectra are rebuilt from the restored PSF.  The overlapped run must equal the drained one bit for bit, early stop included."""
+    from lib import deconvolution as dc
+    import contextlib, io
+    M, N, MK = 300, 340, 17
+    case = orc.synth_case(M, N, MK, seed=77, blind=blind)
+    res = {}
+    for ov in (0, 2):
+        debug_switch("overlap", ov)
+        dc._drop_jobs()
+        u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 0.0, M, N, 3, MK, 12, 5e-3, 10000.0, blind=blind, conv=FFT)
+        st = dc.richardson_lucy_MM.last
+        res[ov] = (u, psf, st.iterations_done, st.stopped, list(st.trace_M_r[:st.trace_len]))
+    print("blind=%s: %d outer iterations, stopped=%d" % (blind, res[0][2], res[0][3]))
+    assert res[0][2] == res[2][2] and res[0][3] == res[2][3] and res[0][4] == res[2][4]
+    assert np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][1], res[2][1])
+    dc._drop_jobs()
+
+
+def test_few_persistent_workgroups_walk_many_units(debug_switch):
+    """the unit walk with a grid that is no multiple of eight and far smaller than the unit count (test hook max_wgs)"""
+    from lib import _native as nv
+    debug_switch("max_wgs", 5)
+    M, N, MK = 333, 410, 23
+    job, case, psf = make_job(M, N, MK, seed=5)
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False, conv=FFT)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    full = conv_valid64(case["u0"], psf)
+    assert np.max(np.abs(e - (full - case["image"]))) / np.max(np.abs(full)) < CONV_TOL
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    assert rel_err(job.read(nv.BUF_GRADU), corr_full64(e.astype(np.float64), psf)) < CONV_TOL
+    job.close()
+
+
+@pytest.mark.parametrize("M,N,MK", [(90, 100, 15), (150, 260, 17), (200, 120, 31), (300, 310, 23), (230, 333, 45), (190, 170, 63)])
+def test_fft_psf_gradient_against_float64(M, N, MK):
+    """A12 + A13 on the tiles (k_gradk_fft): the residual of the frame's own synthesis (e' = conv(u, psf) - image, as in the loop) against u,
+    float64 direct sums, the gate of every other gradient kernel (1e-5 of max |gradk|; measured 1 - 3e-7)."""
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=MK + N, blind=True)
+    rng = np.random.default_rng(17)
+    u = (case["u0"] + 0.03 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=True, conv=FFT)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e = job.read(nv.BUF_ERROR)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk = job.read(nv.BUF_GRADK)
+    ref = gradk64(u.astype(np.float64), e.astype(np.float64))
+    err = rel_err(gk, ref)
+    print("%dx%d K=%d: PSF gradient on the tiles %.2e" % (M, N, MK, err))
+    assert err < 1e-5
+    job.close()
