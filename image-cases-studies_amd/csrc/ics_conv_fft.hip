@@ -814,7 +814,10 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
   double* twd = sm;
   double* Gs = sm + 256;
   const int tid = threadIdx.x;
-  const int o = blockIdx.x / 12, c = (blockIdx.x / 4) % 3, kx0 = (blockIdx.x & 3) * 32;
+  // one workgroup per (orientation, channel, 32 columns kx, 32 rows ky): 96 of them; each builds the G of its columns itself (K^2 x 32
+  // products) and then its 32 x 32 values of S (K each).  (24 workgroups with all 128 rows each took 30 us at 31 x 31, 65 us at 63 x 63 --
+  // per inner iteration of a blind run.)
+  const int o = blockIdx.x / 48, c = (blockIdx.x / 16) % 3, kx0 = ((blockIdx.x >> 2) & 3) * 32, ky0 = (blockIdx.x & 3) * 32;
   if (tid < 128) {
     double sn, cs;
     sincospi((double)tid / 64.0, &sn, &cs);
@@ -832,8 +835,8 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
     Gs[2 * i] = re; Gs[2 * i + 1] = im;
   }
   __syncthreads();
-  for (int i = tid; i < 128 * 32; i += 256) {
-    const int ky = i >> 5, kxl = i & 31;
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int ky = ky0 + (i >> 5), kxl = i & 31;
     double re = 0.0, im = 0.0;
     for (int aa = 0; aa < K; ++aa) {
       const double gr = Gs[2 * (aa * 32 + kxl)], gi = Gs[2 * (aa * 32 + kxl) + 1];
@@ -854,7 +857,7 @@ size_t ics_conv_fft_spectrum_floats() { return (size_t)3 * ICS_FFT_P * ICS_FFT_P
 
 hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s) {
   const size_t lds = (256 + (size_t)K * 32 * 2) * sizeof(double);   // 35 KB at K = 65
-  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(24), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr));
+  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(96), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr));
   return hipGetLastError();
 }
 
