@@ -32,7 +32,7 @@ def main():
     opt = {sys.argv[i][2:]: int(sys.argv[i + 1]) for i in range(1, len(sys.argv) - 1) if sys.argv[i].startswith("--")}
     size, psf = opt.get("size", 4096), opt.get("psf", 15)
     kernels = {"k_conv_mfma<%d, 0," % psf: "synth_residual", "k_conv_mfma<%d, 1," % psf: "backproject", "k_gradk_mfma<": "psf_gradient",
-               "k_synth_gradk<%d," % psf: "synth_gradk"}
+               "k_synth_gradk<%d," % psf: "synth_gradk", "k_conv_fft<0,": "synth_residual", "k_conv_fft<1,": "backproject", "k_gradk_fft<": "psf_gradient"}
     sq2 = counters(args[0], ["SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"], kernels)
     sq3 = counters(args[1], ["GRBM_GUI_ACTIVE"], kernels)
     conv_flops = 2.0 * psf * psf * 3 * size * size
@@ -40,12 +40,16 @@ def main():
     out = {}
     for k, c in sq2.items():
         n = c["SQ_INSTS_MFMA"]
+        if not n:      # (the transform-tile kernels issue no matrix instructions: fp32 VALU butterflies)
+            out[k] = {"insts": 0, "valu_insts": int(c["SQ_INSTS_VALU"]), "lds_insts": int(c["SQ_INSTS_LDS"]), "useful_flops": int(useful[k])}
+            continue
         gui = sq3.get(k, {}).get("GRBM_GUI_ACTIVE")
         out[k] = {"insts": int(n), "busy_cycles": int(c["SQ_VALU_MFMA_BUSY_CYCLES"]),
                   "busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui / 8.0), 4) if gui else None,
                   "valu_per_mfma": round((c["SQ_INSTS_VALU"] - n) / n, 2), "lds_per_mfma": round(c["SQ_INSTS_LDS"] / n, 2),
                   "issued_flops": int(n * 16384), "useful_flops": int(useful[k]), "useful_over_issued": round(useful[k] / (n * 16384), 3)}
-    print(json.dumps({"_comment": __doc__.strip(), "workload": {"size": size, "psf": psf}, "kernels": out}, indent=1))
+    import os
+    print(json.dumps({"_comment": __doc__.strip(), "workload": {"size": size, "psf": psf}, "commit": os.environ.get("ICS_COMMIT", "unrecorded"), "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":

@@ -9,7 +9,12 @@ import sys
 
 def kernel_names(psf):
     return {"k_conv_mfma<%d, 0," % psf: "synth_residual", "k_conv_mfma<%d, 1," % psf: "backproject", "k_update_rows<0>": "update",
-            "k_gradk_mfma<": "psf_gradient", "k_synth_gradk<%d," % psf: "synth_gradk"}
+            "k_gradk_mfma<": "psf_gradient", "k_synth_gradk<%d," % psf: "synth_gradk",
+            # the transform-tile pipeline (ics_conv_fft.hip, ics_planar.hip): its own key, `kernels_fft`
+            "k_conv_fft<0,": "synth_residual", "k_conv_fft<1,": "backproject", "k_update_planar": "update", "k_gradk_fft<": "psf_gradient"}
+
+
+FFT_NAMES = ("k_conv_fft<", "k_update_planar", "k_gradk_fft<")
 
 
 KERNELS = {}
@@ -20,6 +25,8 @@ def counters(path, name):
     out, cur = {}, None
     for line in open(path):
         if not line.startswith(" "):
+            if any(n in line for n in FFT_NAMES):
+                counters.fft = True
             cur = next((v for k, v in KERNELS.items() if k in line), None) if "avg_us" not in line and len(line.split()) < 8 else None
         elif cur and name in line:
             m = re.search(r"mean ([0-9.e+]+)", line)
@@ -41,7 +48,9 @@ def main():
         w = write.get(k, 0.0)
         kern[k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": w, "hbm_bytes": int((2 * fetch[k] + w) * 1024), "algorithmic_bytes": ALGO[k] * px}
         kern[k]["ratio"] = round(kern[k]["hbm_bytes"] / kern[k]["algorithmic_bytes"], 3)
-    out = {"_comment": __doc__.strip(), "workload": {"size": size, "psf": psf}, "kernels_matrix": kern}
+    import os
+    key = "kernels_fft" if getattr(counters, "fft", False) else "kernels_matrix"
+    out = {"_comment": __doc__.strip(), "workload": {"size": size, "psf": psf}, "commit": os.environ.get("ICS_COMMIT", "unrecorded"), key: kern}
     if len(args) > 2:   # the two-kernel gradient path (ICS_FUSED_GRADK=0), fetch side only
         f2 = counters(args[2], "FETCH_SIZE")
         out["two_kernel_gradient_path_fetch_KiB"] = {k: f2[k] for k in ("synth_residual", "psf_gradient") if k in f2}
