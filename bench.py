@@ -362,7 +362,7 @@ def main():
     matrix = lab["matrix"]
 
     # Order of the measurements.  (1) `cold_start`: W warm-up + K steps exactly as they come after the host-side frame synthesis (the GPU
-    # has idled for seconds: the first ~50 steps run while the clocks ramp) -- reported, not `value`.  (2) a clock pre-heat
+    # has idled for seconds: the first ~50 steps run while the clocks ramp, NOTES_r03.md 4c) -- reported, not `value`.  (2) a clock pre-heat
     # of PREHEAT untimed steps on EVERY rank at EVERY N (so that N = 1 and N = 8 are measured in the same state).  (3) the contract's
     # measurement: W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides -> `value`.
     PREHEAT = 0 if args.no_preheat else 150
@@ -410,7 +410,7 @@ def main():
                  "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[omode], "frac_of_8TBps": round(ogb / HBM_PEAK_GBPS, 4)}
 
     # beside `value` (never instead of it): a SUSTAINED measurement -- 25 warm-up + 200 timed steps whatever --steps / --warmup were --
-    # with its own kernel table.  A 20-step run after 5 warm-up steps is timed while the clocks still ramp;
+    # with its own kernel table.  A 20-step run after 5 warm-up steps is timed while the clocks still ramp (NOTES_r02.md section 4a);
     # this block is what the per-kernel fractions in DESIGN.md are quoted from.
     sustained = None
     if grp.size == 1 and not args.no_sustained:

@@ -851,7 +851,7 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
 // PSF sizes 3 ... 65.  Explicit: conv = ICS_CONV_FFT (also through the stage API); under ICS_CONV_AUTO inside ics_rl_run where it measured
 // ahead of the matrix-core kernels (fft_preferred); ICS_CONV_PATH=fft|matrix|vector overrides AUTO.
 static bool fft_preferred(const IcsGeom& g) {
-  // measured on MI355X: per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
+  // measured on MI355X (NOTES_r05.md): per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
   // the Toeplitz matrix-core kernels pay K^2.  scripts/ab_fft.py, ms per inner iteration, matrix cores -> tiles (non-blind / blind):
   // 2048^2 17: 0.173 -> 0.200 / 0.317 -> 0.368; 21: 0.271 -> 0.198 / 0.437 -> 0.379; 31: 0.303 -> 0.181 / 0.492 -> 0.383;
   // 4096^2 17: level / 1.110 -> 1.141; 21: 0.949 -> 0.616 / 1.599 -> 1.135; 1448^2 31: 0.194 -> 0.131 / 0.327 -> 0.274; 1024^2 31: 0.117 -> 0.104 / 0.201 -> 0.215.
@@ -890,7 +890,7 @@ static bool use_big_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
 // i.e. the Kb x Kb kernel on a shifted pointer with a geometry that differs in K and pad only (mode 0 tiles start at the kernel's
 // own pad: all three pointers move by pad - Kb/2 so that this is the image origin).  The blocks are summed as a chain through the
 // kernels' own operand frames, alternating between the result frame and a scratch frame (do_conv_blocks); the maxima of A7 are taken
-// over the sum by k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see DESIGN.md 4c.
+// over the sum by k_band_reduce.  2048^2, 63 x 63: 1.24 / 1.50 ms (run-time-sized fp32 kernel) -> see NOTES_r03.md 4c.
 static bool use_block_conv(const ics_rl* j, const ics_rl_params* p, int mode) {
   if (!j->blk_conv || mode == 2 || p->tv_mode != ICS_TV_SHIPPED || p->conv == ICS_CONV_VECTOR) return false;
   if (psf_blocks_only(j->g.K)) return true;   // (no other path: ICS_CONV_PATH does not apply)
@@ -910,7 +910,7 @@ static int do_conv_blocks(ics_rl* j, int mode, const ics_rl_params* p, int slot,
   // T_{-1} = s_0 * image: the image itself for an odd number of blocks, a negated copy of it (blk_negf) for an even one.  T_q alternates
   // between the result frame and the scratch frame so that the last one lands in the result.  Same sums in the same order as adding the
   // blocks one by one (IEEE negation is exact and rounding is symmetric), one launch and 36 B/px less per block after the first, and no
-  // frame of zeros read as the image operand.  (255 x 255 at 2048^2: synthesis 8.8 -> see DESIGN.md 4d.)
+  // frame of zeros read as the image operand.  (255 x 255 at 2048^2: synthesis 8.8 -> see NOTES_r04.md 4d.)
   const int nq = nb * nb;
   if (mode == 0 && !(nq & 1) && !j->negf_valid) {
     HIPCHK(ics_launch_frame_neg(j->blk_negf, j->f, j->frame_floats, j->ctx->stream));
@@ -1125,7 +1125,7 @@ static int do_synth_gradk(ics_rl* j, const ics_rl_params* p, int store_all, Prof
   a.store_all = store_all;
   // tile height: 32-row tiles with three workgroups per CU, or 64-row tiles with two (ics_synth_gradk_mfma.hip); debug switch fused_rs
   // Measured on MI355X (blind, ms per inner iteration, 64-row -> 32-row form): 255^2 (deblur_module's blind window: 16 tiles of 64 x 64 on
-  // 256 CUs) 0.1095 -> 0.0985, 1024^2 0.1415 -> 0.1316, 2048^2 0.275 -> 0.266; 4096^2 level.  Hence 32-row tiles up to
+  // 256 CUs) 0.1095 -> 0.0985, 1024^2 0.1415 -> 0.1316, 2048^2 0.275 -> 0.266; 4096^2 level (NOTES_r03.md 4c).  Hence 32-row tiles up to
   // 2500 tiles of 64 x 64 (~3200^2), 64-row tiles above.
   const int frs = ics_debug().fused_rs.load(std::memory_order_relaxed);
   a.rs = frs == 2 || frs == 4 ? frs : ((long)j->g.tiles_x * j->g.tiles_y <= 2500 ? 2 : ICS_FUSED_DEFAULT_RS);

@@ -19,7 +19,6 @@ namespace {
 constexpr int BIG_TA = 8;                  // kernel rows per staged block
 constexpr int BIG_TH = 64, BIG_TW = 64;    // output tile of the convolution (256 threads: two rows x 8 pixels each)
 constexpr int BIG_KMAX = 127;
-constexpr int BIG_K8MAX = 128;
 // staged columns per row: LW = 64 + K8 + 8 (run time: the LDS a workgroup takes, and with it the workgroups per CU, follow the PSF size)
 constexpr int BIG_RING = BIG_TH + BIG_TA;               // staged rows: a ring, eight new rows per block of kernel rows
 static inline int big_lw(int K) { return BIG_TW + ((K + 7) & ~7) + 8; }

@@ -75,13 +75,22 @@ namespace icsfft {
 // s_waitcnt vmcnt(n) for the register prefetch of the next unit does not degrade to vmcnt(0) behind the epilogue's stores.
 // The host pass (CPU emulation, tools/bench_conv_fft.hip) indexes pointers.
 #define ICS_FFT_NONE 0x20000000
+// (ablation builds of tools/bench_conv_fft.hip, -DICS_FFT_ABL_NOMEM=mask: what a unit costs without some of its global memory traffic --
+//  1 spectrum, 2 epilogue operands, 4 window, 8 stores; -DICS_FFT_ABL_NOMATH: without its butterflies)
+#ifndef ICS_FFT_ABL_NOMEM
+#define ICS_FFT_ABL_NOMEM 0
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t gbuf;
 __device__ __forceinline__ gbuf make_gbuf(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000); }
 __device__ __forceinline__ float ld_f32(gbuf b, int vi, int si) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * vi, 4 * si, 0)); }
 __device__ __forceinline__ void st_f32(gbuf b, int vi, int si, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * vi, 4 * si, 0); }
 __device__ __forceinline__ v2f ld_v2f(gbuf b, int vi, int si) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, 8 * vi, 8 * si, 0)); }
-__device__ __forceinline__ v4f ld_f32x4(gbuf b, int vi, int si) { return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(b, 4 * vi, 4 * si, 0)); }
+template <int KIND = 0>   // (KIND: the ablation mask bit of this access, 0 = never ablated)
+__device__ __forceinline__ v4f ld_f32x4(gbuf b, int vi, int si) {
+  if (KIND & ICS_FFT_ABL_NOMEM) { const float x = (float)(vi + si); return (v4f){x, x, x, x}; }
+  return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(b, 4 * vi, 4 * si, 0));
+}
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 // (the s_nop behind the store, with the data registers as its operands: a buffer store of more than 8 bytes reads its data registers for a
 //  few cycles after it issues, and a vector instruction that rewrites one of them right behind it changes what is stored.  The compiler's
@@ -90,6 +99,7 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 //  (tools/bench_conv_fft.hip found it: the first pixel of the quads of lanes 12-15 of every row group but the first).  Keeping the data
 //  alive across two wait states costs nothing here: eight stores per thread and unit)
 __device__ __forceinline__ void st_f32x4(gbuf b, int vi, int si, v4f v) {
+  if (ICS_FFT_ABL_NOMEM & 8) { asm volatile("" :: "v"(v), "v"(vi), "s"(si)); return; }
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), b, 4 * vi, 4 * si, 0);
   asm volatile("s_nop 2" :: "v"(v) : "memory");
 }
@@ -99,6 +109,7 @@ static inline gbuf make_gbuf(const void* p) { return p; }
 static inline float ld_f32(gbuf b, int vi, int si) { return vi >= ICS_FFT_NONE ? 0.f : static_cast<const float*>(b)[vi + si]; }
 static inline void st_f32(gbuf b, int vi, int si, float v) { if (vi < ICS_FFT_NONE) const_cast<float*>(static_cast<const float*>(b))[vi + si] = v; }
 static inline v2f ld_v2f(gbuf b, int vi, int si) { return static_cast<const v2f*>(b)[vi + si]; }
+template <int KIND = 0>
 static inline v4f ld_f32x4(gbuf b, int vi, int si) {
   if (vi >= ICS_FFT_NONE) return (v4f){0.f, 0.f, 0.f, 0.f};
   const float* p = static_cast<const float*>(b) + vi + si;
@@ -192,6 +203,9 @@ template <int DIR> ICS_FFT_HD void fft4_r2(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
 
 // 8 points, natural order in, natural order out.  n = 2 n1 + n2, k = k1 + 4 k2.
 template <int DIR> ICS_FFT_HD void fft8(v2f (&v)[8]) {
+#if defined(ICS_FFT_ABL_NOMATH) && defined(__HIP_DEVICE_COMPILE__)   // (ablation: the stage's LDS traffic without its butterflies)
+  return;
+#endif
   constexpr float R = 0.70710678118654752440f;
   v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
   fft4<DIR>(e0, e1, e2, e3);
@@ -207,6 +221,9 @@ template <int DIR> ICS_FFT_HD void fft8(v2f (&v)[8]) {
 
 // 16 points, natural order in, natural order out.  n = 4 n1 + n2, k = k1 + 4 k2.
 template <int DIR> ICS_FFT_HD void fft16(v2f (&v)[16]) {
+#if defined(ICS_FFT_ABL_NOMATH) && defined(__HIP_DEVICE_COMPILE__)   // (ablation: the stage's LDS traffic without its butterflies)
+  return;
+#endif
   constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
   v2f a[4][4];   // a[n2][k1]
 #pragma unroll
@@ -300,6 +317,14 @@ __device__ __forceinline__ v2f lds_ld(const v2f* p) {   // (the low half of a ge
 static inline v2f lds_ld(const v2f* p) { return *p; }
 #endif
 
+// "everything requested above is issued before anything below": keeps the scheduler from sinking LDS reads next to their first use, which
+// turns fifteen twiddle reads into fifteen serial LDS round trips (seen in the ISA of stage E: ds_read / s_waitcnt lgkmcnt(0) / multiply, x 15)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ICS_FFT_ISSUE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ICS_FFT_ISSUE_FENCE() do { } while (0)
+#endif
+
 // Thread mappings.  x-major (stages A, B, F, G): wave w -> selector w & 7, columns 64 (w >> 3) + lane.  Row-owner (C, D, E): wave w -> rows
 // 8 w + (lane >> 3), selector lane & 7.  Row-quad (the unit's boundaries, 16-byte global accesses): rows (tid >> 5) + 32 i, i < 4, pixels
 // 4 (tid & 31) .. + 3 -- a half-wave covers one 512-byte row segment.
@@ -317,7 +342,7 @@ ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, 
     const int X = u.ox[t] - pad + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad by construction
     const int vo = (u.has[t] && X <= xlast) ? mem.lin.org + Y0 * pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pw[t][i] = ld_f32x4(mem.in, (Y0 + 32 * i <= ylast) ? vo : ICS_FFT_NONE, 32 * i * pitch);
+    for (int i = 0; i < 4; ++i) pw[t][i] = ld_f32x4<4>(mem.in, (Y0 + 32 * i <= ylast) ? vo : ICS_FFT_NONE, 32 * i * pitch);
   }
 }
 // ... and its way into the tile buffer: z = tile 0 + i tile 1, natural [row][pixel] layout (two 16-byte LDS stores per row group)
@@ -377,9 +402,21 @@ ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   if (TWB == 8) {
 #pragma unroll
     for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+    ICS_FFT_ISSUE_FENCE();
   }
   fft16<1>(v);
   v2f* const rowp = lds + row * ICS_FFT_PITCH;
+  if (TWB == 8) {      // the second eight twiddles are requested before the first eight products: those cover their round trip
+    v2f tw2[8];
+#pragma unroll
+    for (int k1 = 8; k1 < 16; ++k1) tw2[k1 - 8] = lds_ld(twl + ((j * k1) & 127));
+    ICS_FFT_ISSUE_FENCE();
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) rowp[8 * k1 + ((j + k1) & 7)] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
+#pragma unroll
+    for (int k1 = 8; k1 < 16; ++k1) rowp[8 * k1 + ((j + k1) & 7)] = cmul(v[k1], tw2[k1 - 8]);
+    return;
+  }
 #pragma unroll
   for (int h = 0; h < 16 / TWB; ++h) {
     if (TWB != 8 || h > 0) {
@@ -405,7 +442,7 @@ ICS_FFT_HD int spec_index(int c, int ky, int kx) {   // position of S_c[ky][kx] 
 ICS_FFT_HD void load_spectrum(const Mem& mem, int c, int tid, v2f (&sp)[2][8]) {
 #pragma unroll
   for (int l = 0; l < 8; ++l) {
-    const v4f p = ld_f32x4(mem.spec, 4 * tid, (c * 8 + l) * ICS_FFT_THREADS * 4);
+    const v4f p = ld_f32x4<1>(mem.spec, 4 * tid, (c * 8 + l) * ICS_FFT_THREADS * 4);
     sp[l >> 2][2 * (l & 3)] = (v2f){p.x, p.y};
     sp[l >> 2][2 * (l & 3) + 1] = (v2f){p.z, p.w};
   }
@@ -460,19 +497,19 @@ ICS_FFT_HD void stage_d_inverse(const v2f (&z)[2][8], v2f* lds, int tid) {
 // E: conj twiddle, inverse radix-16 over k1 -> x = j + 8 m
 ICS_FFT_HD void stage_e(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
-  v2f v[16], tw[8];
+  v2f v[16], tw[16];
   const v2f* cb[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) cb[s] = rd + row * ICS_FFT_PITCH + ((j + s) & 7);
+  // all fifteen twiddles and the sixteen values requested in one go (the scheduler otherwise sinks each twiddle read next to its product:
+  // fifteen serial LDS round trips per wave in a stage every wave of the CU is in at the same time)
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(cb[k1 & 7] + 8 * k1);
+  ICS_FFT_ISSUE_FENCE();
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {                                              // (the twiddles in two halves of eight: registers)
-#pragma unroll
-    for (int k1 = 8 * h; k1 < 8 * h + 8; ++k1) if (k1) tw[k1 - 8 * h] = lds_ld(twl + ((j * k1) & 127));
-#pragma unroll
-    for (int k1 = 8 * h; k1 < 8 * h + 8; ++k1) if (k1) v[k1] = cmulc(v[k1], tw[k1 - 8 * h]);
-  }
+  for (int k1 = 1; k1 < 16; ++k1) v[k1] = cmulc(v[k1], tw[k1]);
   fft16<-1>(v);
   v2f* wp = lds + row * ICS_FFT_PITCH + j;
 #pragma unroll
@@ -504,7 +541,19 @@ ICS_FFT_HD uint32_t key_of(float f) { return (f != f) ? 0xFFC00000u : ics_f2key(
 // stores the values it kept at the end.  A quad's lane address says "this row group of this tile is mine" or is a dropped access; pixels
 // of a valid quad beyond the output region are stored as zeros (they land in the frame's border ring / slack, which holds zeros).
 struct Ops { v4f a[2][4], b[2][4], tv[2][4]; };   // [tile][row group].  mode 1: a = u, b = ut, tv = T frame (TV kinds)
-struct Maxima { float mg, mu; bool nan_g, nan_u, any; };
+// The maxima of A6 / A7 over a unit's valid pixels, in a form that costs two or three vector operations per pixel and no lane masks:
+//   ag  = max over pixels of (bits of g) & 0x7FFFFFFF as an unsigned integer: the bits of |g| order like |g| itself and every NaN lies above
+//         +inf (0x7F800000), so one integer maximum carries both max |g| and "a NaN was seen";
+//   mu  = float maximum of u (v_max_f32 drops NaNs), au = the same integer maximum of |u| bits, kept only for its NaN test;
+//   any = a valid pixel was seen (row groups outside the tile / region contribute nothing).
+struct Maxima { uint32_t ag, au, any; float mu; };
+ICS_FFT_HD void maxima_init(Maxima& mx) { mx.ag = 0u; mx.au = 0u; mx.any = 0u; mx.mu = -__builtin_inff(); }
+ICS_FFT_HD uint32_t fbits(float f) { return __builtin_bit_cast(uint32_t, f); }
+// the unit's two keys (0 = nothing seen, canonical NaN key = largest: a NaN propagates like np.amax)
+ICS_FFT_HD void maxima_keys(const Maxima& mx, uint32_t& kg, uint32_t& ku) {
+  kg = mx.ag > 0x7F800000u ? 0xFFC00000u : (mx.any ? ics_f2key(__builtin_bit_cast(float, mx.ag)) : 0u);
+  ku = mx.au > 0x7F800000u ? 0xFFC00000u : (mx.any ? ics_f2key(mx.mu) : 0u);
+}
 
 // lane address of row group 0 of tile t in frame layout L, or ICS_FFT_NONE; `rows` = number of this lane's row groups inside the tile (0..4)
 ICS_FFT_HD int quad_lane(const IcsFftArgs& a, const Unit& u, const Lay& L, int tid, int t, int& rows, int& X) {
@@ -522,7 +571,7 @@ ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, i
     int rows, X;
     const int vo = quad_lane(a, u, mem.lf, tid, t, rows, X);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) f[t][i] = ld_f32x4(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
+    for (int i = 0; i < 4; ++i) f[t][i] = ld_f32x4<2>(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
   }
 }
 // mode 1: the operands under tile t
@@ -534,9 +583,9 @@ ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int
   const int vt = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.ltv.org;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    o.a[t][i] = ld_f32x4(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
-    o.b[t][i] = ld_f32x4(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
-    if (TV) o.tv[t][i] = ld_f32x4(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
+    o.a[t][i] = ld_f32x4<2>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
+    o.b[t][i] = ld_f32x4<2>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+    if (TV) o.tv[t][i] = ld_f32x4<2>(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
   }
 }
 // the finished values of row group i: r[t] = 4 pixels of tile t
@@ -547,21 +596,24 @@ ICS_FFT_HD void read_quads(const v2f* lds, int tid, int i, v4f (&r)[2]) {
   r[0] = (v4f){z0.x, z0.z, z1.x, z1.z};
   r[1] = (v4f){z0.y, z0.w, z1.y, z1.w};
 }
-ICS_FFT_HD void store_quad(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, int i, v4f val) {
-  int rows, X;
-  const int vo = quad_lane(a, u, mem.lout, tid, t, rows, X);
-  // pixels beyond the output region: zeros into the border ring / slack
-  val = (v4f){X >= a.ox0 ? val.x : 0.f, (X + 1 >= a.ox0 && X + 1 < a.ox1) ? val.y : 0.f, (X + 2 >= a.ox0 && X + 2 < a.ox1) ? val.z : 0.f, X + 3 < a.ox1 ? val.w : 0.f};
-  st_f32x4(mem.out, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lout.pitch, val);
+// mode 0 takes the lane address and the pixel masks of a tile ONCE per unit (as eight store_quad calls the address arithmetic of the
+// epilogue was 300 of a unit's 1310 vector instructions); `edge` (wave-uniform) = the tile reaches beyond the output region's columns
+struct QuadOut { int vo, rows, X; };
+ICS_FFT_HD void store_quad_at(const IcsFftArgs& a, const Mem& mem, const QuadOut& q, bool edge, int i, v4f val) {
+  if (edge) {
+    const int X = q.X;
+    val = (v4f){X >= a.ox0 ? val.x : 0.f, (X + 1 >= a.ox0 && X + 1 < a.ox1) ? val.y : 0.f, (X + 2 >= a.ox0 && X + 2 < a.ox1) ? val.z : 0.f, X + 3 < a.ox1 ? val.w : 0.f};
+  }
+  st_f32x4(mem.out, i < q.rows ? q.vo : ICS_FFT_NONE, 32 * i * mem.lout.pitch, val);
 }
 // mode 1: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7 on row group i of tile t; the PAM kinds replace the stored value by G
 template <bool TV>
-ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx) {
-  const int r0 = tid >> 5, xq = tid & 31;
+ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx, const QuadOut& q, bool edge) {
   const float lambd = a.c.lambd;
-  const int lim = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;
-  const int X0 = u.ox[t] + 4 * xq, Y = u.oy[t] + r0 + 32 * i;
-  const bool row_ok = u.has[t] && 4 * xq < a.V && r0 + 32 * i < lim;
+  const int X0 = q.X, Y = u.oy[t] + (tid >> 5) + 32 * i;
+  const bool row_ok = i < q.rows;         // (quad_lane: tile present, quad inside the tile's valid columns and the region, row group inside)
+  uint32_t qg = 0u, qu = 0u, qany = 0u;
+  float qm = -__builtin_inff();
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float rv = r[e], uv = o.a[t][i][e], tv = o.b[t][i][e];
@@ -572,12 +624,22 @@ ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, 
       g = (float)(((double)o.tv[t][i][e] + (double)ICS_FMUL(lambd, rv)) + (double)ICS_FSUB(uv, tv) / 4.0);
     else
       g = ICS_FADD(ICS_FMUL(lambd, rv), ICS_FMUL(ICS_FSUB(uv, tv), 0.5f));                                          // pyx:519
-    if (row_ok && X >= a.ox0 && X < a.ox1) {
-      mx.mg = __builtin_fmaxf(mx.mg, __builtin_fabsf(g));
-      mx.mu = __builtin_fmaxf(mx.mu, uv);
-      mx.nan_g |= (g != g); mx.nan_u |= (uv != uv);
-      mx.any = true;
+    if (edge) {                                        // (wave-uniform) first / last tile of a tile row: per-pixel column test
+      const bool ok = row_ok && X >= a.ox0 && X < a.ox1;
+      qg = __builtin_elementwise_max(qg, ok ? (fbits(g) & 0x7FFFFFFFu) : 0u);
+      qu = __builtin_elementwise_max(qu, ok ? (fbits(uv) & 0x7FFFFFFFu) : 0u);
+      qm = __builtin_fmaxf(qm, ok ? uv : -__builtin_inff());
+      qany |= ok ? 1u : 0u;
+    } else {
+      qg = __builtin_elementwise_max(qg, fbits(g) & 0x7FFFFFFFu);
+      qu = __builtin_elementwise_max(qu, fbits(uv) & 0x7FFFFFFFu);
+      qm = __builtin_fmaxf(qm, uv);
     }
+  }
+  if (edge) { mx.ag = __builtin_elementwise_max(mx.ag, qg); mx.au = __builtin_elementwise_max(mx.au, qu); mx.mu = __builtin_fmaxf(mx.mu, qm); mx.any |= qany; }
+  else {
+    mx.ag = __builtin_elementwise_max(mx.ag, row_ok ? qg : 0u); mx.au = __builtin_elementwise_max(mx.au, row_ok ? qu : 0u);
+    mx.mu = __builtin_fmaxf(mx.mu, row_ok ? qm : -__builtin_inff()); mx.any |= row_ok ? 1u : 0u;
   }
 }
 
@@ -668,28 +730,54 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     // frames: it requests those of the second tile here and takes its maxima in a second pass, and the second tile of the next unit's
     // window goes out between the passes (registers: 128 per thread with 1024 of them).
     if (MODE == 1) load_ops<TV>(a, mem, u, opaque(tid), 1, ops);
-    Maxima mx; mx.mg = 0.f; mx.mu = -__builtin_inff(); mx.nan_g = mx.nan_u = mx.any = false;
+    Maxima mx; maxima_init(mx);
     v4f res[4][2];
+    // lane address and row-group count of the two tiles ONCE per unit (as eight store_quad calls the address arithmetic of the epilogue
+    // was 300 of a unit's 1310 vector instructions).  u.ox is wave-uniform: interior tiles -- all but the first and last of a tile row --
+    // need no per-pixel column tests.
+    QuadOut qo[2];
+    const int te = opaque(tid);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      read_quads(lds, opaque(tid), i, res[i]);
-      if (MODE == 0) {
+    for (int t = 0; t < 2; ++t) qo[t].vo = quad_lane(a, u, mem.lout, te, t, qo[t].rows, qo[t].X);
+    const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        read_quads(lds, opaque(tid), i, res[i]);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
-      } else maxima_quad<TV>(a, u, opaque(tid), 0, i, res[i][0], ops, mx);
-      asm volatile("" ::: "memory");
-    }
-    if (MODE == 1) {
+        asm volatile("" ::: "memory");
+      }
+      if (edge) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) store_quad_at(a, mem, qo[t], true, i, res[i][t]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) store_quad_at(a, mem, qo[t], false, i, res[i][t]);
+      }
+    } else {
+      // first pass: tile 0 leaves as soon as its maxima are taken (its operands' registers are free for the second window then), tile 1's
+      // values wait in res[.][1] for their operands
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        read_quads(lds, opaque(tid), i, res[i]);
+        if (edge) { maxima_quad<TV>(a, u, te, 0, i, res[i][0], ops, mx, qo[0], true); store_quad_at(a, mem, qo[0], true, i, res[i][0]); }
+        else { maxima_quad<TV>(a, u, te, 0, i, res[i][0], ops, mx, qo[0], false); store_quad_at(a, mem, qo[0], false, i, res[i][0]); }
+        asm volatile("" ::: "memory");
+      }
       load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) maxima_quad<TV>(a, u, opaque(tid), 1, i, res[i][1], ops, mx);
+      for (int i = 0; i < 4; ++i) {
+        if (edge) { maxima_quad<TV>(a, u, te, 1, i, res[i][1], ops, mx, qo[1], true); store_quad_at(a, mem, qo[1], true, i, res[i][1]); }
+        else { maxima_quad<TV>(a, u, te, 1, i, res[i][1], ops, mx, qo[1], false); store_quad_at(a, mem, qo[1], false, i, res[i][1]); }
+      }
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) store_quad(a, mem, u, opaque(tid), t, i, res[i][t]);
     ICS_FFT_STAMP(8);
     if (n + G < a.nunits) {
       store_window(pw, lds, opaque(tid));      // (the slots this thread just read)
@@ -701,8 +789,8 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     ++round;
 #endif
     if (MODE == 1) {   // (u.c is uniform)
-      const uint32_t kg = mx.nan_g ? 0xFFC00000u : (mx.any ? ics_f2key(mx.mg) : 0u);   // NaN propagates like np.amax
-      const uint32_t ku = mx.nan_u ? 0xFFC00000u : (mx.any ? ics_f2key(mx.mu) : 0u);
+      uint32_t kg, ku;
+      maxima_keys(mx, kg, ku);
 #pragma unroll
       for (int c = 0; c < 3; ++c)
         if (u.c == c) { accg[c] = accg[c] > kg ? accg[c] : kg; accu[c] = accu[c] > ku ? accu[c] : ku; }

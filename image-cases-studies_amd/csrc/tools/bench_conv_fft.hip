@@ -169,17 +169,20 @@ int emulate(int M, int K, int N) {
       for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
       for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
       for (int t = 0; t < 1024; ++t) {
-        icsfft::Maxima mx = {0.f, 0.f, false, false, false};
+        icsfft::Maxima mx; icsfft::maxima_init(mx);
         v4f fimg[2][4];
         icsfft::Ops o;
         if (mode == 0) icsfft::load_image(a, mem, u, t, fimg);
         else { icsfft::load_ops<true>(a, mem, u, t, 0, o); icsfft::load_ops<true>(a, mem, u, t, 1, o); }
+        icsfft::QuadOut qo[2];
+        for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
+        const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;    // (as the kernel)
         for (int i = 0; i < 4; ++i) {
           v4f r[2];
           icsfft::read_quads(lds.data(), t, i, r);
           if (mode == 0) { r[0] -= fimg[0][i]; r[1] -= fimg[1][i]; }
-          else { icsfft::maxima_quad<true>(a, u, t, 0, i, r[0], o, mx); icsfft::maxima_quad<true>(a, u, t, 1, i, r[1], o, mx); }
-          icsfft::store_quad(a, mem, u, t, 0, i, r[0]); icsfft::store_quad(a, mem, u, t, 1, i, r[1]);
+          else { icsfft::maxima_quad<true>(a, u, t, 0, i, r[0], o, mx, qo[0], edge); icsfft::maxima_quad<true>(a, u, t, 1, i, r[1], o, mx, qo[1], edge); }
+          icsfft::store_quad_at(a, mem, qo[0], edge, i, r[0]); icsfft::store_quad_at(a, mem, qo[1], edge, i, r[1]);
         }
       }
     }

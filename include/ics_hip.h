@@ -107,7 +107,7 @@ typedef struct ics_rl_params {
                                    convolution (one kernel, u ping-pong, bit-identical results).  Default 0:
                                    measured SLOWER on MI355X at 4096^2/15x15 (0.67 ms vs 0.28 + 0.19 ms),
                                    the 1.8x halo recompute with two IEEE divisions per element outweighs
-                                   the saved frame pass                            */
+                                   the saved frame pass (NOTES_r01.md section 4)                            */
   int conv;                     /* ICS_CONV_*: which kernels run the convolutions A1/A3 and the PSF gradient A13    */
   int flags;                    /* ICS_FLAG_* bits, 0 = defaults                                                     */
   int band_row0, band_row1;     /* ICS_STAGE_BAND_* only: the rows [row0, row1) this job OWNS when one image is split into

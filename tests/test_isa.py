@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 # The only kernels allowed to spill: the OPT-IN fused update + convolution kernel (ics_rl_params.fuse = 1, default 0, measured
-# slower than the separate kernels -- DESIGN.md section 4), template mode 2 of k_conv.  Everything else must be clean.
+# slower than the separate kernels -- NOTES_r01.md section 4), template mode 2 of k_conv.  Everything else must be clean.
 ALLOWED = re.compile(r"^k_conv<\d+, 2, 2, \d+, \d+>")
 
 
