@@ -393,7 +393,7 @@ extern "C" int ics_rl_create(ics_ctx* c, int M, int N, int MK, ics_rl** out) {
   j->frame_floats = ics_frame_floats(j->g);
   j->origin = ics_origin_offset(j->g);
   // the matrix-core kernels address a frame through a raw buffer descriptor with 32-bit byte offsets
-  if (j->frame_floats * 4 >= ((size_t)1 << 31)) {
+  if (j->frame_floats * 4 >= (size_t)ICS_FRAME_LIMIT_BYTES) {
     delete j;
     return fail(ICS_ENOSUP, "a %d x %d frame with a %d x %d PSF takes %.2f GB; frames are limited to 2 GiB (about 13000 x 13000 px)", M, N, MK, MK,
                 (double)ics_frame_floats(ics_make_geom(M, N, MK)) * 4e-9);
@@ -1284,6 +1284,11 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
 }
 extern "C" int ics_rl_describe(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) { return describe_impl(j, p, r); }
 // the same for a shape alone: no device, no job (the predicates read the geometry and which weight tables a job of this PSF size owns)
+extern "C" unsigned long long ics_rl_frame_bytes(int M, int N, int MK) {
+  if (M < 1 || N < 1 || MK < 3 || !(MK & 1) || !psf_supported(MK)) return 0ull;
+  return (unsigned long long)ics_frame_floats(ics_make_geom(M, N, MK)) * 4ull;
+}
+
 extern "C" int ics_describe(int M, int N, int MK, const ics_rl_params* p, ics_rl_route* r) {
   if (M < 1 || N < 1 || MK < 3 || !(MK & 1)) return fail(ICS_EINVAL, "bad shape: M=%d N=%d MK=%d (MK odd >= 3)", M, N, MK);
   if (!psf_supported(MK)) return fail(ICS_ENOSUP, "PSF size %d not supported (odd sizes 3..%d)", MK, ICS_PSF_MAX);

@@ -883,14 +883,18 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
   }
 }
 
-// gradk[a][b][c] = sum of the blocks of the workgroups that kept channel c (block % 3 == c), in double, in block order
+// gradk[a][b][c] = sum of the blocks of the workgroups that kept channel c (block % 3 == c), in double.  One wave per value: lane l adds
+// blocks c + 3 l, c + 3 (l + 64), ... and the 64 lane sums meet in a fixed butterfly (the same bits run after run).  (One thread per value
+// with its 85 serial loads took 27 us, 7 % of the gradient kernel it follows.)
 __global__ __launch_bounds__(256) void k_gradk_fft_reduce(const float* __restrict__ partial, int nblocks, int K, float* __restrict__ gradk) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= 3 * K * K) return;
   const int c = i % 3, ab = i / 3;
   double s = 0.0;
-  for (int b = c; b < nblocks; b += 3) s += (double)partial[(size_t)b * K * K + ab];
-  gradk[i] = (float)s;
+  for (int b = c + 3 * lane; b < nblocks; b += 192) s += (double)partial[(size_t)b * K * K + ab];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) gradk[i] = (float)s;
 }
 
 // ---- spectrum: S_o,c[ky][kx] = conj( sum_{a,b} W_o[a][b][c] w^(a ky + b kx) ) / 128^2,  w = exp(-2 pi i / 128), stored at spec_index(c, ky, kx) ----
@@ -1012,7 +1016,7 @@ hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g
   auto kern = icsfft::k_gradk_fft<0>;
   if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
-  hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 255) / 256), dim3(256), 0, s, partial, grid, g.K, gradk);
+  hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 3) / 4), dim3(256), 0, s, partial, grid, g.K, gradk);
   return hipGetLastError();
 }
 #endif

@@ -83,6 +83,14 @@ def describe(M, N, MK, params):
     return r
 
 
+FRAME_LIMIT_BYTES = 1 << 31      # include/ics_hip.h ICS_FRAME_LIMIT_BYTES
+
+
+def frame_bytes(M, N, MK):
+    """ics_rl_frame_bytes: device bytes of one frame buffer of such a job, 0 for an invalid shape (no device needed)."""
+    return int(load().ics_rl_frame_bytes(int(M), int(N), int(MK)))
+
+
 class NativeError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("libics_hip error %d: %s" % (code, message))
@@ -122,6 +130,7 @@ def load():
     lib.ics_rl_stage.argtypes = [vp, ci, C.POINTER(RLParams)]
     lib.ics_rl_describe.argtypes = [vp, C.POINTER(RLParams), C.POINTER(RLRoute)]; lib.ics_rl_describe.restype = ci
     lib.ics_describe.argtypes = [ci, ci, ci, C.POINTER(RLParams), C.POINTER(RLRoute)]; lib.ics_describe.restype = ci
+    lib.ics_rl_frame_bytes.argtypes = [ci, ci, ci]; lib.ics_rl_frame_bytes.restype = C.c_ulonglong
     lib.ics_rl_read.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_write.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ics_rl_read_rows.argtypes = [vp, ci, ci, ci, vp]

@@ -61,6 +61,23 @@ def _cache_limit():
         return _JOB_CACHE_MAX_BYTES
 
 
+_FRAME_LIMIT = _native.FRAME_LIMIT_BYTES     # (a test lowers it to send small frames through the same routing)
+
+
+def _bands_needed(M, N, MK, limit=None):
+    """1 when an M x N job's frames stay below the library's 2 GiB frame limit, else the smallest number of row bands whose jobs (a band's
+    rows plus MK // 2 halo rows either side) do; ValueError when no split helps (a single row of pixels too wide, bands thinner than the halo)."""
+    limit = _FRAME_LIMIT if limit is None else limit
+    if _native.frame_bytes(M, N, MK) < limit:
+        return 1
+    pad = MK // 2
+    for k in range(2, M // max(2 * pad, 1) + 1):
+        rows = -(-M // k) + 2 * pad                # the tallest band with its halos
+        if _native.frame_bytes(min(rows, M), N, MK) < limit:
+            return k
+    raise ValueError("a %d x %d image with a %d x %d PSF cannot be cut into row bands below the %d-byte frame limit" % (M, N, MK, MK, limit))
+
+
 def _get_job(M, N, MK):
     """Keep the device frames of the most recent problem sizes alive (least recently used out): deblur_module calls the
     solver once or twice per pyramid level, and the reference's per-call allocation of 13 scratch frames (pyx:378-390) is
@@ -215,6 +232,18 @@ def richardson_lucy_MM(image, u, psf, top, bottom, left, right, tau, M, N, C, MK
         # the reference does not validate shapes (it would read out of bounds); the GPU path cannot do that
         raise ValueError("expected image (%d,%d,3), u (%d,%d,3), psf (%d,%d,3); got %s, %s, %s" %
                          (M, N, M + 2 * (MK // 2), N + 2 * (MK // 2), MK, MK, image.shape, u.shape, psf.shape))
+    nbands = _bands_needed(M, N, MK)
+    if nbands > 1:
+        # a frame of 2 GiB and more (about 13 000 x 13 000 px): the kernels address a frame with 32-bit offsets.  The reference has no such
+        # limit (pyx:341), so the call goes through the row bands of lib/banded.py -- all of them on this GPU -- instead of failing.
+        if tv_mode != 0 or flags != 0:
+            raise ValueError("a %d x %d image needs row bands (frames of 2 GiB and more), which are built for the shipped loop (tv_mode 0, flags 0)" % (M, N))
+        from .banded import richardson_lucy_MM_banded
+        _drop_jobs()
+        out = richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N, C, MK, iterations, step_factor, lambd, blind, correlation,
+                                        bands=nbands, devices=[_native.default_device()] * nbands, conv=conv)
+        richardson_lucy_MM.last = richardson_lucy_MM_banded.last
+        return out
     job = _get_job(M, N, MK)
     job.upload(image, u, psf)
     params = job.params(top, bottom, left, right, tau, iterations, step_factor, lambd, blind, correlation, channels=C,

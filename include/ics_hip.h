@@ -232,6 +232,11 @@ typedef struct ics_rl_route {
 int ics_rl_describe(ics_rl *job, const ics_rl_params *params, ics_rl_route *route);
 /* The same for a shape alone -- no device and no job needed (a benchmark or a test labels its lines before anything is allocated). */
 int ics_describe(int M, int N, int MK, const ics_rl_params *params, ics_rl_route *route);
+/* Bytes ONE frame buffer of such a job takes on the device (aprons and tile padding included), 0 for an invalid shape: ics_rl_create refuses
+   2 GiB and more (32-bit buffer offsets in the kernels).  No device needed.  lib/deconvolution.py uses it to send larger images through the row
+   bands on one GPU (lib/banded.py) instead of failing -- the reference, lib/deconvolution.pyx:341, has no such limit. */
+#define ICS_FRAME_LIMIT_BYTES 0x80000000ull
+unsigned long long ics_rl_frame_bytes(int M, int N, int MK);
 
 /* Stage-level entry points (parity tests, profiling).  They operate on the job's device frames. */
 #define ICS_STAGE_SYNTH_RESIDUAL 1 /* A1+A2: error = conv_valid(u, psf) - image   (pyx:477-488)   */

@@ -58,6 +58,79 @@ def test_nonblind_fp32_bands_are_bit_identical_to_one_job(bands):
     assert [l for l in log1.splitlines() if "DoF" not in l] == [l for l in log2.splitlines() if "DoF" not in l]
 
 
+def test_frame_limit_routing_decision():
+    """ics_rl_frame_bytes / lib.deconvolution._bands_needed: frames of 2 GiB and more (the kernels' 32-bit offsets) go through the row bands on
+    one GPU instead of being refused -- the reference has no size limit (pyx:341).  No device needed."""
+    from lib import _native, deconvolution as dc
+    assert _native.frame_bytes(0, 10, 9) == 0 and _native.frame_bytes(10, 10, 8) == 0 and _native.frame_bytes(10, 10, 257) == 0
+    b = _native.frame_bytes(4096, 4096, 15)
+    assert 4110 * 4110 * 12 <= b < 1.1 * 4110 * 4110 * 12                    # aprons and tile padding: a few per cent
+    assert _native.frame_bytes(8192, 4096, 15) > b
+    assert dc._bands_needed(4096, 4096, 15) == 1 and dc._bands_needed(12000, 12000, 31) == 1
+    assert _native.frame_bytes(13500, 13500, 15) >= _native.FRAME_LIMIT_BYTES and dc._bands_needed(13500, 13500, 15) == 2
+    k = dc._bands_needed(30000, 20000, 31)
+    assert k >= 4 and _native.frame_bytes(-(-30000 // k) + 30, 20000, 31) < _native.FRAME_LIMIT_BYTES
+    assert _native.frame_bytes(-(-30000 // (k - 1)) + 30, 20000, 31) >= _native.FRAME_LIMIT_BYTES      # the smallest such split
+    with pytest.raises(ValueError):
+        dc._bands_needed(100, 200, 9, limit=1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blind", [False, True])
+def test_frames_beyond_the_limit_take_the_row_bands_by_themselves(monkeypatch, blind):
+    """richardson_lucy_MM itself, with the frame limit lowered so that a 300 x 200 frame needs bands: the same result as the single job
+    (non-blind with fp32 products: bit for bit), the reference's printed lines, `.last` filled."""
+    from lib import deconvolution as dc
+    M, N, MK = 300, 200, 9
+    case = orc.synth_case(M, N, MK, seed=12, blind=blind)
+    win = (100, 181, 40, 141)
+    conv = 1
+    u1, p1, log1, st1 = run_single(case, M, N, MK, win, 1e9 if not blind else 0.0, 2, blind, conv, flags=1 if blind else 0)
+    monkeypatch.setattr(dc, "_FRAME_LIMIT", 500000)
+    assert dc._bands_needed(M, N, MK) >= 3
+    u2, p2, log2, st2 = run_single(case, M, N, MK, win, 1e9 if not blind else 0.0, 2, blind, conv)
+    assert st2.iterations_done == st1.iterations_done == 2
+    if not blind:
+        assert np.array_equal(u1, u2)
+    else:
+        assert rel_err(u2, u1) < 2e-6 and rel_err(p2, p1) < 2e-6
+    assert [l for l in log1.splitlines() if "DoF" not in l][:3] == [l for l in log2.splitlines() if "DoF" not in l][:3] or blind
+    with pytest.raises(ValueError):
+        dc.richardson_lucy_MM(case["image"].copy(), case["u0"].copy(), case["psf0"].copy(), *win, 0.0, M, N, 3, MK, 1, 1e-3, 1e4, blind=blind, tv_mode=2)
+
+
+@pytest.mark.gpu
+def test_a_frame_of_more_than_2_GiB_runs_through_richardson_lucy_MM():
+    """13 600 x 13 600 x 3 fp32 = 2.2 GB per frame, beyond what one job's kernels address: the wrapper cuts it into row bands on the one GPU.
+    Non-blind with fp32 products is independent of the cut (every pixel accumulates its taps in the same order), so the automatic split and
+    an explicit five-band run must agree bit for bit."""
+    from lib import _native, banded, deconvolution as dc
+    M = N = 13600
+    MK = 9
+    assert _native.frame_bytes(M, N, MK) >= _native.FRAME_LIMIT_BYTES
+    rng = np.random.default_rng(5)
+    image = rng.random((M, N, 3), dtype=np.float32)
+    image *= 0.8
+    image += 0.1
+    u0 = np.pad(image, ((4, 4), (4, 4), (0, 0)), mode="edge")
+    k1 = np.exp(-0.5 * ((np.arange(MK) - 4) / 1.5) ** 2)
+    psf0 = np.repeat((np.outer(k1, k1) / np.outer(k1, k1).sum())[:, :, None], 3, axis=2).astype(np.float32)
+    win = (6000, 6255, 7000, 7255)
+    with pytest.raises(_native.NativeError):
+        _native.RLJob(M, N, MK)                                             # the single job refuses this frame
+    u1 = u0.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = dc.richardson_lucy_MM(image, u1, psf0.copy(), *win, 1e9, M, N, 3, MK, 1, 1e-3, 1e4, blind=False, conv=1)
+    assert np.shares_memory(out, u1) and dc.richardson_lucy_MM.last.iterations_done == 1 and not dc.richardson_lucy_MM.last.has_nan
+    assert np.isfinite(u1[::97, ::89]).all() and not np.array_equal(u1[4:-4:97, 4:-4:89], u0[4:-4:97, 4:-4:89])
+    u2 = u0.copy()
+    del u0
+    with contextlib.redirect_stdout(io.StringIO()):
+        banded.richardson_lucy_MM_banded(image, u2, psf0.copy(), *win, 1e9, M, N, 3, MK, 1, 1e-3, 1e4, blind=False, conv=1, bands=5)
+    for r in range(0, M + 8, 1700):
+        assert np.array_equal(u1[r:r + 1700], u2[r:r + 1700])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("bands,conv", [(2, 0), (3, 0), (3, 1)])
 def test_blind_bands_match_one_job(bands, conv):
