@@ -11,13 +11,17 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "big"      # PSF sizes 129 ... 255 (tap blocks only)
 only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]      # re-run these problems of the sequence only ...
 f64 = os.environ.get("FUZZ_F64") == "1"                                          # ... and place both results against float64 convolutions
+conv = int(os.environ.get("FUZZ_CONV", "0"))                                      # ics_rl_params.conv of the device runs (3: transform tiles, PSF sizes <= 65)
+smax = int(os.environ.get("FUZZ_MAX", "200"))                                     # largest frame side
 worst = 0.0
 nfail = nrefnan = 0
 for it in range(n):
     MK = int(rng.choice([3, 9, 15, 17, 21, 23, 31, 33, 37, 39, 41, 45, 49, 51, 57, 63, 65, 71, 89, 127]))
     if big:
         MK = int(rng.choice([129, 131, 133, 145, 165, 167, 199, 231, 253, 255]))
-    M, N = int(rng.integers(max(8, MK // 3), 200)), int(rng.integers(max(8, MK // 3), 200))
+    if conv == 3:
+        MK = int(rng.choice([3, 5, 9, 15, 17, 19, 21, 23, 27, 31, 33, 37, 45, 49, 51, 57, 63, 65]))
+    M, N = int(rng.integers(max(8, MK // 3), smax)), int(rng.integers(max(8, MK // 3), smax))
     blind = bool(rng.integers(0, 2))
     case = orc.synth_case(M, N, MK, seed=int(rng.integers(0, 1 << 30)), blind=blind)
     t, l = int(rng.integers(0, max(1, M // 3))), int(rng.integers(0, max(1, N // 3)))
@@ -52,7 +56,7 @@ for it in range(n):
         orc._conv_direct = keep
     u, psf = case["u0"].copy(), case["psf0"].copy()
     with contextlib.redirect_stdout(io.StringIO()):
-        dc.richardson_lucy_MM(case["image"].copy(), u, psf, *args, blind=blind)
+        dc.richardson_lucy_MM(case["image"].copy(), u, psf, *args, blind=blind, conv=conv)
     if np.isnan(u).any() or np.isnan(psf).any():              # finite inputs: this library never returns NaN (black regions: the 0/0 rule, ics_hip.h)
         print("MK %3d  %3dx%3d blind=%d var=%d: NaN in the device result (%d / %d)   <-- FAIL" % (MK, M, N, blind, var, np.isnan(u).sum(), np.isnan(psf).sum()))
         nfail += 1
