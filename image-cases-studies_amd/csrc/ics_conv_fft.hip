@@ -576,13 +576,13 @@ ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, i
 }
 // mode 1: the operands under tile t
 template <bool TV>
-ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, Ops& o) {
+ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, Ops& o, int i0 = 0, int i1 = 4) {
   int rows, X;
   const int va = quad_lane(a, u, mem.lu, tid, t, rows, X);
   const int vb = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.lut.org;      // (the same geometry: all frames of a job are)
   const int vt = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.ltv.org;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = i0; i < i1; ++i) {
     o.a[t][i] = ld_f32x4<2>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
     o.b[t][i] = ld_f32x4<2>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
     if (TV) o.tv[t][i] = ld_f32x4<2>(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
@@ -663,6 +663,12 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 // workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also waits for the global loads and stores in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef ICS_FFT_M1_EARLY
+#define ICS_FFT_M1_EARLY 1      // mode 1: row groups of tile 1's operands requested before stage F already (0: all at the start of the epilogue)
+#endif
+#ifndef ICS_FFT_M1_WIN
+#define ICS_FFT_M1_WIN 0        // mode 1: tile 1 of the next window requested at the start of the epilogue instead of between its passes
+#endif
 template <int MODE, bool TV>
 __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   extern __shared__ __attribute__((aligned(16))) v2f lds[];
@@ -717,7 +723,10 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     v4f fimg[2][4];
     Ops ops;
     if (MODE == 0) load_image(a, mem, u, opaque(tid), fimg);
-    else load_ops<TV>(a, mem, u, opaque(tid), 0, ops);
+    else {
+      load_ops<TV>(a, mem, u, opaque(tid), 0, ops);
+      if (ICS_FFT_M1_EARLY > 0) load_ops<TV>(a, mem, u, opaque(tid), 1, ops, 0, ICS_FFT_M1_EARLY);   // (stages F and G leave registers for part of tile 1's operands)
+    }
     lds_barrier();
     ICS_FFT_STAMP(5);
     stage_b<-1>(lds, opaque(tid));
@@ -729,7 +738,10 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     // row-quad epilogue, row group by row group (at most one group's raw values alive beside the operands).  Mode 1 has two operand
     // frames: it requests those of the second tile here and takes its maxima in a second pass, and the second tile of the next unit's
     // window goes out between the passes (registers: 128 per thread with 1024 of them).
-    if (MODE == 1) load_ops<TV>(a, mem, u, opaque(tid), 1, ops);
+    if (MODE == 1) {
+      load_ops<TV>(a, mem, u, opaque(tid), 1, ops, ICS_FFT_M1_EARLY, 4);
+      if (ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
+    }
     Maxima mx; maxima_init(mx);
     v4f res[4][2];
     // lane address and row-group count of the two tiles ONCE per unit (as eight store_quad calls the address arithmetic of the epilogue
@@ -771,7 +783,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
         else { maxima_quad<TV>(a, u, te, 0, i, res[i][0], ops, mx, qo[0], false); store_quad_at(a, mem, qo[0], false, i, res[i][0]); }
         asm volatile("" ::: "memory");
       }
-      load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
+      if (!ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (edge) { maxima_quad<TV>(a, u, te, 1, i, res[i][1], ops, mx, qo[1], true); store_quad_at(a, mem, qo[1], true, i, res[i][1]); }
