@@ -850,12 +850,15 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
 // fp32 throughout, with the update pass and the matrix-core PSF gradient on the mirrors as well.  Shipped loop only (tv_mode 0, fuse 0),
 // PSF sizes 3 ... 65.  Explicit: conv = ICS_CONV_FFT (also through the stage API); under ICS_CONV_AUTO inside ics_rl_run where it measured
 // ahead of the matrix-core kernels (fft_preferred); ICS_CONV_PATH=fft|matrix|vector overrides AUTO.
-static bool fft_preferred(const IcsGeom& g) {
+static bool fft_preferred(const IcsGeom& g, bool blind) {
   // measured on MI355X (NOTES_r05.md): per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
-  // the Toeplitz matrix-core kernels pay K^2.  scripts/ab_fft.py, ms per inner iteration, matrix cores -> tiles (non-blind / blind):
-  // 2048^2 17: 0.173 -> 0.200 / 0.317 -> 0.368; 21: 0.271 -> 0.198 / 0.437 -> 0.379; 31: 0.303 -> 0.181 / 0.492 -> 0.383;
-  // 4096^2 17: level / 1.110 -> 1.141; 21: 0.949 -> 0.616 / 1.599 -> 1.135; 1448^2 31: 0.194 -> 0.131 / 0.327 -> 0.274; 1024^2 31: 0.117 -> 0.104 / 0.201 -> 0.215.
-  return g.K >= 19 && (long)g.uM * g.uN >= 1500000L;
+  // the Toeplitz matrix-core kernels pay K^2.  scripts/ab_fft.py at the end of round 5, ms per inner iteration, matrix cores -> tiles
+  // (non-blind / blind):  1024^2 31: 0.118 -> 0.146 / 0.251 -> 0.192;  1448^2 21: 0.162 -> 0.149 / 0.272 -> 0.252;  31: 0.198 -> 0.131 / 0.331 -> 0.248;
+  // 2048^2 17: 0.168 -> 0.183 / level;  19: 0.257 -> 0.181 / 0.427 -> 0.324;  4096^2 15: level / 0.848 -> 0.944 (the fused A11 + A13 kernel);
+  // 17: 0.616 -> 0.599 / 1.104 -> 0.937;  19: 0.901 -> 0.597 / 1.545 -> 0.936;  6144^2 17: 1.285 -> 1.233 / 2.388 -> 1.836.
+  const long px = (long)g.uM * g.uN;
+  if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
+  return g.K == 17 && px >= 8000000L;
 }
 static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (!ics_conv_fft_supported(j->g.K) || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
@@ -863,7 +866,7 @@ static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_ru
   if (p->conv != ICS_CONV_AUTO || !in_run) return false;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
   if (env == 3) return true;
-  return env == 0 && fft_preferred(j->g);
+  return env == 0 && fft_preferred(j->g, p->blind != 0);
 }
 
 // tv_mode 1 rewrites the image in every inner iteration (pyx:547-549 live): a copy would have to be rebuilt each time
