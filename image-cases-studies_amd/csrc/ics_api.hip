@@ -1281,7 +1281,7 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
     else r->gradk_family = use_matrix_gradk(j, p) ? 2 : 4;
     r->gradk_fp16_split = r->gradk_family <= 3;
   }
-  r->image_in_accumulator_order = (matrix && use_image_acc(p) && ics_conv_mfma_rs(j->g.K, j->g) != 0) || (r->gradk_family == 1 && use_image_acc(p));
+  r->image_in_accumulator_order = (matrix && use_image_acc(p) && ics_conv_mfma_rs(j->g.K, j->g, j->ctx ? j->ctx->cus : 256) != 0) || (r->gradk_family == 1 && use_image_acc(p));   // (no HIP call on this path: ics_describe has no context and assumes an MI355X's 256 CUs)
   r->graph = use_graph(j, p) ? 1 : 0;
   return ICS_OK;
 }
@@ -1475,6 +1475,9 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
         RC(pack_weights(j, 0, 0.f, 0, s));
       }
       inner_done -= INNER;
+      // the dropped iteration's event brackets do not enter ms_kernel[] / launches[] (they describe iterations that count); its device time
+      // stays inside ms_total, which is the span of the whole call
+      if (enq >= 2 && j->ev_pairs.size() > ev_mark[(enq - 2) & 1]) j->ev_pairs.resize(ev_mark[(enq - 2) & 1]);
       return ICS_OK;
     };
     while (enq < p->iterations && !stop) {                    // pyx:460

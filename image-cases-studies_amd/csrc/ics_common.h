@@ -271,4 +271,4 @@ hipError_t ics_launch_conv_mfma(int mode, const IcsConvArgs& a, hipStream_t s);
 bool ics_conv_mfma_supported(int K);
 bool ics_conv_mfma_preferred(int K);   // what ICS_CONV_AUTO picks
 size_t ics_conv_mfma_table_floats(int K);
-int ics_conv_mfma_rs(int K, const IcsGeom& g);   // 2 / 4: tile height mode 0 will run with (accumulator-order image layout), 0: none
+int ics_conv_mfma_rs(int K, const IcsGeom& g, int cus = -1);   // 2 / 4: tile height mode 0 will run with (accumulator-order image layout), 0: none

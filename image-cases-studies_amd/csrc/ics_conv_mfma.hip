@@ -1206,12 +1206,12 @@ bool ics_conv_mfma_preferred(int K) { return ics_conv_mfma_supported(K); }
 
 // Tile height (fragment row stride RS = 2: 32 rows, 4: 64 rows) launch_k() picks for this PSF size and frame, 0 for the 8-wave
 // kernels (K >= 23): the caller prepares the accumulator-order image (ics_image_acc.h) of that layout for mode 0.
-int ics_conv_mfma_rs(int K, const IcsGeom& g) {
+int ics_conv_mfma_rs(int K, const IcsGeom& g, int cus) {   // cus < 0: the current device's (launch paths); the shape-only describe path passes a count
   if (K >= 23) return 0;
   if (K <= 15) {   // 16-row tiles on small frames (TileRs::has1): no accumulator-order image for them
     const int frs = ics_debug().conv_rs.load(std::memory_order_relaxed);
     const long t32 = (long)((g.N + 63) / 64) * ((g.M + 31) / 32);
-    if (!ICS_MFMA_NO_RS1 && (frs == 1 || (frs == 0 && t32 < (long)ics_device_cus(ics_current_device())))) return 0;
+    if (!ICS_MFMA_NO_RS1 && (frs == 1 || (frs == 0 && t32 < (long)(cus >= 0 ? cus : ics_device_cus(ics_current_device()))))) return 0;
   }
   bool rs2 = K <= 21 && (K >= 15 || (long)g.tiles_x * g.tiles_y <= 3000);
   if (K <= 13) {   // both heights are built
