@@ -490,7 +490,7 @@ def main():
             # the headline's default path forms its products from two fp16 terms per operand (22 significand bits); the same workload with
             # fp32 products throughout, every round, beside it: packed-fp32 vector convolutions + fp32-MFMA gradient, and the fp32 transform tiles
             out["fp32_product_paths"] = {"vector (ics_conv.hip + fp32-MFMA PSF gradient)": timed_run(ctx, M, MK, blind, 0, 1, 50, 10),
-                                         "fft tiles (ics_conv_fft.hip; PSF gradient on the matrix cores)": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
+                                         "fft tiles (ics_conv_fft.hip: convolutions and PSF gradient as fp32 transforms)": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
             oc = {}
             oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)

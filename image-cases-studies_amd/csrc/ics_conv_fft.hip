@@ -255,7 +255,9 @@ template <int DIR> ICS_FFT_HD void fft16(v2f (&v)[16]) {
 struct IcsFftArgs {
   IcsConvArgs c;        // frames, operands, reduction slots, geometry (c.w / c.bt / c.facc / c.sched unused)
   const v2f* spec;      // [3][128][128]: conj(DFT2(W_c)) / 128^2 of this orientation (k_fft_spectrum)
-  int V;                // valid output pixels per tile edge = 128 - K + 1
+  int V;                // valid output pixels per tile ROW: 128 - K + 1 rounded down to whole quads
+  int Vy;               // valid output ROWS per tile = 128 - K + 1: rows need no rounding to quads, and two more rows per tile save a whole round of
+                        // units at some sizes (6144^2 / 31 x 31 back-projection: 65 x 65 tiles -> 63 x 65 = exactly 24 units per CU instead of 24.8)
   int tiles_x, ntiles, nunits;
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
   int gx0;                  // first column of the tile grid: ox0 rounded down to a multiple of 4, so that every 16-byte access of a plane row
@@ -282,7 +284,7 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
     const int ti = 2 * pair + t;
     u.has[t] = ti < a.ntiles;
     const int ty = ti / a.tiles_x, tx = ti - ty * a.tiles_x;
-    u.oy[t] = a.oy0 + ty * a.V; u.ox[t] = a.gx0 + tx * a.V;
+    u.oy[t] = a.oy0 + ty * a.Vy; u.ox[t] = a.gx0 + tx * a.V;
   }
   return u;
 }
@@ -558,7 +560,7 @@ ICS_FFT_HD void maxima_keys(const Maxima& mx, uint32_t& kg, uint32_t& ku) {
 // lane address of row group 0 of tile t in frame layout L, or ICS_FFT_NONE; `rows` = number of this lane's row groups inside the tile (0..4)
 ICS_FFT_HD int quad_lane(const IcsFftArgs& a, const Unit& u, const Lay& L, int tid, int t, int& rows, int& X) {
   const int r0 = tid >> 5, xq = tid & 31;
-  const int lim = a.oy1 - u.oy[t] < a.V ? a.oy1 - u.oy[t] : a.V;      // output rows of this tile
+  const int lim = a.oy1 - u.oy[t] < a.Vy ? a.oy1 - u.oy[t] : a.Vy;      // output rows of this tile
   X = u.ox[t] + 4 * xq;
   const bool ok = u.has[t] && 4 * xq < a.V && X < a.ox1 && r0 < lim;
   rows = ok ? (lim - r0 + 31) >> 5 : 0;                                // row groups i with r0 + 32 i < lim
@@ -971,12 +973,13 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->planar = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
-  a->V = (ICS_FFT_P - g.K + 1) & ~3;     // valid pixels per tile edge, whole quads (16-byte stores never straddle two tiles)
+  a->Vy = ICS_FFT_P - g.K + 1;           // valid rows per tile: all of them
+  a->V = a->Vy & ~3;                     // valid pixels per tile row, whole quads (16-byte stores never straddle two tiles)
   if (mode == 0) { a->oy0 = g.pad; a->ox0 = g.pad; a->oy1 = g.pad + g.M; a->ox1 = g.pad + g.N; }
   else { a->oy0 = 0; a->ox0 = 0; a->oy1 = g.uM; a->ox1 = g.uN; }
   a->gx0 = a->ox0 & ~3;
   a->tiles_x = (a->ox1 - a->gx0 + a->V - 1) / a->V;
-  const int tiles_y = (a->oy1 - a->oy0 + a->V - 1) / a->V;
+  const int tiles_y = (a->oy1 - a->oy0 + a->Vy - 1) / a->Vy;
   a->ntiles = a->tiles_x * tiles_y;
   a->nunits = 3 * ((a->ntiles + 1) / 2);
 }

@@ -153,7 +153,7 @@ int emulate(int M, int K, int N) {
     if (g_planar) ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.pu.data() : h.pe.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec.data(), &a);
     else ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.u.data() : h.e.data(), out.data(), h.f.data(), h.u.data(), h.ut.data(), red), (const float*)spec.data(), &a);
     a.planar = 63;
-    printf("mode %d: V %d, tiles %d (x %d), units %d\n", mode, a.V, a.ntiles, a.tiles_x, a.nunits);
+    printf("mode %d: V %d x %d, tiles %d (x %d), units %d\n", mode, a.Vy, a.V, a.ntiles, a.tiles_x, a.nunits);
     const icsfft::Mem mem = icsfft::make_mem(a);
     std::vector<v2f> twl(128);
     for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
