@@ -76,7 +76,7 @@ namespace icsfft {
 // The host pass (CPU emulation, tools/bench_conv_fft.hip) indexes pointers.
 #define ICS_FFT_NONE 0x20000000
 // (ablation builds of tools/bench_conv_fft.hip, -DICS_FFT_ABL_NOMEM=mask: what a unit costs without some of its global memory traffic --
-//  1 spectrum, 2 epilogue operands, 4 window, 8 stores; -DICS_FFT_ABL_NOMATH: without its butterflies)
+//  1 spectrum, 2 epilogue operands (mode 1: tile 0's), 4 window, 8 stores, 16 mode 1's operands of tile 1; -DICS_FFT_ABL_NOMATH: without its butterflies)
 #ifndef ICS_FFT_ABL_NOMEM
 #define ICS_FFT_ABL_NOMEM 0
 #endif
@@ -585,8 +585,13 @@ ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int
   const int vt = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.ltv.org;
 #pragma unroll
   for (int i = i0; i < i1; ++i) {
-    o.a[t][i] = ld_f32x4<2>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
-    o.b[t][i] = ld_f32x4<2>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+    if (t == 0) {   // (ablation kinds: 2 = tile 0's operands and mode 0's image, 16 = tile 1's)
+      o.a[t][i] = ld_f32x4<2>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
+      o.b[t][i] = ld_f32x4<2>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+    } else {
+      o.a[t][i] = ld_f32x4<16>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
+      o.b[t][i] = ld_f32x4<16>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+    }
     if (TV) o.tv[t][i] = ld_f32x4<2>(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
   }
 }
