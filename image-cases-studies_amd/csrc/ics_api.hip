@@ -1643,7 +1643,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       break;
     default: return fail(ICS_EINVAL, "unknown stage %d", stage);
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if (!(p->flags & ICS_FLAG_STAGE_ASYNC)) HIPCHK(hipStreamSynchronize(s));
   return ICS_OK;
 }
 

@@ -25,6 +25,7 @@ ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0
 # stages / buffers
 STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK, STAGE_BAND_REDUCE, STAGE_BAND_MASK_E = range(1, 13)
 FLAG_NO_FUSED_GRADK = 1   # ics_rl_params.flags (include/ics_hip.h ICS_FLAG_*)
+FLAG_STAGE_ASYNC = 2      # ics_rl_stage returns once the stage is queued
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV, BUF_RED = range(10)
 CONV_AUTO, CONV_VECTOR, CONV_MATRIX, CONV_FFT = range(4)   # ics_rl_params.conv (include/ics_hip.h ICS_CONV_*)
 SCALAR_NAMES = ("dt0", "dt1", "dt2", "maxu0", "maxu1", "maxu2", "maxg0", "maxg1", "maxg2", "dtpsf", "M_r", "Hu", "varu",

@@ -229,8 +229,13 @@ class BandRank:
         ctx = nv.Context.get(bd.device)
         self.job = nv.RLJob(bd.b - bd.a, self.N, self.MK, ctx)
         self.sj = nv.RLJob(bottom - top, self.N, self.MK, ctx) if self.R == 0 else None
+        # stages are queued, not waited for (ICS_FLAG_STAGE_ASYNC): the collectives and the row exchanges run on the job's stream, the host
+        # waits where it reads -- the statistics' scalars, once per outer iteration (ICS_BAND_ASYNC=0: a synchronisation per stage, as before round 5)
+        import os
+        flags = nv.FLAG_NO_FUSED_GRADK | (nv.FLAG_STAGE_ASYNC if os.environ.get("ICS_BAND_ASYNC", "1") != "0" else 0)
+        self.fused_ok = MK <= 15 and conv in (nv.CONV_AUTO, nv.CONV_MATRIX)               # ICS_STAGE_SYNTH_GRADK exists (matrix-core path)
         self._P = lambda **kw: self.job.params(top - bd.a, bottom - bd.a, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C,
-                                               conv=conv, flags=nv.FLAG_NO_FUSED_GRADK, **kw)
+                                               conv=conv, flags=flags, **kw)
         self._sP = self.sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv) if self.sj else None
 
     def upload(self, image, u, psf):
@@ -294,13 +299,16 @@ class BandRank:
         sc = {"Hu": float("nan"), "varu": float("nan"), "M_r": 0.0, "dof_min": 0.0, "dof_max": 0.0}
         it, stop = 0, 0
         M_r = M_r_prev = np.float32(0.0)
+        one = self.W == 1                                                                 # a single band: no halos, nothing to combine
+        fused = one and blind and self.fused_ok
         while it < iterations and not stop:                                               # pyx:460
             job.stage(nv.STAGE_MAJORIZE, P())                                             # pyx:462
             for itt in range(INNER):                                                      # pyx:473
                 job.stage(nv.STAGE_SYNTH_RESIDUAL, P())                                   # A1 + A2
                 job.stage(nv.STAGE_BACKPROJECT, P())                                      # A3
-                job.stage(nv.STAGE_BAND_REDUCE, P(band_rows=(bd.lu0, bd.lu1)))
-                group.reduce_band_keys(job)                                               # (1) in place on the device (RCCL), no host hop
+                if not one:                                                               # (a single band owns every row: the back-projection's own maxima)
+                    job.stage(nv.STAGE_BAND_REDUCE, P(band_rows=(bd.lu0, bd.lu1)))
+                    group.reduce_band_keys(job)                                           # (1) in place on the device (RCCL), no host hop
                 job.stage(nv.STAGE_UPDATE, P())                                           # A5 - A10
                 # (2) my first 2 pad owned rows go up, the rows below my owned ones arrive from below; then the other way round
                 up = None if bd.first else (bd.lu0, 2 * pad, R - 1)
@@ -308,13 +316,20 @@ class BandRank:
                 if self.W > 1:
                     group.exchange_rows(job, nv.BUF_U, send=up, recv=None if bd.last else (bd.lu1, 2 * pad, R + 1))
                     group.exchange_rows(job, nv.BUF_U, send=dn, recv=None if bd.first else (bd.lu0 - 2 * pad, 2 * pad, R - 1))
-                if blind:                                                                 # pyx:555
+                if blind and fused:                                                       # one band, PSF <= 15: A11 + A12 + A13 in the fused kernel
+                    job.stage(nv.STAGE_SYNTH_GRADK, P())
+                    if itt == INNER - 1:
+                        sc = self._statistics()
+                    job.stage(nv.STAGE_PSF_UPDATE, P())                                   # A14 - A17
+                elif blind:                                                               # pyx:555
                     job.stage(nv.STAGE_SYNTH_RESIDUAL, P())                               # A11
                     if itt == INNER - 1:
                         sc = self._statistics()                                           # A18 + A19 need the unmasked residual
-                    job.stage(nv.STAGE_BAND_MASK_E, P(band_rows=(bd.y0 - bd.a, bd.y1 - bd.a)))
+                    if not one:
+                        job.stage(nv.STAGE_BAND_MASK_E, P(band_rows=(bd.y0 - bd.a, bd.y1 - bd.a)))
                     job.stage(nv.STAGE_PSF_GRADIENT, P())                                 # A12 + A13 over the owned rows
-                    group.reduce_band_gradk(job)                                          # (3) one float64 all-reduce on the device
+                    if not one:
+                        group.reduce_band_gradk(job)                                      # (3) one float64 all-reduce on the device
                     job.stage(nv.STAGE_PSF_UPDATE, P())                                   # A14 - A17
                 elif itt == INNER - 1:
                     sc = self._statistics()

@@ -123,6 +123,10 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      ICS_FUSED_GRADK=0 does the same for an unmodified caller.  With the fused kernel the
                                      residual frame (ICS_BUF_ERROR) holds e' of pyx:555-565 only on the 64x64 tiles that
                                      meet the stats window -- the only place the loop reads it (pyx:600-601,627)         */
+#define ICS_FLAG_STAGE_ASYNC 2    /* ics_rl_stage: return when the stage is queued on the job's stream instead of when it has run.  Everything
+                                     that reads the job (ics_rl_read*, ics_rl_scalars, the row exchanges, the all-reduces) goes through the same
+                                     stream, so a sequence of stages needs no host synchronisation of its own (lib/banded.py BandRank: one
+                                     per outer iteration, where the stop decision is taken).  Ignored by ics_rl_run.  */
 
 #define ICS_CONV_AUTO 0   /* matrix-core kernels at every size (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33;
                              PSF gradient: MK <= 31 directly, above as tap blocks of <= 31 x 31); env

@@ -298,6 +298,25 @@ def test_rank_mode_bands_one_process_per_band(tmp_path, world):
 
 
 @pytest.mark.gpu
+def test_rank_mode_with_one_band_is_the_single_job(tmp_path):
+    """One rank = one band that owns every row: no halos, no combining passes, stages queued without host synchronisation
+    (ICS_FLAG_STAGE_ASYNC), the fused A11 + A13 kernel in the blind loop -- the stage-API form of ics_rl_run's loop (`bench.py --bands 1`).
+    The same kernels on the same data: bit-identical to the single job, blind and non-blind."""
+    M, N, MK = 300, 260, 15
+    win = (110, 191, 60, 201)
+    for blind in (False, True):
+        case = orc.synth_case(M, N, MK, seed=9, blind=blind)
+        u1, p1, log1, st1 = run_single(case, M, N, MK, win, 1e9 if not blind else 0.0, 3, blind, 0)
+        sub = tmp_path / ("b%d" % blind); sub.mkdir()
+        u2, parts = run_ranks(sub, dict(M=M, N=N, MK=MK, blind=blind, conv=0, iters=3, seed=9, win=win, tau=1e9 if not blind else 0.0), 1)
+        assert int(parts[0]["done"]) == st1.iterations_done
+        assert np.array_equal(u1, u2)
+        if blind:
+            assert np.array_equal(parts[0]["psf"], p1)
+        assert [l for l in log1.splitlines() if "DoF" not in l] == [l for l in str(parts[0]["log"]).splitlines() if "DoF" not in l]
+
+
+@pytest.mark.gpu
 def test_rccl_row_exchange_with_a_one_rank_communicator(tmp_path):
     """ics_rl_exchange_rows over RCCL itself (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd between device frames): all a
     single-GPU box allows is a communicator of one rank exchanging rows with itself -- rows [3, 8) of the u frame must arrive as
