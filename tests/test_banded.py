@@ -101,11 +101,17 @@ def test_frames_beyond_the_limit_take_the_row_bands_by_themselves(monkeypatch, b
 
 @pytest.mark.gpu
 def test_a_frame_of_more_than_2_GiB_runs_through_richardson_lucy_MM():
-    """13 600 x 13 600 x 3 fp32 = 2.2 GB per frame, beyond what one job's kernels address: the wrapper cuts it into row bands on the one GPU.
+    """16 384 x 16 384 x 3 fp32 = 3.2 GB per frame, beyond what one job's kernels address: the wrapper cuts it into row bands on the one GPU.
     Non-blind with fp32 products is independent of the cut (every pixel accumulates its taps in the same order), so the automatic split and
     an explicit five-band run must agree bit for bit."""
     from lib import _native, banded, deconvolution as dc
-    M = N = 13600
+    M = N = 16384                                                            # 3.2 GB per frame; three host arrays of that size below
+    try:
+        avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] >> 20
+    except Exception:
+        avail = 0
+    if avail < 48:
+        M = N = 13600                                                       # (2.2 GB per frame) on a host with less memory to spare
     MK = 9
     assert _native.frame_bytes(M, N, MK) >= _native.FRAME_LIMIT_BYTES
     rng = np.random.default_rng(5)
@@ -116,6 +122,7 @@ def test_a_frame_of_more_than_2_GiB_runs_through_richardson_lucy_MM():
     k1 = np.exp(-0.5 * ((np.arange(MK) - 4) / 1.5) ** 2)
     psf0 = np.repeat((np.outer(k1, k1) / np.outer(k1, k1).sum())[:, :, None], 3, axis=2).astype(np.float32)
     win = (6000, 6255, 7000, 7255)
+    assert dc._bands_needed(M, N, MK) == 2
     with pytest.raises(_native.NativeError):
         _native.RLJob(M, N, MK)                                             # the single job refuses this frame
     u1 = u0.copy()
