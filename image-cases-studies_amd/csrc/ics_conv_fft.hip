@@ -41,7 +41,10 @@
 
 #define ICS_FFT_P 128
 #define ICS_FFT_PITCH 136
-#define ICS_FFT_LDS_BYTES (ICS_FFT_P * ICS_FFT_PITCH * 8 + 128 * 8)   /* the tile + the twiddle table */
+#define ICS_FFT_TWS 17         /* the twiddle table behind the tile: T[j][k1] = w^(j k1), j < 8, k1 < 16, rows of 17 entries (34 dwords: the eight j of a
+                                  wave's lanes fall into different banks), so that a lane's fifteen reads are ONE address + immediate offsets */
+#define ICS_FFT_TW_ENTRIES (8 * ICS_FFT_TWS)
+#define ICS_FFT_LDS_BYTES (ICS_FFT_P * ICS_FFT_PITCH * 8 + ICS_FFT_TW_ENTRIES * 8)   /* the tile + the twiddle table */
 #define ICS_FFT_THREADS 1024
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -259,6 +262,7 @@ struct IcsFftArgs {
   int Vy;               // valid output ROWS per tile = 128 - K + 1: rows need no rounding to quads, and two more rows per tile save a whole round of
                         // units at some sizes (6144^2 / 31 x 31 back-projection: 65 x 65 tiles -> 63 x 65 = exactly 24 units per CU instead of 24.8)
   int tiles_x, ntiles, nunits;
+  unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1: the unit decode divides by a multiply (a run-time divisor costs ~15 vector instructions per division)
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
   int gx0;                  // first column of the tile grid: ox0 rounded down to a multiple of 4, so that every 16-byte access of a plane row
                             // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
@@ -283,7 +287,7 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
   for (int t = 0; t < 2; ++t) {
     const int ti = 2 * pair + t;
     u.has[t] = ti < a.ntiles;
-    const int ty = ti / a.tiles_x, tx = ti - ty * a.tiles_x;
+    const int ty = (int)(((unsigned long long)(unsigned)ti * a.tiles_x_magic) >> 32), tx = ti - ty * a.tiles_x;   // ti / tiles_x (fill_args: exact for ti * tiles_x < 2^32)
     u.oy[t] = a.oy0 + ty * a.Vy; u.ox[t] = a.gx0 + tx * a.V;
   }
   return u;
@@ -403,7 +407,7 @@ ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   for (int m = 0; m < 16; ++m) v[m] = lds_ld(rp + 8 * m);
   if (TWB == 8) {
 #pragma unroll
-    for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+    for (int k1 = 1; k1 < 8; ++k1) tw[k1] = lds_ld(twl + j * ICS_FFT_TWS + k1);
     ICS_FFT_ISSUE_FENCE();
   }
   fft16<1>(v);
@@ -411,7 +415,7 @@ ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   if (TWB == 8) {      // the second eight twiddles are requested before the first eight products: those cover their round trip
     v2f tw2[8];
 #pragma unroll
-    for (int k1 = 8; k1 < 16; ++k1) tw2[k1 - 8] = lds_ld(twl + ((j * k1) & 127));
+    for (int k1 = 8; k1 < 16; ++k1) tw2[k1 - 8] = lds_ld(twl + j * ICS_FFT_TWS + k1);
     ICS_FFT_ISSUE_FENCE();
 #pragma unroll
     for (int k1 = 0; k1 < 8; ++k1) rowp[8 * k1 + ((j + k1) & 7)] = k1 ? cmul(v[k1], tw[k1]) : v[k1];
@@ -423,7 +427,7 @@ ICS_FFT_HD void stage_c(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   for (int h = 0; h < 16 / TWB; ++h) {
     if (TWB != 8 || h > 0) {
 #pragma unroll
-      for (int k1 = TWB * h; k1 < TWB * h + TWB; ++k1) if (k1) tw[k1 - TWB * h] = lds_ld(twl + ((j * k1) & 127));
+      for (int k1 = TWB * h; k1 < TWB * h + TWB; ++k1) if (k1) tw[k1 - TWB * h] = lds_ld(twl + j * ICS_FFT_TWS + k1);
     }
 #pragma unroll
     for (int k1 = TWB * h; k1 < TWB * h + TWB; ++k1) rowp[8 * k1 + ((j + k1) & 7)] = k1 ? cmul(v[k1], tw[k1 - TWB * h]) : v[k1];
@@ -506,7 +510,7 @@ ICS_FFT_HD void stage_e(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   // all fifteen twiddles and the sixteen values requested in one go (the scheduler otherwise sinks each twiddle read next to its product:
   // fifteen serial LDS round trips per wave in a stage every wave of the CU is in at the same time)
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + ((j * k1) & 127));
+  for (int k1 = 1; k1 < 16; ++k1) tw[k1] = lds_ld(twl + j * ICS_FFT_TWS + k1);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(cb[k1 & 7] + 8 * k1);
   ICS_FFT_ISSUE_FENCE();
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
   const int tid = threadIdx.x;
   const int G = gridDim.x;
-  if (tid < 128) twl[tid] = tw128(tid);
+  if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
   const Mem mem = make_mem(a, MODE);
   // workgroup b runs on XCD b % 8 (observed dispatch): consecutive unit slots q go to one XCD, so the three channel units of a tile pair
   // (n = 3 pair + c) share that XCD's L2.  Affects speed only.
@@ -846,7 +850,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
   extern __shared__ __attribute__((aligned(16))) v2f lds[];
   v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
   const int tid = threadIdx.x;
-  if (tid < 128) twl[tid] = tw128(tid);
+  if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
   const Mem mem = make_mem(a, 0);                 // in = u, f = e' (the geometry of mode 0: tiles of the M x N interior)
   const int c = (int)blockIdx.x % 3, slot = (int)blockIdx.x / 3, nslots = (int)gridDim.x / 3, npairs = (a.ntiles + 1) / 2;
   v2f acc[2][8];
@@ -986,6 +990,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->tiles_x = (a->ox1 - a->gx0 + a->V - 1) / a->V;
   const int tiles_y = (a->oy1 - a->oy0 + a->Vy - 1) / a->Vy;
   a->ntiles = a->tiles_x * tiles_y;
+  a->tiles_x_magic = (unsigned)(0x100000000ull / (unsigned)a->tiles_x) + 1u;
   a->nunits = 3 * ((a->ntiles + 1) / 2);
 }
 

@@ -155,8 +155,8 @@ int emulate(int M, int K, int N) {
     a.planar = 63;
     printf("mode %d: V %d x %d, tiles %d (x %d), units %d\n", mode, a.Vy, a.V, a.ntiles, a.tiles_x, a.nunits);
     const icsfft::Mem mem = icsfft::make_mem(a);
-    std::vector<v2f> twl(128);
-    for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
+    std::vector<v2f> twl(ICS_FFT_TW_ENTRIES);
+    for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
     for (int n = 0; n < a.nunits; ++n) {
       const icsfft::Unit u = icsfft::decode_unit(a, n);
       for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
@@ -221,8 +221,8 @@ int emulate_gradk(int M, int K, int N) {
   // a residual with structure (as in the loop: e' = conv(u) - image), not the harness' white noise alone
   for (size_t i = 0; i < h.nf; ++i) h.e[i] = h.e[i] + 0.01f * (h.u[i] - 0.5f) * (h.f[i] != 0.f);
   to_planar(h, h.e, h.pe);
-  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(128);
-  for (int t = 0; t < 128; ++t) twl[t] = icsfft::tw128(t);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES);
+  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
   IcsConvArgs c = conv_args(h, 0, h.pu.data(), h.pe.data(), h.pe.data(), h.pu.data(), h.pu.data(), nullptr);
   IcsFftArgs a;
   ics_conv_fft_fill_args(0, c, nullptr, &a);
