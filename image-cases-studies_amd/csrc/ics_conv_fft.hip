@@ -305,8 +305,8 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   m.lin = make_lay(g, a.planar & ICS_FFT_PL_IN); m.lout = make_lay(g, a.planar & ICS_FFT_PL_OUT); m.lf = make_lay(g, a.planar & ICS_FFT_PL_F);
   m.lu = make_lay(g, a.planar & ICS_FFT_PL_U); m.lut = make_lay(g, a.planar & ICS_FFT_PL_UT); m.ltv = make_lay(g, a.planar & ICS_FFT_PL_TV);
   m.in = make_gbuf(a.c.in - m.lin.org); m.out = make_gbuf(a.c.out - m.lout.org);
-  m.f = mode == 1 ? m.in : make_gbuf(a.c.f - m.lf.org);
-  m.u = mode == 0 ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
+  m.f = (mode == 1 || mode == 2) ? m.in : make_gbuf(a.c.f - m.lf.org);
+  m.u = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.ut - m.lut.org);
   m.tv = (a.c.tv && mode != 0) ? make_gbuf(a.c.tv - m.ltv.org) : m.in;
   m.spec = make_gbuf(a.spec);
   return m;
@@ -729,12 +729,12 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     stage_d(sp, lds, opaque(tid));
     wave_sync();
     ICS_FFT_STAMP(4);
-    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
+    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 1 ? 1 : 2);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
     stage_e(lds, lds, twl, opaque(tid));
     v4f fimg[2][4];
     Ops ops;
     if (MODE == 0) load_image(a, mem, u, opaque(tid), fimg);
-    else {
+    else if (MODE == 1) {
       load_ops<TV>(a, mem, u, opaque(tid), 0, ops);
       if (ICS_FFT_M1_EARLY > 0) load_ops<TV>(a, mem, u, opaque(tid), 1, ops, 0, ICS_FFT_M1_EARLY);   // (stages F and G leave registers for part of tile 1's operands)
     }
@@ -763,14 +763,16 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) qo[t].vo = quad_lane(a, u, mem.lout, te, t, qo[t].rows, qo[t].X);
     const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
-    if (MODE == 0) {
+    if (MODE != 1) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         read_quads(lds, opaque(tid), i, res[i]);
+        if (MODE == 0) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
+            for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
+        }
         asm volatile("" ::: "memory");
       }
       if (edge) {
@@ -996,10 +998,10 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
 
 hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s);
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, int planar, hipStream_t s) {
-  if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+  if (mode < 0 || mode > 2) return hipErrorInvalidValue;      // 2 = the back-projection alone: no operands, no maxima (the PAM kinds take theirs in k_pam_combine)
   if (planar != ICS_FFT_PL_ALL) return hipErrorInvalidValue;   // every frame a channel-planar mirror: the kernel moves 4 pixels of a plane row per access
   IcsFftArgs a;
-  ics_conv_fft_fill_args(mode, c, spec, &a);
+  ics_conv_fft_fill_args(mode == 2 ? 1 : mode, c, spec, &a);
   a.planar = planar;
   return ics_launch_conv_fft_args(mode, a, s);
 }
@@ -1014,8 +1016,9 @@ hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s
   if (a.c.tv && a.c.tv_kind) return hipErrorInvalidValue;
   auto k0 = icsfft::k_conv_fft<0, false>;
   auto k1 = icsfft::k_conv_fft<1, false>;
-  auto kern = mode == 0 ? k0 : k1;
-  const int slot = mode == 0 ? 0 : 1;
+  auto k2 = icsfft::k_conv_fft<2, false>;
+  auto kern = mode == 0 ? k0 : (mode == 1 ? k1 : k2);
+  const int slot = mode;
   if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
   return hipGetLastError();

@@ -46,11 +46,14 @@ def test_labels_follow_the_library_routing(MK, blind):
 def test_route_switches():
     from lib import _native as nv
     # transform tiles under AUTO (csrc/ics_api.hip fft_preferred, measured with scripts/ab_fft.py): 17 x 17 from 8 Mpx, 19 x 19 ... 65 x 65 from
-    # 1.5 Mpx (blind: 1 Mpx), never for 15 x 15 (the fused A11 + A13 kernel) and never for the TV variants
+    # 1.5 Mpx (blind: 1 Mpx), never for 15 x 15 (the fused A11 + A13 kernel)
     assert _route(4096, 17, True).conv_family == 5 and _route(4096, 17, False).conv_family == 5 and _route(2048, 17, True).conv_family == 1
     assert _route(1024, 31, True).conv_family == 5 and _route(1024, 31, False).conv_family == 1 and _route(1448, 21, False).conv_family == 5
     assert _route(4096, 15, True).conv_family == 1 and _route(6144, 15, False).conv_family == 1
-    assert _route(4096, 31, True, tv_mode=3).conv_family == 1 and _route(4096, 67, True).conv_family == 2
+    assert _route(4096, 67, True).conv_family == 2
+    # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
+    assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 6
+    assert _route(4096, 31, True, tv_mode=1).conv_family == 1 and _route(2048, 15, False, tv_mode=2).conv_family == 1
     assert _route(4096, 15, True).gradk_family == 1 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK if hasattr(nv, "FLAG_NO_FUSED_GRADK") else 1).gradk_family == 2
     assert _route(4096, 15, True).image_in_accumulator_order == 1 and _route(4096, 15, True, tv_mode=1).image_in_accumulator_order == 0
     assert _route(4096, 15, True).graph == 0 and _route(512, 9, False).graph == 0      # one hipGraph per outer iteration: opt-in (ICS_GRAPH=1; measured without gain)

@@ -178,6 +178,41 @@ def test_gpu_pam_run_matches_ext_oracle(M, N, MK, blind, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,N,MK,blind,kind", [(150, 140, 31, True, 2), (200, 180, 21, False, 2), (150, 140, 31, True, 3), (260, 300, 45, True, 2)])
+def test_gpu_pam_with_the_convolutions_on_the_transform_tiles(M, N, MK, blind, kind):
+    """The PAM kinds with conv = ICS_CONV_FFT (AUTO takes this route for wide PSFs on large frames): convolutions and PSF gradient on
+    the fp32 transform tiles, TV term / combination G = T + lambd gradu / update on the HWC frames (csrc/ics_api.hip do_conv_hyb,
+    ics_planar.hip k_pam_combine).  Same arithmetic around other convolution kernels: the run must agree with the fp32-product HWC path."""
+    from lib import deconvolution as dc
+    case = orc.synth_case(M, N, MK, seed=M + MK + kind, blind=blind)
+    args = (*orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 2, 1e-3, 50.0)
+    res = {}
+    for conv in (1, 3):
+        img, u, psf = case["image"].copy(), case["u0"].copy(), case["psf0"].copy()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            dc.richardson_lucy_MM(img, u, psf, *args, blind=blind, tv_mode=kind, conv=conv)
+        st = dc.richardson_lucy_MM.last
+        assert np.array_equal(img, case["image"]) and not st.has_nan and st.iterations_done == 2
+        res[conv] = (u, psf, st.M_r, st.Hu, buf.getvalue())
+    d = np.abs(res[3][0] - res[1][0]) / np.abs(res[1][0]).max()
+    ep = rel_err(res[3][1], res[1][1])
+    print("tv_mode=%d %dx%d k%d blind=%d tiles vs HWC fp32: u max %.2e (beyond 1e-5: %.2e), psf %.2e" % (kind, M, N, MK, blind, d.max(), np.mean(d > 1e-5), ep))
+    assert ep < 1e-5
+    if kind == 3:
+        assert np.mean(d > 1e-5) < 2e-3 and d.max() < 5e-3          # (arg-max flips of the collaborative term, as in the oracle comparison above)
+    elif blind:
+        assert d.max() < 1e-5
+    else:   # non-blind epsilon = 1e-6: the TV term of nearly flat pixels amplifies 1e-7 differences of the convolutions (see the test below)
+        assert d.max() < 1e-4 and np.mean(d > 1e-5) < 1e-3
+    assert abs(res[3][2] - res[1][2]) <= 2e-3 * abs(res[1][2]) and abs(res[3][3] - res[1][3]) <= 1e-4 * abs(res[1][3])
+    assert len(res[3][4].splitlines()) == len(res[1][4].splitlines())
+    from lib import _native as nv
+    with pytest.raises(nv.NativeError):                                 # the active MM-TV kind stays off the tiles
+        dc.richardson_lucy_MM(case["image"].copy(), case["u0"].copy(), case["psf0"].copy(), *args, blind=blind, tv_mode=1, conv=3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("MK", [45, 63])
 def test_nonblind_pam_at_large_psf_deviation_is_the_tv_term_of_nearly_flat_pixels(MK):
     """Round-3 fuzz: non-blind PAM (tv_mode 2, epsilon = 1e-6) at PSF sizes 45 ... 63 deviated by 1e-5 ... 1e-3 from the extended oracle.
