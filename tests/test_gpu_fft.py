@@ -106,7 +106,9 @@ def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
     assert r.conv_family == 1
     r = describe(2048, 2048, 45, conv=FFT)
     assert r.conv_family == 5 and r.gradk_family == 6
-    r = describe(2048, 2048, 31, tv_mode=2)
+    r = describe(2048, 2048, 31, tv_mode=2)          # the PAM kinds: convolutions and PSF gradient on the tiles, the rest on the HWC frames
+    assert r.conv_family == 5 and r.gradk_family == 6
+    r = describe(2048, 2048, 31, tv_mode=1)          # active MM-TV: matrix cores
     assert r.conv_family == 1
 
 
