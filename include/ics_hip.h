@@ -134,13 +134,15 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 49, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
-#define ICS_CONV_FFT 3    /* transform tiles (ics_conv_fft.hip, round 5; MK <= 65, shipped loop): A1 / A3 / A11 as 128 x 128 overlap-save
+#define ICS_CONV_FFT 3    /* transform tiles (ics_conv_fft.hip, round 5; MK <= 65): A1 / A3 / A11 as 128 x 128 overlap-save
                              FFTs held in LDS, fp32 throughout -- the reference's own method (scipy's complex64 FFT over the frame,
                              lib/deconvolution.pyx:478,491), tile by tile; against float64 direct sums 2 - 5e-7 of the largest
                              convolution value.  The frames live as channel-planar mirrors for the duration of a run; the PSF gradient
                              runs on the same tiles (two forward transforms per tile pair, products added up in the frequency domain; env
                              ICS_FFT_GRADK=0: on the matrix cores).  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 19 on for frames
-                             >= 1.5 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.  Where image and u are exactly 0 the
+                             >= 1.5 Mpx (blind: 1 Mpx) and for MK = 17 from 8 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.
+                             The PAM kinds (tv_mode 2, 3) take it for their convolutions and PSF gradient, with the TV term, the
+                             combination G = T + lambd * gradu and the update on the HWC frames; tv_mode 1 is refused.  Where image and u are exactly 0 the
                              transforms return rounding noise instead of exact zeros, like the reference's (see "DoF ratio" below) */
 
 /* Accuracy of the matrix-core path (tests/test_gpu_precision.py drives it with adversarial inputs).  Every fp32 operand x of a
