@@ -262,7 +262,7 @@ struct IcsFftArgs {
   int Vy;               // valid output ROWS per tile = 128 - K + 1: rows need no rounding to quads, and two more rows per tile save a whole round of
                         // units at some sizes (6144^2 / 31 x 31 back-projection: 65 x 65 tiles -> 63 x 65 = exactly 24 units per CU instead of 24.8)
   int tiles_x, ntiles, nunits;
-  unsigned tiles_x_magic;   // floor(2^32 / tiles_x) + 1: the unit decode divides by a multiply (a run-time divisor costs ~15 vector instructions per division)
+  unsigned long long tiles_x_magic;   // floor(2^32 / tiles_x) + 1 (33 bits for tiles_x = 1): the unit decode divides by a multiply
   int oy0, ox0, oy1, ox1;   // output region in u-frame coordinates (mode 0: the M x N interior; mode 1: the whole u-frame)
   int gx0;                  // first column of the tile grid: ox0 rounded down to a multiple of 4, so that every 16-byte access of a plane row
                             // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
@@ -287,7 +287,7 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
   for (int t = 0; t < 2; ++t) {
     const int ti = 2 * pair + t;
     u.has[t] = ti < a.ntiles;
-    const int ty = (int)(((unsigned long long)(unsigned)ti * a.tiles_x_magic) >> 32), tx = ti - ty * a.tiles_x;   // ti / tiles_x (fill_args: exact for ti * tiles_x < 2^32)
+    const int ty = (int)(((unsigned long long)(unsigned)ti * a.tiles_x_magic) >> 32), tx = ti - ty * a.tiles_x;   // ti / tiles_x (fill_args: exact for ti * tiles_x < 2^32; the magic is 2^32 + 1 for one tile column)
     u.oy[t] = a.oy0 + ty * a.Vy; u.ox[t] = a.gx0 + tx * a.V;
   }
   return u;
@@ -992,7 +992,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->tiles_x = (a->ox1 - a->gx0 + a->V - 1) / a->V;
   const int tiles_y = (a->oy1 - a->oy0 + a->Vy - 1) / a->Vy;
   a->ntiles = a->tiles_x * tiles_y;
-  a->tiles_x_magic = (unsigned)(0x100000000ull / (unsigned)a->tiles_x) + 1u;
+  a->tiles_x_magic = 0x100000000ull / (unsigned)a->tiles_x + 1ull;
   a->nunits = 3 * ((a->ntiles + 1) / 2);
 }
 

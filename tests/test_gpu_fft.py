@@ -32,7 +32,8 @@ def make_job(M, N, MK, seed=0, blind=False):
 
 
 @pytest.mark.parametrize("M,N,MK", [(40, 50, 3), (70, 131, 9), (90, 100, 15), (114, 114, 15), (115, 229, 15), (150, 260, 17), (99, 197, 31),
-                                    (200, 120, 31), (84, 169, 45), (130, 70, 63), (64, 129, 65), (300, 310, 23)])
+                                    (200, 120, 31), (84, 169, 45), (130, 70, 63), (64, 129, 65), (300, 310, 23),
+                                    (300, 100, 5), (260, 99, 9), (176, 108, 17), (400, 60, 31)])   # (the last four: ONE tile column, several tile rows)
 def test_fft_convolutions_against_float64(M, N, MK):
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=MK + M)
@@ -176,7 +177,7 @@ def test_few_persistent_workgroups_walk_many_units(debug_switch):
     job.close()
 
 
-@pytest.mark.parametrize("M,N,MK", [(90, 100, 15), (150, 260, 17), (200, 120, 31), (300, 310, 23), (230, 333, 45), (190, 170, 63)])
+@pytest.mark.parametrize("M,N,MK", [(90, 100, 15), (150, 260, 17), (200, 120, 31), (300, 310, 23), (230, 333, 45), (190, 170, 63), (300, 100, 5), (176, 108, 17)])
 def test_fft_psf_gradient_against_float64(M, N, MK):
     """A12 + A13 on the tiles (k_gradk_fft): the residual of the frame's own synthesis (e' = conv(u, psf) - image, as in the loop) against u,
     float64 direct sums, the gate of every other gradient kernel (1e-5 of max |gradk|; measured 1 - 3e-7)."""
