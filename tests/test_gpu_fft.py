@@ -196,3 +196,28 @@ def test_fft_psf_gradient_against_float64(M, N, MK):
     print("%dx%d K=%d: PSF gradient on the tiles %.2e" % (M, N, MK, err))
     assert err < 1e-5
     job.close()
+
+
+@pytest.mark.parametrize("blind", [False, True])
+def test_nan_in_the_image_on_the_tiles_is_reported_not_raised(blind):
+    """pyx:671-672: NaN is printed, never raised.  The reference's own frame-wide FFT convolution turns one NaN pixel into an all-NaN
+    frame; on the tiles it fills the tiles it touches and the step sizes (maxima as integer keys: a NaN is the largest key) carry it to
+    every pixel with the first update -- either way the call returns, reports it and prints the reference's line."""
+    import contextlib, io
+    from lib import deconvolution as dc
+    M, N, MK = 260, 300, 21
+    case = orc.synth_case(M, N, MK, seed=2, blind=blind)
+    case["image"][100, 120, 1] = np.nan
+    u, psf = case["u0"].copy(), case["psf0"].copy()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        dc.richardson_lucy_MM(case["image"].copy(), u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 1, 1e-3, 1e4, blind=blind, conv=FFT)
+    st = dc.richardson_lucy_MM.last
+    assert st.has_nan and "has NaN after DoF correction" in buf.getvalue()
+    u_r, psf_r = case["u0"].copy(), case["psf0"].copy()
+    with np.errstate(all="ignore"):
+        orc.richardson_lucy_MM(case["image"].copy(), u_r, psf_r, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 1, 1e-3, 1e4, blind=blind, quiet=True)
+    assert np.array_equal(np.isnan(u), np.isnan(u_r)) and np.isnan(u[:, :, 1]).all()      # the NaN's channel, whole frame: as far as in the reference
+    if blind:
+        assert np.array_equal(np.isnan(psf), np.isnan(psf_r))
+    dc._drop_jobs()
