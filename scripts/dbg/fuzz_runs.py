@@ -65,7 +65,7 @@ for it in range(n):
         # the reference met an exact zero in its FFT noise inside a black region (common for black columns, rare for black rows) and lost
         # the frame; compare with the float64-direct oracle, which carries the rule, instead
         nrefnan += 1
-        if big:      # (float64 direct sums of 65 025 taps per value: minutes per case in numpy)
+        if big or M * N * MK * MK > 4e8:      # (float64 direct sums: 65 025 taps per value at the big PSF sizes, or a megapixel frame -- minutes per case in numpy)
             print("   (reference = NaN by an exact zero of its FFT noise; not compared at this PSF size)")
             continue
         u_ref, psf_ref = case["u0"].copy(), case["psf0"].copy()
