@@ -451,7 +451,7 @@ def main():
             dom = max((k for k in kern if k in BYTES_PER_PX), key=lambda k: kern[k]["ms"] * kern[k]["launches"])
             bytes_launch = BYTES_PER_PX[dom] * M * N
             ach = bytes_launch / (kern[dom]["ms"] * 1e-3) / 1e9
-            roof = {"bound": "hbm", "limiter": ("issue / lds / matrix pipe (hbm is the yardstick)" if matrix else "fp32 valu (hbm is the yardstick)") if dom != "update" else "hbm",
+            roof = {"bound": "hbm", "limiter": ("issue / lds / matrix pipe (hbm is the yardstick)" if matrix else ("lds transfers + the CU's vector-memory path, which do not overlap (hbm is the yardstick; NOTES_r05.md)" if lab["traffic_key"] == "kernels_fft" else "fp32 valu (hbm is the yardstick)")) if dom != "update" else "hbm",
                     "bound_note": "HBM (8 TB/s) is the yardstick north_star sets and what `achieved` / `peak` / `frac` are quoted against; what LIMITS the matrix-core kernels is issue / LDS / "
                     "matrix-pipe time, not bytes (traffic < algorithmic bytes for the fused kernel; SQ and FETCH / WRITE passes under profiles/) -- see `mfma`", "kernel": dom,
                     "mfma": mfma_counters(dom, M, MK), "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
