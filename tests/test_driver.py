@@ -139,6 +139,26 @@ def test_device_resident_driver_against_the_oracle_solver(pyramid, preview, blur
 
 
 @pytest.mark.gpu
+def test_driver_with_a_wide_blur_on_a_large_picture_takes_the_transform_tiles(debug_switch, capsys):
+    """`deblur_module` on a 1500 x 1400 picture with a 21-px blur: the non-blind passes over the whole picture (2.2 Mpx, 21 x 21 and the
+    pyramid's 15 x 15 ... below) are what ICS_CONV_AUTO sends to the transform tiles; the blind passes on the 255-px mask window stay
+    on the matrix cores.  The same call with the tiles switched off (debug switch conv_path = matrix) must give the same picture and PSF."""
+    import deconvolve as dv
+    rng = np.random.default_rng(3)
+    coarse = rng.random((1500 // 8 + 2, 1400 // 8 + 2, 3))
+    pic = (np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:1500, :1400] * 200 + 20).astype(np.uint8)
+    kw = dict(mask=[750, 700], mask_size=255, display=False, iterations=3, save=False)
+    out_t, psf_t = dv.deblur_module(pic, "t", ".", 21, **kw)
+    capsys.readouterr()
+    debug_switch("conv_path", 2)
+    out_m, psf_m = dv.deblur_module(pic, "m", ".", 21, **kw)
+    capsys.readouterr()
+    assert out_t.shape == out_m.shape == (1500, 1400, 3) and np.isfinite(out_t).all()
+    assert np.abs(psf_t - psf_m).max() < 1e-5
+    assert np.abs(out_t.astype(np.float64) - out_m).max() / 65535 < 5e-5, np.abs(out_t.astype(np.float64) - out_m).max()
+
+
+@pytest.mark.gpu
 def test_device_image_operations_match_numpy():
     from lib import _native
     import resize_oracle as ro
