@@ -848,7 +848,8 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
   if (p->conv == ICS_CONV_VECTOR) return false;
   if (p->conv == ICS_CONV_MATRIX) return true;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
-  return env == 2 || (env == 0 && ics_conv_mfma_preferred(j->g.K));
+  // (ICS_CONV_PATH=fft where the tiles do not run -- single stages, tv_mode 1, PSF sizes above 65: what AUTO would take)
+  return env == 2 || ((env == 0 || env == 3) && ics_conv_mfma_preferred(j->g.K));
 }
 
 // The FFT-tile pipeline (ics_conv_fft.hip; round 5): A1 / A3 / A11 as LDS-resident 128 x 128 overlap-save transforms on planar mirrors,
