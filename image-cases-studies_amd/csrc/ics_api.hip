@@ -885,7 +885,9 @@ static bool use_fft_hybrid(const ics_rl* j, const ics_rl_params* p, bool in_run)
   if (p->conv != ICS_CONV_AUTO) return false;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
   if (env == 3) return true;
-  return env == 0 && j->g.K >= 19 && (long)j->g.uM * j->g.uN >= 1500000L;
+  // scripts: bench.py --tv-mode 2, ICS_CONV_PATH=matrix -> fft, ms per inner iteration: 1448^2 / 31 blind 0.357 -> 0.297; 2048^2 / 21 blind 0.470 -> 0.396,
+  // non-blind 0.271 -> 0.259; 4096^2 / 19 blind 1.563 -> 1.132; 1100^2 / 45 blind 0.432 -> 0.310
+  return env == 0 && j->g.K >= 19 && (long)j->g.uM * j->g.uN >= (p->blind ? 1000000L : 1500000L);
 }
 
 // tv_mode 1 rewrites the image in every inner iteration (pyx:547-549 live): a copy would have to be rebuilt each time
