@@ -136,6 +136,22 @@ def test_a_frame_of_more_than_2_GiB_runs_through_richardson_lucy_MM():
         banded.richardson_lucy_MM_banded(image, u2, psf0.copy(), *win, 1e9, M, N, 3, MK, 1, 1e-3, 1e4, blind=False, conv=1, bands=5)
     for r in range(0, M + 8, 1700):
         assert np.array_equal(u1[r:r + 1700], u2[r:r + 1700])
+    # the blind loop on the same frame with the default (matrix-core) kernels: the automatic split against an explicit three-band one
+    # (different tilings of the split operands: 1e-6, as in the small blind band tests)
+    del u2
+    u1[...] = np.pad(image, ((4, 4), (4, 4), (0, 0)), mode="edge")
+    p1 = psf0.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        dc.richardson_lucy_MM(image, u1, p1, *win, 0.0, M, N, 3, MK, 1, 1e-3, 1e4, blind=True)
+    assert dc.richardson_lucy_MM.last.iterations_done == 1 and not dc.richardson_lucy_MM.last.has_nan
+    u3 = np.pad(image, ((4, 4), (4, 4), (0, 0)), mode="edge")
+    p3 = psf0.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        banded.richardson_lucy_MM_banded(image, u3, p3, *win, 0.0, M, N, 3, MK, 1, 1e-3, 1e4, blind=True, bands=3)
+    assert rel_err(p3, p1) < 2e-6 and not np.array_equal(p1, psf0)
+    den = float(np.abs(u1[::53, ::47]).max())
+    for r in range(0, M + 8, 1700):
+        assert float(np.abs(u3[r:r + 1700] - u1[r:r + 1700]).max()) / den < 2e-6
 
 
 @pytest.mark.gpu
