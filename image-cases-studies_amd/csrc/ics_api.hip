@@ -197,11 +197,6 @@ struct ics_rl {
   float *spec_conv, *spec_corr;
   bool fft_on;
   bool plf_valid;                       // the mirror of the image frame still mirrors it (every writer of j->f calls image_changed)
-  // PAM kinds (tv_mode 2 / 3) with a wide PSF on a large frame: only the convolutions and the PSF gradient run on the tiles, the TV term,
-  // the combination G = T + lambd gradu and the update stay HWC kernels (fft_hyb).  plu_src = the HWC frame the mirror of u was last
-  // converted from while nothing has written that frame since (nullptr: convert before the next tile kernel that reads u).
-  bool fft_hyb;
-  const float* plu_src;
 };
 
 static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
@@ -483,14 +478,14 @@ static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hip
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
   if (j->blk_conv) HIPCHK(ics_launch_pack_blocks(j->psf, j->g.K, j->blk_kb, j->blk_n, j->blk_conv, j->blk_corr, ics_conv_mfma_table_floats(j->blk_kb), s));
-  if (j->fft_on || j->fft_hyb) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s));   // conj(DFT2(W)) / 128^2 of both orientations
+  if (j->fft_on) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s));   // conj(DFT2(W)) / 128^2 of both orientations
   return ICS_OK;
 }
 
 // ---- FFT-tile pipeline: mirrors ---------------------------------------------------------------------------------------------------------
 // every HWC frame buffer the pipeline touches gets a planar mirror (zero-filled: the aprons of a mirror are never written either)
 static int ensure_planar(ics_rl* j) {
-  float* want[] = {j->u, j->u2, j->ut, j->gr, j->f, j->e, j->e2};
+  float* want[] = {j->u, j->u2, j->ut, j->gr, j->f, j->e, j->e2, j->tvf};
   for (float* h : want) {
     if (!h || pl_of(j, h)) continue;
     if (j->ntwins >= 8) return fail(ICS_ESTATE, "planar mirror table full");
@@ -514,7 +509,7 @@ static int from_planar(ics_rl* j, float* hwc, hipStream_t s) {   // the u-frame 
 }
 struct FftScope {   // fft_on for the duration of a run / stage, whatever path leaves it
   ics_rl* j;
-  ~FftScope() { if (j) { j->fft_on = false; j->fft_hyb = false; j->plu_src = nullptr; } }
+  ~FftScope() { if (j) j->fft_on = false; }
 };
 
 extern "C" int ics_rl_upload(ics_rl* j, const float* image, const float* u, const float* psf) {
@@ -866,28 +861,25 @@ static bool fft_preferred(const IcsGeom& g, bool blind) {
   if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
   return g.K == 17 && px >= 8000000L;
 }
-static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
-  if (!ics_conv_fft_supported(j->g.K) || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
-  if (p->conv == ICS_CONV_FFT) return true;
-  if (p->conv != ICS_CONV_AUTO || !in_run) return false;
-  const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
-  if (env == 3) return true;
-  return env == 0 && fft_preferred(j->g, p->blind != 0);
-}
-
-// The PAM kinds (tv_mode 2 / 3): their T / G operands are HWC frames, so only the two convolutions and the PSF gradient go to the tiles
-// and one conversion of u per inner iteration plus the combination pass G = T + lambd gradu (k_pam_combine) pay for it.  Measured on
-// MI355X, blind 6144^2 / 31 x 31, tv_mode 3: 4.1 ms per inner iteration on the matrix cores, see NOTES_r05.md for the hybrid.
-static bool use_fft_hybrid(const ics_rl* j, const ics_rl_params* p, bool in_run) {
-  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !in_run) return false;
+static bool pam_on_tiles(const ics_rl* j, const ics_rl_params* p, bool in_run) {   // the routing rule of the PAM kinds (tv_mode 2 / 3)
+  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !in_run) return false;        // (single stages of the TV variants run on the HWC kernels)
   if (p->tv_mode != ICS_TV_PAM_ISO && p->tv_mode != ICS_TV_PAM_COLLAB) return false;
   if (p->conv == ICS_CONV_FFT) return true;
   if (p->conv != ICS_CONV_AUTO) return false;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
   if (env == 3) return true;
-  // scripts: bench.py --tv-mode 2, ICS_CONV_PATH=matrix -> fft, ms per inner iteration: 1448^2 / 31 blind 0.357 -> 0.297; 2048^2 / 21 blind 0.470 -> 0.396,
+  // bench.py --tv-mode 2, ICS_CONV_PATH=matrix -> fft (measured with the convolutions and the gradient on the tiles only), ms per inner iteration: 1448^2 / 31 blind 0.357 -> 0.297; 2048^2 / 21 blind 0.470 -> 0.396,
   // non-blind 0.271 -> 0.259; 4096^2 / 19 blind 1.563 -> 1.132; 1100^2 / 45 blind 0.432 -> 0.310
   return env == 0 && j->g.K >= 19 && (long)j->g.uM * j->g.uN >= (p->blind ? 1000000L : 1500000L);
+}
+static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
+  if (p->tv_mode != ICS_TV_SHIPPED) return pam_on_tiles(j, p, in_run);   // PAM kinds: TV term, back-projection epilogue and update on the mirrors too
+  if (!ics_conv_fft_supported(j->g.K) || p->fuse) return false;
+  if (p->conv == ICS_CONV_FFT) return true;
+  if (p->conv != ICS_CONV_AUTO || !in_run) return false;
+  const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
+  if (env == 3) return true;
+  return env == 0 && fft_preferred(j->g, p->blind != 0);
 }
 
 // tv_mode 1 rewrites the image in every inner iteration (pyx:547-549 live): a copy would have to be rebuilt each time
@@ -983,6 +975,10 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
   a.f = porg(j, j->f); a.u = porg(j, j->u); a.ut = porg(j, ut_of(j));
   a.red = red_of(j) + slot * ICS_RED_STRIDE;
   a.step = p->step_factor; a.blind = p->blind;
+  if (p->tv_mode >= ICS_TV_PAM_ISO && mode == 1) {   // PAM kinds: the epilogue takes u and T, stores G = T + lambd gradu
+    a.tv = j->tvf ? porg(j, j->tvf) : nullptr; a.tv_kind = p->tv_mode;
+    if (!a.tv) return fail(ICS_ESTATE, "FFT pipeline: the TV frame has no planar mirror");
+  }
   if (!a.in || !a.out || !a.f || !a.u || !a.ut) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
   HIPCHK(ics_launch_conv_fft(mode, a, mode == 1 ? j->spec_corr : j->spec_conv, ICS_FFT_PL_ALL, j->ctx->stream));
@@ -990,34 +986,8 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
   return ICS_OK;
 }
 
-// the PAM kinds on the tiles (use_fft_hybrid): u is converted when it has changed since its last conversion, the back-projection is
-// followed by the pass that forms G = T + lambd gradu in the HWC frame and takes the maxima (the tile kernel runs in its mode 2: the plain
-// back-projection, no operands)
-static int do_conv_hyb(ics_rl* j, int mode, const ics_rl_params* p, int slot, Prof& pr) {
-  hipStream_t s = j->ctx->stream;
-  IcsConvArgs a;
-  memset(&a, 0, sizeof a);
-  a.g = j->g; a.lambd = p->lambd;
-  if (mode == 1) { a.in = porg(j, j->e); a.out = porg(j, j->gr); }
-  else { a.in = porg(j, j->u); a.out = porg(j, j->e); }
-  a.f = porg(j, j->f); a.u = porg(j, j->u); a.ut = porg(j, ut_of(j));
-  a.red = red_of(j) + slot * ICS_RED_STRIDE;
-  a.step = p->step_factor; a.blind = p->blind;
-  if (!a.in || !a.out || !a.f || !a.u || !a.ut || !j->tvf) return fail(ICS_ESTATE, "FFT pipeline (PAM): a frame has no planar mirror");
-  RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
-  if (mode == 0 && j->plu_src != j->u) { RC(to_planar(j, j->u, s)); j->plu_src = j->u; }
-  HIPCHK(ics_launch_conv_fft(mode == 1 ? 2 : 0, a, mode == 1 ? j->spec_corr : j->spec_conv, ICS_FFT_PL_ALL, s));   // (2: back-projection without operands and maxima)
-  if (mode == 1) {
-    HIPCHK(hipMemsetAsync(a.red + ICS_RED_MAXG, 0, 6 * sizeof(uint32_t), s));
-    HIPCHK(ics_launch_pam_combine(porg(j, j->gr), org(j, j->tvf), org(j, j->u), org(j, j->gr), j->g, p->lambd, a.red, s));
-  }
-  RC(pr.end());
-  return ICS_OK;
-}
-
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   if (j->fft_on && mode != 2) return do_conv_fft(j, mode, p, slot, pr);
-  if (j->fft_hyb && mode != 2) return do_conv_hyb(j, mode, p, slot, pr);
   if (use_block_conv(j, p, mode)) return do_conv_blocks(j, mode, p, slot, pr);
   IcsConvArgs a;
   a.g = j->g; a.lambd = p->lambd;
@@ -1069,7 +1039,6 @@ static int do_update(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, 
     j->ut = j->u; j->u = j->u2; j->u2 = old_ut;
     j->ut_is_u = false;
   }
-  j->plu_src = nullptr;   // (fft_hyb: the HWC kernel above wrote the frame that is `u` now)
   return ICS_OK;
 }
 
@@ -1083,6 +1052,10 @@ static int do_tvterm(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   IcsTvTermArgs a;
   a.u = org(j, j->u); a.ut = org(j, ut_of(j)); a.f = org(j, j->f); a.tv = org(j, j->tvf);
   a.red = red_of(j) + slot * ICS_RED_STRIDE; a.epsilon = p->blind ? 1e-2f : 1e-6f; a.kind = p->tv_mode; a.geo = j->g;
+  if (j->fft_on) {   // PAM kinds on the planar mirrors (the kernel reads u and writes T; ut and f are not touched by these kinds)
+    a.u = porg(j, j->u); a.tv = porg(j, j->tvf); a.planar = 1;
+    if (!a.u || !a.tv) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+  }
   RC(pr.begin(ICS_K_UPDATE));   // accounted with the elementwise class
   HIPCHK(ics_launch_tvterm(a, j->ctx->stream));
   RC(pr.end());
@@ -1140,10 +1113,7 @@ static int do_gradk_split(ics_rl* j, Prof& pr) {
 static bool use_fft_gradk(const ics_rl* j) { return j->fft_on && ics_debug().fft_gradk.load(std::memory_order_relaxed) != 0; }
 
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
-  if (j->fft_hyb && j->plu_src != j->u) {   // (A11 converted u already; a caller that comes here first converts now)
-    RC(to_planar(j, j->u, j->ctx->stream)); j->plu_src = j->u;
-  }
-  if (use_fft_gradk(j) || j->fft_hyb) {
+  if (use_fft_gradk(j)) {
     RC(pr.begin(ICS_K_PSF_GRADIENT));
     HIPCHK(ics_launch_gradk_fft(porg(j, j->u), porg(j, j->e), j->g, j->partial, j->gradk, j->ctx->stream));
     RC(pr.end());
@@ -1167,7 +1137,7 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
 #endif
 // A11 + A13 in one kernel where it exists (matrix-core path, MK <= 15): ics_synth_gradk_mfma.hip
 static bool use_fused_gradk(const ics_rl* j, const ics_rl_params* p) {
-  if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv || j->fft_on || j->fft_hyb) return false;
+  if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv || j->fft_on) return false;
   if (p->flags & ICS_FLAG_NO_FUSED_GRADK) return false;
   return ics_debug().fused_gradk.load(std::memory_order_relaxed) != 0 && use_matrix_conv(j, p) && use_matrix_gradk(j, p);
 }
@@ -1219,10 +1189,10 @@ static int do_stats(ics_rl* j, const ics_rl_params* p, Prof& pr, int rearm = 0, 
     HIPCHK(hipMemcpyAsync(j->scal + ICS_SC_MR, nan3, sizeof nan3, hipMemcpyHostToDevice, j->ctx->stream));
     return ICS_OK;
   }
-  if (j->fft_on || j->fft_hyb) {   // A18 / A19 read HWC frames: bring the window of e and u over from the mirrors (u-frame rows [top, bottom + 2 pad))
+  if (j->fft_on) {   // A18 / A19 read HWC frames: bring the window of e and u over from the mirrors (u-frame rows [top, bottom + 2 pad))
     const int pad2 = 2 * j->g.pad;
     HIPCHK(ics_launch_planar_convert(false, pl_of(j, j->e), j->e, j->g, false, p->top, p->bottom + pad2, p->left, p->right + pad2, st));
-    if (j->fft_on) HIPCHK(ics_launch_planar_convert(false, pl_of(j, j->u), j->u, j->g, false, p->top, p->bottom + pad2, p->left, p->right + pad2, st));   // (fft_hyb: u is an HWC frame)
+    HIPCHK(ics_launch_planar_convert(false, pl_of(j, j->u), j->u, j->g, false, p->top, p->bottom + pad2, p->left, p->right + pad2, st));
   }
   IcsStatsArgs a;
   a.e = org(j, j->e); a.u = org(j, j->u); a.scal = j->scal; a.dofkeys = dof_of(j); a.dacc = j->dacc; a.ukey = j->ukey;
@@ -1273,7 +1243,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
 // with hipGraphLaunch.  Not with profiling (events between the kernels), not with the opt-in fused update + convolution (its own
 // ping-pong), not with an empty window (host-side NaN upload).  Default: frames up to 1.2 Mpx; debug switch `graph` = 0 / 1 forces.
 static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
-  if (p->profile || p->fuse || j->win_empty || use_fft_pipeline(j, p, true) || use_fft_hybrid(j, p, true)) return false;
+  if (p->profile || p->fuse || j->win_empty || use_fft_pipeline(j, p, true)) return false;
   const int g = ics_debug().graph.load(std::memory_order_relaxed);
   if (g >= 0) return g != 0;
   return (long)j->g.uM * j->g.uN <= 1200000L;
@@ -1317,8 +1287,7 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
   RC(check_params(j, p));
   memset(r, 0, sizeof *r);
   r->struct_size = sizeof(ics_rl_route);
-  const bool hyb = use_fft_hybrid(j, p, true);
-  const bool fft = use_fft_pipeline(j, p, true) || hyb;   // (hyb: the convolutions and the gradient on the tiles, the rest HWC)
+  const bool fft = use_fft_pipeline(j, p, true);
   struct Flag { ics_rl* j; bool was; ~Flag() { j->fft_on = was; } } flag{j, j->fft_on};   // (the gradient's predicates read it)
   j->fft_on = fft;
   const bool blocks = !fft && use_block_conv(j, p, 0), matrix = !fft && !blocks && use_matrix_conv(j, p);
@@ -1375,10 +1344,6 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     j->fft_on = true;
     RC(ensure_planar(j));
     RC(to_planar(j, j->u, s));
-    if (!j->plf_valid) { RC(to_planar(j, j->f, s)); j->plf_valid = true; }
-  } else if (use_fft_hybrid(j, p, true)) {   // PAM kinds: convolutions and PSF gradient on the tiles, everything else on the HWC frames
-    j->fft_hyb = true; j->plu_src = nullptr;
-    RC(ensure_planar(j));
     if (!j->plf_valid) { RC(to_planar(j, j->f, s)); j->plf_valid = true; }
   }
   {  // everything but the caller's in-fields is overwritten
@@ -1513,7 +1478,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     if (!j->ev_body[0])
       for (int i = 0; i < 2; ++i) { HIPCHK(hipEventCreateWithFlags(&j->ev_body[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&j->ev_stats[i], hipEventDisableTiming)); }
     if (!j->e2) RC(dalloc(c, &j->e2, j->frame_floats));
-    if (j->fft_on || j->fft_hyb) RC(ensure_planar(j));       // (a mirror for e2 as well)
+    if (j->fft_on) RC(ensure_planar(j));                     // (a mirror for e2 as well)
     const size_t npsf = (size_t)3 * j->g.K * j->g.K;
     if (p->blind && !j->psf_bak) RC(dalloc(c, &j->psf_bak, 2 * npsf, false));
     const hipStream_t st2 = ovl == 1 ? c->stream2 : s;      // where the statistics run
@@ -1524,7 +1489,6 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       HIPCHK(hipStreamSynchronize(s));
       if (st2 != s) HIPCHK(hipStreamSynchronize(st2));
       { float* t = j->u; j->u = j->ut; j->ut = t; }           // the majoriser frame of the dropped iteration is u of the one before
-      j->plu_src = nullptr;
       { float* t = j->e; j->e = j->e2; j->e2 = t; }
       if (p->blind) {
         HIPCHK(hipMemcpyAsync(j->psf, j->psf_bak, npsf * 4, hipMemcpyDeviceToDevice, s));
@@ -1608,7 +1572,6 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     consume(j->h_scal);
   }
   if (j->fft_on) { RC(from_planar(j, j->u, s)); RC(from_planar(j, j->e, s)); }   // the HWC frames are the job's state between calls
-  else if (j->fft_hyb) RC(from_planar(j, j->e, s));
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));
   int hflags[4] = {0, 0, 0, 0};

@@ -305,8 +305,8 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   m.lin = make_lay(g, a.planar & ICS_FFT_PL_IN); m.lout = make_lay(g, a.planar & ICS_FFT_PL_OUT); m.lf = make_lay(g, a.planar & ICS_FFT_PL_F);
   m.lu = make_lay(g, a.planar & ICS_FFT_PL_U); m.lut = make_lay(g, a.planar & ICS_FFT_PL_UT); m.ltv = make_lay(g, a.planar & ICS_FFT_PL_TV);
   m.in = make_gbuf(a.c.in - m.lin.org); m.out = make_gbuf(a.c.out - m.lout.org);
-  m.f = (mode == 1 || mode == 2) ? m.in : make_gbuf(a.c.f - m.lf.org);
-  m.u = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.ut - m.lut.org);
+  m.f = mode == 1 ? m.in : make_gbuf(a.c.f - m.lf.org);
+  m.u = mode == 0 ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
   m.tv = (a.c.tv && mode != 0) ? make_gbuf(a.c.tv - m.ltv.org) : m.in;
   m.spec = make_gbuf(a.spec);
   return m;
@@ -546,7 +546,7 @@ ICS_FFT_HD uint32_t key_of(float f) { return (f != f) ? 0xFFC00000u : ics_f2key(
 // stage F; mode 1 walks its operands (u, ut[, T]) row group by row group, group i + 1 requested before the maxima of group i are taken, and
 // stores the values it kept at the end.  A quad's lane address says "this row group of this tile is mine" or is a dropped access; pixels
 // of a valid quad beyond the output region are stored as zeros (they land in the frame's border ring / slack, which holds zeros).
-struct Ops { v4f a[2][4], b[2][4], tv[2][4]; };   // [tile][row group].  mode 1: a = u, b = ut, tv = T frame (TV kinds)
+struct Ops { v4f a[2][4], b[2][4]; };   // [tile][row group].  mode 1: a = u, b = ut -- or, for the PAM kinds (TV kernel, tv_kind >= 2), b = the T frame
 // The maxima of A6 / A7 over a unit's valid pixels, in a form that costs two or three vector operations per pixel and no lane masks:
 //   ag  = max over pixels of (bits of g) & 0x7FFFFFFF as an unsigned integer: the bits of |g| order like |g| itself and every NaN lies above
 //         +inf (0x7F800000), so one integer maximum carries both max |g| and "a NaN was seen";
@@ -580,23 +580,23 @@ ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, i
     for (int i = 0; i < 4; ++i) f[t][i] = ld_f32x4<2>(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
   }
 }
-// mode 1: the operands under tile t
+// mode 1: the operands under tile t.  The PAM kinds (build-defined tv_mode 2 / 3; ics_conv.hip's epilogue for them) need u and the TV
+// term T = -div(p) instead of u and ut: two operand frames either way (a third does not fit 128 registers).
 template <bool TV>
 ICS_FFT_HD void load_ops(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int t, Ops& o, int i0 = 0, int i1 = 4) {
   int rows, X;
-  const int va = quad_lane(a, u, mem.lu, tid, t, rows, X);
-  const int vb = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.lut.org;      // (the same geometry: all frames of a job are)
-  const int vt = va == ICS_FFT_NONE ? va : va - mem.lu.org + mem.ltv.org;
+  const int va = quad_lane(a, u, mem.lu, tid, t, rows, X);   // (the same geometry: all frames of a job are)
+  const bool pam = TV && a.c.tv_kind >= 2;
 #pragma unroll
   for (int i = i0; i < i1; ++i) {
+    const int vo = i < rows ? va : ICS_FFT_NONE;
     if (t == 0) {   // (ablation kinds: 2 = tile 0's operands and mode 0's image, 16 = tile 1's)
-      o.a[t][i] = ld_f32x4<2>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
-      o.b[t][i] = ld_f32x4<2>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+      o.a[t][i] = ld_f32x4<2>(mem.u, vo, 32 * i * mem.lu.pitch);
+      o.b[t][i] = pam ? ld_f32x4<2>(mem.tv, vo, 32 * i * mem.ltv.pitch) : ld_f32x4<2>(mem.ut, vo, 32 * i * mem.lut.pitch);
     } else {
-      o.a[t][i] = ld_f32x4<16>(mem.u, i < rows ? va : ICS_FFT_NONE, 32 * i * mem.lu.pitch);
-      o.b[t][i] = ld_f32x4<16>(mem.ut, i < rows ? vb : ICS_FFT_NONE, 32 * i * mem.lut.pitch);
+      o.a[t][i] = ld_f32x4<16>(mem.u, vo, 32 * i * mem.lu.pitch);
+      o.b[t][i] = pam ? ld_f32x4<16>(mem.tv, vo, 32 * i * mem.ltv.pitch) : ld_f32x4<16>(mem.ut, vo, 32 * i * mem.lut.pitch);
     }
-    if (TV) o.tv[t][i] = ld_f32x4<2>(mem.tv, i < rows ? vt : ICS_FFT_NONE, 32 * i * mem.ltv.pitch);
   }
 }
 // the finished values of row group i: r[t] = 4 pixels of tile t
@@ -621,7 +621,7 @@ ICS_FFT_HD void store_quad_at(const IcsFftArgs& a, const Mem& mem, const QuadOut
 template <bool TV>
 ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx, const QuadOut& q, bool edge) {
   const float lambd = a.c.lambd;
-  const int X0 = q.X, Y = u.oy[t] + (tid >> 5) + 32 * i;
+  const int X0 = q.X;
   const bool row_ok = i < q.rows;         // (quad_lane: tile present, quad inside the tile's valid columns and the region, row group inside)
   uint32_t qg = 0u, qu = 0u, qany = 0u;
   float qm = -__builtin_inff();
@@ -630,9 +630,7 @@ ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, 
     const float rv = r[e], uv = o.a[t][i][e], tv = o.b[t][i][e];
     const int X = X0 + e;
     float g;
-    if (TV && a.c.tv_kind >= 2) { g = (float)((double)o.tv[t][i][e] + (double)ICS_FMUL(lambd, rv)); r[e] = g; }     // PAM: G = T + lambd*gradu, stored
-    else if (TV && a.c.tv_kind == 1 && Y >= 1 && Y <= a.c.g.uM - 2 && X >= 1 && X <= a.c.g.uN - 2)                  // active MM-TV, pyx:517
-      g = (float)(((double)o.tv[t][i][e] + (double)ICS_FMUL(lambd, rv)) + (double)ICS_FSUB(uv, tv) / 4.0);
+    if (TV && a.c.tv_kind >= 2) { g = (float)((double)tv + (double)ICS_FMUL(lambd, rv)); r[e] = g; }     // PAM: G = T + lambd*gradu, stored (o.b holds T)
     else
       g = ICS_FADD(ICS_FMUL(lambd, rv), ICS_FMUL(ICS_FSUB(uv, tv), 0.5f));                                          // pyx:519
     if (edge) {                                        // (wave-uniform) first / last tile of a tile row: per-pixel column test
@@ -729,12 +727,12 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     stage_d(sp, lds, opaque(tid));
     wave_sync();
     ICS_FFT_STAMP(4);
-    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 1 ? 1 : 2);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
+    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
     stage_e(lds, lds, twl, opaque(tid));
     v4f fimg[2][4];
     Ops ops;
     if (MODE == 0) load_image(a, mem, u, opaque(tid), fimg);
-    else if (MODE == 1) {
+    else {
       load_ops<TV>(a, mem, u, opaque(tid), 0, ops);
       if (ICS_FFT_M1_EARLY > 0) load_ops<TV>(a, mem, u, opaque(tid), 1, ops, 0, ICS_FFT_M1_EARLY);   // (stages F and G leave registers for part of tile 1's operands)
     }
@@ -763,16 +761,14 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) qo[t].vo = quad_lane(a, u, mem.lout, te, t, qo[t].rows, qo[t].X);
     const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
-    if (MODE != 1) {
+    if (MODE == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         read_quads(lds, opaque(tid), i, res[i]);
-        if (MODE == 0) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
-        }
+          for (int e = 0; e < 4; ++e) res[i][t][e] = ICS_FSUB(res[i][t][e], fimg[t][i][e]);        // pyx:488
         asm volatile("" ::: "memory");
       }
       if (edge) {
@@ -998,10 +994,10 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
 
 hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s);
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, int planar, hipStream_t s) {
-  if (mode < 0 || mode > 2) return hipErrorInvalidValue;      // 2 = the back-projection alone: no operands, no maxima (the PAM kinds take theirs in k_pam_combine)
+  if (mode != 0 && mode != 1) return hipErrorInvalidValue;
   if (planar != ICS_FFT_PL_ALL) return hipErrorInvalidValue;   // every frame a channel-planar mirror: the kernel moves 4 pixels of a plane row per access
   IcsFftArgs a;
-  ics_conv_fft_fill_args(mode == 2 ? 1 : mode, c, spec, &a);
+  ics_conv_fft_fill_args(mode, c, spec, &a);
   a.planar = planar;
   return ics_launch_conv_fft_args(mode, a, s);
 }
@@ -1011,14 +1007,15 @@ hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s
   int grid = ics_device_cus(dev);
   if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
   if (grid > a.nunits) grid = a.nunits;
-  // (the epilogue carries the TV kinds of ics_conv.hip behind a template flag; the library routes only the shipped loop here and does not
-  //  instantiate that form: with the T operand the kernel does not fit 128 registers)
-  if (a.c.tv && a.c.tv_kind) return hipErrorInvalidValue;
+  // (mode 1 with the T frame: the PAM kinds, whose epilogue takes u and T where the shipped loop takes u and ut.  The active MM-TV kind
+  //  needs all three and does not fit 128 registers: not built)
+  if (a.c.tv && a.c.tv_kind == 1) return hipErrorInvalidValue;
+  const bool pam = mode == 1 && a.c.tv && a.c.tv_kind >= 2;
   auto k0 = icsfft::k_conv_fft<0, false>;
   auto k1 = icsfft::k_conv_fft<1, false>;
-  auto k2 = icsfft::k_conv_fft<2, false>;
-  auto kern = mode == 0 ? k0 : (mode == 1 ? k1 : k2);
-  const int slot = mode;
+  auto k1t = icsfft::k_conv_fft<1, true>;
+  auto kern = mode == 0 ? k0 : (pam ? k1t : k1);
+  const int slot = pam ? 2 : mode;
   if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
   return hipGetLastError();

@@ -32,6 +32,7 @@ struct IcsTvTermArgs {
   float epsilon;       // 1e-2 blind / 1e-6 non-blind (pyx:434-437)
   int kind;            // 1 MM-TV term, 2 isotropic TV gradient, 3 collaborative L-inf,1,1 TV gradient
   IcsGeom geo;
+  int planar = 0;      // kinds 2 / 3 only: u and tv are ORIGINS of channel-planar mirrors (ics_common.h), the transform-tile pipeline's frames
 };
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s);
 
@@ -76,7 +77,6 @@ hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hi
 // src / dst: buffer STARTS; rows [y0, y1), pixels [x0, x1) in u-frame coordinates (widened to 4-pixel groups), or the whole buffer
 hipError_t ics_launch_planar_convert(bool to_planar, const float* src, float* dst, const IcsGeom& g, bool whole, int y0, int y1, int x0, int x1, hipStream_t s);
 hipError_t ics_launch_update_planar(const IcsUpdateArgs& a, hipStream_t s);   // frame pointers = origins of planar mirrors
-hipError_t ics_launch_pam_combine(const float* grp, const float* tv, const float* u, float* gout, const IcsGeom& g, float lambd, uint32_t* red, hipStream_t s);
 bool ics_conv_fft_supported(int K);
 size_t ics_conv_fft_spectrum_floats();                                        // per orientation
 hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s);

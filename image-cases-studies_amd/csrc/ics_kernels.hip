@@ -369,9 +369,11 @@ __global__ __launch_bounds__(256) void k_tvterm(IcsTvTermArgs a, int seg_fast) {
 // window; 1 / sqrt comes from v_rsq_f32 (1 ulp).  ~10 instructions per value; results within ~2e-7 of pam_term() relative to
 // max |T| (tests/test_tv_mode.py gates 2e-6 against oracle/rl_ext_oracle.py; these modes have no reference implementation).
 // =================================================================================================
-template <bool COLLAB>
+template <bool COLLAB, bool PL = false>   // PL: u and T are channel-planar mirrors -- the same arithmetic on the same values, bit for bit
 __global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a, int TVSEG /* rows a thread walks: 16 on large frames, fewer where that leaves the chip idle */) {
   const IcsGeom& G = a.geo;
+  const int ppitch = PL ? ics_ppitch(G) : 0;
+  const size_t plane = PL ? ics_plane_floats(G) : 0;
   const int ngx = G.tiles_x * 16;
   const int nseg = (G.uM + TVSEG - 1) / TVSEG;
   const long total = (long)nseg * ngx;
@@ -380,6 +382,17 @@ __global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a, int TVSEG /
   bool nan_t[3] = {false, false, false};
   const float e2 = __fmul_rn(a.epsilon, a.epsilon);
   auto load_row = [&](int y, int xp, float (&row)[20]) {   // pixels xp - 1 .. xp + 5 (20 floats)
+    if (PL) {   // per plane: the pixel to the left, the aligned quad, the pixel to the right (row[18], row[19] are never read)
+      const ptrdiff_t o = (ptrdiff_t)y * ppitch + xp;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* pc = a.u + c * plane + o;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(pc);
+        row[c] = pc[-1]; row[3 + c] = q.x; row[6 + c] = q.y; row[9 + c] = q.z; row[12 + c] = q.w; row[15 + c] = pc[4];
+      }
+      row[18] = row[19] = 0.f;
+      return;
+    }
     const ptrdiff_t o = (ptrdiff_t)y * G.pitch + 3 * (xp - 1);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -440,7 +453,11 @@ __global__ __launch_bounds__(256) void k_tvterm_pam(IcsTvTermArgs a, int TVSEG /
           if (x < G.uN) { mt[c] = __builtin_fmaxf(mt[c], __builtin_fabsf(t)); nan_t[c] |= (t != t); }
         }
       }
-      if (xp + 3 < G.uN) {
+      if (PL) {   // (the quad's pixels beyond uN lie in the mirror's apron: T = 0 there by the x <= uN - 2 test above)
+        const ptrdiff_t op = (ptrdiff_t)y * ppitch + xp;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const f32x4 w = {T[c], T[3 + c], T[6 + c], T[9 + c]}; *reinterpret_cast<f32x4*>(a.tv + c * plane + op) = w; }
+      } else if (xp + 3 < G.uN) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) { const f32x4 w = {T[4*j], T[4*j+1], T[4*j+2], T[4*j+3]}; reinterpret_cast<f32x4*>(a.tv + o)[j] = w; }
       } else {
@@ -1025,7 +1042,8 @@ hipError_t ics_launch_band_mask_e(float* e, const IcsGeom& g, int i0, int i1, hi
 }
 
 hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
-  const bool exact = ics_debug().pam_exact.load(std::memory_order_relaxed) != 0;
+  const bool exact = ics_debug().pam_exact.load(std::memory_order_relaxed) != 0 && !a.planar;   // (the per-value cross-check form reads HWC frames)
+  if (a.planar && a.kind < 2) return hipErrorInvalidValue;
   if (a.kind == 1 && exact) hipLaunchKernelGGL(k_tvterm<1>, dim3(1024), dim3(256), 0, s, a, 1);
   else if (a.kind == 1) {
     // as for the PAM kinds below: enough threads for ~4 waves per SIMD, at most ICS_TVMM_SEG rows per thread
@@ -1048,8 +1066,12 @@ hipError_t ics_launch_tvterm(const IcsTvTermArgs& a, hipStream_t s) {
     seg = seg < 2 ? 2 : (seg > 16 ? 16 : seg);
     const long nthreads = (((long)a.geo.uM + seg - 1) / seg) * cols;
     long nblk = (nthreads + 255) / 256; nblk = nblk > 2048 ? 2048 : (nblk < 1 ? 1 : nblk);
-    if (a.kind == 2) hipLaunchKernelGGL(k_tvterm_pam<false>, dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
-    else hipLaunchKernelGGL(k_tvterm_pam<true>, dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+    if (a.planar) {
+      if (a.kind == 2) hipLaunchKernelGGL((k_tvterm_pam<false, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+      else hipLaunchKernelGGL((k_tvterm_pam<true, true>), dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+    }
+    else if (a.kind == 2) hipLaunchKernelGGL((k_tvterm_pam<false, false>), dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
+    else hipLaunchKernelGGL((k_tvterm_pam<true, false>), dim3((unsigned)nblk), dim3(256), 0, s, a, seg);
   }
   return hipGetLastError();
 }

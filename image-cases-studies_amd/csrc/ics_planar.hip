@@ -96,9 +96,10 @@ __global__ __launch_bounds__(256) void k_update_planar(IcsUpdateArgs a, int ppit
       const int x = x0 + e;
       const bool inside = yin && (x >= G.pad) && (x < G.pad + G.N);
       const float uv = uq[e], gv = gq[e];
-      const float g = __fadd_rn(__fmul_rn(lambd, gv), __fmul_rn(__fsub_rn(uv, tq[e]), 0.5f));
+      // (PAM kinds: the back-projection wrote G = T + lambd gradu; no DoF blend -- k_update_rows, ics_kernels.hip)
+      const float g = a.tv_kind >= 2 ? gv : __fadd_rn(__fmul_rn(lambd, gv), __fmul_rn(__fsub_rn(uv, tq[e]), 0.5f));
       float un = __fsub_rn(uv, __fmul_rn(dtc, g));
-      if (inside) {
+      if (inside && a.tv_kind < 2) {
         const float fv = fq[e];
         const float d = ics_dof_ratio(gv, fv);
         float D = __fmul_rn(d, d);
@@ -133,77 +134,7 @@ __global__ __launch_bounds__(256) void k_update_planar(IcsUpdateArgs a, int ppit
   }
 }
 
-// PAM kinds (tv_mode 2 / 3, build-defined; ics_conv.hip's epilogue for them) behind a back-projection that ran on the transform tiles:
-//   G = T + lambd * gradu   (double sum rounded once, like the HWC kernels)  ->  HWC frame `gout`, maxima of |G_k| and u_k (pyx:523-524)
-// gradu comes from the planar mirror the tiles wrote, T and u are HWC frames.  One thread = 4 pixels x 3 channels of a u-frame row.
-__global__ __launch_bounds__(256) void k_pam_combine(const float* __restrict__ grp, const float* __restrict__ tv, const float* __restrict__ u,
-                                                    float* __restrict__ gout, IcsGeom G, int ppitch, size_t plane, float lambd, uint32_t* __restrict__ red) {
-  __shared__ uint32_t sh[4][6];
-  const int nq = (G.uN + 3) / 4;
-  const long total = (long)G.uM * nq;
-  uint32_t kg[3] = {0u, 0u, 0u}, ku[3] = {0u, 0u, 0u};
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
-    const int y = (int)(t / nq), x0 = 4 * (int)(t - (long)y * nq);
-    const size_t oh = (size_t)y * G.pitch + 3 * (size_t)x0, op = (size_t)y * ppitch + x0;
-    float r[12], tq[12], uq[12];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(grp + c * plane + op));
-      r[c] = a.x; r[3 + c] = a.y; r[6 + c] = a.z; r[9 + c] = a.w;
-    }
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(tv + oh + 4 * h)), b = *reinterpret_cast<const f32x4*>(u + oh + 4 * h);
-      tq[4 * h] = a.x; tq[4 * h + 1] = a.y; tq[4 * h + 2] = a.z; tq[4 * h + 3] = a.w;
-      uq[4 * h] = b.x; uq[4 * h + 1] = b.y; uq[4 * h + 2] = b.z; uq[4 * h + 3] = b.w;
-    }
-    float g[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) {
-      g[e] = (float)((double)tq[e] + (double)__fmul_rn(lambd, r[e]));
-      if (x0 + e / 3 < G.uN) {
-        const float ag = __builtin_fabsf(g[e]);
-        const uint32_t k1 = (ag != ag) ? 0xFFC00000u : ics_f2key(ag), k2 = (uq[e] != uq[e]) ? 0xFFC00000u : ics_f2key(uq[e]);
-        const int c = e % 3;
-        kg[c] = kg[c] > k1 ? kg[c] : k1; ku[c] = ku[c] > k2 ? ku[c] : k2;
-      }
-    }
-    if (x0 + 3 < G.uN) {
-#pragma unroll
-      for (int h = 0; h < 3; ++h) *reinterpret_cast<f32x4*>(gout + oh + 4 * h) = (f32x4){g[4 * h], g[4 * h + 1], g[4 * h + 2], g[4 * h + 3]};
-    } else {
-#pragma unroll
-      for (int e = 0; e < 12; ++e)
-        if (x0 + e / 3 < G.uN) gout[oh + e] = g[e];
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 3; ++c) { kg[c] = wave_max_u32(kg[c]); ku[c] = wave_max_u32(ku[c]); }
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { sh[threadIdx.x >> 6][c] = kg[c]; sh[threadIdx.x >> 6][3 + c] = ku[c]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 6) {
-    uint32_t m = sh[0][threadIdx.x];
-    for (int w = 1; w < 4; ++w) m = m > sh[w][threadIdx.x] ? m : sh[w][threadIdx.x];
-    uint32_t* slot = red + (threadIdx.x < 3 ? ICS_RED_MAXG + threadIdx.x : ICS_RED_MAXU + (threadIdx.x - 3));
-    if (m > *slot) atomicMax(slot, m);
-  }
-}
-
 }  // namespace
-
-// G = T + lambd * gradu with its maxima (k_pam_combine): grp = ORIGIN of the planar gradu mirror; tv, u, gout = origins of HWC frames;
-// red = the iteration's reduction slot, whose MAXG / MAXU keys the caller has zeroed on the same stream
-hipError_t ics_launch_pam_combine(const float* grp, const float* tv, const float* u, float* gout, const IcsGeom& g, float lambd, uint32_t* red, hipStream_t s) {
-  const long total = (long)g.uM * ((g.uN + 3) / 4);
-  long blocks = (total + 255) / 256;
-  const long cap = (long)ics_device_cus(ics_current_device()) * 6;
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(k_pam_combine, dim3((unsigned)blocks), dim3(256), 0, s, grp, tv, u, gout, g, ics_ppitch(g), ics_plane_floats(g), lambd, red);
-  return hipGetLastError();
-}
 
 // `hwc` / `planar`: buffer STARTS (not origins).  Rows [y0, y1) and pixels [x0, x1) in u-frame coordinates, widened to whole 4-pixel groups
 // and clipped to the buffer; whole = every allocated row and pixel (aprons included).

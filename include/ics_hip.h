@@ -141,8 +141,8 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                              runs on the same tiles (two forward transforms per tile pair, products added up in the frequency domain; env
                              ICS_FFT_GRADK=0: on the matrix cores).  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 19 on for frames
                              >= 1.5 Mpx (blind: 1 Mpx) and for MK = 17 from 8 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.
-                             The PAM kinds (tv_mode 2, 3) take it for their convolutions and PSF gradient, with the TV term, the
-                             combination G = T + lambd * gradu and the update on the HWC frames; tv_mode 1 is refused.  Where image and u are exactly 0 the
+                             The PAM kinds (tv_mode 2, 3) run on it as well (TV term, back-projection epilogue G = T + lambd * gradu and
+                             update on the planar mirrors); tv_mode 1 is refused.  Where image and u are exactly 0 the
                              transforms return rounding noise instead of exact zeros, like the reference's (see "DoF ratio" below) */
 
 /* Accuracy of the matrix-core path (tests/test_gpu_precision.py drives it with adversarial inputs).  Every fp32 operand x of a

@@ -55,7 +55,7 @@ def test_no_default_path_kernel_spills_or_uses_scratch(tmp_path):
     assert len(tab) > 150, len(tab)
     # the kernels the verdict named, plus one of every family, must be present (a renamed kernel must not escape the check)
     for must in ("k_conv_mfma<15, 0, 2, 1>", "k_conv_mfma<15, 1, 2, 1>", "k_conv_mfma<9, 1, 2, 1>", "k_conv_mfma<11, 1, 2, 1>", "k_conv_mfma<31, 1, 4, 2>",
-                 "k_synth_gradk<15, true>", "k_synth_gradk<15, false>", "k_gradk_mfma<1, false>", "k_gradk_mfma<2, false>", "k_gradk_mfma<2, true>", "icsfft::k_conv_fft<0, false>", "icsfft::k_conv_fft<1, false>", "icsfft::k_conv_fft<2, false>", "icsfft::k_gradk_fft<0>", "k_pam_combine", "k_update_planar", "k_update_rows<0>", "k_psf", "k_gradk<4, 4>", "k_conv<39, 2, 0, 2, 16>",
+                 "k_synth_gradk<15, true>", "k_synth_gradk<15, false>", "k_gradk_mfma<1, false>", "k_gradk_mfma<2, false>", "k_gradk_mfma<2, true>", "icsfft::k_conv_fft<0, false>", "icsfft::k_conv_fft<1, false>", "icsfft::k_conv_fft<1, true>", "icsfft::k_gradk_fft<0>", "k_update_planar", "k_update_rows<0>", "k_psf", "k_gradk<4, 4>", "k_conv<39, 2, 0, 2, 16>",
                  "k_conv_mfma<45, 0, 2, 2>", "k_conv_mfma<49, 1, 2, 2>", "k_conv_big<0>", "k_conv_big<1>", "k_gradk_big", "k_fft_cols", "k_fft_mr"):
         assert any(k.startswith(must) for k in tab), must
     bad = {k: v for k, v in tab.items() if (v.get("vgpr_spill_count", 0) or v.get("private_segment_fixed_size", 0)) and not ALLOWED.match(k)}

@@ -180,9 +180,10 @@ def test_gpu_pam_run_matches_ext_oracle(M, N, MK, blind, kind):
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,MK,blind,kind", [(150, 140, 31, True, 2), (200, 180, 21, False, 2), (150, 140, 31, True, 3), (260, 300, 45, True, 2)])
 def test_gpu_pam_with_the_convolutions_on_the_transform_tiles(M, N, MK, blind, kind):
-    """The PAM kinds with conv = ICS_CONV_FFT (AUTO takes this route for wide PSFs on large frames): convolutions and PSF gradient on
-    the fp32 transform tiles, TV term / combination G = T + lambd gradu / update on the HWC frames (csrc/ics_api.hip do_conv_hyb,
-    ics_planar.hip k_pam_combine).  Same arithmetic around other convolution kernels: the run must agree with the fp32-product HWC path."""
+    """The PAM kinds with conv = ICS_CONV_FFT (AUTO takes this route for wide PSFs on large frames): the whole inner iteration on the
+    channel-planar mirrors -- TV term (k_tvterm_pam<.., PL>), convolutions and PSF gradient on the fp32 transform tiles, the back-projection's
+    epilogue forming G = T + lambd gradu with its maxima (k_conv_fft<1, true>), the update (k_update_planar).  Same arithmetic around other
+    convolution kernels: the run must agree with the fp32-product HWC path."""
     from lib import deconvolution as dc
     case = orc.synth_case(M, N, MK, seed=M + MK + kind, blind=blind)
     args = (*orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 2, 1e-3, 50.0)
