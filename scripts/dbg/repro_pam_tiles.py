@@ -1,3 +1,4 @@
+"""tv_mode 2 with conv = 1 (fp32 HWC kernels) against conv = 3 (planar mirrors + transform tiles): where and how far they differ (the frame-wide 1e-3 of the one-tile-column decode bug showed up here)."""
 import contextlib, io, os, sys
 import numpy as np
 ROOT = "/root/repo"
