@@ -716,8 +716,10 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     ICS_FFT_STAMP(0);
     lds_barrier();
     ICS_FFT_STAMP(1);
+#ifndef ICS_FFT_ABL_SKIP_BF   /* (ablation: a unit without its two radix-8 column passes -- what an LDS round trip with its barrier costs) */
     stage_b<1>(lds, opaque(tid));
     lds_barrier();
+#endif
     ICS_FFT_STAMP(2);
     v2f sp[2][8];
     load_spectrum(mem, u.c, opaque(tid), sp);      // (stage C's arithmetic covers their trip to L2; inside stage D the waves queued up on it)
@@ -738,8 +740,10 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     }
     lds_barrier();
     ICS_FFT_STAMP(5);
+#ifndef ICS_FFT_ABL_SKIP_BF
     stage_b<-1>(lds, opaque(tid));
     lds_barrier();
+#endif
     ICS_FFT_STAMP(6);
     stage_g(lds, opaque(tid));
     lds_barrier();
