@@ -65,6 +65,21 @@ def test_struct_layout_matches_the_header(tmp_path):
     assert re.search(r"typedef int \(\*ics_rl_progress_fn\)", open(HEADER).read())
 
 
+def test_python_constants_equal_the_header():
+    """lib/_native.py restates the header's #defines by hand: every one it restates must carry the header's value."""
+    import re
+    from lib import _native as nv
+    text = open(HEADER).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(ICS_[A-Z0-9_]+)\s+\(?(-?(?:0x[0-9a-fA-F]+|\d+))(?:ull)?\)?", text)}
+    pairs = {"ICS_ABI_VERSION": nv.ICS_ABI_VERSION, "ICS_ENOMEM": nv.ICS_ENOMEM, "ICS_ENOSUP": nv.ICS_ENOSUP, "ICS_ENODEV": nv.ICS_ENODEV,
+             "ICS_CONV_AUTO": nv.CONV_AUTO, "ICS_CONV_VECTOR": nv.CONV_VECTOR, "ICS_CONV_MATRIX": nv.CONV_MATRIX, "ICS_CONV_FFT": nv.CONV_FFT,
+             "ICS_FLAG_NO_FUSED_GRADK": nv.FLAG_NO_FUSED_GRADK, "ICS_FLAG_STAGE_ASYNC": nv.FLAG_STAGE_ASYNC, "ICS_FRAME_LIMIT_BYTES": nv.FRAME_LIMIT_BYTES,
+             "ICS_STAGE_SYNTH_RESIDUAL": nv.STAGE_SYNTH_RESIDUAL, "ICS_STAGE_BAND_MASK_E": nv.STAGE_BAND_MASK_E, "ICS_STAGE_SYNTH_GRADK": nv.STAGE_SYNTH_GRADK}
+    for name, value in pairs.items():
+        assert name in defs, name
+        assert defs[name] == value, (name, defs[name], value)
+
+
 def test_debug_switches_are_not_in_the_public_header_and_round_trip():
     """ICS_TEST_* style hooks live behind ics_debug_set (csrc/ics_common.h), outside include/ics_hip.h, and no launch path
     calls getenv (round-2 verdict: test hooks in the production launch path)."""

@@ -211,6 +211,12 @@ def test_gpu_pam_with_the_convolutions_on_the_transform_tiles(M, N, MK, blind, k
     from lib import _native as nv
     with pytest.raises(nv.NativeError):                                 # the active MM-TV kind stays off the tiles
         dc.richardson_lucy_MM(case["image"].copy(), case["u0"].copy(), case["psf0"].copy(), *args, blind=blind, tv_mode=1, conv=3)
+    job = nv.RLJob(M, N, MK)                                            # ... and so do single stages of the TV variants (ICS_ENOSUP, not a silent other path)
+    job.upload(case["image"], case["u0"], case["psf0"])
+    with pytest.raises(nv.NativeError) as ei:
+        job.stage(nv.STAGE_BACKPROJECT, job.params(*orc.default_window(M, N, MK), 1e9, 1, 1e-3, 50.0, blind, tv_mode=kind, conv=3))
+    assert ei.value.code == nv.ICS_ENOSUP
+    job.close()
 
 
 @pytest.mark.gpu
