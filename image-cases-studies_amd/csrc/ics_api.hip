@@ -225,7 +225,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -236,7 +236,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -1132,6 +1132,21 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   return ICS_OK;
 }
 
+// A11 + A13 as one three-transform unit on the tiles (k_synth_gradk_fft): wherever the pipeline takes its gradient on the tiles
+static bool use_fused_fft(const ics_rl* j, const ics_rl_params* p) {
+  return use_fft_gradk(j) && !p->fuse && !(p->flags & ICS_FLAG_NO_FUSED_GRADK) && ics_debug().fft_fused.load(std::memory_order_relaxed) != 0;
+}
+static int do_synth_gradk_fft(ics_rl* j, const ics_rl_params* p, int store_all, Prof& pr) {
+  const float *u = porg(j, j->u), *f = porg(j, j->f);
+  float* e = porg(j, j->e);
+  if (!u || !f || !e) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+  const int pad = j->g.pad;
+  RC(pr.begin(ICS_K_SYNTH_GRADK));
+  HIPCHK(ics_launch_synth_gradk_fft(u, f, e, j->spec_conv, j->g, p->top + pad, p->bottom + pad, p->left + pad, p->right + pad, store_all, j->partial, j->gradk, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
 #ifndef ICS_FUSED_DEFAULT_RS
 #define ICS_FUSED_DEFAULT_RS 4
 #endif
@@ -1296,6 +1311,7 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
   if (p->blind) {
     const bool fused = !p->fuse && use_fused_gradk(j, p);
     if (fused) r->gradk_family = 1;
+    else if (use_fused_fft(j, p)) r->gradk_family = 7;
     else if (use_fft_gradk(j)) r->gradk_family = 6;
     else if (use_split_gradk(j, p)) r->gradk_family = 3;
     else if (ics_big_supported(j->g.K)) r->gradk_family = 5;
@@ -1380,6 +1396,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
     const bool fuse = p->fuse != 0;
     const bool fused_gk = p->blind && !fuse && use_fused_gradk(j, p);
+    const bool fused_fft = p->blind && !fuse && use_fused_fft(j, p);
     bool have_e = false;  // error already produced by a fused update+synth kernel
     for (int itt = 0; itt < INNER; ++itt) {                   // pyx:473
       const int last = itt == INNER - 1;
@@ -1395,9 +1412,10 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
         else {
           RC(do_update(j, p, itt, last, pr));
           if (fused_gk) RC(do_synth_gradk(j, p, 0, pr));      // A11 + A12 + A13, e' stays on chip
+          else if (fused_fft) RC(do_synth_gradk_fft(j, p, 0, pr));   // the same on the transform tiles
           else RC(do_conv(j, 0, p, itt, 0, pr));
         }
-        if (fuse || !fused_gk) RC(do_gradk(j, p, pr));        // A12+A13
+        if (fuse || !(fused_gk || fused_fft)) RC(do_gradk(j, p, pr));   // A12+A13
         RC(do_psf(j, p, pr));                                 // A14-A17
       } else if (fuse && !last) {
         RC(do_conv(j, 2, p, itt, 0, pr));                     // A5-A10 fused with A1+A2 of itt+1
@@ -1602,7 +1620,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   // stage writes are copied back after -- slow and simple; ics_rl_run converts at its boundaries only
   FftScope fft_scope{j};
   const bool fft_stage = use_fft_pipeline(j, p, false) && (stage == ICS_STAGE_SYNTH_RESIDUAL || stage == ICS_STAGE_BACKPROJECT || stage == ICS_STAGE_UPDATE ||
-                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE);
+                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE || stage == ICS_STAGE_SYNTH_GRADK);
   if (fft_stage) {
     j->fft_on = true;
     RC(ensure_planar(j));
@@ -1652,6 +1670,11 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       HIPCHK(ics_launch_band_mask_e(org(j, j->e), j->g, p->band_row0, p->band_row1, s));
       break;
     case ICS_STAGE_SYNTH_GRADK:
+      if (j->fft_on) {   // conv = ICS_CONV_FFT: the fused unit of the transform tiles, every tile stores its residual
+        RC(pack_weights(j, 0, 0.f, 0, s));
+        RC(do_synth_gradk_fft(j, p, 1, pr));
+        break;
+      }
       if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_GRADK is built for PSF sizes <= 15");
       RC(pack_weights(j, 0, 0.f, 0, s));
       RC(do_synth_gradk(j, p, 1, pr));

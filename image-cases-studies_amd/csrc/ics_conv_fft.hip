@@ -268,6 +268,8 @@ struct IcsFftArgs {
                             // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
                             // some lanes); the pixels in front of ox0 are stored as zeros, like those behind ox1
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
+  int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
+  int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
 };
 
@@ -500,6 +502,58 @@ ICS_FFT_HD void stage_d_inverse(const v2f (&z)[2][8], v2f* lds, int tid) {
   }
 }
 
+// Stage D of the fused A11 + A13 unit (k_synth_gradk_fft).  First use: as stage_d, and the window's 2-D spectrum stays behind in `zu`
+// (the same (ky, kx) in the same slot for every tile: stage_d_forward's layout).  Second use, on the residual tile: its spectrum goes
+// straight into the workgroup's sum  acc += DFT(t) conj(DFT(e'))  -- eight values at a time, the residual's spectrum is never whole in registers.
+ICS_FFT_HD void stage_d_keep(const v2f (&sp)[2][8], v2f* lds, int tid, v2f (&zu)[2][8]) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    v2f v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = lds_ld(lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s);
+    fft8<1>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) { zu[s][k2] = v[k2]; v[k2] = cmul(v[k2], sp[s][k2]); }
+    fft8<-1>(v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lds[row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s] = v[j];
+  }
+}
+ICS_FFT_HD void stage_d_acc(const v2f* lds, int tid, const v2f (&zu)[2][8], v2f (&acc)[2][8]) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    v2f v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = lds_ld(lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s);
+    fft8<1>(v);
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) acc[s][k2] += cmulc(zu[s][k2], v[k2]);
+  }
+}
+
+// E with its twiddles requested four at a time (the fused unit holds 64 registers of spectra beside this stage: as stage_c<4>)
+ICS_FFT_HD void stage_e_lean(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
+  v2f v[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) v[k1] = lds_ld(rd + row * ICS_FFT_PITCH + ((j + k1) & 7) + 8 * k1);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    v2f tw[4];
+#pragma unroll
+    for (int k1 = 4 * h; k1 < 4 * h + 4; ++k1) if (k1) tw[k1 - 4 * h] = lds_ld(twl + j * ICS_FFT_TWS + k1);
+    ICS_FFT_ISSUE_FENCE();
+#pragma unroll
+    for (int k1 = 4 * h; k1 < 4 * h + 4; ++k1) if (k1) v[k1] = cmulc(v[k1], tw[k1 - 4 * h]);
+  }
+  fft16<-1>(v);
+  v2f* wp = lds + row * ICS_FFT_PITCH + j;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) wp[8 * m] = v[m];
+}
+
 // E: conj twiddle, inverse radix-16 over k1 -> x = j + 8 m
 ICS_FFT_HD void stage_e(const v2f* rd, v2f* lds, const v2f* twl, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), j = lane & 7;
@@ -580,6 +634,16 @@ ICS_FFT_HD void load_image(const IcsFftArgs& a, const Mem& mem, const Unit& u, i
     for (int i = 0; i < 4; ++i) f[t][i] = ld_f32x4<2>(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
   }
 }
+// (row groups [i0, i1) of both tiles only)
+ICS_FFT_HD void load_image_rows(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&f)[2][4], int i0, int i1) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int rows, X;
+    const int vo = quad_lane(a, u, mem.lf, tid, t, rows, X);
+#pragma unroll
+    for (int i = i0; i < i1; ++i) f[t][i] = ld_f32x4<2>(mem.f, i < rows ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
+  }
+}
 // mode 1: the operands under tile t.  The PAM kinds (build-defined tv_mode 2 / 3; ics_conv.hip's epilogue for them) need u and the TV
 // term T = -div(p) instead of u and ut: two operand frames either way (a third does not fit 128 registers).
 template <bool TV>
@@ -617,6 +681,33 @@ ICS_FFT_HD void store_quad_at(const IcsFftArgs& a, const Mem& mem, const QuadOut
   }
   st_f32x4(mem.out, i < q.rows ? q.vo : ICS_FFT_NONE, 32 * i * mem.lout.pitch, val);
 }
+// Fused A11 + A13 unit: the residual of row group i, e' = r - image (pyx:563-565) on the tile's valid pixels inside the M x N interior and
+// exact zeros everywhere else of the 128 x 128 tile (what k_gradk_fft reads back from the residual frame), goes back into the slots it
+// was read from -- the operand of the second forward transform -- and, for tiles under the stop-test window, to the residual frame.
+ICS_FFT_HD void residual_quads(const IcsFftArgs& a, const Mem& mem, const QuadOut (&qo)[2], bool edge, bool store, v2f* lds, int tid, int i, const v4f (&fimg)[2][4]) {
+  v4f r[2];
+  read_quads(lds, tid, i, r);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const bool row_ok = i < qo[t].rows;
+    const int X = qo[t].X;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = ICS_FSUB(r[t][e], fimg[t][i][e]);        // pyx:565
+      const bool ok = edge ? (row_ok && X + e >= a.ox0 && X + e < a.ox1) : row_ok;
+      r[t][e] = ok ? d : 0.f;
+    }
+  }
+  const int r0 = tid >> 5, xq = tid & 31;
+  v4f* wp = reinterpret_cast<v4f*>(lds + (r0 + 32 * i) * ICS_FFT_PITCH + 4 * xq);
+  wp[0] = (v4f){r[0].x, r[1].x, r[0].y, r[1].y};
+  wp[1] = (v4f){r[0].z, r[1].z, r[0].w, r[1].w};
+  if (store) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) st_f32x4(mem.out, i < qo[t].rows ? qo[t].vo : ICS_FFT_NONE, 32 * i * mem.lout.pitch, r[t]);
+  }
+}
+
 // mode 1: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7 on row group i of tile t; the PAM kinds replace the stored value by G
 template <bool TV>
 ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx, const QuadOut& q, bool edge) {
@@ -908,6 +999,117 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
   }
 }
 
+// ---- A11 + A12 + A13 (pyx:555-571) as ONE unit on the tiles: three transforms where k_conv_fft<0> + k_gradk_fft run four -------------------
+// Per tile pair and channel, with t = the two 128 x 128 windows of u (real / imaginary part):
+//     T = DFT(t)                                          A B C D        kept in registers (sixteen values per thread)
+//     r = IDFT(S T);  e' = (r - image) on the valid V x Vy pixels inside the interior, 0 elsewhere       D E F G + row-quad epilogue, IN the tile buffer
+//     acc += T conj(DFT(e'))                              A B C D        the workgroup's running sum, as k_gradk_fft
+// The residual never leaves the CU (it is stored only under the stop-test window, whose statistics read it: pyx:600-601, 627), the window
+// is read once instead of twice and transformed once.  The same stage functions in the same order as the two kernels it replaces and the
+// same walk (workgroup = channel blockIdx % 3, pairs slot, slot + nslots, ...): e' and the K x K blocks are bit-identical to theirs.
+// Registers (1024 threads: 128): acc and T stay alive through the unit, so the sixteen-point stages run in their lean forms and the
+// two prefetches sit beside eight-point stages only: the image quads are requested behind stage G's last LDS write (in flight through the
+// barrier), the next unit's window in front of the second stage D.
+#ifndef ICS_FFT_FUSED_IMG_EARLY
+#define ICS_FFT_FUSED_IMG_EARLY 2
+#endif
+template <int DUMMY>
+__global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs a, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) v2f lds[];
+  v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
+  const int tid = threadIdx.x;
+  if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
+  const Mem mem = make_mem(a, 0);                 // in = u, f = image, out = e' (the geometry of mode 0: tiles of the M x N interior)
+  const int c = (int)blockIdx.x % 3, slot = (int)blockIdx.x / 3, nslots = (int)gridDim.x / 3, npairs = (a.ntiles + 1) / 2;
+  v2f acc[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
+  if (slot < npairs) {
+    v4f pw[2][4];
+    load_window(a, mem, decode_unit(a, 3 * slot + c), opaque(tid), pw);
+    store_window(pw, lds, opaque(tid));
+    lds_barrier();
+    stage_a(lds, opaque(tid));
+  }
+  for (int p = slot; p < npairs; p += nslots) {
+    const Unit u = decode_unit(a, 3 * p + c);
+    lds_barrier();
+    stage_b<1>(lds, opaque(tid));
+    lds_barrier();
+    v2f zu[2][8];
+    {
+      v2f sp[2][8];
+      load_spectrum(mem, c, opaque(tid), sp);
+      stage_c<4>(lds, lds, twl, opaque(tid));
+      wave_sync();
+      stage_d_keep(sp, lds, opaque(tid), zu);
+    }
+    wave_sync();
+    stage_e_lean(lds, lds, twl, opaque(tid));
+    lds_barrier();
+    stage_b<-1>(lds, opaque(tid));
+    lds_barrier();
+    stage_g(lds, opaque(tid));
+    {
+      // the image quads in two halves of two row groups: the first is requested behind stage G's last LDS write (in flight through the
+      // barrier), the second in front of the first half's arithmetic -- 96 registers of spectra and image beside the epilogue otherwise
+      v4f fimg[2][4];
+      load_image_rows(a, mem, u, opaque(tid), fimg, 0, ICS_FFT_FUSED_IMG_EARLY);
+      lds_barrier();
+      load_image_rows(a, mem, u, opaque(tid), fimg, ICS_FFT_FUSED_IMG_EARLY, 4);
+      QuadOut qo[2];
+      const int te = opaque(tid);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) qo[t].vo = quad_lane(a, u, mem.lout, te, t, qo[t].rows, qo[t].X);
+      const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+      bool store = a.store_all != 0;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) store = store || (u.has[t] && u.oy[t] < a.wy1 && u.oy[t] + a.Vy > a.wy0 && u.ox[t] < a.wx1 && u.ox[t] + a.V > a.wx0);   // (uniform)
+      if (store) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) residual_quads(a, mem, qo, edge, true, lds, te, i, fimg);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) residual_quads(a, mem, qo, edge, false, lds, te, i, fimg);
+      }
+    }
+    lds_barrier();
+    stage_a(lds, opaque(tid));
+    lds_barrier();
+    stage_b<1>(lds, opaque(tid));
+    lds_barrier();
+    stage_c<4>(lds, lds, twl, opaque(tid));
+    wave_sync();
+    {
+      v4f pw[2][4];
+      load_window(a, mem, decode_unit(a, 3 * (p + nslots) + c), opaque(tid), pw);   // next unit (beyond the last one: dropped accesses)
+      stage_d_acc(lds, opaque(tid), zu, acc);
+      if (p + nslots < npairs) {
+        lds_barrier();                              // (every wave has read its rows)
+        store_window(pw, lds, opaque(tid));
+        lds_barrier();
+        stage_a(lds, opaque(tid));
+      }
+    }
+  }
+  lds_barrier();
+  stage_d_inverse(acc, lds, opaque(tid));
+  wave_sync();
+  stage_e(lds, lds, twl, opaque(tid));
+  lds_barrier();
+  stage_b<-1>(lds, opaque(tid));
+  lds_barrier();
+  stage_g(lds, opaque(tid));
+  lds_barrier();
+  const int K = a.c.g.K;
+  for (int i = tid; i < K * K; i += ICS_FFT_THREADS) {
+    const int aa = i / K, bb = i - aa * K;
+    partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
+  }
+}
+
 // gradk[a][b][c] = sum of the blocks of the workgroups that kept channel c (block % 3 == c), in double.  One wave per value: lane l adds
 // blocks c + 3 l, c + 3 (l + 64), ... and the 64 lane sums meet in a fixed butterfly (the same bits run after run).  (One thread per value
 // with its 85 serial loads took 27 us, 7 % of the gradient kernel it follows.)
@@ -982,6 +1184,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->c = c;
   a->trace = nullptr;
   a->planar = 0;
+  a->wy0 = a->wy1 = a->wx0 = a->wx1 = 0; a->store_all = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->Vy = ICS_FFT_P - g.K + 1;           // valid rows per tile: all of them
@@ -1043,6 +1246,28 @@ hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g
   const int npairs = (a.ntiles + 1) / 2;
   if (grid > 3 * npairs) grid = 3 * npairs;
   auto kern = icsfft::k_gradk_fft<0>;
+  if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
+  hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 3) / 4), dim3(256), 0, s, partial, grid, g.K, gradk);
+  return hipGetLastError();
+}
+// A11 + A12 + A13 in one kernel: u, f, e = origins of channel-planar mirrors; spec = the convolution orientation's spectrum; the window
+// (u-frame coordinates) says which tiles store their residual; partial: ics_gradk_fft_blocks() * K * K floats
+hipError_t ics_launch_synth_gradk_fft(const float* u, const float* f, float* e, const float* spec, const IcsGeom& g, int wy0, int wy1, int wx0, int wx1, int store_all,
+                                      float* partial, float* gradk, hipStream_t s) {
+  IcsConvArgs c;
+  memset(&c, 0, sizeof c);
+  c.g = g; c.in = u; c.f = f; c.out = e; c.u = u; c.ut = u;
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(0, c, spec, &a);
+  a.planar = ICS_FFT_PL_ALL;
+  a.wy0 = wy0; a.wy1 = wy1; a.wx0 = wx0; a.wx1 = wx1; a.store_all = store_all;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  int grid = ics_gradk_fft_blocks(ics_device_cus(dev));
+  const int npairs = (a.ntiles + 1) / 2;
+  if (grid > 3 * npairs) grid = 3 * npairs;
+  auto kern = icsfft::k_synth_gradk_fft<0>;
   if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
   hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 3) / 4), dim3(256), 0, s, partial, grid, g.K, gradk);

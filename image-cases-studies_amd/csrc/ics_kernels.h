@@ -92,6 +92,11 @@ hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& a, const float* spec
 // A12 + A13 on the same tiles (fp32): u, e = origins of planar mirrors; partial = ics_gradk_fft_blocks(cus) * K * K floats of scratch
 int ics_gradk_fft_blocks(int cus);
 hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g, float* partial, float* gradk, hipStream_t s);
+// A11 + A12 + A13 as one unit per tile pair (three transforms instead of four; the residual stays in the tile buffer and is stored only for
+// tiles under the window [wy0, wy1) x [wx0, wx1) of u-frame coordinates, or everywhere with store_all): bit-identical to
+// ics_launch_conv_fft(0) followed by ics_launch_gradk_fft
+hipError_t ics_launch_synth_gradk_fft(const float* u, const float* f, float* e, const float* spec, const IcsGeom& g, int wy0, int wy1, int wx0, int wx1, int store_all,
+                                      float* partial, float* gradk, hipStream_t s);
 
 // ---- zero-fill of up to ICS_ZERO_MAX device blocks in one launch (the ~24 buffers of a new job: one launch instead of 24 memsets) ----
 #define ICS_ZERO_MAX 32

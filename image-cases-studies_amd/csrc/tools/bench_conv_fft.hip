@@ -256,6 +256,75 @@ int emulate_gradk(int M, int K, int N) {
   return rel < 1e-5 ? 0 : 1;
 }
 
+
+// the fused A11 + A13 unit (k_synth_gradk_fft), stage by stage as the kernel runs them: e' (every tile stored) against float64 direct sums and
+// BIT FOR BIT against the emulation of k_conv_fft<0>; the K x K x 3 gradient against float64 sums over that e'
+int emulate_fused(int M, int K, int N) {
+  Host h = make_host(M, N, K);
+  std::vector<v2f> spec;
+  host_spectrum(h, 0, spec);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES);
+  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
+  std::vector<float> pout(h.pnf, 0.f);
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(0, conv_args(h, 0, h.pu.data(), pout.data(), h.pf.data(), h.pu.data(), h.pu.data(), nullptr), (const float*)spec.data(), &a);
+  a.planar = 63; a.store_all = 1;
+  const icsfft::Mem mem = icsfft::make_mem(a, 0);
+  std::vector<float> gk((size_t)K * K * 3, 0.f);
+  const int npairs = (a.ntiles + 1) / 2;
+  for (int ch = 0; ch < 3; ++ch) {
+    std::vector<v2f> acc((size_t)1024 * 16, (v2f){0.f, 0.f}), zu((size_t)1024 * 16);
+    for (int p = 0; p < npairs; ++p) {
+      const icsfft::Unit u = icsfft::decode_unit(a, 3 * p + ch);
+      for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) {
+        v2f sp[2][8], z[2][8];
+        icsfft::load_spectrum(mem, u.c, t, sp);
+        icsfft::stage_d_keep(sp, lds.data(), t, z);
+        for (int i = 0; i < 16; ++i) zu[(size_t)t * 16 + i] = z[i >> 3][i & 7];
+      }
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e_lean(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) {
+        v4f fimg[2][4];
+        icsfft::load_image(a, mem, u, t, fimg);
+        icsfft::QuadOut qo[2];
+        for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
+        const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+        for (int i = 0; i < 4; ++i) icsfft::residual_quads(a, mem, qo, edge, true, lds.data(), t, i, fimg);
+      }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) {
+        v2f z[2][8], ac[2][8];
+        for (int i = 0; i < 16; ++i) { z[i >> 3][i & 7] = zu[(size_t)t * 16 + i]; ac[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; }
+        icsfft::stage_d_acc(lds.data(), t, z, ac);
+        for (int i = 0; i < 16; ++i) acc[(size_t)t * 16 + i] = ac[i >> 3][i & 7];
+      }
+    }
+    for (int t = 0; t < 1024; ++t) { v2f z[2][8]; for (int i = 0; i < 16; ++i) z[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; icsfft::stage_d_inverse(z, lds.data(), t); }
+    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+    for (int aa = 0; aa < K; ++aa)
+      for (int bb = 0; bb < K; ++bb) gk[((size_t)aa * K + bb) * 3 + ch] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x / 16384.f;
+  }
+  std::vector<float> e(h.nf, 0.f);
+  from_planar(h, pout, e);
+  double wa;
+  const double rel = check(h, 0, e, 1, &wa);
+  // everything of the residual frame outside the interior must still be zero (the gradient sums over the interior only; check() looked inside)
+  const double relg = check_gradk(h, e, gk, 3);
+  printf("emulation %d x %d, K = %d, fused A11 + A13: residual relative to max |conv| = %.3e, PSF gradient relative to max |gradk| = %.3e  %s\n", M, N, K, rel, relg,
+         (rel < 5e-6 && relg < 1e-5) ? "OK" : "FAIL");
+  return (rel < 5e-6 && relg < 1e-5) ? 0 : 1;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 int gpu(int M, int K, int N, int reps) {
@@ -363,6 +432,43 @@ int gpu(int M, int K, int N, int reps) {
     float msg; CK(hipEventElapsedTime(&msg, e0, e1));
     printf("  PSF gradient on the tiles: %.4f ms per launch (kernel + reduction)\n", msg / reps);
   }
+  {   // the fused A11 + A13 unit against the two kernels it replaces: bit for bit (same stage functions, same order, same walk), then timed
+    float *de2, *dpart, *dgk, *dpart2, *dgk2;
+    CK(hipMalloc(&de2, fb)); CK(hipMemset(de2, 0, fb)); CK(hipMemset(dout, 0, fb));
+    CK(hipMalloc(&dpart, (size_t)768 * K * K * 4)); CK(hipMalloc(&dgk, (size_t)3 * K * K * 4));
+    CK(hipMalloc(&dpart2, (size_t)768 * K * K * 4)); CK(hipMalloc(&dgk2, (size_t)3 * K * K * 4));
+    IcsConvArgs a = conv_args(h, 0, du, dout, df, du, dut, dred);
+    IcsFftArgs fa; ics_conv_fft_fill_args(0, a, dspec0, &fa);
+    fa.planar = 63;
+    CK(ics_launch_conv_fft_args(0, fa, 0));
+    CK(ics_launch_gradk_fft(du + h.porg, dout + h.porg, h.g, dpart, dgk, 0));
+    CK(ics_launch_synth_gradk_fft(du + h.porg, df + h.porg, de2 + h.porg, dspec0, h.g, 0, 0, 0, 0, 1, dpart2, dgk2, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> ra(h.pnf), rb(h.pnf), g1((size_t)3 * K * K), g2((size_t)3 * K * K);
+    CK(hipMemcpy(ra.data(), dout, fb, hipMemcpyDeviceToHost)); CK(hipMemcpy(rb.data(), de2, fb, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(g1.data(), dgk, g1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(g2.data(), dgk2, g2.size() * 4, hipMemcpyDeviceToHost));
+    size_t nde = 0, ndg = 0; double gm = 0, gd = 0;
+    for (size_t i = 0; i < h.pnf; ++i) nde += memcmp(&ra[i], &rb[i], 4) != 0;
+    for (size_t i = 0; i < g1.size(); ++i) { ndg += memcmp(&g1[i], &g2[i], 4) != 0; gm = fmax(gm, fabs(g1[i])); gd = fmax(gd, fabs(g1[i] - g2[i])); }
+    printf("fused A11 + A13 against k_conv_fft<0> + k_gradk_fft: %zu residual values differ, %zu gradient values differ (max |d| %.3e of %.3e)  %s\n", nde, ndg, gd, gm, (nde || ndg) ? "FAIL" : "OK");
+    if (nde || ndg) rc = 1;
+    // a window in the middle of the frame: only the tiles under it store
+    const int wy0 = h.g.pad + M / 2 - 100, wx0 = h.g.pad + N / 2 - 100;
+    for (int all = 1; all >= 0; --all) {
+      for (int i = 0; i < 3; ++i) CK(ics_launch_synth_gradk_fft(du + h.porg, df + h.porg, de2 + h.porg, dspec0, h.g, wy0, wy0 + 200, wx0, wx0 + 200, all, dpart2, dgk2, 0));
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < reps; ++i) CK(ics_launch_synth_gradk_fft(du + h.porg, df + h.porg, de2 + h.porg, dspec0, h.g, wy0, wy0 + 200, wx0, wx0 + 200, all, dpart2, dgk2, 0));
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float msf; CK(hipEventElapsedTime(&msf, e0, e1));
+      const int npairs = (fa.ntiles + 1) / 2;
+      printf("  fused A11 + A13 (%s): %.4f ms per launch (kernel + reduction), %d pairs x 3 on 255 workgroups = %d rounds, %.2f us per unit\n", all ? "every tile stores e'" : "window tiles store e'",
+             msf / reps, npairs, (npairs + 84) / 85, 1e3 * msf / reps / ((npairs + 84) / 85));
+    }
+    CK(hipMemcpy(g2.data(), dgk2, g2.size() * 4, hipMemcpyDeviceToHost));
+    ndg = 0;
+    for (size_t i = 0; i < g1.size(); ++i) ndg += memcmp(&g1[i], &g2[i], 4) != 0;
+    if (ndg) { printf("  windowed store changed the gradient: FAIL\n"); rc = 1; }
+  }
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -376,7 +482,7 @@ int gpu(int M, int K, int N, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
-    return emulate(M, K, N) | emulate_gradk(M, K, N);
+    return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N);
   }
   const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
   return gpu(M, K, N, reps);

@@ -73,7 +73,7 @@ class RLRoute(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("conv_family", C.c_int), ("conv_fp16_split", C.c_int), ("gradk_family", C.c_int),
                 ("gradk_fp16_split", C.c_int), ("image_in_accumulator_order", C.c_int), ("graph", C.c_int)]
     CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big", 5: "fft-tiles"}
-    GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big", 6: "fft-tiles"}
+    GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big", 6: "fft-tiles", 7: "fused-fft-tiles"}
 
 
 def describe(M, N, MK, params):

@@ -226,7 +226,8 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
  * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip), 5 fp32 transform tiles on planar
  * mirrors (ics_conv_fft.hip);  PSF gradient A13 -- 1 fused with
  * A11 (k_synth_gradk, MK <= 15), 2 fp16-split matrix cores (k_gradk_mfma), 3 the same as tap blocks (MK >= 33), 4 fp32 MFMA
- * (k_gradk), 5 run-time-sized fp32 (k_gradk_big), 6 fp32 transform tiles (k_gradk_fft, ics_conv_fft.hip); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
+ * (k_gradk), 5 run-time-sized fp32 (k_gradk_big), 6 fp32 transform tiles (k_gradk_fft, ics_conv_fft.hip),
+ * 7 fused with A11 on the fp32 transform tiles (k_synth_gradk_fft: three transforms per tile pair); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
  * stage are formed from two fp16 terms per operand (22 significand bits, fp32 accumulation), 0 = fp32 products. */
 typedef struct ics_rl_route {
   uint32_t struct_size; /* in: sizeof(ics_rl_route) */

@@ -40,9 +40,9 @@ import rl_mm_oracle as orc  # noqa: E402
 CASES = [
     dict(name="nb_2048_k15_deep", M=2048, N=2048, MK=15, blind=0, iters=10, chain=1, step=1e-3, seed=2048, noise_floor=True),
     dict(name="nb_2048_k15_s1e-4", M=2048, N=2048, MK=15, blind=0, iters=50, chain=1, step=1e-4, seed=2048, noise_floor=False),
-    dict(name="bl_4096_k15_deep", M=4096, N=4096, MK=15, blind=1, iters=2, chain=5, step=1e-3, seed=4096),
+    dict(name="bl_4096_k15_deep", M=4096, N=4096, MK=15, blind=1, iters=2, chain=10, step=1e-3, seed=4096),
     dict(name="bl_4096_k15_stop", M=4096, N=4096, MK=15, blind=1, iters=10, chain=1, step=1e-3, seed=4096),
-    dict(name="bl_6144_k31_deep", M=6144, N=6144, MK=31, blind=1, iters=2, chain=1, step=1e-3, seed=6144),
+    dict(name="bl_6144_k31_deep", M=6144, N=6144, MK=31, blind=1, iters=2, chain=5, step=1e-3, seed=6144),
 ]
 
 _num = r"([-+0-9.eE]+|nan|inf)"

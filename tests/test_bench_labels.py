@@ -30,7 +30,7 @@ def test_labels_follow_the_library_routing(MK, blind):
         assert lab["conv"] == nv.RLRoute.CONV_FAMILIES[r.conv_family] and lab["gradk"] == nv.RLRoute.GRADK_FAMILIES[r.gradk_family]
         if conv == nv.CONV_AUTO and 19 <= MK <= 65:      # round 5: fp32 transform tiles for wide PSFs on frames >= 1.5 Mpx, the PSF gradient included
             assert r.conv_fp16_split == 0 and r.conv_family == 5 and "FFT tiles" in lab["dtype_note"] and lab["dtype"] == "f32"
-            assert r.gradk_family == (6 if blind else 0) and r.gradk_fp16_split == 0
+            assert r.gradk_family == (7 if blind else 0) and r.gradk_fp16_split == 0      # round 6: A11 + A13 fused on the tiles
             small = _route(512, MK, blind, conv)         # ... and the matrix cores below that
             assert small.conv_fp16_split == 1 and small.conv_family == (1 if MK <= 49 else 2)
         elif conv == nv.CONV_AUTO:    # every PSF size has a matrix-core path since round 3
@@ -52,7 +52,7 @@ def test_route_switches():
     assert _route(4096, 15, True).conv_family == 1 and _route(6144, 15, False).conv_family == 1
     assert _route(4096, 67, True).conv_family == 2
     # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
-    assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 6
+    assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 7
     assert _route(4096, 31, True, tv_mode=1).conv_family == 1 and _route(2048, 15, False, tv_mode=2).conv_family == 1
     assert _route(4096, 15, True).gradk_family == 1 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK if hasattr(nv, "FLAG_NO_FUSED_GRADK") else 1).gradk_family == 2
     assert _route(4096, 15, True).image_in_accumulator_order == 1 and _route(4096, 15, True, tv_mode=1).image_in_accumulator_order == 0

@@ -98,7 +98,8 @@ def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
     def describe(M, N, MK, **kw):
         return nv.describe(M, N, MK, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True, **kw))
     r = describe(2048, 2048, 31)
-    assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 6 and r.gradk_fp16_split == 0
+    assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 7 and r.gradk_fp16_split == 0      # A11 + A13 fused on the tiles (round 6)
+    assert describe(2048, 2048, 31, flags=nv.FLAG_NO_FUSED_GRADK).gradk_family == 6
     r = describe(2048, 2048, 17)
     assert r.conv_family == 1
     r = describe(2048, 2048, 15)
@@ -106,9 +107,9 @@ def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
     r = describe(300, 300, 31)
     assert r.conv_family == 1
     r = describe(2048, 2048, 45, conv=FFT)
-    assert r.conv_family == 5 and r.gradk_family == 6
+    assert r.conv_family == 5 and r.gradk_family == 7
     r = describe(2048, 2048, 31, tv_mode=2)          # the PAM kinds: convolutions and PSF gradient on the tiles, the rest on the HWC frames
-    assert r.conv_family == 5 and r.gradk_family == 6
+    assert r.conv_family == 5 and r.gradk_family == 7
     r = describe(2048, 2048, 31, tv_mode=1)          # active MM-TV: matrix cores
     assert r.conv_family == 1
 
@@ -196,6 +197,61 @@ def test_fft_psf_gradient_against_float64(M, N, MK):
     print("%dx%d K=%d: PSF gradient on the tiles %.2e" % (M, N, MK, err))
     assert err < 1e-5
     job.close()
+
+
+@pytest.mark.parametrize("M,N,MK", [(90, 100, 15), (114, 114, 15), (115, 229, 15), (150, 260, 17), (200, 120, 31), (300, 310, 23), (230, 333, 45), (190, 170, 63),
+                                    (64, 129, 65), (300, 100, 5), (176, 108, 17), (40, 50, 3), (700, 900, 15)])
+def test_fused_residual_and_gradient_unit(M, N, MK):
+    """A11 + A12 + A13 (pyx:555-571) as ONE unit per tile pair on the tiles (k_synth_gradk_fft: transform of the window, product, inverse,
+    residual in the tile buffer, its transform, product with the kept window spectrum -- three transforms instead of four).
+    Against float64 direct sums at the gates of the two kernels it replaces, and BIT FOR BIT against those two kernels."""
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=MK + N, blind=True)
+    rng = np.random.default_rng(17)
+    u = (case["u0"] + 0.03 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=True, conv=FFT)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    e2 = job.read(nv.BUF_ERROR)
+    job.stage(nv.STAGE_PSF_GRADIENT, p)
+    gk2 = job.read(nv.BUF_GRADK)
+    job.write(nv.BUF_ERROR, np.full_like(e2, 7.0))           # the fused stage must rewrite every pixel of the residual
+    job.write(nv.BUF_GRADK, np.zeros_like(gk2))
+    job.stage(nv.STAGE_SYNTH_GRADK, p)
+    e, gk = job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK)
+    full = conv_valid64(u, psf)
+    err_e = np.max(np.abs(e - (full - case["image"]))) / np.max(np.abs(full))
+    err_g = rel_err(gk, gradk64(u.astype(np.float64), e.astype(np.float64)))
+    print("%dx%d K=%d: fused unit residual %.2e gradient %.2e" % (M, N, MK, err_e, err_g))
+    assert err_e < CONV_TOL and err_g < 1e-5
+    assert np.array_equal(e, e2) and np.array_equal(gk, gk2)
+    assert np.array_equal(job.read(nv.BUF_U), u)
+    job.close()
+
+
+@pytest.mark.parametrize("MK,tv_mode", [(15, 0), (31, 0), (23, 2)])
+def test_whole_blind_run_with_the_fused_unit_equals_the_two_kernel_run(MK, tv_mode, debug_switch):
+    """ics_rl_run on the tiles with A11 + A13 fused (the residual stored under the stop-test window only) against the same run with the two
+    kernels: u, PSF, every stop-test scalar bit for bit; with few persistent workgroups (many pairs per workgroup) as well."""
+    from lib import deconvolution as dc
+    import contextlib, io
+    M, N = 500, 620
+    case = orc.synth_case(M, N, MK, seed=MK, blind=True)
+    for wgs in (0, 7):
+        res = {}
+        for fused in (1, 0):
+            debug_switch("fft_fused", fused)
+            debug_switch("max_wgs", wgs)
+            dc._drop_jobs()
+            u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
+            with contextlib.redirect_stdout(io.StringIO()):
+                dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 3, 1e-3, 10000.0, blind=True, conv=FFT, tv_mode=tv_mode)
+            st = dc.richardson_lucy_MM.last
+            assert st.iterations_done == 3 and not st.has_nan
+            res[fused] = (u, psf, list(st.trace_M_r[:3]), list(st.trace_Hu[:3]), list(st.trace_varu[:3]))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+        assert res[0][2:] == res[1][2:]
+    dc._drop_jobs()
 
 
 @pytest.mark.parametrize("blind", [False, True])
