@@ -509,7 +509,18 @@ static int from_planar(ics_rl* j, float* hwc, hipStream_t s) {   // the u-frame 
 }
 struct FftScope {   // fft_on for the duration of a run / stage, whatever path leaves it
   ics_rl* j;
-  ~FftScope() { if (j) j->fft_on = false; }
+  bool back = false;   // ics_rl_run: the mirrors hold newer data than the HWC frames (set once the run has started, cleared by the regular conversion)
+  // an error return in the middle of a run: bring u and the residual back from the mirrors as well as the device still allows, so that a
+  // later ics_rl_read / stage sees the state the failed run left, not a rotated buffer with stale HWC contents
+  ~FftScope() {
+    if (!j) return;
+    if (j->fft_on && back) {
+      if (pl_of(j, j->u)) (void)from_planar(j, j->u, j->ctx->stream);
+      if (pl_of(j, j->e)) (void)from_planar(j, j->e, j->ctx->stream);
+      (void)hipStreamSynchronize(j->ctx->stream); (void)hipGetLastError();
+    }
+    j->fft_on = false;
+  }
 };
 
 extern "C" int ics_rl_upload(ics_rl* j, const float* image, const float* u, const float* psf) {
@@ -857,12 +868,22 @@ static bool fft_preferred(const IcsGeom& g, bool blind) {
   // (non-blind / blind):  1024^2 31: 0.118 -> 0.146 / 0.251 -> 0.192;  1448^2 21: 0.162 -> 0.149 / 0.272 -> 0.252;  31: 0.198 -> 0.131 / 0.331 -> 0.248;
   // 2048^2 17: 0.168 -> 0.183 / level;  19: 0.257 -> 0.181 / 0.427 -> 0.324;  4096^2 15: level / 0.848 -> 0.944 (the fused A11 + A13 kernel);
   // 17: 0.616 -> 0.599 / 1.104 -> 0.937;  19: 0.901 -> 0.597 / 1.545 -> 0.936;  6144^2 17: 1.285 -> 1.233 / 2.388 -> 1.836.
+  // Round 6, with A11 + A13 fused into one three-transform unit (k_synth_gradk_fft), scripts/ab_fft.py, matrix cores -> tiles (non-blind / blind):
+  // 2048^2 15: 0.164 -> 0.185 / 0.237 -> 0.284 (three rounds of units where 2.004 would do);  17: 0.170 -> 0.183 / 0.315 -> 0.286;  1448^2 17: blind 0.195 -> 0.187;
+  // 2900^2 15: level / 0.455 -> 0.431;  17: 0.341 -> 0.311 / 0.576 -> 0.433;  4096^2 9: 0.512 -> 0.574 / 0.730 -> 0.764;  13: level / 0.790 -> 0.766;
+  // 15: 0.593 -> 0.579 / 0.834 -> 0.785;  6144^2 15: 1.262 -> 1.199 / 1.835 -> 1.680;  8192^2 15: level / 3.256 -> 2.947.
   const long px = (long)g.uM * g.uN;
   if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
-  return g.K == 17 && px >= 8000000L;
+  if (g.K == 17) return px >= (blind ? 2000000L : 8000000L);
+  return g.K >= 13 && px >= (blind ? 8000000L : 16000000L);
 }
+// The tile kernels address a channel-planar mirror through ONE raw buffer resource with 32-bit byte offsets (ics_conv_fft.hip make_gbuf:
+// num_records 2^31 - 1).  A mirror's rows are padded to 64 floats per plane, so for some shapes it is a little LARGER than the HWC frame it
+// mirrors: a frame accepted just under the 2 GiB frame limit can have a mirror whose last plane ends beyond 2^31 bytes -- loads there
+// would read 0, stores would be dropped, silently (e.g. 18784 x 9256 with a 33 x 33 PSF).  Such shapes never take the tiles.
+static bool fft_mirror_fits(const IcsGeom& g) { return ics_planar_floats(g) * sizeof(float) < 0x7FFFFFFFull; }
 static bool pam_on_tiles(const ics_rl* j, const ics_rl_params* p, bool in_run) {   // the routing rule of the PAM kinds (tv_mode 2 / 3)
-  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !in_run) return false;        // (single stages of the TV variants run on the HWC kernels)
+  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !in_run || !fft_mirror_fits(j->g)) return false;        // (single stages of the TV variants run on the HWC kernels)
   if (p->tv_mode != ICS_TV_PAM_ISO && p->tv_mode != ICS_TV_PAM_COLLAB) return false;
   if (p->conv == ICS_CONV_FFT) return true;
   if (p->conv != ICS_CONV_AUTO) return false;
@@ -874,7 +895,7 @@ static bool pam_on_tiles(const ics_rl* j, const ics_rl_params* p, bool in_run) {
 }
 static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (p->tv_mode != ICS_TV_SHIPPED) return pam_on_tiles(j, p, in_run);   // PAM kinds: TV term, back-projection epilogue and update on the mirrors too
-  if (!ics_conv_fft_supported(j->g.K) || p->fuse) return false;
+  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !fft_mirror_fits(j->g)) return false;
   if (p->conv == ICS_CONV_FFT) return true;
   if (p->conv != ICS_CONV_AUTO || !in_run) return false;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
@@ -1240,6 +1261,9 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_FFT) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
   if (p->conv == ICS_CONV_FFT && (!ics_conv_fft_supported(j->g.K) || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse))
     return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 65, the shipped loop and the PAM kinds (tv_mode 0, 2, 3; fuse 0)");
+  if (p->conv == ICS_CONV_FFT && !fft_mirror_fits(j->g))
+    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the channel-planar mirror of a %d x %d frame with a %d x %d PSF is %zu bytes, beyond the 2^31 - 1 the tile kernels address "
+                "(ICS_CONV_AUTO runs such a frame on the matrix cores)", j->g.M, j->g.N, j->g.K, j->g.K, ics_planar_floats(j->g) * sizeof(float));
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && !j->blk_conv) return fail(ICS_ENOSUP, "ICS_CONV_MATRIX: no matrix-core path for this PSF size");
   if (p->conv == ICS_CONV_MATRIX && !j->bt_conv && p->tv_mode != ICS_TV_SHIPPED)   // (the tap-block path has no TV epilogue; never run the fp32 kernels under an explicit MATRIX request)
     return fail(ICS_ENOSUP, "ICS_CONV_MATRIX with tv_mode %d: PSF sizes above 49 run on the matrix cores as tap blocks, which exist for the shipped loop only", p->tv_mode);
@@ -1358,9 +1382,16 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
   FftScope fft_scope{j};
   if (use_fft_pipeline(j, p, true)) {   // the frames live as channel-planar mirrors for the duration of the run (ics_planar.hip)
     j->fft_on = true;
-    RC(ensure_planar(j));
+    int rc_pl = ensure_planar(j);
+    // the mirrors are 7 - 8 more frame-sized buffers: when they do not fit and the tiles were AUTO's choice, the run goes on on the HWC
+    // kernels, which need nothing more (an explicit ICS_CONV_FFT, and the PAM kinds' explicit request, report the failure)
+    if (rc_pl == ICS_ENOMEM && p->conv == ICS_CONV_AUTO) { j->fft_on = false; (void)hipGetLastError(); }
+    else if (rc_pl != ICS_OK) return rc_pl;
+  }
+  if (j->fft_on) {
     RC(to_planar(j, j->u, s));
     if (!j->plf_valid) { RC(to_planar(j, j->f, s)); j->plf_valid = true; }
+    fft_scope.back = true;
   }
   {  // everything but the caller's in-fields is overwritten
     ics_rl_stats in = *st;
@@ -1589,7 +1620,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     RC(pr.collect(ms, launches));
     consume(j->h_scal);
   }
-  if (j->fft_on) { RC(from_planar(j, j->u, s)); RC(from_planar(j, j->e, s)); }   // the HWC frames are the job's state between calls
+  if (j->fft_on) { RC(from_planar(j, j->u, s)); RC(from_planar(j, j->e, s)); fft_scope.back = false; }   // the HWC frames are the job's state between calls
   HIPCHK(ics_launch_hasnan(org(j, j->u), j->g, j->flags + 1, s));
   HIPCHK(hipEventRecord(j->ev_end, s));
   int hflags[4] = {0, 0, 0, 0};

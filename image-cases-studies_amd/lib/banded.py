@@ -74,7 +74,14 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
     u_c = np.ascontiguousarray(u, dtype=np.float32)
     psf_c = np.ascontiguousarray(psf, dtype=np.float32)
     nv = _native
+    # the statistics job holds image rows [top, bottom) at the frame's full width: it is a job like any other and has the same 2 GiB frame
+    # limit.  Checked before anything is allocated (the library would refuse it with ICS_ENOSUP after the band jobs were built).
+    if not (0 < nv.frame_bytes(bottom - top, N, MK) < nv.FRAME_LIMIT_BYTES):
+        raise ValueError("stop-test window rows [%d, %d) of a %d-px-wide frame: its statistics job would hold %d bytes per frame buffer, the limit is %d "
+                         "(choose a window of fewer rows; the reference's drivers pass the 255-px mask window, deconvolve.py:277-313)"
+                         % (top, bottom, N, nv.frame_bytes(bottom - top, N, MK), nv.FRAME_LIMIT_BYTES))
     pool = ThreadPoolExecutor(max_workers=len(B))
+    sj = None
 
     def par(fn):
         return list(pool.map(fn, B))
@@ -84,10 +91,7 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
         bd.job.upload(image_c[bd.a:bd.b], u_c[bd.a:bd.b + 2 * pad], psf_c)
         bd.P = lambda **kw: bd.job.params(top - bd.a, bottom - bd.a, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C,
                                           conv=conv, flags=nv.FLAG_NO_FUSED_GRADK, **kw)
-    par(setup)
-    # the statistics job: image rows [top, bottom) of the frame (u rows [top, bottom + 2 pad))
-    sj = nv.RLJob(bottom - top, N, MK, nv.Context.get(devices[0]))
-    sP = sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv)
+    sP = None
 
     # Rows move between jobs device to device (`ics_rl_copy_rows`: same GPU, or peer access over xGMI); if two devices cannot
     # reach each other the library says ICS_ENOSUP once and every transfer goes through the host from then on.
@@ -134,6 +138,10 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
     it, stop = 0, 0
     M_r = M_r_prev = 0.0
     try:
+        par(setup)
+        # the statistics job: image rows [top, bottom) of the frame (u rows [top, bottom + 2 pad))
+        sj = nv.RLJob(bottom - top, N, MK, nv.Context.get(devices[0]))
+        sP = sj.params(0, bottom - top, left, right, tau, 1, step_factor, lambd, blind, correlation, channels=C, conv=conv)
         while it < iterations and not stop:                                               # pyx:460
             par(lambda bd: bd.job.stage(nv.STAGE_MAJORIZE, bd.P()))                       # pyx:462
             for itt in range(INNER):                                                      # pyx:473
@@ -194,7 +202,8 @@ def richardson_lucy_MM_banded(image, u, psf, top, bottom, left, right, tau, M, N
         for bd in B:
             if bd.job is not None:
                 bd.job.close()
-        sj.close()
+        if sj is not None:
+            sj.close()
         pool.shutdown()
     _report(st, top, bottom, left, right, lambd)
     richardson_lucy_MM_banded.last = st
@@ -226,6 +235,8 @@ class BandRank:
         if not (0 <= top < bottom <= self.M):
             raise ValueError("stats window rows [%d, %d) outside the %d image rows" % (top, bottom, self.M))
         self.win, self.tau, self.blind, self.stop_test = (top, bottom, left, right), tau, bool(blind), stop_test
+        if not (0 < nv.frame_bytes(bottom - top, self.N, self.MK) < nv.FRAME_LIMIT_BYTES):   # (every rank: the same answer everywhere, before anything is built)
+            raise ValueError("stop-test window rows [%d, %d) of a %d-px-wide frame: its statistics job would exceed the %d-byte frame limit" % (top, bottom, self.N, nv.FRAME_LIMIT_BYTES))
         ctx = nv.Context.get(bd.device)
         self.job = nv.RLJob(bd.b - bd.a, self.N, self.MK, ctx)
         self.sj = nv.RLJob(bottom - top, self.N, self.MK, ctx) if self.R == 0 else None

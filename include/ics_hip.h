@@ -123,10 +123,15 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      ICS_FUSED_GRADK=0 does the same for an unmodified caller.  With the fused kernel the
                                      residual frame (ICS_BUF_ERROR) holds e' of pyx:555-565 only on the 64x64 tiles that
                                      meet the stats window -- the only place the loop reads it (pyx:600-601,627)         */
-#define ICS_FLAG_STAGE_ASYNC 2    /* ics_rl_stage: return when the stage is queued on the job's stream instead of when it has run.  Everything
-                                     that reads the job (ics_rl_read*, ics_rl_scalars, the row exchanges, the all-reduces) goes through the same
-                                     stream, so a sequence of stages needs no host synchronisation of its own (lib/banded.py BandRank: one
-                                     per outer iteration, where the stop decision is taken).  Ignored by ics_rl_run.  */
+#define ICS_FLAG_STAGE_ASYNC 2    /* ics_rl_stage: return when the stage is queued on the job's stream instead of when it has run.  The ordering
+                                     contract, as implemented: ics_rl_read*, ics_rl_scalars, ics_rl_copy_rows and the all-reduces are queued on
+                                     (or synchronise with) the job's stream, so they see every stage queued before them.  ics_rl_exchange_rows
+                                     is HOST-SYNCHRONOUS on both sides: it first drains the job's stream, runs its send / receive on the
+                                     group's own stream and returns when that stream has drained -- stages queued after it see the halo rows,
+                                     stages queued before it have finished.  A stage under ICS_CONV_FFT converts its frames back and drains the
+                                     stream whatever this flag says.  So a sequence of stages needs no host synchronisation of its own
+                                     (lib/banded.py BandRank: one per outer iteration, where the stop decision is taken); code that removes the
+                                     exchange's host waits must replace them by events between the two streams.  Ignored by ics_rl_run.  */
 
 #define ICS_CONV_AUTO 0   /* matrix-core kernels at every size (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33;
                              PSF gradient: MK <= 31 directly, above as tap blocks of <= 31 x 31); env
@@ -220,7 +225,10 @@ int ics_rl_download(ics_rl *job, float *u, float *psf_local, float *psf_caller);
  * iteration (to read the stop-test scalars), never inside the 5 inner iterations. */
 int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
 
-/* Which kernels ics_rl_run / ics_rl_stage will launch for this job and these parameters (PSF size, params.conv, tv_mode, fuse,
+/* Which kernels ics_rl_run will launch for this job and these parameters.  (ics_rl_stage takes the same route EXCEPT for the transform
+ * tiles: single stages run on them only under an explicit params.conv = ICS_CONV_FFT with tv_mode 0 -- under ICS_CONV_AUTO, and for the PAM
+ * kinds, a stage-driven loop such as lib/banded.py runs the matrix-core / vector kernels where ics_rl_run would take the tiles; describe
+ * such a loop with params.conv = ICS_CONV_MATRIX.)  Inputs: (PSF size, params.conv, tv_mode, fuse,
  * flags, the ICS_CONV_PATH override): the library's own routing predicates, so that a benchmark labels its precision and traffic
  * figures from what actually runs.  Families:  convolutions A1/A3 -- 1 fp16-split matrix cores (whole PSF), 2 the same as tap blocks
  * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip), 5 fp32 transform tiles on planar

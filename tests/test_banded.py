@@ -75,6 +75,18 @@ def test_frame_limit_routing_decision():
         dc._bands_needed(100, 200, 9, limit=1000)
 
 
+def test_a_statistics_window_beyond_the_frame_limit_is_refused_before_anything_is_built(monkeypatch):
+    """the statistics job of the row bands holds the window's rows at the frame's full width -- a job like any other, with the
+    same 2 GiB limit.  A window that tall is refused with a clear ValueError BEFORE a band job exists (no device here: building one would
+    raise NativeError, so the ValueError also proves the order)."""
+    from lib import _native, banded
+    M, N, MK = 400, 300, 9
+    monkeypatch.setattr(_native, "FRAME_LIMIT_BYTES", _native.frame_bytes(200, N, MK))
+    img, u, psf = np.zeros((M, N, 3), np.float32), np.zeros((M + 8, N + 8, 3), np.float32), np.zeros((MK, MK, 3), np.float32)
+    with pytest.raises(ValueError, match="statistics job"):
+        banded.richardson_lucy_MM_banded(img, u, psf, 10, 390, 10, 290, 0.0, M, N, 3, MK, 1, 1e-3, 1e4, blind=False, bands=4, devices=[0] * 4)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("blind", [False, True])
 def test_frames_beyond_the_limit_take_the_row_bands_by_themselves(monkeypatch, blind):

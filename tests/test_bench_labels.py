@@ -45,21 +45,35 @@ def test_labels_follow_the_library_routing(MK, blind):
 
 def test_route_switches():
     from lib import _native as nv
-    # transform tiles under AUTO (csrc/ics_api.hip fft_preferred, measured with scripts/ab_fft.py): 17 x 17 from 8 Mpx, 19 x 19 ... 65 x 65 from
-    # 1.5 Mpx (blind: 1 Mpx), never for 15 x 15 (the fused A11 + A13 kernel)
-    assert _route(4096, 17, True).conv_family == 5 and _route(4096, 17, False).conv_family == 5 and _route(2048, 17, True).conv_family == 1
+    # transform tiles under AUTO (csrc/ics_api.hip fft_preferred, measured with scripts/ab_fft.py; round 6, with A11 + A13 fused on the tiles):
+    # 19 x 19 ... 65 x 65 from 1.5 Mpx (blind: 1 Mpx), 17 x 17 from 8 Mpx (blind: 2 Mpx), 13 x 13 and 15 x 15 from 16 Mpx (blind: 8 Mpx), never below 13
+    assert _route(4096, 17, True).conv_family == 5 and _route(4096, 17, False).conv_family == 5
+    assert _route(2048, 17, True).conv_family == 5 and _route(2048, 17, False).conv_family == 1 and _route(1024, 17, True).conv_family == 1
     assert _route(1024, 31, True).conv_family == 5 and _route(1024, 31, False).conv_family == 1 and _route(1448, 21, False).conv_family == 5
-    assert _route(4096, 15, True).conv_family == 1 and _route(6144, 15, False).conv_family == 1
+    assert _route(4096, 15, True).conv_family == 5 and _route(4096, 15, False).conv_family == 5 and _route(2900, 15, True).conv_family == 5
+    assert _route(2048, 15, True).conv_family == 1 and _route(2900, 15, False).conv_family == 1 and _route(6144, 13, True).conv_family == 5
+    assert _route(6144, 9, True).conv_family == 1 and _route(6144, 11, False).conv_family == 1
     assert _route(4096, 67, True).conv_family == 2
     # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
     assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 7
     assert _route(4096, 31, True, tv_mode=1).conv_family == 1 and _route(2048, 15, False, tv_mode=2).conv_family == 1
-    assert _route(4096, 15, True).gradk_family == 1 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK if hasattr(nv, "FLAG_NO_FUSED_GRADK") else 1).gradk_family == 2
-    assert _route(4096, 15, True).image_in_accumulator_order == 1 and _route(4096, 15, True, tv_mode=1).image_in_accumulator_order == 0
+    assert _route(2048, 15, True).gradk_family == 1 and _route(2048, 15, True, flags=nv.FLAG_NO_FUSED_GRADK).gradk_family == 2
+    assert _route(4096, 15, True).gradk_family == 7 and _route(4096, 15, True, flags=nv.FLAG_NO_FUSED_GRADK).gradk_family == 6      # the tiles' own fused unit / two kernels
+    assert _route(2048, 15, True).image_in_accumulator_order == 1 and _route(2048, 15, True, tv_mode=1).image_in_accumulator_order == 0
+    assert _route(4096, 15, True).image_in_accumulator_order == 0
     assert _route(4096, 15, True).graph == 0 and _route(512, 9, False).graph == 0      # one hipGraph per outer iteration: opt-in (ICS_GRAPH=1; measured without gain)
     with pytest.raises(nv.NativeError) as ei:      # an explicit MATRIX request is never served by fp32 kernels
         _route(512, 55, True, conv=nv.CONV_MATRIX, tv_mode=2)
     assert ei.value.code == nv.ICS_ENOSUP
+    # a planar mirror pads every plane row to 64 floats and can be LARGER than the HWC frame it mirrors -- 18784 x 9256 with a
+    # 33 x 33 PSF passes the 2 GiB frame limit and its mirror does not fit the tile kernels' 32-bit offsets: AUTO keeps the matrix cores, an
+    # explicit request for the tiles is refused
+    pr = nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True)
+    assert 0 < nv.frame_bytes(18784, 9256, 33) < nv.FRAME_LIMIT_BYTES
+    assert nv.describe(18784, 9256, 33, pr).conv_family == 1 and nv.describe(9000, 9256, 33, pr).conv_family == 5
+    with pytest.raises(nv.NativeError) as ei:
+        nv.describe(18784, 9256, 33, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True, conv=nv.CONV_FFT))
+    assert ei.value.code == nv.ICS_ENOSUP and "mirror" in str(ei.value)
     big = _route(512, 129, True)                   # 129 ... 255: tap blocks on the matrix cores and nothing else
     assert (big.conv_family, big.conv_fp16_split, big.gradk_family) == (2, 1, 3)
     with pytest.raises(nv.NativeError) as ei:
