@@ -195,6 +195,8 @@ struct ics_rl {
   Twin twins[8];
   int ntwins;
   float *spec_conv, *spec_corr;
+  float* fspec;         // mode 2 of the tile convolutions (A1 + A3 in one unit): the image windows' spectra, valid while fspec_valid
+  bool fspec_valid;
   bool fft_on;
   bool plf_valid;                       // the mirror of the image frame still mirrors it (every writer of j->f calls image_changed)
 };
@@ -225,7 +227,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -236,7 +238,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -371,6 +373,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   for (int i = 0; i < j->ntwins; ++i) if (j->twins[i].pl) j->ctx->pool.release(j->twins[i].pl);
   if (j->spec_conv) j->ctx->pool.release(j->spec_conv);
   if (j->spec_corr) j->ctx->pool.release(j->spec_corr);
+  if (j->fspec) j->ctx->pool.release(j->fspec);
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
   for (int i = 0; i < 2; ++i) { if (j->ev_body[i]) hipEventDestroy(j->ev_body[i]); if (j->ev_stats[i]) hipEventDestroy(j->ev_stats[i]); }
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -453,7 +456,7 @@ static int copy_out(ics_rl* j, float* frame, float* host, int rows, int cols_px,
 }
 
 // the accumulator-order copies of the image follow the image frame: every writer of j->f calls this
-static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; j->negf_valid = false; j->plf_valid = false; }
+static inline void image_changed(ics_rl* j) { j->facc_valid[0] = j->facc_valid[1] = false; j->negf_valid = false; j->plf_valid = false; j->fspec_valid = false; }
 
 // (re)build the accumulator-order image for tile height 16 * RS if it is missing or stale; queued on the job's stream
 static int ensure_image_acc(ics_rl* j, int RS) {
@@ -1007,6 +1010,56 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
   return ICS_OK;
 }
 
+// Mode 2 of the tiles: A1 + A2 + A3 in ONE unit per tile pair (k_conv_fft<2>): interior tiles stay in the frequency domain between the two
+// convolutions -- one forward and one inverse transform instead of two of each, at 128 - 2 K + 2 valid pixels a side instead of 128 - K + 1,
+// which pays for small PSFs.  Inside ics_rl_run only (the residual frame is not produced: the statistics' window of it comes from a
+// window-sized launch of mode 0 where the loop does not rewrite it anyway), shipped loop only.
+#ifndef ICS_CONV2_MAX_K
+#define ICS_CONV2_MAX_K 21
+#endif
+static bool use_conv2(const ics_rl* j, const ics_rl_params* p) {
+  if (!j->fft_on || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
+  const int sw = ics_debug().fft_conv2.load(std::memory_order_relaxed);
+  if (sw == 0 || !ics_conv2_fft_supported(j->g)) return false;
+  return sw == 2 || j->g.K <= ICS_CONV2_MAX_K;
+}
+static int do_conv2(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
+  if (!j->fspec) RC(dalloc(j->ctx, &j->fspec, ics_conv2_fft_fspec_floats(j->g), false));
+  if (!j->fspec_valid) {
+    if (!porg(j, j->f)) return fail(ICS_ESTATE, "FFT pipeline: the image has no planar mirror");
+    HIPCHK(ics_launch_fft_image_spectrum(porg(j, j->f), j->g, j->fspec, j->ctx->stream));
+    j->fspec_valid = true;
+  }
+  IcsConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.g = j->g; a.lambd = p->lambd;
+  a.in = porg(j, j->u); a.out = porg(j, j->gr); a.f = porg(j, j->f); a.u = porg(j, j->u); a.ut = porg(j, ut_of(j));
+  a.red = red_of(j) + slot * ICS_RED_STRIDE;
+  a.step = p->step_factor; a.blind = p->blind;
+  if (!a.in || !a.out || !a.f || !a.ut) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+  RC(pr.begin(ICS_K_SYNTH_BACKPROJECT));
+  HIPCHK(ics_launch_conv2_fft(a, j->spec_conv, j->spec_corr, j->fspec, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+// A1 + A2 over the stop-test window alone (the tiles that cover image rows [top, bottom) x columns [left, right)): what A18 / A19 read of the
+// residual (pyx:600-601, 627) when mode 2 ran the iteration
+static int do_conv_fft_window(ics_rl* j, const ics_rl_params* p, Prof& pr) {
+  IcsConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.g = j->g; a.lambd = p->lambd;
+  a.in = porg(j, j->u); a.out = porg(j, j->e); a.f = porg(j, j->f); a.u = a.in; a.ut = a.in;
+  if (!a.in || !a.out || !a.f) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
+  const int pad = j->g.pad;
+  int y0 = p->top + pad, y1 = p->bottom + pad, x0 = p->left + pad, x1 = p->right + pad;
+  if (y0 < pad) y0 = pad; if (x0 < pad) x0 = pad; if (y1 > pad + j->g.M) y1 = pad + j->g.M; if (x1 > pad + j->g.N) x1 = pad + j->g.N;
+  if (y0 >= y1 || x0 >= x1) return ICS_OK;
+  RC(pr.begin(ICS_K_SYNTH));
+  HIPCHK(ics_launch_conv_fft_region(a, j->spec_conv, y0, x0, y1, x1, j->ctx->stream));
+  RC(pr.end());
+  return ICS_OK;
+}
+
 static int do_conv(ics_rl* j, int mode, const ics_rl_params* p, int slot, int want_dof, Prof& pr) {
   if (j->fft_on && mode != 2) return do_conv_fft(j, mode, p, slot, pr);
   if (use_block_conv(j, p, mode)) return do_conv_blocks(j, mode, p, slot, pr);
@@ -1428,16 +1481,23 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     const bool fuse = p->fuse != 0;
     const bool fused_gk = p->blind && !fuse && use_fused_gradk(j, p);
     const bool fused_fft = p->blind && !fuse && use_fused_fft(j, p);
+    // (blind without the fused A11 + A13 unit: A11 rewrites the whole residual frame, nothing more to do; either way the window is there)
+    const bool conv2 = use_conv2(j, p);
     bool have_e = false;  // error already produced by a fused update+synth kernel
     for (int itt = 0; itt < INNER; ++itt) {                   // pyx:473
       const int last = itt == INNER - 1;
       // profile = k: bracket the launches of every k-th inner iteration only (k = 1: all).  Event records
       // between dependent kernels cost ~4 % of a 4096^2 blind iteration, a sample of them does not.
       Prof& pr = (p->profile > 0 && inner_done % p->profile == 0) ? pr_on : pr_off;
+      if (conv2) {
+        RC(do_conv2(j, p, itt, pr));                          // A1 + A2 + A3 (+A7) in one unit per tile pair; the residual frame is not written ...
+        if (!p->blind && last) RC(do_conv_fft_window(j, p, pr));   // ... so the statistics' window of it is (blind: A11 rewrites it, do_synth_gradk_fft)
+      } else {
       if (!have_e) RC(do_conv(j, 0, p, itt, 0, pr));          // A1+A2
       have_e = false;
       if (tv) RC(do_tvterm(j, p, itt, pr));                   // pyx:495-496 (live only in tv_mode 1)
       RC(do_conv(j, 1, p, itt, 0, pr));                       // A3 (+A7)
+      }
       if (p->blind) {                                         // pyx:555
         if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
         else {
@@ -1651,7 +1711,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   // stage writes are copied back after -- slow and simple; ics_rl_run converts at its boundaries only
   FftScope fft_scope{j};
   const bool fft_stage = use_fft_pipeline(j, p, false) && (stage == ICS_STAGE_SYNTH_RESIDUAL || stage == ICS_STAGE_BACKPROJECT || stage == ICS_STAGE_UPDATE ||
-                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE || stage == ICS_STAGE_SYNTH_GRADK);
+                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE || stage == ICS_STAGE_SYNTH_GRADK || stage == ICS_STAGE_SYNTH_BACKPROJECT);
   if (fft_stage) {
     j->fft_on = true;
     RC(ensure_planar(j));
@@ -1709,6 +1769,13 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       if (!ics_synth_gradk_supported(j->g.K) || !j->bt_conv) return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_GRADK is built for PSF sizes <= 15");
       RC(pack_weights(j, 0, 0.f, 0, s));
       RC(do_synth_gradk(j, p, 1, pr));
+      break;
+    case ICS_STAGE_SYNTH_BACKPROJECT:
+      if (!j->fft_on || p->tv_mode != ICS_TV_SHIPPED || !ics_conv2_fft_supported(j->g))
+        return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_BACKPROJECT needs params.conv = ICS_CONV_FFT, tv_mode 0 and a PSF of at most 57 x 57");
+      RC(pack_weights(j, 0, 0.f, 0, s));
+      HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
+      RC(do_conv2(j, p, 0, pr));
       break;
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
     case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;

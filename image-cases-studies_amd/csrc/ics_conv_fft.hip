@@ -127,7 +127,7 @@ static inline void st_f32x4(gbuf b, int vi, int si, v4f v) {
 // where pixel (Y, X, c) of a channel-planar frame lives: index = org + Y * pitch + X + c * cmul  (ics_common.h: ics_ppitch, ics_plane_floats)
 struct Lay { int org, pitch, cmul; };
 struct Mem {
-  gbuf in, out, f, u, ut, tv, spec;
+  gbuf in, out, f, u, ut, tv, spec, spec1, fspec;
   Lay lin, lout, lf, lu, lut, ltv;
 };
 
@@ -258,6 +258,7 @@ template <int DIR> ICS_FFT_HD void fft16(v2f (&v)[16]) {
 struct IcsFftArgs {
   IcsConvArgs c;        // frames, operands, reduction slots, geometry (c.w / c.bt / c.facc / c.sched unused)
   const v2f* spec;      // [3][128][128]: conj(DFT2(W_c)) / 128^2 of this orientation (k_fft_spectrum)
+  const v2f* spec1;     // mode 2 (k_conv_fft<2>: A1 + A3 in one unit): `spec` = the convolution orientation's, `spec1` = the correlation orientation's
   int V;                // valid output pixels per tile ROW: 128 - K + 1 rounded down to whole quads
   int Vy;               // valid output ROWS per tile = 128 - K + 1: rows need no rounding to quads, and two more rows per tile save a whole round of
                         // units at some sizes (6144^2 / 31 x 31 back-projection: 65 x 65 tiles -> 63 x 65 = exactly 24 units per CU instead of 24.8)
@@ -268,6 +269,8 @@ struct IcsFftArgs {
                             // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
                             // some lanes); the pixels in front of ox0 are stored as zeros, like those behind ox1
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
+  int wpad;                 // a tile's window starts wpad pixels up and left of its first output pixel: pad (one convolution), 2 pad (k_conv2_fft: two in a row)
+  float* fspec;             // k_conv2_fft: DFT of the image windows of every unit, [unit][8][1024] quads in load_spectrum's order (k_fft_image_spectrum)
   int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
   int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
@@ -308,9 +311,12 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   m.lu = make_lay(g, a.planar & ICS_FFT_PL_U); m.lut = make_lay(g, a.planar & ICS_FFT_PL_UT); m.ltv = make_lay(g, a.planar & ICS_FFT_PL_TV);
   m.in = make_gbuf(a.c.in - m.lin.org); m.out = make_gbuf(a.c.out - m.lout.org);
   m.f = mode == 1 ? m.in : make_gbuf(a.c.f - m.lf.org);
-  m.u = mode == 0 ? m.in : make_gbuf(a.c.u - m.lu.org); m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
+  m.u = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.u - m.lu.org);    // (mode 2 convolves u itself: the window's frame is the operand frame)
+  m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
   m.tv = (a.c.tv && mode != 0) ? make_gbuf(a.c.tv - m.ltv.org) : m.in;
   m.spec = make_gbuf(a.spec);
+  m.spec1 = (mode == 2 || mode == -1) ? make_gbuf(a.spec1) : m.spec;
+  m.fspec = (mode == 2 || mode == -1) ? make_gbuf(a.fspec) : m.spec;
   return m;
 }
 
@@ -344,7 +350,7 @@ static inline v2f lds_ld(const v2f* p) { return *p; }
 // through the apron's zeros (a quad that starts inside [.., uN + pad) ends inside the apron, ax >= pad + 3; quads beyond it are dropped).
 ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&pw)[2][4], int t0 = 0, int t1 = 2) {
   const int r0 = tid >> 5, xq = tid & 31;
-  const int pad = a.c.g.pad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
+  const int pad = a.wpad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
 #pragma unroll
   for (int t = t0; t < t1; ++t) {
     const int X = u.ox[t] - pad + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad by construction
@@ -455,6 +461,46 @@ ICS_FFT_HD void load_spectrum(const Mem& mem, int c, int tid, v2f (&sp)[2][8]) {
     sp[l >> 2][2 * (l & 3) + 1] = (v2f){p.z, p.w};
   }
 }
+// one half (s = 0 / 1: the eight values of one pass of stage D) of a thread's sixteen spectrum values, from a buffer in load_spectrum's layout
+// whose block of 8 x 1024 quads starts at quad index `blk` (a channel of the weight spectra, a unit of the image spectra)
+template <int KIND>
+ICS_FFT_HD void load_spectrum_half(gbuf b, int blk, int tid, int s, v2f (&sp)[8]) {
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const v4f p = ld_f32x4<KIND>(b, 4 * tid, (blk + 4 * s + l) * ICS_FFT_THREADS * 4);
+    sp[2 * l] = (v2f){p.x, p.y};
+    sp[2 * l + 1] = (v2f){p.z, p.w};
+  }
+}
+// ... and the way out: a thread's sixteen values as block `blk` of such a buffer (k_fft_image_spectrum)
+ICS_FFT_HD void store_spectrum(gbuf b, int blk, int tid, const v2f (&z)[2][8]) {
+#pragma unroll
+  for (int l = 0; l < 8; ++l) {
+    const v2f z0 = z[l >> 2][2 * (l & 3)], z1 = z[l >> 2][2 * (l & 3) + 1];
+    st_f32x4(b, 4 * tid, (blk + l) * ICS_FFT_THREADS * 4, (v4f){z0.x, z0.y, z1.x, z1.y});
+  }
+}
+// Stage D of the fused A1 + A3 unit (k_conv2_fft), interior tiles: with T = the window's spectrum (after the radix-8 pass),
+//     G = S1 . (16384 S0 T - F),     F = the UNNORMALISED transform of the image window (k_fft_image_spectrum),
+// i.e. the spectrum of corr(conv(u) - image): both weight spectra carry the 1 / 128^2 of an inverse transform, the first one's is undone
+// (a power of two: exact).  One forward and one inverse transform where k_conv_fft<0> + k_conv_fft<1> run two of each.
+ICS_FFT_HD void stage_d2_half(const v2f (&s0)[8], const v2f (&s1)[8], const v2f (&fs)[8], v2f* lds, int tid, int s) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+  v2f v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = lds_ld(lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s);
+  fft8<1>(v);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) {
+    const v2f st = cmul(v[k2], s0[k2]);
+    const v2f x = __builtin_elementwise_fma(st, (v2f){16384.f, 16384.f}, -fs[k2]);
+    v[k2] = cmul(x, s1[k2]);
+  }
+  fft8<-1>(v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lds[row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s] = v[j];
+}
+
 // D: radix-8 over j -> kx = k1 + 16 k2, multiply by the spectrum, inverse radix-8 over k2 -> j, same slots
 ICS_FFT_HD void stage_d(const v2f (&sp)[2][8], v2f* lds, int tid) {
   const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
@@ -708,6 +754,55 @@ ICS_FFT_HD void residual_quads(const IcsFftArgs& a, const Mem& mem, const QuadOu
   }
 }
 
+// ---- mode 2 (k_conv_fft<2>): A1 + A2 + A3 of a tile pair in one unit -----------------------------------------------------------------------
+// The residual a back-projection tile reads is the M x N interior's (zero outside, pyx:482-491).  A tile whose residual window -- the
+// V2 + 2 pad pixels a side around it -- lies inside the interior needs no mask and runs in the frequency domain alone (stage_d2_half); the
+// tiles of the outer ring take both transforms pairs, with the mask in between (`border`).  u-frame coordinates.
+ICS_FFT_HD bool tile_is_border(const IcsFftArgs& a, int oy, int ox) {
+  const IcsGeom& g = a.c.g;
+  return oy - g.pad < g.pad || oy + a.Vy + g.pad > g.pad + g.M || ox - g.pad < g.pad || ox + a.V + g.pad > g.pad + g.N;
+}
+ICS_FFT_HD bool unit_is_border(const IcsFftArgs& a, const Unit& u) {
+  return tile_is_border(a, u.oy[0], u.ox[0]) || (u.has[1] && tile_is_border(a, u.oy[1], u.ox[1]));
+}
+// border units, between the two transform pairs: the tile buffer holds conv(u) of the window that starts (pad, pad) before the output
+// tile; e = conv - image inside the interior, 0 outside it (pyx:488 and the zero extension of mode "full", pyx:491), back into the slots
+// it was read from.  Row-quad ownership; the image quads of all four row groups are requested first.
+ICS_FFT_HD void residual_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, v2f* lds, int tid) {
+  const IcsGeom& g = a.c.g;
+  const int r0 = tid >> 5, xq = tid & 31, pad = g.pad;
+  v4f f[2][4];
+  int X[2], Y0[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    X[t] = u.ox[t] - pad + 4 * xq; Y0[t] = u.oy[t] - pad + r0;
+    const int vo = (u.has[t] && X[t] + 3 >= pad && X[t] < pad + g.N) ? mem.lf.org + Y0[t] * mem.lf.pitch + X[t] + mem.lf.cmul * u.c : ICS_FFT_NONE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int Y = Y0[t] + 32 * i;
+      f[t][i] = ld_f32x4<2>(mem.f, (Y >= pad && Y < pad + g.M) ? vo : ICS_FFT_NONE, 32 * i * mem.lf.pitch);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v4f r[2];
+    read_quads(lds, tid, i, r);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int Y = Y0[t] + 32 * i;
+      const bool row_ok = u.has[t] && Y >= pad && Y < pad + g.M;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = ICS_FSUB(r[t][e], f[t][i][e]);                 // pyx:488
+        r[t][e] = (row_ok && X[t] + e >= pad && X[t] + e < pad + g.N) ? d : 0.f;
+      }
+    }
+    v4f* wp = reinterpret_cast<v4f*>(lds + (r0 + 32 * i) * ICS_FFT_PITCH + 4 * xq);
+    wp[0] = (v4f){r[0].x, r[1].x, r[0].y, r[1].y};
+    wp[1] = (v4f){r[0].z, r[1].z, r[0].w, r[1].w};
+  }
+}
+
 // mode 1: g = lambd gradu + (u - ut)/2 (pyx:519) for the maxima of A7 on row group i of tile t; the PAM kinds replace the stored value by G
 template <bool TV>
 ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, int i, v4f& r, const Ops& o, Maxima& mx, const QuadOut& q, bool edge) {
@@ -763,6 +858,9 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 // workgroup barrier that waits for this wave's LDS traffic only (__syncthreads() also waits for the global loads and stores in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef ICS_FFT_M2_ORDER
+#define ICS_FFT_M2_ORDER 1   /* mode 2: 0 = the second halves of the weight spectra requested in front of stage D's first pass, 1 = behind it */
+#endif
 #ifndef ICS_FFT_M1_EARLY
 #define ICS_FFT_M1_EARLY 1      // mode 1: row groups of tile 1's operands requested before stage F already (0: all at the start of the epilogue)
 #endif
@@ -812,6 +910,62 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     lds_barrier();
 #endif
     ICS_FFT_STAMP(2);
+    if (MODE == 2) {
+      // A1 + A3 in one unit (see stage_d2_half): interior tiles stay in the frequency domain between the two convolutions
+      if (!unit_is_border(a, u)) {
+        v2f fs[2][8], s0[8], s1[8];
+        load_spectrum_half<1>(mem.fspec, 8 * n, opaque(tid), 0, fs[0]);       // the image windows' spectrum of this unit: from HBM, requested first
+        load_spectrum_half<1>(mem.fspec, 8 * n, opaque(tid), 1, fs[1]);
+        load_spectrum_half<1>(mem.spec, 8 * u.c, opaque(tid), 0, s0);
+        load_spectrum_half<1>(mem.spec1, 8 * u.c, opaque(tid), 0, s1);
+        stage_c<4>(lds, lds, twl, opaque(tid));
+        wave_sync();
+#if ICS_FFT_M2_ORDER == 0
+        v2f s0b[8], s1b[8];                                                  // the second halves of the weight spectra (L2) behind the first pass of stage D
+        load_spectrum_half<1>(mem.spec, 8 * u.c, opaque(tid), 1, s0b);
+        load_spectrum_half<1>(mem.spec1, 8 * u.c, opaque(tid), 1, s1b);
+        stage_d2_half(s0, s1, fs[0], lds, opaque(tid), 0);
+        stage_d2_half(s0b, s1b, fs[1], lds, opaque(tid), 1);
+#else
+        stage_d2_half(s0, s1, fs[0], lds, opaque(tid), 0);
+        load_spectrum_half<1>(mem.spec, 8 * u.c, opaque(tid), 1, s0);
+        load_spectrum_half<1>(mem.spec1, 8 * u.c, opaque(tid), 1, s1);
+        stage_d2_half(s0, s1, fs[1], lds, opaque(tid), 1);
+#endif
+        wave_sync();
+      } else {
+        // the outer ring: conv, residual with its mask in the tile buffer, then the correlation (four transforms, as the two kernels)
+        {
+          v2f sp[2][8];
+          load_spectrum(mem, u.c, opaque(tid), sp);
+          stage_c(lds, lds, twl, opaque(tid));
+          wave_sync();
+          stage_d(sp, lds, opaque(tid));
+        }
+        wave_sync();
+        stage_e(lds, lds, twl, opaque(tid));
+        lds_barrier();
+        stage_b<-1>(lds, opaque(tid));
+        lds_barrier();
+        stage_g(lds, opaque(tid));
+        lds_barrier();
+        residual_window(a, mem, u, lds, opaque(tid));
+        lds_barrier();
+        stage_a(lds, opaque(tid));
+        lds_barrier();
+        stage_b<1>(lds, opaque(tid));
+        lds_barrier();
+        {
+          v2f sp[2][8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) load_spectrum_half<1>(mem.spec1, 8 * u.c, opaque(tid), h, sp[h]);
+          stage_c(lds, lds, twl, opaque(tid));
+          wave_sync();
+          stage_d(sp, lds, opaque(tid));
+        }
+        wave_sync();
+      }
+    } else {
     v2f sp[2][8];
     load_spectrum(mem, u.c, opaque(tid), sp);      // (stage C's arithmetic covers their trip to L2; inside stage D the waves queued up on it)
     stage_c(lds, lds, twl, opaque(tid));
@@ -819,6 +973,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     ICS_FFT_STAMP(3);
     stage_d(sp, lds, opaque(tid));
     wave_sync();
+    }
     ICS_FFT_STAMP(4);
     load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
     stage_e(lds, lds, twl, opaque(tid));
@@ -842,7 +997,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     // row-quad epilogue, row group by row group (at most one group's raw values alive beside the operands).  Mode 1 has two operand
     // frames: it requests those of the second tile here and takes its maxima in a second pass, and the second tile of the next unit's
     // window goes out between the passes (registers: 128 per thread with 1024 of them).
-    if (MODE == 1) {
+    if (MODE >= 1) {
       load_ops<TV>(a, mem, u, opaque(tid), 1, ops, ICS_FFT_M1_EARLY, 4);
       if (ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
     }
@@ -904,7 +1059,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
 #ifdef ICS_FFT_TRACE
     ++round;
 #endif
-    if (MODE == 1) {   // (u.c is uniform)
+    if (MODE >= 1) {   // (u.c is uniform)
       uint32_t kg, ku;
       maxima_keys(mx, kg, ku);
 #pragma unroll
@@ -912,7 +1067,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
         if (u.c == c) { accg[c] = accg[c] > kg ? accg[c] : kg; accu[c] = accu[c] > ku ? accu[c] : ku; }
     }
   }
-  if (MODE == 1) {
+  if (MODE >= 1) {
     // the workgroup's maxima: wave maxima -> one conditional atomic per wave, channel and value at the END of the kernel (inside the loop
     // the read of the running maximum waited for every store in flight)
 #pragma unroll
@@ -996,6 +1151,37 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
   for (int i = tid; i < K * K; i += ICS_FFT_THREADS) {
     const int aa = i / K, bb = i - aa * K;
     partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
+  }
+}
+
+// ---- the image side of mode 2: F = DFT of the two image windows of every unit (unnormalised), once per image ----------------------------------
+// k_conv_fft<2> subtracts it from 16384 S0 T in stage D -- the "- image" of pyx:488 in the frequency domain.  The window of a unit's tile
+// starts (pad, pad) before the tile's first output pixel (where the residual window of the back-projection starts); the image frame is zero
+// outside the M x N interior.  Stored in load_spectrum's order, one block of 8 x 1024 quads per unit: 128 KB per unit, read once per inner
+// iteration (HBM), written once per upload of the image.  `a` = the mode-2 geometry with in = the image's planar mirror and wpad = pad.
+template <int DUMMY>
+__global__ __launch_bounds__(ICS_FFT_THREADS) void k_fft_image_spectrum(IcsFftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) v2f lds[];
+  v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
+  const int tid = threadIdx.x;
+  if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
+  const Mem mem = make_mem(a, 2);
+  for (int n = blockIdx.x; n < a.nunits; n += gridDim.x) {
+    const Unit u = decode_unit(a, n);
+    v4f pw[2][4];
+    load_window(a, mem, u, opaque(tid), pw);
+    lds_barrier();                                // (the previous unit's stage D has read the tile)
+    store_window(pw, lds, opaque(tid));
+    lds_barrier();
+    stage_a(lds, opaque(tid));
+    lds_barrier();
+    stage_b<1>(lds, opaque(tid));
+    lds_barrier();
+    stage_c(lds, lds, twl, opaque(tid));
+    wave_sync();
+    v2f z[2][8];
+    stage_d_forward(lds, opaque(tid), z);
+    store_spectrum(mem.fspec, 8 * n, opaque(tid), z);
   }
 }
 
@@ -1185,10 +1371,12 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->trace = nullptr;
   a->planar = 0;
   a->wy0 = a->wy1 = a->wx0 = a->wx1 = 0; a->store_all = 0;
+  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->Vy = ICS_FFT_P - g.K + 1;           // valid rows per tile: all of them
   a->V = a->Vy & ~3;                     // valid pixels per tile row, whole quads (16-byte stores never straddle two tiles)
+  if (mode == 2) { a->Vy = ICS_FFT_P - 2 * g.K + 2; a->V = a->Vy & ~3; a->wpad = 2 * g.pad; }   // A1 + A3 in one unit: the valid part of two convolutions in a row
   if (mode == 0) { a->oy0 = g.pad; a->ox0 = g.pad; a->oy1 = g.pad + g.M; a->ox1 = g.pad + g.N; }
   else { a->oy0 = 0; a->ox0 = 0; a->oy1 = g.uM; a->ox1 = g.uN; }
   a->gx0 = a->ox0 & ~3;
@@ -1200,16 +1388,32 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
 }
 
 hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s);
+hipError_t ics_launch_conv_fft_region(const IcsConvArgs& c, const float* spec, int oy0, int ox0, int oy1, int ox1, hipStream_t s);
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& c, const float* spec, int planar, hipStream_t s) {
-  if (mode != 0 && mode != 1) return hipErrorInvalidValue;
+  if (mode != 0 && mode != 1) return hipErrorInvalidValue;   // (mode 2: ics_launch_conv2_fft)
   if (planar != ICS_FFT_PL_ALL) return hipErrorInvalidValue;   // every frame a channel-planar mirror: the kernel moves 4 pixels of a plane row per access
   IcsFftArgs a;
   ics_conv_fft_fill_args(mode, c, spec, &a);
   a.planar = planar;
   return ics_launch_conv_fft_args(mode, a, s);
 }
+// mode 0 over a part of the interior only: the tiles that cover output rows [oy0, oy1) x columns [ox0, ox1) of the u-frame (a window of the
+// residual; what lies outside the region inside a stored quad is written as zero, the rest of the frame is not touched)
+hipError_t ics_launch_conv_fft_region(const IcsConvArgs& c, const float* spec, int oy0, int ox0, int oy1, int ox1, hipStream_t s) {
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(0, c, spec, &a);
+  a.planar = ICS_FFT_PL_ALL;
+  a.oy0 = oy0; a.ox0 = ox0; a.oy1 = oy1; a.ox1 = ox1;
+  a.gx0 = a.ox0 & ~3;
+  a.tiles_x = (a.ox1 - a.gx0 + a.V - 1) / a.V;
+  const int tiles_y = (a.oy1 - a.oy0 + a.Vy - 1) / a.Vy;
+  a.ntiles = a.tiles_x * tiles_y;
+  a.tiles_x_magic = 0x100000000ull / (unsigned)a.tiles_x + 1ull;
+  a.nunits = 3 * ((a.ntiles + 1) / 2);
+  return ics_launch_conv_fft_args(0, a, s);
+}
 hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s) {
-  static std::atomic<bool> configured[3][ICS_MAX_DEVICES];
+  static std::atomic<bool> configured[5][ICS_MAX_DEVICES];
   const int dev = ics_current_device();
   int grid = ics_device_cus(dev);
   if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
@@ -1221,8 +1425,10 @@ hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s
   auto k0 = icsfft::k_conv_fft<0, false>;
   auto k1 = icsfft::k_conv_fft<1, false>;
   auto k1t = icsfft::k_conv_fft<1, true>;
-  auto kern = mode == 0 ? k0 : (pam ? k1t : k1);
-  const int slot = pam ? 2 : mode;
+  auto k2 = icsfft::k_conv_fft<2, false>;
+  if (mode == 2 && (pam || !a.spec1 || !a.fspec)) return hipErrorInvalidValue;   // (mode 2 serves the shipped loop)
+  auto kern = mode == 2 ? k2 : (mode == 0 ? k0 : (pam ? k1t : k1));
+  const int slot = mode == 2 ? 3 : (pam ? 2 : mode);
   if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
   return hipGetLastError();
@@ -1272,5 +1478,44 @@ hipError_t ics_launch_synth_gradk_fft(const float* u, const float* f, float* e, 
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
   hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 3) / 4), dim3(256), 0, s, partial, grid, g.K, gradk);
   return hipGetLastError();
+}
+// ---- mode 2: A1 + A2 + A3 in one unit per tile pair (k_conv_fft<2>) ---------------------------------------------------------------------------
+// valid output per tile: 128 - 2 K + 2 pixels a side; the per-unit image spectra must stay addressable with 32-bit byte offsets
+size_t ics_conv2_fft_fspec_floats(const IcsGeom& g) {
+  IcsConvArgs c; memset(&c, 0, sizeof c); c.g = g;
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(2, c, nullptr, &a);
+  return (size_t)a.nunits * 8 * ICS_FFT_THREADS * 4;
+}
+bool ics_conv2_fft_supported(const IcsGeom& g) {
+  if (!ics_conv_fft_supported(g.K) || ICS_FFT_P - 2 * g.K + 2 < 16) return false;
+  return ics_conv2_fft_fspec_floats(g) * sizeof(float) < 0x7FFFFFFFull;
+}
+// f = origin of the image's planar mirror; fspec = ics_conv2_fft_fspec_floats(g) floats
+hipError_t ics_launch_fft_image_spectrum(const float* f, const IcsGeom& g, float* fspec, hipStream_t s) {
+  IcsConvArgs c;
+  memset(&c, 0, sizeof c);
+  c.g = g; c.in = f; c.f = f; c.out = const_cast<float*>(f); c.u = f; c.ut = f;
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(2, c, nullptr, &a);
+  a.planar = ICS_FFT_PL_ALL; a.wpad = g.pad; a.fspec = fspec; a.spec = reinterpret_cast<const v2f*>(fspec); a.spec1 = a.spec;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  int grid = ics_device_cus(dev);
+  if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
+  if (grid > a.nunits) grid = a.nunits;
+  auto kern = icsfft::k_fft_image_spectrum<0>;
+  if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+// c: in = u = the u mirror's origin, out = the back-projection's, f = the image's, ut, red, lambd as for mode 1; spec_conv / spec_corr = the two
+// weight spectra; fspec = the image spectra of THIS image and geometry
+hipError_t ics_launch_conv2_fft(const IcsConvArgs& c, const float* spec_conv, const float* spec_corr, const float* fspec, hipStream_t s) {
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(2, c, spec_conv, &a);
+  a.planar = ICS_FFT_PL_ALL;
+  a.spec1 = reinterpret_cast<const v2f*>(spec_corr); a.fspec = const_cast<float*>(fspec);
+  return ics_launch_conv_fft_args(2, a, s);
 }
 #endif

@@ -89,6 +89,14 @@ hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, fl
 #define ICS_FFT_PL_TV 32
 #define ICS_FFT_PL_ALL 63
 hipError_t ics_launch_conv_fft(int mode, const IcsConvArgs& a, const float* spec, int planar, hipStream_t s);
+// mode 2 (k_conv_fft<2>): A1 + A2 + A3 in ONE unit per tile pair -- interior tiles stay in the frequency domain between the two convolutions
+// (one forward, one inverse transform; the image enters as the precomputed spectra of its windows), the tiles of the outer ring mask the
+// residual in between.  Valid output 128 - 2 K + 2 pixels a side: for small PSFs.  The residual frame is NOT written.
+hipError_t ics_launch_conv_fft_region(const IcsConvArgs& c, const float* spec, int oy0, int ox0, int oy1, int ox1, hipStream_t s);   // mode 0 over the tiles of a window
+size_t ics_conv2_fft_fspec_floats(const IcsGeom& g);
+bool ics_conv2_fft_supported(const IcsGeom& g);
+hipError_t ics_launch_fft_image_spectrum(const float* f, const IcsGeom& g, float* fspec, hipStream_t s);
+hipError_t ics_launch_conv2_fft(const IcsConvArgs& c, const float* spec_conv, const float* spec_corr, const float* fspec, hipStream_t s);
 // A12 + A13 on the same tiles (fp32): u, e = origins of planar mirrors; partial = ics_gradk_fft_blocks(cus) * K * K floats of scratch
 int ics_gradk_fft_blocks(int cus);
 hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g, float* partial, float* gradk, hipStream_t s);

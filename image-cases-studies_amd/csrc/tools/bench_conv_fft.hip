@@ -325,6 +325,199 @@ int emulate_fused(int M, int K, int N) {
   return (rel < 5e-6 && relg < 1e-5) ? 0 : 1;
 }
 
+// float64 reference of A1 + A2 + A3 from u and the image alone: e = conv(u) - image on the interior (double), g = corr(e zero-extended)
+void reference_conv2(const Host& h, std::vector<double>& gref) {
+  const IcsGeom& g = h.g;
+  std::vector<double> e((size_t)g.uM * g.uN * 3, 0.0);
+  for (int y = g.pad; y < g.pad + g.M; ++y)
+    for (int x = g.pad; x < g.pad + g.N; ++x)
+      for (int c = 0; c < 3; ++c) e[((size_t)y * g.uN + x) * 3 + c] = direct(h, 0, y, x, c) - (double)h.f[h.org + (size_t)y * g.pitch + 3 * x + c];
+  gref.assign((size_t)g.uM * g.uN * 3, 0.0);
+  for (int y = 0; y < g.uM; ++y)
+    for (int x = 0; x < g.uN; ++x)
+      for (int c = 0; c < 3; ++c) {
+        double s = 0.0;
+        for (int a = 0; a < g.K; ++a) {
+          const int yy = y + a - g.pad;
+          if (yy < 0 || yy >= g.uM) continue;
+          for (int b = 0; b < g.K; ++b) {
+            const int xx = x + b - g.pad;
+            if (xx < 0 || xx >= g.uN) continue;
+            s += (double)h.psf[((size_t)a * g.K + b) * 3 + c] * e[((size_t)yy * g.uN + xx) * 3 + c];
+          }
+        }
+        gref[((size_t)y * g.uN + x) * 3 + c] = s;
+      }
+}
+double check_conv2(const Host& h, const std::vector<float>& out, const std::vector<double>& gref, double* worst_abs) {
+  const IcsGeom& g = h.g;
+  double worst = 0, m = 0;
+  for (int y = 0; y < g.uM; ++y)
+    for (int x = 0; x < g.uN; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const double r = gref[((size_t)y * g.uN + x) * 3 + c];
+        m = fmax(m, fabs(r));
+        const double d = fabs(r - (double)out[h.org + (size_t)y * g.pitch + 3 * x + c]);
+        if (getenv("ICS_FFT_DEBUG") && d > 1e-4) fprintf(stderr, "conv2 %d %d %d got %.6g want %.6g\n", y, x, c, out[h.org + (size_t)y * g.pitch + 3 * x + c], r);
+        worst = fmax(worst, d);
+      }
+  *worst_abs = worst;
+  return worst / m;
+}
+
+// the stage sequence of k_conv_fft<mode> (mode 0 / 1) on the host: `in` -> `pout` (planar)
+void emulate_mode(const Host& h, int mode, const std::vector<float>& pin, std::vector<float>& pout) {
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES), spec;
+  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
+  host_spectrum(h, mode, spec);
+  pout.assign(h.pnf, 0.f);
+  uint32_t red[16] = {0};
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(mode, conv_args(h, mode, pin.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec.data(), &a);
+  a.planar = 63;
+  const icsfft::Mem mem = icsfft::make_mem(a);
+  for (int n = 0; n < a.nunits; ++n) {
+    const icsfft::Unit u = icsfft::decode_unit(a, n);
+    for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+    for (int t = 0; t < 1024; ++t) { v2f sp[2][8]; icsfft::load_spectrum(mem, u.c, t, sp); icsfft::stage_d(sp, lds.data(), t); }
+    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) {
+      icsfft::Maxima mx; icsfft::maxima_init(mx);
+      v4f fimg[2][4];
+      icsfft::Ops o;
+      if (mode == 0) icsfft::load_image(a, mem, u, t, fimg);
+      else { icsfft::load_ops<false>(a, mem, u, t, 0, o); icsfft::load_ops<false>(a, mem, u, t, 1, o); }
+      icsfft::QuadOut qo[2];
+      for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
+      const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+      for (int i = 0; i < 4; ++i) {
+        v4f r[2];
+        icsfft::read_quads(lds.data(), t, i, r);
+        if (mode == 0) { r[0] -= fimg[0][i]; r[1] -= fimg[1][i]; }
+        else { icsfft::maxima_quad<false>(a, u, t, 0, i, r[0], o, mx, qo[0], edge); icsfft::maxima_quad<false>(a, u, t, 1, i, r[1], o, mx, qo[1], edge); }
+        icsfft::store_quad_at(a, mem, qo[0], edge, i, r[0]); icsfft::store_quad_at(a, mem, qo[1], edge, i, r[1]);
+      }
+    }
+  }
+}
+
+// mode 2 (k_conv_fft<2>), stage by stage as the kernel runs them, with the image spectra of k_fft_image_spectrum
+int emulate_conv2(int M, int K, int N) {
+  Host h = make_host(M, N, K);
+  // a realistic residual: the image is the frame's own synthesis plus noise (make_host's image is unrelated to u: |e| ~ |u|, which hides
+  // cancellation in the frequency domain)
+  for (int y = h.g.pad; y < h.g.pad + M; ++y)
+    for (int x = h.g.pad; x < h.g.pad + N; ++x)
+      for (int c = 0; c < 3; ++c) {
+        const size_t o = h.org + (size_t)y * h.g.pitch + 3 * x + c;
+        h.f[o] = (float)(direct(h, 0, y, x, c) + 5e-3 * ((double)rand() / RAND_MAX - 0.5));
+      }
+  to_planar(h, h.f, h.pf);
+  std::vector<v2f> spec0, spec1;
+  host_spectrum(h, 0, spec0); host_spectrum(h, 1, spec1);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES);
+  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
+  std::vector<float> pout(h.pnf, 0.f);
+  uint32_t red[16] = {0};
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(2, conv_args(h, 1, h.pu.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec0.data(), &a);
+  a.planar = 63; a.spec1 = spec1.data();
+  std::vector<float> fspec((size_t)a.nunits * 8 * 1024 * 4, 0.f);
+  a.fspec = fspec.data();
+  printf("mode 2: V %d x %d, tiles %d (x %d), units %d\n", a.Vy, a.V, a.ntiles, a.tiles_x, a.nunits);
+  {   // k_fft_image_spectrum
+    IcsFftArgs b = a;
+    b.c.in = b.c.f; b.wpad = h.g.pad;
+    const icsfft::Mem mem = icsfft::make_mem(b, 2);
+    for (int n = 0; n < b.nunits; ++n) {
+      const icsfft::Unit u = icsfft::decode_unit(b, n);
+      for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(b, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) {
+        v2f z[2][8];
+        icsfft::stage_d_forward(lds.data(), t, z);
+        icsfft::store_spectrum(mem.fspec, 8 * n, t, z);
+      }
+    }
+  }
+  const icsfft::Mem mem = icsfft::make_mem(a, 2);
+  int nborder = 0;
+  for (int n = 0; n < a.nunits; ++n) {
+    const icsfft::Unit u = icsfft::decode_unit(a, n);
+    for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw); icsfft::store_window(pw, lds.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+    if (!icsfft::unit_is_border(a, u)) {
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t)
+        for (int hf = 0; hf < 2; ++hf) {
+          v2f fs[8], s0[8], s1[8];
+          icsfft::load_spectrum_half<1>(mem.fspec, 8 * n, t, hf, fs); icsfft::load_spectrum_half<1>(mem.spec, 8 * u.c, t, hf, s0); icsfft::load_spectrum_half<1>(mem.spec1, 8 * u.c, t, hf, s1);
+          icsfft::stage_d2_half(s0, s1, fs, lds.data(), t, hf);
+        }
+    } else {
+      ++nborder;
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) { v2f sp[2][8]; icsfft::load_spectrum(mem, u.c, t, sp); icsfft::stage_d(sp, lds.data(), t); }
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::residual_window(a, mem, u, lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) {
+        v2f sp[2][8];
+        for (int hf = 0; hf < 2; ++hf) icsfft::load_spectrum_half<1>(mem.spec1, 8 * u.c, t, hf, sp[hf]);
+        icsfft::stage_d(sp, lds.data(), t);
+      }
+    }
+    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+    for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+    for (int t = 0; t < 1024; ++t) {
+      icsfft::Maxima mx; icsfft::maxima_init(mx);
+      icsfft::Ops o;
+      icsfft::load_ops<false>(a, mem, u, t, 0, o); icsfft::load_ops<false>(a, mem, u, t, 1, o);
+      icsfft::QuadOut qo[2];
+      for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
+      const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+      for (int i = 0; i < 4; ++i) {
+        v4f r[2];
+        icsfft::read_quads(lds.data(), t, i, r);
+        icsfft::maxima_quad<false>(a, u, t, 0, i, r[0], o, mx, qo[0], edge); icsfft::maxima_quad<false>(a, u, t, 1, i, r[1], o, mx, qo[1], edge);
+        icsfft::store_quad_at(a, mem, qo[0], edge, i, r[0]); icsfft::store_quad_at(a, mem, qo[1], edge, i, r[1]);
+      }
+    }
+  }
+  std::vector<float> out(h.nf, 0.f);
+  from_planar(h, pout, out);
+  std::vector<double> gref;
+  reference_conv2(h, gref);
+  double wa;
+  const double rel = check_conv2(h, out, gref, &wa);
+  // the yardstick: the two kernels mode 2 replaces, on the same frame against the same float64 reference.  The back-projection of a small
+  // residual e = conv(u) - image inherits conv's absolute rounding (~1e-7 |u|) whatever the path: errors are quoted against max |gradu| and
+  // held to twice what the two-kernel path shows (+ 1e-6)
+  std::vector<float> pe, pg, g2(h.nf, 0.f);
+  emulate_mode(h, 0, h.pu, pe);
+  emulate_mode(h, 1, pe, pg);
+  from_planar(h, pg, g2);
+  double wa2;
+  const double rel2 = check_conv2(h, g2, gref, &wa2);
+  const bool ok = rel < 2 * rel2 + 1e-6;
+  printf("emulation %d x %d, K = %d, mode 2 (A1 + A3 in one unit, %d of %d units on the outer ring): max |d| = %.3e, relative to max |gradu| = %.3e (the two kernels: %.3e)  %s\n", M, N, K, nborder,
+         a.nunits, wa, rel, rel2, ok ? "OK" : "FAIL");
+  return ok ? 0 : 1;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 int gpu(int M, int K, int N, int reps) {
@@ -469,6 +662,75 @@ int gpu(int M, int K, int N, int reps) {
     for (size_t i = 0; i < g1.size(); ++i) ndg += memcmp(&g1[i], &g2[i], 4) != 0;
     if (ndg) { printf("  windowed store changed the gradient: FAIL\n"); rc = 1; }
   }
+  if (ics_conv2_fft_supported(h.g)) {   // mode 2: A1 + A3 in one unit, against the two kernels (and float64 on small frames), then timed
+    // the image = the frame's own synthesis + noise (a realistic, small residual)
+    CK(hipMemset(dout, 0, fb));
+    IcsConvArgs a0 = conv_args(h, 0, du, dout, df, du, dut, dred);
+    {   // f := conv(u) + noise, through mode 0 with a zero image, then noise added on the host
+      std::vector<float> zero(h.pnf, 0.f);
+      CK(hipMemcpy(df, zero.data(), fb, hipMemcpyHostToDevice));
+      IcsFftArgs fa; ics_conv_fft_fill_args(0, a0, dspec0, &fa); fa.planar = 63;
+      CK(ics_launch_conv_fft_args(0, fa, 0)); CK(hipDeviceSynchronize());
+      std::vector<float> pc(h.pnf);
+      CK(hipMemcpy(pc.data(), dout, fb, hipMemcpyDeviceToHost));
+      srand(11);
+      const IcsGeom& g = h.g; const int pp = ics_ppitch(g); const size_t pl = ics_plane_floats(g);
+      for (int c = 0; c < 3; ++c)
+        for (int y = g.pad; y < g.pad + M; ++y)
+          for (int x = g.pad; x < g.pad + N; ++x) pc[c * pl + h.porg + (size_t)y * pp + x] += 5e-3f * ((float)rand() / RAND_MAX - 0.5f);
+      CK(hipMemcpy(df, pc.data(), fb, hipMemcpyHostToDevice));
+      h.pf = pc; from_planar(h, pc, h.f);
+    }
+    float *dg1, *dg2, *dfs;
+    CK(hipMalloc(&dg1, fb)); CK(hipMalloc(&dg2, fb)); CK(hipMemset(dg1, 0, fb)); CK(hipMemset(dg2, 0, fb));
+    const size_t nfs = ics_conv2_fft_fspec_floats(h.g);
+    CK(hipMalloc(&dfs, nfs * 4));
+    IcsFftArgs f0; ics_conv_fft_fill_args(0, a0, dspec0, &f0); f0.planar = 63;
+    IcsConvArgs a1 = conv_args(h, 1, dout, dg1, df, du, dut, dred);
+    IcsFftArgs f1; ics_conv_fft_fill_args(1, a1, dspec1, &f1); f1.planar = 63;
+    IcsConvArgs a2 = conv_args(h, 1, du, dg2, df, du, dut, dred + 16);
+    CK(hipMemset(dred, 0, 1024));
+    CK(ics_launch_conv_fft_args(0, f0, 0)); CK(ics_launch_conv_fft_args(1, f1, 0));
+    CK(ics_launch_fft_image_spectrum(df + h.porg, h.g, dfs, 0));
+    CK(ics_launch_conv2_fft(a2, dspec0, dspec1, dfs, 0));
+    CK(hipDeviceSynchronize());
+    std::vector<float> p1(h.pnf), p2(h.pnf);
+    CK(hipMemcpy(p1.data(), dg1, fb, hipMemcpyDeviceToHost)); CK(hipMemcpy(p2.data(), dg2, fb, hipMemcpyDeviceToHost));
+    double gm = 0, gd = 0;
+    {
+      const IcsGeom& g = h.g; const int pp = ics_ppitch(g); const size_t pl = ics_plane_floats(g);
+      for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < g.uM; ++y)
+          for (int x = 0; x < g.uN; ++x) { const size_t o = c * pl + h.porg + (size_t)y * pp + x; gm = fmax(gm, fabs(p1[o])); gd = fmax(gd, fabs((double)p1[o] - (double)p2[o])); }
+    }
+    uint32_t red[32];
+    CK(hipMemcpy(red, dred, 128, hipMemcpyDeviceToHost));
+    printf("mode 2 (A1 + A3 in one unit) against k_conv_fft<0> + k_conv_fft<1>: max |d| = %.3e of max |gradu| %.3e = %.3e   max |g| keys %.6g / %.6g   max u keys %.6g / %.6g  %s\n", gd, gm, gd / gm,
+           ics_key2f(red[0]), ics_key2f(red[16]), ics_key2f(red[3]), ics_key2f(red[19]), gd / gm < 1e-3 ? "OK" : "FAIL");
+    if (!(gd / gm < 1e-3)) rc = 1;
+    if ((long)M * N <= 700L * 700L) {
+      std::vector<float> g1(h.nf, 0.f), g2(h.nf, 0.f);
+      from_planar(h, p1, g1); from_planar(h, p2, g2);
+      std::vector<double> gref;
+      reference_conv2(h, gref);
+      double w1, w2;
+      const double r1 = check_conv2(h, g1, gref, &w1), r2 = check_conv2(h, g2, gref, &w2);
+      printf("  against float64 (relative to max |gradu|): the two kernels %.3e, mode 2 %.3e  %s\n", r1, r2, r2 < 2 * r1 + 1e-6 ? "OK" : "FAIL");
+      if (!(r2 < 2 * r1 + 1e-6)) rc = 1;
+    }
+    for (int i = 0; i < 3; ++i) CK(ics_launch_conv2_fft(a2, dspec0, dspec1, dfs, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_conv2_fft(a2, dspec0, dspec1, dfs, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float m2; CK(hipEventElapsedTime(&m2, e0, e1));
+    IcsFftArgs f2; ics_conv_fft_fill_args(2, a2, dspec0, &f2);
+    printf("  mode 2: %.4f ms per launch, %d units (%d x %d valid), %.2f us per unit and CU\n", m2 / reps, f2.nunits, f2.Vy, f2.V, 1e3 * m2 / reps / ((f2.nunits + 255) / 256));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < 5; ++i) CK(ics_launch_fft_image_spectrum(df + h.porg, h.g, dfs, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&m2, e0, e1));
+    printf("  image spectra (once per image): %.4f ms, %.1f MB\n", m2 / 5, nfs * 4 / 1e6);
+  }
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -482,7 +744,7 @@ int gpu(int M, int K, int N, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
-    return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N);
+    return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N) | (128 - 2 * K + 2 >= 16 ? emulate_conv2(M, K, N) : 0);
   }
   const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
   return gpu(M, K, N, reps);

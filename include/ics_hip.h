@@ -271,6 +271,8 @@ unsigned long long ics_rl_frame_bytes(int M, int N, int MK);
                                       the keys of ICS_BUF_RED; the caller combines them over the bands and writes them back */
 #define ICS_STAGE_BAND_MASK_E 12   /* residual rows outside image rows [band_row0, band_row1) := 0, so that the PSF gradient
                                       of ICS_STAGE_PSF_GRADIENT sums the owned rows only (the caller adds the bands)       */
+#define ICS_STAGE_SYNTH_BACKPROJECT 13 /* params.conv = ICS_CONV_FFT only: A1 + A2 + A3 (+A7) as ONE unit per tile pair (k_conv_fft<2>): gradu and the
+                                          step-size maxima straight from u and the image; the residual frame is not written   */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -306,7 +308,8 @@ int ics_rl_copy_rows(ics_rl *dst, int dst_which, int dst_row0, ics_rl *src, int 
 #define ICS_K_STATS 6        /* A18/A19 window statistics + FFT */
 #define ICS_K_UPDATE_SYNTH 7 /* fused A5-A10 + A1/A2 (or A11) kernel */
 #define ICS_K_SYNTH_GRADK 8  /* fused A11 + A13 kernel (+ reduction)  */
-#define ICS_KERNEL_COUNT 12  /* (9..11 reserved) */
+#define ICS_K_SYNTH_BACKPROJECT 9 /* A1 + A2 + A3 (+A7) in one unit per tile pair (transform tiles, small PSFs) */
+#define ICS_KERNEL_COUNT 12  /* (10..11 reserved) */
 
 /* ---- small standalone operators ---------------------------------------------------------- */
 /* lib/deconvolution.pyx:73-75 -- in place on a host MK*MK*3 float32 array, computed on device. */

@@ -100,10 +100,12 @@ def test_auto_picks_the_tiles_for_wide_psfs_on_big_frames():
     r = describe(2048, 2048, 31)
     assert r.conv_family == 5 and r.conv_fp16_split == 0 and r.gradk_family == 7 and r.gradk_fp16_split == 0      # A11 + A13 fused on the tiles (round 6)
     assert describe(2048, 2048, 31, flags=nv.FLAG_NO_FUSED_GRADK).gradk_family == 6
-    r = describe(2048, 2048, 17)
-    assert r.conv_family == 1
+    r = describe(2048, 2048, 17)                     # round 6: blind 17 x 17 from 2 Mpx, 13 x 13 / 15 x 15 from 8 Mpx
+    assert r.conv_family == 5 and describe(1024, 1024, 17).conv_family == 1
     r = describe(2048, 2048, 15)
     assert r.conv_family == 1 and r.gradk_family == 1
+    r = describe(4096, 4096, 15)
+    assert r.conv_family == 5 and r.gradk_family == 7
     r = describe(300, 300, 31)
     assert r.conv_family == 1
     r = describe(2048, 2048, 45, conv=FFT)
@@ -251,6 +253,73 @@ def test_whole_blind_run_with_the_fused_unit_equals_the_two_kernel_run(MK, tv_mo
             res[fused] = (u, psf, list(st.trace_M_r[:3]), list(st.trace_Hu[:3]), list(st.trace_varu[:3]))
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
         assert res[0][2:] == res[1][2:]
+    dc._drop_jobs()
+
+
+@pytest.mark.parametrize("M,N,MK", [(500, 640, 15), (420, 700, 9), (330, 350, 21), (300, 310, 23), (40, 50, 3), (700, 300, 5), (300, 100, 5), (620, 410, 13), (450, 450, 17)])
+def test_synthesis_and_back_projection_in_one_unit(M, N, MK):
+    """Mode 2 of the tiles (k_conv_fft<2>, ICS_STAGE_SYNTH_BACKPROJECT): A1 + A2 + A3 (pyx:477-491) of a tile pair in one unit -- tiles whose
+    residual window lies inside the image stay in the frequency domain between the two convolutions (G = S1 (S0 T - F), the image as the
+    precomputed spectra of its windows), the tiles of the outer ring mask the residual in between.  Against float64 sums formed from u and
+    the image alone: the back-projection of a SMALL residual e = conv(u) - image carries conv's absolute rounding (~1e-7 |u|) on every
+    path, so the error is quoted against max |gradu| and held to twice what the two kernels show on the same frame (+ 1e-6); the
+    step-size maxima are exactly those of the stage's own output."""
+    from lib import _native as nv
+    job, case, psf = make_job(M, N, MK, seed=MK + M)
+    rng = np.random.default_rng(7)
+    u = (case["u0"] + 0.01 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u)
+    job.write(nv.BUF_UT, case["u0"])
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=False, conv=FFT)
+    e64 = conv_valid64(u, psf) - case["image"].astype(np.float64)
+    g_ref = corr_full64(e64, psf)
+    job.stage(nv.STAGE_SYNTH_RESIDUAL, p)
+    job.stage(nv.STAGE_BACKPROJECT, p)
+    err2 = rel_err(job.read(nv.BUF_GRADU), g_ref)
+    job.write(nv.BUF_GRADU, np.full_like(u, 3.0))
+    job.stage(nv.STAGE_SYNTH_BACKPROJECT, p)
+    g = job.read(nv.BUF_GRADU)
+    err = rel_err(g, g_ref)
+    print("%dx%d K=%d: one unit %.2e, two kernels %.2e (of max |gradu| = %.2e)" % (M, N, MK, err, err2, np.max(np.abs(g_ref))))
+    assert err < 2 * err2 + 1e-6
+    red = job.red_keys()
+    gg = (np.float32(10000.0) * g + (u - case["u0"]) * np.float32(0.5)).astype(np.float32)
+
+    def key_to_float(k):
+        k = int(k)
+        return np.array([(k & 0x7FFFFFFF) if (k & 0x80000000) else (~k & 0xFFFFFFFF)], np.uint32).view(np.float32)[0]
+    for c in range(3):
+        assert key_to_float(red[c]) == np.max(np.abs(gg[..., c]))
+        assert key_to_float(red[3 + c]) == np.max(u[..., c])
+    assert np.array_equal(job.read(nv.BUF_U), u)
+    job.close()
+
+
+@pytest.mark.parametrize("blind", [False, True])
+@pytest.mark.parametrize("MK", [9, 15])
+def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, blind, debug_switch):
+    """ics_rl_run on the tiles with A1 + A3 as one unit (fft_conv2, default for small PSFs) against the same run with the two kernels:
+    two correct evaluations of the same sums -- u, PSF within 1e-5 after three outer iterations, the stop-test scalars (whose residual
+    window comes from a window-sized launch of mode 0, non-blind, or from the fused A11 + A13 unit, blind) within 2e-3."""
+    from lib import deconvolution as dc
+    import contextlib, io
+    M, N = 700, 820
+    case = orc.synth_case_large(M, N, MK, seed=MK, blind=blind)
+    res = {}
+    for sw in (1, 0):
+        debug_switch("fft_conv2", sw)
+        dc._drop_jobs()
+        u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 3, 1e-3, 10000.0, blind=blind, conv=FFT)
+        st = dc.richardson_lucy_MM.last
+        assert st.iterations_done == 3 and not st.has_nan
+        res[sw] = (u, psf, np.array(st.trace_M_r[:3]), np.array(st.trace_Hu[:3]), np.array(st.trace_varu[:3]))
+    eu, ep = rel_err(res[1][0], res[0][0]), rel_err(res[1][1], res[0][1])
+    print("K=%d blind=%s: one unit vs two kernels u %.2e psf %.2e" % (MK, blind, eu, ep))
+    assert eu < 1e-5 and ep < 1e-5
+    for k in (2, 3, 4):
+        np.testing.assert_allclose(res[1][k], res[0][k], rtol=2e-3)
     dc._drop_jobs()
 
 
