@@ -169,7 +169,7 @@ def cpu_baseline(mode, MK, M_full, budget_s=10.0):
 
 
 def mfma_counters(kernel, M, MK):
-    """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/r04_mfma_counters.json, written by
+    """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/rNN_mfma_counters.json, newest round first, written by
     scripts/make_mfma_json.py from rocprofv3 --pmc runs): static, NOT measured in this run -- like `traffic`."""
     try:
         for name in ("r05_mfma_counters.json", "r05_6144_31_mfma_counters.json", "r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
@@ -252,6 +252,32 @@ def timed_run(ctx, M, MK, blind, tv_mode, conv, steps, warm, seed=0):
     gb = ITER_BYTES_PER_PX[mode] * M * M / (el / steps) / 1e9
     return {"ms_per_step": round(el * 1e3 / steps, 4), "MPixels_per_s_per_iter": round(M * M * steps / el / 1e6, 1),
             "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[mode], "frac_of_8TBps": round(gb / HBM_PEAK_GBPS, 4), "kernels_ms": kern, "steps": steps}
+
+
+def deblur_end_to_end(size=4096, blur=15, iterations=20):
+    """`deblur_module` (the reference's driver, deconvolve.py:65-368: blind pass on the 255-px mask window and non-blind pass on the whole frame,
+    at every pyramid level) end to end on a synthetic 8-bit picture, reference defaults otherwise: seconds per call with the frames
+    resident in HBM (default) and with the frames on the host between the solver calls; the resident call's blind / non-blind split.
+    The first resident call builds the jobs (allocation); the figure is the second."""
+    import contextlib
+    import io
+    import deconvolve as dv
+    rng = np.random.default_rng(0)
+    coarse = rng.random((size // 8 + 2, size // 8 + 2, 3))
+    pic = (np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:size, :size] * 200 + 20).astype(np.uint8)
+    kw = dict(mask=[size // 2, size // 2], mask_size=255, display=False, iterations=iterations, save=False)
+    out = {"picture": "%dx%dx3 uint8, blur width %d, iterations=%d (outer, per solver call), mask 255 px, pyramid %s" % (size, size, blur, iterations, dv.build_pyramid(blur, 10)[1])}
+    for name, dev, reps in (("frames_resident_in_hbm", True, 2), ("frames_on_host_between_solver_calls", False, 1)):
+        dt = None
+        for _ in range(reps):
+            with contextlib.redirect_stdout(io.StringIO()):
+                t = time.perf_counter()
+                dv.deblur_module(pic, "t", ".", blur, device_resident=dev, **kw)
+                dt = time.perf_counter() - t
+        out[name] = {"seconds": round(dt, 4)}
+        if dev:
+            out[name]["phase_seconds"] = {k: round(v, 4) for k, v in dv.deblur_module.last_phase_seconds.items()}
+    return out
 
 
 def bench_bands(args, grp):
@@ -432,6 +458,8 @@ def main():
     per_rank = grp.gather([st.ms_total, float(st.iterations_done), float(st.M_r), float(st.has_nan)])
     rccl = grp.describe()
     rccl["ranks_gathered"] = len(per_rank)
+    rccl["hardware_note"] = ("an RCCL communicator with more than one rank has never run in this build's history: every box it was given had one GPU "
+                             "(the N > 1 path is covered by gloo world-size-2 tests on CPU, tests/test_multi_gpu.py)") if grp.size == 1 else "this run is the N > 1 evidence"
     job.close()
     if grp.rank == 0:
         ms_per_step = elapsed * 1e3 / steps
@@ -467,11 +495,12 @@ def main():
         out = {
             "metric": "MPixels/sec/iter RL-TV deconv @%d^2x3 fp32, %dx%d PSF" % (M, MK, MK),
             "value": round(value, 1), "unit": "MPixels/s/iter", "n_gpus": grp.size, "steps": steps, "warmup": warm,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "cold_start_ms_per_step": cold["ms_per_step"] if cold else None,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": lab["dtype"], "data": "synthetic",
-            "dtype_note": lab["dtype_note"],
-            "order": ("cold_start (W + K steps after idle, reported beside), %d untimed pre-heat steps, then the contract's W warm-up + K timed steps = `value`" % PREHEAT) if PREHEAT else "W warm-up + K timed steps (no pre-heat)",
             "cold_start": cold,
+            "order": ("cold_start (W + K steps after idle, reported beside), %d untimed pre-heat steps, then the contract's W warm-up + K timed steps = `value`" % PREHEAT) if PREHEAT else "W warm-up + K timed steps (no pre-heat)",
+            "dtype_note": lab["dtype_note"],
             "config": {"workload": "%s Richardson-Lucy MM (lib/deconvolution.pyx loop as shipped: the TV term is arithmetically dead in the reference, tv_mode %d), %dx%dx3 fp32, %dx%d PSF, one frame per GPU, "
                                    "stop test evaluated every outer iteration" % ("blind" if blind else "non-blind", args.tv_mode, M, N, MK, MK),
                        "mode": args.mode, "tv_mode": args.tv_mode, "conv": lab["conv"], "psf_gradient": lab["gradk"], "step_is": "one inner iteration (5 per outer iteration)", "parallelism": "image-per-gpu x%d" % grp.size,
@@ -488,10 +517,11 @@ def main():
         if grp.size == 1 and not args.no_other_configs and args.size == 4096 and args.psf == 15 and args.tv_mode == 0 and not args.fuse:
             # secondary lines (never `value`): the other BASELINE.json configurations and the build-defined TV variants they name
             out["conv_rel_err_vs_f64"] = conv_rel_err(ctx, MK)
-            # the headline's default path forms its products from two fp16 terms per operand (22 significand bits); the same workload with
-            # fp32 products throughout, every round, beside it: packed-fp32 vector convolutions + fp32-MFMA gradient, and the fp32 transform tiles
-            out["fp32_product_paths"] = {"vector (ics_conv.hip + fp32-MFMA PSF gradient)": timed_run(ctx, M, MK, blind, 0, 1, 50, 10),
-                                         "fft tiles (ics_conv_fft.hip: convolutions and PSF gradient as fp32 transforms)": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
+            # since round 6 the headline's default path is fp32 throughout (transform tiles); the same workload on the other two kernel families,
+            # every round, beside it: packed-fp32 vector convolutions + fp32-MFMA gradient, and the matrix cores with fp16x2-split operands
+            out["other_product_paths"] = {"fp32 products, vector (ics_conv.hip + fp32-MFMA PSF gradient)": timed_run(ctx, M, MK, blind, 0, 1, 50, 10),
+                                          "fp16x2-split products on the matrix cores (ics_conv_mfma.hip, fused A11 + A13 kernel; the headline path of rounds 1-5)": timed_run(ctx, M, MK, blind, 0, 2, 50, 10),
+                                          "fp32 transform tiles (ics_conv_fft.hip), forced with --conv fft": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
             oc = {}
             oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)
@@ -504,6 +534,8 @@ def main():
             # beyond BASELINE.json: the largest PSF of the reference's own examples (deconvolve.py:409, blur width 45)
             oc["example blind 4096^2 45x45 (shipped loop; reference deconvolve.py:409)"] = timed_run(ctx, 4096, 45, True, 0, conv, 10, 5)
             out["other_configs"] = oc
+            out["deblur_module_end_to_end"] = {"4096^2 blur 15, reference defaults (iterations=20)": deblur_end_to_end(4096, 15, 20),
+                                               "2048^2 blur 15, reference defaults (iterations=20)": deblur_end_to_end(2048, 15, 20)}
         if not args.no_cpu_baseline and grp.size == 1:   # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(args.mode, MK, M)
         print(json.dumps(out))

@@ -78,10 +78,19 @@ namespace icsfft {
 // s_waitcnt vmcnt(n) for the register prefetch of the next unit does not degrade to vmcnt(0) behind the epilogue's stores.
 // The host pass (CPU emulation, tools/bench_conv_fft.hip) indexes pointers.
 #define ICS_FFT_NONE 0x20000000
-// (ablation builds of tools/bench_conv_fft.hip, -DICS_FFT_ABL_NOMEM=mask: what a unit costs without some of its global memory traffic --
-//  1 spectrum, 2 epilogue operands (mode 1: tile 0's), 4 window, 8 stores, 16 mode 1's operands of tile 1; -DICS_FFT_ABL_NOMATH: without its butterflies)
-#ifndef ICS_FFT_ABL_NOMEM
-#define ICS_FFT_ABL_NOMEM 0
+// Measurement hooks (per-wave phase timeline, ablations): empty in the library; the harness builds of tools/bench_conv_fft.hip define
+// ICS_FFT_PROBES and get their bodies from tools/ics_conv_fft_probe.h.
+#ifdef ICS_FFT_PROBES
+#include "tools/ics_conv_fft_probe.h"
+#else
+#define ICS_FFT_PROBE_SKIP_LOAD(KIND, vi, si)
+#define ICS_FFT_PROBE_SKIP_STORE(v, vi, si)
+#define ICS_FFT_PROBE_SKIP_MATH() do { } while (0)
+#define ICS_FFT_PROBE_COLUMN_PASS(x) do { x } while (0)
+#define ICS_FFT_PROBE_TRACE_DECL() do { } while (0)
+#define ICS_FFT_STAMP(i) do { } while (0)
+#define ICS_FFT_PROBE_TRACE_NEXT() do { } while (0)
+#define ICS_FFT_PROBE_STAGGER() do { } while (0)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __amdgpu_buffer_rsrc_t gbuf;
@@ -89,9 +98,9 @@ __device__ __forceinline__ gbuf make_gbuf(const void* p) { return __builtin_amdg
 __device__ __forceinline__ float ld_f32(gbuf b, int vi, int si) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b, 4 * vi, 4 * si, 0)); }
 __device__ __forceinline__ void st_f32(gbuf b, int vi, int si, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), b, 4 * vi, 4 * si, 0); }
 __device__ __forceinline__ v2f ld_v2f(gbuf b, int vi, int si) { return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(b, 8 * vi, 8 * si, 0)); }
-template <int KIND = 0>   // (KIND: the ablation mask bit of this access, 0 = never ablated)
+template <int KIND = 0>   // (KIND: which class of access this is -- spectrum 1, operands 2 / 16, window 4 -- for the harness' ablation hook)
 __device__ __forceinline__ v4f ld_f32x4(gbuf b, int vi, int si) {
-  if (KIND & ICS_FFT_ABL_NOMEM) { const float x = (float)(vi + si); return (v4f){x, x, x, x}; }
+  ICS_FFT_PROBE_SKIP_LOAD(KIND, vi, si)
   return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(b, 4 * vi, 4 * si, 0));
 }
 typedef uint32_t u4v __attribute__((ext_vector_type(4)));
@@ -102,7 +111,7 @@ typedef uint32_t u4v __attribute__((ext_vector_type(4)));
 //  (tools/bench_conv_fft.hip found it: the first pixel of the quads of lanes 12-15 of every row group but the first).  Keeping the data
 //  alive across two wait states costs nothing here: eight stores per thread and unit)
 __device__ __forceinline__ void st_f32x4(gbuf b, int vi, int si, v4f v) {
-  if (ICS_FFT_ABL_NOMEM & 8) { asm volatile("" :: "v"(v), "v"(vi), "s"(si)); return; }
+  ICS_FFT_PROBE_SKIP_STORE(v, vi, si)
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), b, 4 * vi, 4 * si, 0);
   asm volatile("s_nop 2" :: "v"(v) : "memory");
 }
@@ -206,9 +215,7 @@ template <int DIR> ICS_FFT_HD void fft4_r2(v2f& a0, v2f& a1, v2f& a2, v2f& a3) {
 
 // 8 points, natural order in, natural order out.  n = 2 n1 + n2, k = k1 + 4 k2.
 template <int DIR> ICS_FFT_HD void fft8(v2f (&v)[8]) {
-#if defined(ICS_FFT_ABL_NOMATH) && defined(__HIP_DEVICE_COMPILE__)   // (ablation: the stage's LDS traffic without its butterflies)
-  return;
-#endif
+  ICS_FFT_PROBE_SKIP_MATH();
   constexpr float R = 0.70710678118654752440f;
   v2f e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
   fft4<DIR>(e0, e1, e2, e3);
@@ -224,9 +231,7 @@ template <int DIR> ICS_FFT_HD void fft8(v2f (&v)[8]) {
 
 // 16 points, natural order in, natural order out.  n = 4 n1 + n2, k = k1 + 4 k2.
 template <int DIR> ICS_FFT_HD void fft16(v2f (&v)[16]) {
-#if defined(ICS_FFT_ABL_NOMATH) && defined(__HIP_DEVICE_COMPILE__)   // (ablation: the stage's LDS traffic without its butterflies)
-  return;
-#endif
+  ICS_FFT_PROBE_SKIP_MATH();
   constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, R = 0.70710678118654752440f;
   v2f a[4][4];   // a[n2][k1]
 #pragma unroll
@@ -878,22 +883,14 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   // workgroup b runs on XCD b % 8 (observed dispatch): consecutive unit slots q go to one XCD, so the three channel units of a tile pair
   // (n = 3 pair + c) share that XCD's L2.  Affects speed only.
   const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
-#ifdef ICS_FFT_TRACE
-  int round = 0;
-#define ICS_FFT_STAMP(i) do { if ((tid & 63) == 0 && round < 16 && a.trace) a.trace[(((size_t)blockIdx.x * 16 + round) * 16 + (tid >> 6)) * 10 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define ICS_FFT_STAMP(i) do { } while (0)
-#endif
+  ICS_FFT_PROBE_TRACE_DECL();
   uint32_t accg[3] = {0u, 0u, 0u}, accu[3] = {0u, 0u, 0u};   // the workgroup's maxima as order-preserving keys (0 = nothing seen, NaN = largest)
   // A unit's window is requested one unit ahead (registers).  It enters the tile buffer -- and runs its stage A -- at the END of the unit
   // before it, behind that unit's stores: there the compiler knows exactly what is in flight (the window loads, then the stores) and waits
   // with vmcnt(n_stores).  (Consumed at the top of the loop the wait became vmcnt(0): the loop header merges the first entry, where
   // nothing follows the loads.)
   v4f pw[2][4];
-#ifdef ICS_FFT_STAGGER
-  // workgroups start a fraction of a unit apart (measured: no effect -- what bounds a unit's memory phases is its own CU's texture addresser)
-  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3) * ICS_FFT_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
+  ICS_FFT_PROBE_STAGGER();
   if (q < a.nunits) {
     load_window(a, mem, decode_unit(a, q), opaque(tid), pw);
     store_window(pw, lds, opaque(tid));
@@ -905,10 +902,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     ICS_FFT_STAMP(0);
     lds_barrier();
     ICS_FFT_STAMP(1);
-#ifndef ICS_FFT_ABL_SKIP_BF   /* (ablation: a unit without its two radix-8 column passes -- what an LDS round trip with its barrier costs) */
-    stage_b<1>(lds, opaque(tid));
-    lds_barrier();
-#endif
+    ICS_FFT_PROBE_COLUMN_PASS(stage_b<1>(lds, opaque(tid)); lds_barrier(););
     ICS_FFT_STAMP(2);
     if (MODE == 2) {
       // A1 + A3 in one unit (see stage_d2_half): interior tiles stay in the frequency domain between the two convolutions
@@ -986,10 +980,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     }
     lds_barrier();
     ICS_FFT_STAMP(5);
-#ifndef ICS_FFT_ABL_SKIP_BF
-    stage_b<-1>(lds, opaque(tid));
-    lds_barrier();
-#endif
+    ICS_FFT_PROBE_COLUMN_PASS(stage_b<-1>(lds, opaque(tid)); lds_barrier(););
     ICS_FFT_STAMP(6);
     stage_g(lds, opaque(tid));
     lds_barrier();
@@ -1056,9 +1047,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
       stage_a(lds, opaque(tid));
     }
     ICS_FFT_STAMP(9);
-#ifdef ICS_FFT_TRACE
-    ++round;
-#endif
+    ICS_FFT_PROBE_TRACE_NEXT();
     if (MODE >= 1) {   // (u.c is uniform)
       uint32_t kg, ku;
       maxima_keys(mx, kg, ku);

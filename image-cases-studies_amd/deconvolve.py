@@ -23,26 +23,25 @@ from lib import deconvolution as dc
 
 
 def pad_image(image, pad, mode="edge"):
-    """deconvolve.py:24-37 -- pad the two spatial axes of an H x W x 3 image, float32 C-contiguous."""
-    R = np.pad(image[..., 0], pad, mode=mode)
-    G = np.pad(image[..., 1], pad, mode=mode)
-    B = np.pad(image[..., 2], pad, mode=mode)
-    u = np.dstack((R, G, B))
-    return np.ascontiguousarray(u, np.float32)
+    """deconvolve.py:24-37 -- grow the two spatial axes of an H x W x 3 picture; `pad` is whatever numpy.pad takes for a 2-D array
+    (a width, a (before, after) pair for both axes, or one pair per axis); the channel axis is never padded.  float32, C-contiguous."""
+    widths = np.broadcast_to(np.asarray(pad, dtype=int), (2, 2))
+    grown = np.pad(np.asarray(image), (tuple(widths[0]), tuple(widths[1]), (0, 0)), mode=mode)
+    return np.ascontiguousarray(grown, dtype=np.float32)
 
 
 def build_pyramid(psf_size, lambd):
-    """deconvolve.py:40-60 -- scales 1, 1/sqrt2, ... and the odd kernel sizes >= 3 that go with them."""
-    images = [1.]
-    kernels = [psf_size]
-    while kernels[-1] > 3:
-        kernels.append(int(np.ceil(kernels[-1] / np.sqrt(2))))
-        images.append(images[-1] / np.sqrt(2))
-        if kernels[-1] % 2 == 0:
-            kernels[-1] -= 1
-        if kernels[-1] < 3:
-            kernels[-1] = 3
-    return images, kernels
+    """deconvolve.py:40-60 -- the coarse-to-fine schedule: every level shrinks the picture by sqrt(2) and the PSF with it, the PSF size
+    rounded up and then made odd (never below 3); the last level is the first whose PSF is 3 x 3.  Returns (scales, sizes), finest first.
+    (`lambd` is accepted and unused, as in the reference.)"""
+    root2 = np.sqrt(2)
+    scales, sizes = [1.], [psf_size]
+    while sizes[-1] > 3:
+        k = int(np.ceil(sizes[-1] / root2))
+        k -= 1 - k % 2                      # even -> the odd size below
+        sizes.append(max(k, 3))
+        scales.append(scales[-1] / root2)
+    return scales, sizes
 
 
 def resize_bicubic(img, shape):
@@ -276,8 +275,13 @@ def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, 
     if not pyramid:
         images, kernels = images[:1], kernels[:1]
     deb = pic_d.copy()
+    import time
+    from lib import _native
+    phases = deblur_module.last_phase_seconds = {}      # wall time per phase of this call, device drained at the phase boundaries (bench.py reports it)
     try:
         for case in ["blind", "non-blind"]:
+            _native.Context.get().synchronize()
+            t_case = time.perf_counter()
             print("\n===== %s DECONVOLUTION =====" % case)
             deb.close()
             deb = pic_d.copy()
@@ -327,6 +331,8 @@ def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, 
                 H1, W1, _ = deb.shape
                 deb, old = deb.crop(1, H1 - 1, 1, W1 - 1), deb               # :322-323
                 old.close()
+            _native.Context.get().synchronize()
+            phases[case] = time.perf_counter() - t_case
     except KeyboardInterrupt:
         pass
     deb.gamma(1.0, 2.2, 2 ** 16 - 1, clip01=True)                           # :346-352
@@ -345,6 +351,9 @@ def _deblur_device(pic, filename, dest_path, blur_width, confidence, tolerance, 
     if save:
         utils.save(out, filename, dest_path)
     return out, psf
+
+
+deblur_module.last_phase_seconds = {}
 
 
 if __name__ == '__main__':
