@@ -1014,8 +1014,12 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
 // convolutions -- one forward and one inverse transform instead of two of each, at 128 - 2 K + 2 valid pixels a side instead of 128 - K + 1,
 // which pays for small PSFs.  Inside ics_rl_run only (the residual frame is not produced: the statistics' window of it comes from a
 // window-sized launch of mode 0 where the loop does not rewrite it anyway), shipped loop only.
+// scripts/ab_conv2.py on MI355X, ms per inner iteration, two kernels -> one unit (non-blind / blind): 1024^2 9: 0.093 -> 0.080 / 0.144 -> 0.125;  15: 0.101 -> 0.085 /
+// 0.156 -> 0.136;  25: 0.109 -> 0.100 / 0.172 -> 0.161;  2048^2 15: 0.186 -> 0.154 / 0.293 -> 0.250;  21: 0.187 -> 0.178 / 0.294 -> 0.281;  25: 0.201 -> 0.175 / 0.319 -> 0.283;
+// 31: 0.184 -> 0.230 / 0.306 -> 0.351;  4096^2 9: 0.572 -> 0.470 / 0.775 -> 0.668;  15: 0.581 -> 0.518 / 0.797 -> 0.714 (another box: 0.576 -> 0.485 / 0.794 -> 0.686);
+// 21: 0.600 -> 0.561 / 0.828 -> 0.774;  25: level / 0.867 -> 0.859;  31: 0.636 -> 0.735 / 0.909 -> 0.990.
 #ifndef ICS_CONV2_MAX_K
-#define ICS_CONV2_MAX_K 21
+#define ICS_CONV2_MAX_K 25
 #endif
 static bool use_conv2(const ics_rl* j, const ics_rl_params* p) {
   if (!j->fft_on || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;

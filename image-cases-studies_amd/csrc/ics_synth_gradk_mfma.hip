@@ -37,24 +37,15 @@
 #define ICS_FUSED_INTERLEAVE 1
 #endif
 
-// phase timing probe (tools/bench_synth_gradk.hip -DICS_FUSED_TIMING): per-wave cycle totals between the marks
-#ifdef ICS_FUSED_TIMING
-__device__ unsigned long long ics_fused_ticks[17];
-#define FTICK_INIT unsigned long long tk_prev = __builtin_readcyclecounter(), tk_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define FTICK(i) do { const unsigned long long tk_now = __builtin_readcyclecounter(); tk_acc[i] += tk_now - tk_prev; tk_prev = tk_now; } while (0)
-#define FTICK_FLUSH do { if ((threadIdx.x & 63) == 0) { for (int i = 0; i < 16; ++i) atomicAdd(&ics_fused_ticks[i], tk_acc[i]); atomicAdd(&ics_fused_ticks[16], 1ull); } } while (0)
-#elif defined(ICS_FUSED_TRACE)
-// phase timeline (tools/bench_synth_gradk.hip -DICS_FUSED_TRACE; format of ics_conv_mfma.hip's ICS_MFMA_TRACE, scripts/trace_conv_mfma.py):
-// lane 0 of every wave records (100 MHz wall clock << 8 | mark) at each mark; entry 0 = HW_ID | XCC_ID << 32.  1024 entries per wave.
-__device__ unsigned long long* ics_fused_trace_buf;
-#define FTICK_INIT unsigned long long* tr_ = ics_fused_trace_buf + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 1024; int tri_ = 0; \
-  if ((threadIdx.x & 63) == 0) { tr_[tri_++] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); tr_[tri_++] = (wall_clock64() << 8) | 15; }
-#define FTICK(i) do { if ((threadIdx.x & 63) == 0 && tri_ < 1023) tr_[tri_++] = (wall_clock64() << 8) | (i); } while (0)
-#define FTICK_FLUSH do { if ((threadIdx.x & 63) == 0) tr_[tri_] = 0; } while (0)
+// Measurement hooks (phase timing, timeline, ablations): empty in the library; the harness builds of tools/bench_synth_gradk.hip define
+// ICS_FUSED_PROBES and get their bodies from tools/ics_synth_gradk_probe.h.
+#ifdef ICS_FUSED_PROBES
+#include "tools/ics_synth_gradk_probe.h"
 #else
 #define FTICK_INIT
 #define FTICK(i)
 #define FTICK_FLUSH
+#define ICS_FUSED_ABL(mask) 0
 #endif
 #ifndef ICS_FUSED_GK_INTERLEAVE
 #define ICS_FUSED_GK_INTERLEAVE 1
@@ -77,10 +68,6 @@ __device__ unsigned long long* ics_fused_trace_buf;
 #endif
 #ifndef ICS_FUSED_F01
 #define ICS_FUSED_F01 0   /* image operand of channels 0 and 1 in one dwordx2 request (0: one dword request per channel) */
-#endif
-#ifndef ICS_FUSED_ABLATE
-#define ICS_FUSED_ABLATE 0   /* tools/bench_synth_gradk.hip: 1 no gradient loop, 2 no convolution loop, 4 no e' planes, 8 no conversion of channels 1, 2, 16 no image operand,
-                                32 no funnel shifts (operands taken unshifted), 64 no MFMAs (operands kept alive), 128 no workgroup barriers */
 #endif
 
 #ifndef ICS_FUSED_WSPLIT
@@ -171,20 +158,20 @@ __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); retur
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global load (vmcnt(0)):
 // with the image operand or the next tile's rows in flight it stalled the whole workgroup for an HBM round trip.
 __device__ __forceinline__ void lds_barrier() {
-  if (ICS_FUSED_ABLATE & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (ICS_FUSED_ABL(128)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-// timing probes (ICS_FUSED_ABLATE): the matrix instruction, or a stand-in that keeps its operands alive; the funnel shift or its first operand
+// harness hooks (ICS_FUSED_ABL, a constant 0 in the library): the matrix instruction, or a stand-in that keeps its operands alive; the funnel shift or its first operand
 __device__ __forceinline__ f4 f_mfma32(h8 a, h8 b, f4 c) {
-  if (ICS_FUSED_ABLATE & 64) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+  if (ICS_FUSED_ABL(64)) { asm volatile("" :: "v"(a), "v"(b)); return c; }
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f4 f_mfma16(h4 a, h4 b, f4 c) {
-  if (ICS_FUSED_ABLATE & 64) { asm volatile("" :: "v"(a), "v"(b)); return c; }
+  if (ICS_FUSED_ABL(64)) { asm volatile("" :: "v"(a), "v"(b)); return c; }
   return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ uint32_t f_align(uint32_t hi, uint32_t lo, uint32_t sh) {
-  if (ICS_FUSED_ABLATE & 32) return lo;
+  if (ICS_FUSED_ABL(32)) return lo;
   return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
@@ -413,7 +400,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
     auto load_f01 = [&]() {
       if constexpr (ACC) return;
-      else if (ICS_FUSED_ABLATE & 16) {
+      else if (ICS_FUSED_ABL(16)) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -437,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     };
     auto load_f = [&](int ch) {
-      if (ICS_FUSED_ABLATE & 16) {
+      if (ICS_FUSED_ABL(16)) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -458,7 +445,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr uint32_t PB = (uint32_t)((ch & 1) * 2 * C::PLANE);
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = (f4){0.f, 0.f, 0.f, 0.f};
-      if (ICS_FUSED_ABLATE & 2) return;
+      if (ICS_FUSED_ABL(2)) return;
       typedef const __attribute__((address_space(3))) h8* lds_h8p;
       typedef const volatile __attribute__((address_space(3))) u2* lds_vu2p;
       uint32_t wb = wa0; asm volatile("" : "+v"(wb));
@@ -561,7 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- e' -> fp16 (hi, lo) planes: a lane packs (hi | lo << 16), swaps with its column neighbour and stores one dword --
     auto write_e = [&](float s_e) {
       typedef __attribute__((address_space(3))) uint32_t* lds_wp;
-      if (ICS_FUSED_ABLATE & 4) return;
+      if (ICS_FUSED_ABL(4)) return;
       const bool odd = (li & 1) != 0;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -599,7 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int X = 0; X < 2; ++X) g[h][X] = (f4){0.f, 0.f, 0.f, 0.f};
-      if (ICS_FUSED_ABLATE & 1) { tot[ch][0] += scale; return; }
+      if (ICS_FUSED_ABL(1)) { tot[ch][0] += scale; return; }
       uint32_t gav[2], gbv[3];
 #pragma unroll
       for (int j = 0; j < 2; ++j) { gav[j] = ga[j]; asm volatile("" : "+v"(gav[j])); }
@@ -742,7 +729,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wq_store();
 
     ICS_FUSED_CHANNEL(0)
-    if (!(ICS_FUSED_ABLATE & 8)) convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
+    if (!(ICS_FUSED_ABL(8))) convert_channel<C, 1>(raw, s_x, up + 2 * C::PLANE, opaque(tid));
     FTICK(5);
     lds_barrier();                                                     // e'(0) and planes(1) visible
     FTICK(6);
@@ -754,7 +741,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     FTICK(2);
 
     ICS_FUSED_CHANNEL(1)
-    if (!(ICS_FUSED_ABLATE & 8)) convert_channel<C, 2>(raw, s_x, up, opaque(tid));
+    if (!(ICS_FUSED_ABL(8))) convert_channel<C, 2>(raw, s_x, up, opaque(tid));
     FTICK(5);
     lds_barrier();                                                     // e'(1) and planes(2) visible
     FTICK(6);
