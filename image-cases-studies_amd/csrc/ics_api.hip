@@ -875,10 +875,16 @@ static bool fft_preferred(const IcsGeom& g, bool blind) {
   // 2048^2 15: 0.164 -> 0.185 / 0.237 -> 0.284 (three rounds of units where 2.004 would do);  17: 0.170 -> 0.183 / 0.315 -> 0.286;  1448^2 17: blind 0.195 -> 0.187;
   // 2900^2 15: level / 0.455 -> 0.431;  17: 0.341 -> 0.311 / 0.576 -> 0.433;  4096^2 9: 0.512 -> 0.574 / 0.730 -> 0.764;  13: level / 0.790 -> 0.766;
   // 15: 0.593 -> 0.579 / 0.834 -> 0.785;  6144^2 15: 1.262 -> 1.199 / 1.835 -> 1.680;  8192^2 15: level / 3.256 -> 2.947.
+  // ... and with A1 + A3 as one unit per tile pair as well (mode 2, PSF sizes <= 25), profiles/r06_ab_fft.txt (a slow box: the matrix-core blind 4096^2 / 15 line is 0.851 there):
+  // 1448^2 15: 0.097 -> 0.114 / 0.154 -> 0.165;  17: level / 0.195 -> 0.156;  2048^2 9: 0.141 -> 0.158 / 0.210 -> 0.230;  13: level / level;  15: 0.169 -> 0.154 / 0.237 -> 0.250;
+  // 17: 0.170 -> 0.151 / 0.315 -> 0.248;  2900^2 9: 0.286 -> 0.265 / 0.403 -> 0.363;  15: 0.332 -> 0.296 / 0.457 -> 0.400;  4096^2 5: level / 0.683 -> 0.643;  9: 0.532 -> 0.479 /
+  // 0.732 -> 0.662;  15: 0.627 -> 0.526 / 0.851 -> 0.716;  6144^2 9: 1.140 -> 0.999 / 1.622 -> 1.365;  15: 1.256 -> 1.122 / 1.821 -> 1.502.
   const long px = (long)g.uM * g.uN;
   if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
-  if (g.K == 17) return px >= (blind ? 2000000L : 8000000L);
-  return g.K >= 13 && px >= (blind ? 8000000L : 16000000L);
+  if (g.K == 17) return px >= (blind ? 2000000L : 4000000L);
+  if (g.K == 15) return px >= (blind ? 6000000L : 4000000L);
+  if (g.K >= 9) return px >= 6000000L;
+  return px >= 12000000L;
 }
 // The tile kernels address a channel-planar mirror through ONE raw buffer resource with 32-bit byte offsets (ics_conv_fft.hip make_gbuf:
 // num_records 2^31 - 1).  A mirror's rows are padded to 64 floats per plane, so for some shapes it is a little LARGER than the HWC frame it

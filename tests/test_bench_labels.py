@@ -33,6 +33,8 @@ def test_labels_follow_the_library_routing(MK, blind):
             assert r.gradk_family == (7 if blind else 0) and r.gradk_fp16_split == 0      # round 6: A11 + A13 fused on the tiles
             small = _route(512, MK, blind, conv)         # ... and the matrix cores below that
             assert small.conv_fp16_split == 1 and small.conv_family == (1 if MK <= 49 else 2)
+        elif conv == nv.CONV_AUTO and MK == 15 and not blind:      # round 6: non-blind 15 x 15 from 4 Mpx on the tiles (A1 + A3 as one unit)
+            assert r.conv_fp16_split == 0 and r.conv_family == 5 and r.gradk_family == 0 and lab["dtype"] == "f32"
         elif conv == nv.CONV_AUTO:    # every PSF size has a matrix-core path since round 3
             assert r.conv_fp16_split == 1 and r.conv_family == (1 if MK <= 49 else 2)
             assert r.gradk_family == (0 if not blind else (1 if MK <= 15 else (2 if MK <= 31 else 3)))
@@ -40,19 +42,21 @@ def test_labels_follow_the_library_routing(MK, blind):
             assert r.conv_fp16_split == 0 and r.gradk_fp16_split == 0 and lab["dtype"] == "f32"
             assert r.conv_family == (3 if MK <= 63 else 4)
     # the opt-in fused update + convolution kernel is a packed-fp32 kernel whatever AUTO resolves to
-    assert bench.labels(_route(2048, 15, blind, 0, fuse=1), fuse=True)["dtype"] != bench.labels(_route(2048, 15, blind, 0))["dtype"]
+    # (compared where AUTO still resolves to the fp16-split matrix cores: 1024^2)
+    assert bench.labels(_route(1024, 15, blind, 0, fuse=1), fuse=True)["dtype"] != bench.labels(_route(1024, 15, blind, 0))["dtype"]
 
 
 def test_route_switches():
     from lib import _native as nv
-    # transform tiles under AUTO (csrc/ics_api.hip fft_preferred, measured with scripts/ab_fft.py; round 6, with A11 + A13 fused on the tiles):
-    # 19 x 19 ... 65 x 65 from 1.5 Mpx (blind: 1 Mpx), 17 x 17 from 8 Mpx (blind: 2 Mpx), 13 x 13 and 15 x 15 from 16 Mpx (blind: 8 Mpx), never below 13
+    # transform tiles under AUTO (csrc/ics_api.hip fft_preferred, measured with scripts/ab_fft.py; round 6, with A11 + A13 and A1 + A3 fused on the tiles):
+    # 19 x 19 ... 65 x 65 from 1.5 Mpx (blind: 1 Mpx), 17 x 17 from 4 Mpx (blind: 2 Mpx), 15 x 15 from 4 Mpx (blind: 6 Mpx), 9 x 9 ... 13 x 13 from 6 Mpx, smaller from 12 Mpx
     assert _route(4096, 17, True).conv_family == 5 and _route(4096, 17, False).conv_family == 5
-    assert _route(2048, 17, True).conv_family == 5 and _route(2048, 17, False).conv_family == 1 and _route(1024, 17, True).conv_family == 1
+    assert _route(2048, 17, True).conv_family == 5 and _route(2048, 17, False).conv_family == 5 and _route(1024, 17, True).conv_family == 1
     assert _route(1024, 31, True).conv_family == 5 and _route(1024, 31, False).conv_family == 1 and _route(1448, 21, False).conv_family == 5
     assert _route(4096, 15, True).conv_family == 5 and _route(4096, 15, False).conv_family == 5 and _route(2900, 15, True).conv_family == 5
-    assert _route(2048, 15, True).conv_family == 1 and _route(2900, 15, False).conv_family == 1 and _route(6144, 13, True).conv_family == 5
-    assert _route(6144, 9, True).conv_family == 1 and _route(6144, 11, False).conv_family == 1
+    assert _route(2048, 15, True).conv_family == 1 and _route(2048, 15, False).conv_family == 5 and _route(1448, 15, False).conv_family == 1
+    assert _route(6144, 13, True).conv_family == 5 and _route(2900, 9, True).conv_family == 5 and _route(2048, 9, False).conv_family == 1 and _route(2048, 13, True).conv_family == 1
+    assert _route(4096, 5, True).conv_family == 5 and _route(2900, 5, True).conv_family == 1
     assert _route(4096, 67, True).conv_family == 2
     # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
     assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 7
