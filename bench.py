@@ -172,7 +172,7 @@ def mfma_counters(kernel, M, MK):
     """Matrix-pipe counters of `kernel` from the committed SQ pass of this command (profiles/rNN_mfma_counters.json, newest round first, written by
     scripts/make_mfma_json.py from rocprofv3 --pmc runs): static, NOT measured in this run -- like `traffic`."""
     try:
-        for name in ("r05_mfma_counters.json", "r05_6144_31_mfma_counters.json", "r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
+        for name in ("r06_mfma_counters.json", "r06_6144_31_mfma_counters.json", "r05_mfma_counters.json", "r05_6144_31_mfma_counters.json", "r04_mfma_counters.json", "r04_6144_31_mfma_counters.json"):
             fn = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(fn):
                 continue
@@ -467,8 +467,8 @@ def main():
         names = _native.KERNEL_NAMES
         kern = {names[k]: {"ms": round(st.ms_kernel[k], 5), "launches": st.launches[k]} for k in range(len(names)) if st.launches[k]}
         roof = None
-        traffic, traffic_file, traffic_commit = None, "profiles/r05_hbm_traffic.json", "unrecorded"
-        for tf in ("profiles/r05_hbm_traffic.json", "profiles/r05_6144_31_hbm_traffic.json", "profiles/r04_hbm_traffic.json", "profiles/r04_6144_31_hbm_traffic.json"):
+        traffic, traffic_file, traffic_commit = None, "profiles/r06_hbm_traffic.json", "unrecorded"
+        for tf in ("profiles/r06_hbm_traffic.json", "profiles/r06_6144_31_hbm_traffic.json", "profiles/r05_hbm_traffic.json", "profiles/r05_6144_31_hbm_traffic.json", "profiles/r04_hbm_traffic.json", "profiles/r04_6144_31_hbm_traffic.json"):
             try:  # measured HBM bytes per launch (rocprofv3 PMC passes, committed under profiles/): static, NOT measured in this run
                 tj = json.load(open(os.path.join(ROOT, tf)))
                 if tj["workload"] == {"size": M, "psf": MK} and lab["traffic_key"] in tj:

@@ -11,14 +11,16 @@ def kernel_names(psf):
     return {"k_conv_mfma<%d, 0," % psf: "synth_residual", "k_conv_mfma<%d, 1," % psf: "backproject", "k_update_rows<0>": "update",
             "k_gradk_mfma<": "psf_gradient", "k_synth_gradk<%d," % psf: "synth_gradk",
             # the transform-tile pipeline (ics_conv_fft.hip, ics_planar.hip): its own key, `kernels_fft`
-            "k_conv_fft<0,": "synth_residual", "k_conv_fft<1,": "backproject", "k_update_planar": "update", "k_gradk_fft<": "psf_gradient"}
+            "k_conv_fft<0,": "synth_residual", "k_conv_fft<1,": "backproject", "k_update_planar": "update", "k_gradk_fft<": "psf_gradient",
+            # round 6: A1 + A3 as one unit per tile pair, A11 + A13 as one unit per tile pair
+            "k_conv_fft<2,": "synth_backproject", "k_synth_gradk_fft<": "synth_gradk"}
 
 
-FFT_NAMES = ("k_conv_fft<", "k_update_planar", "k_gradk_fft<")
+FFT_NAMES = ("k_conv_fft<", "k_update_planar", "k_gradk_fft<", "k_synth_gradk_fft<")
 
 
 KERNELS = {}
-ALGO = {"synth_residual": 36, "backproject": 48, "update": 60, "psf_gradient": 24, "synth_gradk": 60}   # bytes per pixel
+ALGO = {"synth_residual": 36, "backproject": 48, "update": 60, "psf_gradient": 24, "synth_gradk": 60, "synth_backproject": 84}   # bytes per pixel
 
 
 def counters(path, name):
