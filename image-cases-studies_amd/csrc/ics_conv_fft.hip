@@ -327,9 +327,7 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   m.spec1 = (mode == 2 || mode == -1) ? make_gbuf(a.spec1) : m.spec;
   m.fspec = (mode == 2 || mode == -1) ? make_gbuf(a.fspec) : m.spec;
   // mode 3 (k_synth_gradk_fft<true>: the update pass in front of A11 + A13): in = u, ut, g = the raw back-projection, f, uo = the frame that receives the updated u
-  m.g = mode == 3 ? make_gbuf(a.c.gr - m.lin.org) : m.in;
-  m.uo = mode == 3 ? make_gbuf(a.c.u_out - m.lin.org) : m.out;
-  if (mode == 3) m.ut = make_gbuf(a.c.ut - m.lut.org);
+  m.g = m.in; m.uo = m.out;      // (mode 3 builds these two and `ut` where it uses them: upd_bufs)
   return m;
 }
 
@@ -869,6 +867,19 @@ ICS_FFT_HD UpdOwn upd_own(const IcsFftArgs& a, const Unit& u, int t) {
   return o;
 }
 struct UpdKeys { uint32_t kmin, kmax, knan; };
+// The three frames only the update touches get their buffer resources where they are used, from the kernel arguments (scalar loads), instead
+// of living in twelve scalar registers through the whole unit: this kernel is out of scalar registers as it is, and every spilled one
+// costs a lane of a vector register it is even shorter of.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ const float* scalar_opaque(const float* p) { asm volatile("" : "+s"(p)); return p; }
+#else
+static inline const float* scalar_opaque(const float* p) { return p; }
+#endif
+ICS_FFT_HD void upd_bufs(const IcsFftArgs& a, Mem& m) {
+  m.ut = make_gbuf(scalar_opaque(a.c.ut) - m.lin.org);
+  m.g = make_gbuf(scalar_opaque(a.c.gr) - m.lin.org);
+  m.uo = make_gbuf(scalar_opaque(a.c.u_out) - m.lin.org);
+}
 // the four operands of row group i of tile t: q[0..3] = u, ut, raw back-projection, image -- 4 consecutive pixels of a window row each
 ICS_FFT_HD void upd_load(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int i, int t, v4f (&q)[4]) {
   const int r0 = tid >> 5, xq = tid & 31;
@@ -902,8 +913,7 @@ ICS_FFT_HD v4f upd_apply(const IcsFftArgs& a, const Mem& mem, const Unit& u, flo
     const bool inside = yin && x >= G.pad && x < G.pad + G.N;
     const float fv = q[3][e];
     const float d = upd_dof_ratio(gv, fv);                                                       // pyx:499
-    float D = ICS_FMUL(d, d);
-    if (!a.c.blind) D = ICS_FDIV(D, lambd);                                                      // pyx:502   (uniform)
+    const float D = ICS_FMUL(d, d);                                                              // (pyx:502 divides by lambd in non-blind runs: this unit exists in blind ones only)
     const float vb = ICS_FADD(ICS_FMUL(ICS_FSUB(1.0f, D), v0), ICS_FMUL(D, fv));                 // pyx:552
     const float v = inside ? vb : v0;
     if (a.c.want_dof) {                                                                          // (uniform)
@@ -914,6 +924,7 @@ ICS_FFT_HD v4f upd_apply(const IcsFftArgs& a, const Mem& mem, const Unit& u, flo
       keys.kmax = (cnt && D == D && k > keys.kmax) ? k : keys.kmax;
     }
     un[e] = (yframe && x >= 0 && x < G.uN) ? v : 0.f;      // (outside the u-frame the window reads zeros, and the frame's slack keeps them)
+    ICS_FFT_ISSUE_FENCE();      // (one pixel's quotients at a time: interleaved, four division sequences hold a dozen registers more)
   }
   st_f32x4(mem.uo, mine ? mem.lin.org + Y * mem.lin.pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE, 0, un);
   return un;
@@ -926,17 +937,25 @@ ICS_FFT_HD void upd_store_lds(v2f* lds, int tid, int i, v4f un0, v4f un1) {     
 }
 // The window of a unit through the update: eight steps (row group, tile), the operands of two steps ahead in flight.  q[0] (and q[1]) may
 // already have been requested by the caller (`primed` steps).
+#ifndef ICS_UPD_EARLY
+#define ICS_UPD_EARLY 2   /* the next unit's first operands are requested 0: behind the barrier, 1: in front of the second stage D, 2: behind it, in front of the barrier */
+#endif
+#ifndef ICS_UPD_DEPTH
+#define ICS_UPD_DEPTH 1   /* steps of operands in flight ahead of the one being applied */
+#endif
 template <int PRIMED>
-ICS_FFT_HD void upd_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, float dtc, int tid, v2f* lds, UpdKeys& keys, v4f (&q)[3][4]) {
+ICS_FFT_HD void upd_window(const IcsFftArgs& a, const Mem& mem0, const Unit& u, float dtc, int tid, v2f* lds, UpdKeys& keys, v4f (&q)[3][4]) {
+  Mem mem = mem0;
+  upd_bufs(a, mem);
   if (PRIMED < 1) upd_load(a, mem, u, tid, 0, 0, q[0]);
-  if (PRIMED < 2) upd_load(a, mem, u, tid, 0, 1, q[1]);
+  if (PRIMED < 2 && ICS_UPD_DEPTH > 1) upd_load(a, mem, u, tid, 0, 1, q[1]);
   v4f un0;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     ICS_FFT_ISSUE_FENCE();
-    if (s + 2 < 8) upd_load(a, mem, u, tid, (s + 2) >> 1, (s + 2) & 1, q[(s + 2) % 3]);
+    if (s + ICS_UPD_DEPTH < 8) upd_load(a, mem, u, tid, (s + ICS_UPD_DEPTH) >> 1, (s + ICS_UPD_DEPTH) & 1, q[(s + ICS_UPD_DEPTH) % (ICS_UPD_DEPTH + 1)]);
     ICS_FFT_ISSUE_FENCE();
-    const v4f un = upd_apply(a, mem, u, dtc, tid, s >> 1, s & 1, q[s % 3], keys);
+    const v4f un = upd_apply(a, mem, u, dtc, tid, s >> 1, s & 1, q[s % (ICS_UPD_DEPTH + 1)], keys);
     if (s & 1) upd_store_lds(lds, tid, s >> 1, un0, un); else un0 = un;
   }
 }
@@ -1284,7 +1303,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_fft_image_spectrum(IcsFftAr
 // two prefetches sit beside eight-point stages only: the image quads are requested behind stage G's last LDS write (in flight through the
 // barrier), the next unit's window in front of the second stage D.
 #ifndef ICS_FFT_FUSED_IMG_EARLY
-#define ICS_FFT_FUSED_IMG_EARLY 2
+#define ICS_FFT_FUSED_IMG_EARLY 3   /* row groups of the image requested ahead of the barrier in front of the residual epilogue (the fourth behind it) */
 #endif
 // UPD: the window is formed from (u, ut, raw back-projection, image) through the update pass (upd_window above) instead of being read
 // from the updated u, and the updated u is stored to the frame a.c.u_out on the way: A5 - A10 + A11 + A12 + A13 in one launch.
@@ -1306,6 +1325,11 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
 #define ICS_UPD_FOLD_KEYS(keys) do { if (a.c.want_dof) { \
     const uint32_t m_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)~ics_wave_max_u32(~(keys).kmin)), x_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ics_wave_max_u32((keys).kmax)); \
     wkmin = m_ < wkmin ? m_ : wkmin; wkmax = x_ > wkmax ? x_ : wkmax; wknan |= (uint32_t)__builtin_amdgcn_readfirstlane((int)ics_wave_max_u32((keys).knan)); } } while (0)
+  v2f acc[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
   if (slot < npairs) {
     if (UPD) {
       v4f q[3][4];
@@ -1321,11 +1345,6 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
     lds_barrier();
     stage_a(lds, opaque(tid));
   }
-  v2f acc[2][8];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
   for (int p = slot; p < npairs; p += nslots) {
     const Unit u = decode_unit(a, 3 * p + c);
     lds_barrier();
@@ -1379,14 +1398,22 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
       const bool more = p + nslots < npairs;
       const Unit un = decode_unit(a, 3 * (p + nslots) + c);
       v4f q[3][4];
-      if (more) { upd_load(a, mem, un, opaque(tid), 0, 0, q[0]); upd_load(a, mem, un, opaque(tid), 0, 1, q[1]); }   // the first row group of the next unit's operands in flight through stage D
+#if ICS_UPD_EARLY == 1
+      if (more) { Mem mu = mem; upd_bufs(a, mu); upd_load(a, mu, un, opaque(tid), 0, 0, q[0]); if (ICS_UPD_DEPTH > 1) upd_load(a, mu, un, opaque(tid), 0, 1, q[1]); }   // the first operands of the next unit in flight through stage D
       ICS_FFT_ISSUE_FENCE();
+#endif
       stage_d_acc(lds, opaque(tid), zu, acc);
       ICS_FFT_ISSUE_FENCE();
       if (more) {
+#if ICS_UPD_EARLY == 2
+        // the first operands of the next unit are requested behind stage D's last read (the window's spectrum is dead: registers) and travel
+        // through the barrier
+        { Mem mu = mem; upd_bufs(a, mu); upd_load(a, mu, un, opaque(tid), 0, 0, q[0]); if (ICS_UPD_DEPTH > 1) upd_load(a, mu, un, opaque(tid), 0, 1, q[1]); }
+        ICS_FFT_ISSUE_FENCE();
+#endif
         lds_barrier();                                            // (every wave has read its rows)
         UpdKeys keys = {0xFFFFFFFFu, 0u, 0u};
-        upd_window<2>(a, mem, un, dtc, opaque(tid), lds, keys, q);
+        upd_window<(ICS_UPD_EARLY == 0 ? 0 : (ICS_UPD_DEPTH > 1 ? 2 : 1))>(a, mem, un, dtc, opaque(tid), lds, keys, q);
         ICS_UPD_FOLD_KEYS(keys);
         lds_barrier();
         stage_a(lds, opaque(tid));
@@ -1605,7 +1632,7 @@ bool ics_upd_synth_gradk_fft_supported(const IcsGeom& g) {
 // ut, gr = the raw back-projection, f = the image, out = the residual frame, red = the back-projection's maxima, scal, dofkeys, step, lambd,
 // blind, want_dof as for the update pass (all origins of channel-planar mirrors); spec_shifted = orientation 2 of ics_launch_fft_spectrum
 hipError_t ics_launch_upd_synth_gradk_fft(const IcsConvArgs& c, const float* spec_shifted, int wy0, int wy1, int wx0, int wx1, int store_all, float* partial, float* gradk, hipStream_t s) {
-  if (!ics_upd_synth_gradk_fft_supported(c.g) || !c.gr || !c.u_out || c.u_out == c.in || !c.ut || !c.red || !c.scal || !c.dofkeys) return hipErrorInvalidValue;
+  if (!ics_upd_synth_gradk_fft_supported(c.g) || !c.blind || !c.gr || !c.u_out || c.u_out == c.in || !c.ut || !c.red || !c.scal || !c.dofkeys) return hipErrorInvalidValue;
   IcsFftArgs a;
   ics_conv_fft_fill_args(0, c, spec_shifted, &a);
   a.planar = ICS_FFT_PL_ALL;
