@@ -34,7 +34,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 # algorithmic bytes per pixel and launch (one fp32 x 3 frame transit T = 12 B/px)
 BYTES_PER_PX = {"synth_residual": 36.0, "backproject": 48.0, "update": 60.0, "psf_gradient": 24.0, "synth_gradk": 60.0,
                 "update_synth": 72.0,
-                "synth_backproject": 84.0, "update_synth_gradk": 120.0}  # update_synth: fused update + convolution, 4 reads + 2 writes; synth_backproject: A1 + A3 in one unit = S1 + S2 of SURVEY.md 8d (the residual is never materialised); update_synth_gradk: S3 + S4 + S5 in one launch
+                "synth_backproject": 84.0}  # update_synth: fused update + convolution, 4 reads + 2 writes; synth_backproject: A1 + A3 in one unit = S1 + S2 of SURVEY.md 8d (the residual is never materialised)
 ITER_BYTES_PER_PX = {"nonblind": 144.0, "blind": 204.0}
 
 

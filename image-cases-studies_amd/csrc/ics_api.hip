@@ -195,7 +195,6 @@ struct ics_rl {
   Twin twins[8];
   int ntwins;
   float *spec_conv, *spec_corr;
-  float* spec_conv_sh;  // the convolution orientation for windows that start ics_synth_gradk_fft_xshift pixels further left (update + A11 + A13 in one launch)
   float* fspec;         // mode 2 of the tile convolutions (A1 + A3 in one unit): the image windows' spectra, valid while fspec_valid
   bool fspec_valid;
   bool fft_on;
@@ -228,7 +227,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_upd", &d.fft_upd}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -239,7 +238,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_upd", &d.fft_upd}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -375,7 +374,6 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   if (j->spec_conv) j->ctx->pool.release(j->spec_conv);
   if (j->spec_corr) j->ctx->pool.release(j->spec_corr);
   if (j->fspec) j->ctx->pool.release(j->fspec);
-  if (j->spec_conv_sh) j->ctx->pool.release(j->spec_conv_sh);
   for (auto& g : j->graphs) hipGraphExecDestroy(g.exec);
   for (int i = 0; i < 2; ++i) { if (j->ev_body[i]) hipEventDestroy(j->ev_body[i]); if (j->ev_stats[i]) hipEventDestroy(j->ev_stats[i]); }
   if (j->h_scal) hipHostFree(j->h_scal);
@@ -483,7 +481,7 @@ static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hip
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
   if (j->blk_conv) HIPCHK(ics_launch_pack_blocks(j->psf, j->g.K, j->blk_kb, j->blk_n, j->blk_conv, j->blk_corr, ics_conv_mfma_table_floats(j->blk_kb), s));
-  if (j->fft_on) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s, j->spec_conv_sh, ics_synth_gradk_fft_xshift(j->g)));   // conj(DFT2(W)) / 128^2 of both orientations (+ the shifted one)
+  if (j->fft_on) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s));   // conj(DFT2(W)) / 128^2 of both orientations
   return ICS_OK;
 }
 
@@ -501,7 +499,6 @@ static int ensure_planar(ics_rl* j) {
   }
   if (!j->spec_conv) RC(dalloc(j->ctx, &j->spec_conv, ics_conv_fft_spectrum_floats()));
   if (!j->spec_corr) RC(dalloc(j->ctx, &j->spec_corr, ics_conv_fft_spectrum_floats()));
-  if (!j->spec_conv_sh && ics_upd_synth_gradk_fft_supported(j->g)) RC(dalloc(j->ctx, &j->spec_conv_sh, ics_conv_fft_spectrum_floats()));
   return ICS_OK;
 }
 // whole-buffer copies HWC -> mirror / mirror -> HWC (run and stage boundaries), and the stop-test window mirror -> HWC
@@ -1234,32 +1231,6 @@ static int do_synth_gradk_fft(ics_rl* j, const ics_rl_params* p, int store_all, 
   return ICS_OK;
 }
 
-// ... and with the update pass in front of it in the same launch (k_synth_gradk_fft<true>): the window is formed from (u, majoriser, raw
-// back-projection, image) through A5 - A10 and the updated u stored to the spare frame on the way; the frames rotate as in do_update
-static bool use_upd_fused_fft(const ics_rl* j, const ics_rl_params* p) {
-  return use_fused_fft(j, p) && p->tv_mode == ICS_TV_SHIPPED && j->spec_conv_sh && ics_upd_synth_gradk_fft_supported(j->g) &&
-         ics_debug().fft_upd.load(std::memory_order_relaxed) != 0;
-}
-static int do_upd_synth_gradk_fft(ics_rl* j, const ics_rl_params* p, int slot, int want_dof, int store_all, Prof& pr) {
-  IcsConvArgs a;
-  memset(&a, 0, sizeof a);
-  a.g = j->g; a.lambd = p->lambd; a.step = p->step_factor; a.blind = p->blind; a.want_dof = want_dof;
-  a.in = porg(j, j->u); a.u = a.in; a.ut = porg(j, ut_of(j)); a.gr = porg(j, j->gr); a.f = porg(j, j->f); a.out = porg(j, j->e);
-  a.u_out = porg(j, j->u2);                               // always the spare frame: the neighbouring tiles read the old values of the halo
-  a.red = red_of(j) + slot * ICS_RED_STRIDE; a.scal = j->scal; a.dofkeys = dof_of(j);
-  if (!a.in || !a.ut || !a.gr || !a.f || !a.out || !a.u_out) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
-  const int pad = j->g.pad;
-  RC(pr.begin(ICS_K_UPDATE_SYNTH_GRADK));
-  HIPCHK(ics_launch_upd_synth_gradk_fft(a, j->spec_conv_sh, p->top + pad, p->bottom + pad, p->left + pad, p->right + pad, store_all, j->partial, j->gradk, j->ctx->stream));
-  RC(pr.end());
-  if (j->ut_is_u) {   // as do_update: the untouched old u is the majoriser now, the stale ut frame becomes the spare
-    float* old_ut = j->ut;
-    j->ut = j->u; j->u = j->u2; j->u2 = old_ut;
-    j->ut_is_u = false;
-  } else { float* t = j->u; j->u = j->u2; j->u2 = t; }
-  return ICS_OK;
-}
-
 #ifndef ICS_FUSED_DEFAULT_RS
 #define ICS_FUSED_DEFAULT_RS 4
 #endif
@@ -1539,7 +1510,6 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       }
       if (p->blind) {                                         // pyx:555
         if (fuse) RC(do_conv(j, 2, p, itt, last, pr));        // A5-A10 fused with A11
-        else if (fused_fft && use_upd_fused_fft(j, p)) RC(do_upd_synth_gradk_fft(j, p, itt, last, 0, pr));   // A5 - A10 + A11 + A12 + A13 in one launch
         else {
           RC(do_update(j, p, itt, last, pr));
           if (fused_gk) RC(do_synth_gradk(j, p, 0, pr));      // A11 + A12 + A13, e' stays on chip
@@ -1751,7 +1721,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
   // stage writes are copied back after -- slow and simple; ics_rl_run converts at its boundaries only
   FftScope fft_scope{j};
   const bool fft_stage = use_fft_pipeline(j, p, false) && (stage == ICS_STAGE_SYNTH_RESIDUAL || stage == ICS_STAGE_BACKPROJECT || stage == ICS_STAGE_UPDATE ||
-                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE || stage == ICS_STAGE_SYNTH_GRADK || stage == ICS_STAGE_SYNTH_BACKPROJECT || stage == ICS_STAGE_UPDATE_SYNTH_GRADK);
+                                                            stage == ICS_STAGE_PSF_GRADIENT || stage == ICS_STAGE_PSF_UPDATE || stage == ICS_STAGE_SYNTH_GRADK || stage == ICS_STAGE_SYNTH_BACKPROJECT);
   if (fft_stage) {
     j->fft_on = true;
     RC(ensure_planar(j));
@@ -1816,14 +1786,6 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       RC(pack_weights(j, 0, 0.f, 0, s));
       HIPCHK(hipMemsetAsync(j->red, 0, 8 * ICS_RED_STRIDE * sizeof(uint32_t), s));
       RC(do_conv2(j, p, 0, pr));
-      break;
-    case ICS_STAGE_UPDATE_SYNTH_GRADK:
-      if (!j->fft_on || p->tv_mode != ICS_TV_SHIPPED || !j->spec_conv_sh || !ics_upd_synth_gradk_fft_supported(j->g))
-        return fail(ICS_ENOSUP, "ICS_STAGE_UPDATE_SYNTH_GRADK needs params.conv = ICS_CONV_FFT, tv_mode 0 and a PSF size whose windows fit the transform when they start on a quad");
-      RC(to_planar(j, j->u2, s));                        // (the spare frame receives the updated u: its mirror's aprons must be what the frame's are)
-      RC(pack_weights(j, 0, 0.f, 0, s));
-      RC(reset_dofkeys(j));
-      RC(do_upd_synth_gradk_fft(j, p, 0, 1, 1, pr));
       break;
     case ICS_STAGE_PSF_UPDATE: RC(do_psf(j, p, pr)); break;
     case ICS_STAGE_MAJORIZE: RC(do_majorize(j, pr)); break;

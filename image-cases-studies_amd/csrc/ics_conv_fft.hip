@@ -59,13 +59,11 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define ICS_FSUB(a, b) __fsub_rn(a, b)
 #define ICS_FADD(a, b) __fadd_rn(a, b)
 #define ICS_FMUL(a, b) __fmul_rn(a, b)
-#define ICS_FDIV(a, b) __fdiv_rn(a, b)
 #else   /* host pass: the CPU emulation of tools/bench_conv_fft.hip (-ffp-contract=off: the same single roundings) */
 #define ICS_FFT_UNIFORM(x) (x)
 #define ICS_FSUB(a, b) ((a) - (b))
 #define ICS_FADD(a, b) ((a) + (b))
 #define ICS_FMUL(a, b) ((a) * (b))
-#define ICS_FDIV(a, b) ((a) / (b))
 #endif
 
 namespace icsfft {
@@ -138,7 +136,7 @@ static inline void st_f32x4(gbuf b, int vi, int si, v4f v) {
 // where pixel (Y, X, c) of a channel-planar frame lives: index = org + Y * pitch + X + c * cmul  (ics_common.h: ics_ppitch, ics_plane_floats)
 struct Lay { int org, pitch, cmul; };
 struct Mem {
-  gbuf in, out, f, u, ut, tv, spec, spec1, fspec, g, uo;
+  gbuf in, out, f, u, ut, tv, spec, spec1, fspec;
   Lay lin, lout, lf, lu, lut, ltv;
 };
 
@@ -277,8 +275,6 @@ struct IcsFftArgs {
                             // some lanes); the pixels in front of ox0 are stored as zeros, like those behind ox1
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
   int wpad;                 // a tile's window starts wpad pixels up and left of its first output pixel: pad (one convolution), 2 pad (k_conv2_fft: two in a row)
-  int xshift;               // the window starts xshift MORE pixels to the left (k_synth_gradk_fft<true>: windows on whole 16-byte quads of the plane rows); the
-                            // weight spectrum it runs with carries the same shift (k_fft_spectrum), so the valid outputs are where they were
   float* fspec;             // k_conv2_fft: DFT of the image windows of every unit, [unit][8][1024] quads in load_spectrum's order (k_fft_image_spectrum)
   int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
   int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
@@ -320,14 +316,12 @@ ICS_FFT_HD Mem make_mem(const IcsFftArgs& a, int mode = -1) {
   m.lu = make_lay(g, a.planar & ICS_FFT_PL_U); m.lut = make_lay(g, a.planar & ICS_FFT_PL_UT); m.ltv = make_lay(g, a.planar & ICS_FFT_PL_TV);
   m.in = make_gbuf(a.c.in - m.lin.org); m.out = make_gbuf(a.c.out - m.lout.org);
   m.f = mode == 1 ? m.in : make_gbuf(a.c.f - m.lf.org);
-  m.u = (mode == 0 || mode == 2 || mode == 3) ? m.in : make_gbuf(a.c.u - m.lu.org);    // (mode 2 convolves u itself: the window's frame is the operand frame)
-  m.ut = (mode == 0 || mode == 3) ? m.in : make_gbuf(a.c.ut - m.lut.org);
+  m.u = (mode == 0 || mode == 2) ? m.in : make_gbuf(a.c.u - m.lu.org);    // (mode 2 convolves u itself: the window's frame is the operand frame)
+  m.ut = mode == 0 ? m.in : make_gbuf(a.c.ut - m.lut.org);
   m.tv = (a.c.tv && mode != 0) ? make_gbuf(a.c.tv - m.ltv.org) : m.in;
   m.spec = make_gbuf(a.spec);
   m.spec1 = (mode == 2 || mode == -1) ? make_gbuf(a.spec1) : m.spec;
   m.fspec = (mode == 2 || mode == -1) ? make_gbuf(a.fspec) : m.spec;
-  // mode 3 (k_synth_gradk_fft<true>: the update pass in front of A11 + A13): in = u, ut, g = the raw back-projection, f, uo = the frame that receives the updated u
-  m.g = m.in; m.uo = m.out;      // (mode 3 builds these two and `ut` where it uses them: upd_bufs)
   return m;
 }
 
@@ -364,7 +358,7 @@ ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, 
   const int pad = a.wpad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
 #pragma unroll
   for (int t = t0; t < t1; ++t) {
-    const int X = u.ox[t] - pad - a.xshift + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad - 3 by construction (the apron is at least pad + 3 wide)
+    const int X = u.ox[t] - pad + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad by construction
     const int vo = (u.has[t] && X <= xlast) ? mem.lin.org + Y0 * pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pw[t][i] = ld_f32x4<4>(mem.in, (Y0 + 32 * i <= ylast) ? vo : ICS_FFT_NONE, 32 * i * pitch);
@@ -849,117 +843,6 @@ ICS_FFT_HD void maxima_quad(const IcsFftArgs& a, const Unit& u, int tid, int t, 
   }
 }
 
-// ---- the update pass in front of the fused unit (k_synth_gradk_fft<true>) -----------------------------------------------------------------------
-// A5 + A6 + A8 + A10 (pyx:499-552) are pointwise: a unit that needs the UPDATED u in its window can form it from the four operands of
-// k_update_planar -- u, the majoriser, the raw back-projection, the image -- while it loads the window, operation for operation (every
-// operation rounded separately: bit-identical to the pass it replaces), and store the part of the frame it owns.  The pass of its own
-// disappears (60 B/px of HBM traffic in a launch that does nothing else) at the price of the halo being updated twice.
-//   * windows start on whole quads of the plane rows (IcsFftArgs::xshift) so that a thread's four pixels are one aligned 16-byte store;
-//   * a tile owns its V x Vy output pixels, the tiles at the rim of the interior also the u-frame's border ring beside them: every pixel of
-//     the u-frame is stored exactly once, into ANOTHER frame than the one read (the neighbours read the old values of the halo);
-//   * the DoF extrema (pyx:593, want_dof) are taken over owned interior pixels, once each.
-struct UpdOwn { int y0, y1, x0, x1; };        // what tile t stores of the updated u (u-frame coordinates; x on whole quads)
-ICS_FFT_HD UpdOwn upd_own(const IcsFftArgs& a, const Unit& u, int t) {
-  UpdOwn o;
-  o.y0 = u.oy[t] == a.oy0 ? 0 : u.oy[t]; o.y1 = u.oy[t] + a.Vy >= a.oy1 ? a.c.g.uM : u.oy[t] + a.Vy;
-  o.x0 = u.ox[t] == a.gx0 ? 0 : u.ox[t]; o.x1 = u.ox[t] + a.V >= a.ox1 ? ((a.c.g.uN + 3) & ~3) : u.ox[t] + a.V;
-  if (!u.has[t]) { o.y0 = o.y1 = 0; o.x0 = o.x1 = 0; }
-  return o;
-}
-struct UpdKeys { uint32_t kmin, kmax, knan; };
-// The three frames only the update touches get their buffer resources where they are used, from the kernel arguments (scalar loads), instead
-// of living in twelve scalar registers through the whole unit: this kernel is out of scalar registers as it is, and every spilled one
-// costs a lane of a vector register it is even shorter of.
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ const float* scalar_opaque(const float* p) { asm volatile("" : "+s"(p)); return p; }
-#else
-static inline const float* scalar_opaque(const float* p) { return p; }
-#endif
-ICS_FFT_HD void upd_bufs(const IcsFftArgs& a, Mem& m) {
-  m.ut = make_gbuf(scalar_opaque(a.c.ut) - m.lin.org);
-  m.g = make_gbuf(scalar_opaque(a.c.gr) - m.lin.org);
-  m.uo = make_gbuf(scalar_opaque(a.c.u_out) - m.lin.org);
-}
-// the four operands of row group i of tile t: q[0..3] = u, ut, raw back-projection, image -- 4 consecutive pixels of a window row each
-ICS_FFT_HD void upd_load(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, int i, int t, v4f (&q)[4]) {
-  const int r0 = tid >> 5, xq = tid & 31;
-  const int pad = a.wpad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
-  const int X = u.ox[t] - pad - a.xshift + 4 * xq, Y = u.oy[t] - pad + r0 + 32 * i;
-  const int vo = (u.has[t] && X <= xlast && Y <= ylast) ? mem.lin.org + Y * pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE;
-  q[0] = ld_f32x4<4>(mem.in, vo, 0); q[1] = ld_f32x4<4>(mem.ut, vo, 0);
-  q[2] = ld_f32x4<4>(mem.g, vo, 0); q[3] = ld_f32x4<4>(mem.f, vo, 0);
-}
-ICS_FFT_HD float upd_dof_ratio(float g, float f) {          // ics_dof_ratio (ics_common.h): IEEE except g == f == 0 exactly -> 1
-  const float d = ICS_FDIV(ICS_FSUB(g, f), ICS_FADD(g, f));
-  return (g == 0.f && f == 0.f) ? 1.0f : d;
-}
-// ... the updated u of those pixels (zero outside the u-frame); where tile t owns them they go to the frame `uo`
-ICS_FFT_HD v4f upd_apply(const IcsFftArgs& a, const Mem& mem, const Unit& u, float dtc, int tid, int i, int t, const v4f (&q)[4], UpdKeys& keys) {
-  const IcsGeom& G = a.c.g;
-  const int r0 = tid >> 5, xq = tid & 31;
-  const float lambd = a.c.lambd;
-  const UpdOwn own = upd_own(a, u, t);
-  const int X = u.ox[t] - a.wpad - a.xshift + 4 * xq, Y = u.oy[t] - a.wpad + r0 + 32 * i;
-  const bool yin = Y >= G.pad && Y < G.pad + G.M, yframe = u.has[t] && Y >= 0 && Y < G.uM;
-  const bool mine = Y >= own.y0 && Y < own.y1 && X >= own.x0 && X < own.x1;      // (whole quads: x0, x1 and X are multiples of 4)
-  v4f un;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int x = X + e;
-    const float uv = q[0][e], gv = q[2][e];
-    const float g = ICS_FADD(ICS_FMUL(lambd, gv), ICS_FMUL(ICS_FSUB(uv, q[1][e]), 0.5f));      // pyx:519
-    const float v0 = ICS_FSUB(uv, ICS_FMUL(dtc, g));                                            // pyx:531
-    // the DoF blend of the interior, computed for every pixel and selected (no divergent branches: a quotient of garbage is discarded)
-    const bool inside = yin && x >= G.pad && x < G.pad + G.N;
-    const float fv = q[3][e];
-    const float d = upd_dof_ratio(gv, fv);                                                       // pyx:499
-    const float D = ICS_FMUL(d, d);                                                              // (pyx:502 divides by lambd in non-blind runs: this unit exists in blind ones only)
-    const float vb = ICS_FADD(ICS_FMUL(ICS_FSUB(1.0f, D), v0), ICS_FMUL(D, fv));                 // pyx:552
-    const float v = inside ? vb : v0;
-    if (a.c.want_dof) {                                                                          // (uniform)
-      const bool cnt = inside && mine;
-      const uint32_t k = ics_f2key(D);
-      keys.knan |= (cnt && D != D) ? 1u : 0u;
-      keys.kmin = (cnt && D == D && k < keys.kmin) ? k : keys.kmin;
-      keys.kmax = (cnt && D == D && k > keys.kmax) ? k : keys.kmax;
-    }
-    un[e] = (yframe && x >= 0 && x < G.uN) ? v : 0.f;      // (outside the u-frame the window reads zeros, and the frame's slack keeps them)
-    ICS_FFT_ISSUE_FENCE();      // (one pixel's quotients at a time: interleaved, four division sequences hold a dozen registers more)
-  }
-  st_f32x4(mem.uo, mine ? mem.lin.org + Y * mem.lin.pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE, 0, un);
-  return un;
-}
-ICS_FFT_HD void upd_store_lds(v2f* lds, int tid, int i, v4f un0, v4f un1) {      // tile 0 real, tile 1 imaginary
-  const int r0 = tid >> 5, xq = tid & 31;
-  v4f* wp = reinterpret_cast<v4f*>(lds + (r0 + 32 * i) * ICS_FFT_PITCH + 4 * xq);
-  wp[0] = (v4f){un0.x, un1.x, un0.y, un1.y};
-  wp[1] = (v4f){un0.z, un1.z, un0.w, un1.w};
-}
-// The window of a unit through the update: eight steps (row group, tile), the operands of two steps ahead in flight.  q[0] (and q[1]) may
-// already have been requested by the caller (`primed` steps).
-#ifndef ICS_UPD_EARLY
-#define ICS_UPD_EARLY 2   /* the next unit's first operands are requested 0: behind the barrier, 1: in front of the second stage D, 2: behind it, in front of the barrier */
-#endif
-#ifndef ICS_UPD_DEPTH
-#define ICS_UPD_DEPTH 1   /* steps of operands in flight ahead of the one being applied */
-#endif
-template <int PRIMED>
-ICS_FFT_HD void upd_window(const IcsFftArgs& a, const Mem& mem0, const Unit& u, float dtc, int tid, v2f* lds, UpdKeys& keys, v4f (&q)[3][4]) {
-  Mem mem = mem0;
-  upd_bufs(a, mem);
-  if (PRIMED < 1) upd_load(a, mem, u, tid, 0, 0, q[0]);
-  if (PRIMED < 2 && ICS_UPD_DEPTH > 1) upd_load(a, mem, u, tid, 0, 1, q[1]);
-  v4f un0;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    ICS_FFT_ISSUE_FENCE();
-    if (s + ICS_UPD_DEPTH < 8) upd_load(a, mem, u, tid, (s + ICS_UPD_DEPTH) >> 1, (s + ICS_UPD_DEPTH) & 1, q[(s + ICS_UPD_DEPTH) % (ICS_UPD_DEPTH + 1)]);
-    ICS_FFT_ISSUE_FENCE();
-    const v4f un = upd_apply(a, mem, u, dtc, tid, s >> 1, s & 1, q[s % (ICS_UPD_DEPTH + 1)], keys);
-    if (s & 1) upd_store_lds(lds, tid, s >> 1, un0, un); else un0 = un;
-  }
-}
-
 }  // namespace icsfft
 
 #if defined(__HIPCC__)
@@ -1303,45 +1186,25 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_fft_image_spectrum(IcsFftAr
 // two prefetches sit beside eight-point stages only: the image quads are requested behind stage G's last LDS write (in flight through the
 // barrier), the next unit's window in front of the second stage D.
 #ifndef ICS_FFT_FUSED_IMG_EARLY
-#define ICS_FFT_FUSED_IMG_EARLY 3   /* row groups of the image requested ahead of the barrier in front of the residual epilogue (the fourth behind it) */
+#define ICS_FFT_FUSED_IMG_EARLY 2
 #endif
-// UPD: the window is formed from (u, ut, raw back-projection, image) through the update pass (upd_window above) instead of being read
-// from the updated u, and the updated u is stored to the frame a.c.u_out on the way: A5 - A10 + A11 + A12 + A13 in one launch.
-template <bool UPD>
+template <int DUMMY>
 __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs a, float* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) v2f lds[];
   v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
   const int tid = threadIdx.x;
   if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
-  const Mem mem = make_mem(a, UPD ? 3 : 0);       // in = u, f = image, out = e' (the geometry of mode 0: tiles of the M x N interior)
+  const Mem mem = make_mem(a, 0);                 // in = u, f = image, out = e' (the geometry of mode 0: tiles of the M x N interior)
   const int c = (int)blockIdx.x % 3, slot = (int)blockIdx.x / 3, nslots = (int)gridDim.x / 3, npairs = (a.ntiles + 1) / 2;
-  float dtc = 0.f;
-  uint32_t wkmin = 0xFFFFFFFFu, wkmax = 0u, wknan = 0u;      // the wave's DoF keys so far (scalar registers: wave-reduced after every window)
-  if (UPD) {   // pyx:524, as k_update_planar: dt = step * max u_c / (max |g_c| + 1e-15) from the back-projection's keys
-    const float maxu = ics_key2f(a.c.red[ICS_RED_MAXU + c]), maxg = ics_key2f(a.c.red[ICS_RED_MAXG + c]);
-    dtc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __fdiv_rn(__fmul_rn(a.c.step, maxu), __fadd_rn(maxg, 1e-15f)))));   // (uniform: a scalar register)
-    if (slot == 0 && tid == 0) { a.c.scal[ICS_SC_DT + c] = dtc; a.c.scal[ICS_SC_MAXU + c] = maxu; a.c.scal[ICS_SC_MAXG + c] = maxg; }
-  }
-#define ICS_UPD_FOLD_KEYS(keys) do { if (a.c.want_dof) { \
-    const uint32_t m_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)~ics_wave_max_u32(~(keys).kmin)), x_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ics_wave_max_u32((keys).kmax)); \
-    wkmin = m_ < wkmin ? m_ : wkmin; wkmax = x_ > wkmax ? x_ : wkmax; wknan |= (uint32_t)__builtin_amdgcn_readfirstlane((int)ics_wave_max_u32((keys).knan)); } } while (0)
   v2f acc[2][8];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
   if (slot < npairs) {
-    if (UPD) {
-      v4f q[3][4];
-      UpdKeys keys = {0xFFFFFFFFu, 0u, 0u};
-      upd_window<0>(a, mem, decode_unit(a, 3 * slot + c), dtc, opaque(tid), lds, keys, q);
-      ICS_UPD_FOLD_KEYS(keys);
-    }
-    else {
-      v4f pw[2][4];
-      load_window(a, mem, decode_unit(a, 3 * slot + c), opaque(tid), pw);
-      store_window(pw, lds, opaque(tid));
-    }
+    v4f pw[2][4];
+    load_window(a, mem, decode_unit(a, 3 * slot + c), opaque(tid), pw);
+    store_window(pw, lds, opaque(tid));
     lds_barrier();
     stage_a(lds, opaque(tid));
   }
@@ -1394,31 +1257,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
     lds_barrier();
     stage_c<4>(lds, lds, twl, opaque(tid));
     wave_sync();
-    if (UPD) {
-      const bool more = p + nslots < npairs;
-      const Unit un = decode_unit(a, 3 * (p + nslots) + c);
-      v4f q[3][4];
-#if ICS_UPD_EARLY == 1
-      if (more) { Mem mu = mem; upd_bufs(a, mu); upd_load(a, mu, un, opaque(tid), 0, 0, q[0]); if (ICS_UPD_DEPTH > 1) upd_load(a, mu, un, opaque(tid), 0, 1, q[1]); }   // the first operands of the next unit in flight through stage D
-      ICS_FFT_ISSUE_FENCE();
-#endif
-      stage_d_acc(lds, opaque(tid), zu, acc);
-      ICS_FFT_ISSUE_FENCE();
-      if (more) {
-#if ICS_UPD_EARLY == 2
-        // the first operands of the next unit are requested behind stage D's last read (the window's spectrum is dead: registers) and travel
-        // through the barrier
-        { Mem mu = mem; upd_bufs(a, mu); upd_load(a, mu, un, opaque(tid), 0, 0, q[0]); if (ICS_UPD_DEPTH > 1) upd_load(a, mu, un, opaque(tid), 0, 1, q[1]); }
-        ICS_FFT_ISSUE_FENCE();
-#endif
-        lds_barrier();                                            // (every wave has read its rows)
-        UpdKeys keys = {0xFFFFFFFFu, 0u, 0u};
-        upd_window<(ICS_UPD_EARLY == 0 ? 0 : (ICS_UPD_DEPTH > 1 ? 2 : 1))>(a, mem, un, dtc, opaque(tid), lds, keys, q);
-        ICS_UPD_FOLD_KEYS(keys);
-        lds_barrier();
-        stage_a(lds, opaque(tid));
-      }
-    } else {
+    {
       v4f pw[2][4];
       load_window(a, mem, decode_unit(a, 3 * (p + nslots) + c), opaque(tid), pw);   // next unit (beyond the last one: dropped accesses)
       stage_d_acc(lds, opaque(tid), zu, acc);
@@ -1441,15 +1280,8 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
   lds_barrier();
   const int K = a.c.g.K;
   for (int i = tid; i < K * K; i += ICS_FFT_THREADS) {
-    const int aa = i / K, bb = i - aa * K;      // (a window that starts xshift pixels further left sees the same lag xshift columns further right)
-    partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb) + a.xshift].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
-  }
-  if (UPD && a.c.want_dof) {   // the DoF extrema of this workgroup's owned interior pixels (pyx:593)
-    if ((tid & 63) == 0) {
-      if (wkmin < a.c.dofkeys[0]) atomicMin(a.c.dofkeys + 0, wkmin);
-      if (wkmax > a.c.dofkeys[1]) atomicMax(a.c.dofkeys + 1, wkmax);
-      if (wknan) atomicOr(a.c.dofkeys + 2, 1u);
-    }
+    const int aa = i / K, bb = i - aa * K;
+    partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
   }
 }
 
@@ -1471,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_gradk_fft_reduce(const float* __restric
 // W_0 = rot180(psf) (mode 0), W_1 = psf (mode 1).  Double accumulation (a PSF value enters with its float32 value, the twiddles from a
 // double table built on the device); one workgroup per (orientation, channel, 32 columns kx): G[a][kx] = sum_b W[a][b] w^(b kx) in LDS,
 // then S[ky][kx] = conj(sum_a G[a][kx] w^(a ky)).
-__global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ psf, int K, v2f* __restrict__ spec0, v2f* __restrict__ spec1, v2f* __restrict__ spec2, int xshift) {
+__global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ psf, int K, v2f* __restrict__ spec0, v2f* __restrict__ spec1) {
   extern __shared__ __attribute__((aligned(16))) double sm[];   // [128][2] twiddles, then [K][32][2] G
   double* twd = sm;
   double* Gs = sm + 256;
@@ -1479,10 +1311,7 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
   // one workgroup per (orientation, channel, 32 columns kx, 32 rows ky): 96 of them; each builds the G of its columns itself (K^2 x 32
   // products) and then its 32 x 32 values of S (K each).  (24 workgroups with all 128 rows each took 30 us at 31 x 31, 65 us at 63 x 63 --
   // per inner iteration of a blind run.)
-  // Orientation 2 (48 more workgroups, when asked for): W_0 again, for windows that start `xshift` pixels further left -- the taps sit xshift
-  // columns further right in the window's frame, b -> b + xshift (k_synth_gradk_fft<true>).
   const int o = blockIdx.x / 48, c = (blockIdx.x / 16) % 3, kx0 = ((blockIdx.x >> 2) & 3) * 32, ky0 = (blockIdx.x & 3) * 32;
-  const int bs = o == 2 ? xshift : 0;
   if (tid < 128) {
     double sn, cs;
     sincospi((double)tid / 64.0, &sn, &cs);
@@ -1493,8 +1322,8 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
     const int aa = i >> 5, kx = kx0 + (i & 31);
     double re = 0.0, im = 0.0;
     for (int b = 0; b < K; ++b) {
-      const double wv = o != 1 ? (double)psf[((K - 1 - aa) * K + (K - 1 - b)) * 3 + c] : (double)psf[(aa * K + b) * 3 + c];
-      const int t = ((b + bs) * kx) & 127;
+      const double wv = o == 0 ? (double)psf[((K - 1 - aa) * K + (K - 1 - b)) * 3 + c] : (double)psf[(aa * K + b) * 3 + c];
+      const int t = (b * kx) & 127;
       re += wv * twd[2 * t]; im += wv * twd[2 * t + 1];
     }
     Gs[2 * i] = re; Gs[2 * i + 1] = im;
@@ -1510,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
       re += gr * wr - gi * wi; im += gr * wi + gi * wr;
     }
     const double sc = 1.0 / (128.0 * 128.0);
-    (o == 0 ? spec0 : (o == 1 ? spec1 : spec2))[spec_index(c, ky, kx0 + kxl)] = (v2f){(float)(re * sc), (float)(-im * sc)};
+    (o == 0 ? spec0 : spec1)[spec_index(c, ky, kx0 + kxl)] = (v2f){(float)(re * sc), (float)(-im * sc)};
   }
 }
 
@@ -1520,10 +1349,9 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
 bool ics_conv_fft_supported(int K) { return K >= 3 && K <= 65 && (K & 1); }
 size_t ics_conv_fft_spectrum_floats() { return (size_t)3 * ICS_FFT_P * ICS_FFT_P * 2; }   // per orientation
 
-hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s, float* spec_conv_shifted, int xshift) {
+hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s) {
   const size_t lds = (256 + (size_t)K * 32 * 2) * sizeof(double);   // 35 KB at K = 65
-  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(spec_conv_shifted ? 144 : 96), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr),
-                     reinterpret_cast<v2f*>(spec_conv_shifted), xshift);
+  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(96), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr));
   return hipGetLastError();
 }
 
@@ -1532,7 +1360,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->trace = nullptr;
   a->planar = 0;
   a->wy0 = a->wy1 = a->wx0 = a->wx1 = 0; a->store_all = 0;
-  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr; a->xshift = 0;
+  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->Vy = ICS_FFT_P - g.K + 1;           // valid rows per tile: all of them
@@ -1620,35 +1448,6 @@ hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g
 }
 // A11 + A12 + A13 in one kernel: u, f, e = origins of channel-planar mirrors; spec = the convolution orientation's spectrum; the window
 // (u-frame coordinates) says which tiles store their residual; partial: ics_gradk_fft_blocks() * K * K floats
-// How far left of (ox - pad) the windows of the update form start so that they begin on a whole quad of the plane rows (tile columns start on
-// quads: ox = gx0 mod 4), and whether the form exists for this PSF size: the shifted window must still hold V valid columns.
-int ics_synth_gradk_fft_xshift(const IcsGeom& g) { return ((g.pad & ~3) - g.pad) & 3; }
-bool ics_upd_synth_gradk_fft_supported(const IcsGeom& g) {
-  if (!ics_conv_fft_supported(g.K)) return false;
-  const int Vy = ICS_FFT_P - g.K + 1, V = Vy & ~3;
-  return V >= 4 && V + g.K - 1 + ics_synth_gradk_fft_xshift(g) <= ICS_FFT_P;
-}
-// A5 - A10 + A11 + A12 + A13 in one launch.  c: in = u = the current u (read), u_out = the frame that receives the updated u (another one),
-// ut, gr = the raw back-projection, f = the image, out = the residual frame, red = the back-projection's maxima, scal, dofkeys, step, lambd,
-// blind, want_dof as for the update pass (all origins of channel-planar mirrors); spec_shifted = orientation 2 of ics_launch_fft_spectrum
-hipError_t ics_launch_upd_synth_gradk_fft(const IcsConvArgs& c, const float* spec_shifted, int wy0, int wy1, int wx0, int wx1, int store_all, float* partial, float* gradk, hipStream_t s) {
-  if (!ics_upd_synth_gradk_fft_supported(c.g) || !c.blind || !c.gr || !c.u_out || c.u_out == c.in || !c.ut || !c.red || !c.scal || !c.dofkeys) return hipErrorInvalidValue;
-  IcsFftArgs a;
-  ics_conv_fft_fill_args(0, c, spec_shifted, &a);
-  a.planar = ICS_FFT_PL_ALL;
-  a.xshift = ics_synth_gradk_fft_xshift(c.g);
-  a.wy0 = wy0; a.wy1 = wy1; a.wx0 = wx0; a.wx1 = wx1; a.store_all = store_all;
-  static std::atomic<bool> configured[ICS_MAX_DEVICES];
-  const int dev = ics_current_device();
-  int grid = ics_gradk_fft_blocks(ics_device_cus(dev));
-  const int npairs = (a.ntiles + 1) / 2;
-  if (grid > 3 * npairs) grid = 3 * npairs;
-  auto kern = icsfft::k_synth_gradk_fft<true>;
-  if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
-  hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * c.g.K * c.g.K + 3) / 4), dim3(256), 0, s, partial, grid, c.g.K, gradk);
-  return hipGetLastError();
-}
 hipError_t ics_launch_synth_gradk_fft(const float* u, const float* f, float* e, const float* spec, const IcsGeom& g, int wy0, int wy1, int wx0, int wx1, int store_all,
                                       float* partial, float* gradk, hipStream_t s) {
   IcsConvArgs c;
@@ -1663,7 +1462,7 @@ hipError_t ics_launch_synth_gradk_fft(const float* u, const float* f, float* e, 
   int grid = ics_gradk_fft_blocks(ics_device_cus(dev));
   const int npairs = (a.ntiles + 1) / 2;
   if (grid > 3 * npairs) grid = 3 * npairs;
-  auto kern = icsfft::k_synth_gradk_fft<false>;
+  auto kern = icsfft::k_synth_gradk_fft<0>;
   if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
   hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce, dim3((3 * g.K * g.K + 3) / 4), dim3(256), 0, s, partial, grid, g.K, gradk);

@@ -79,8 +79,7 @@ hipError_t ics_launch_planar_convert(bool to_planar, const float* src, float* ds
 hipError_t ics_launch_update_planar(const IcsUpdateArgs& a, hipStream_t s);   // frame pointers = origins of planar mirrors
 bool ics_conv_fft_supported(int K);
 size_t ics_conv_fft_spectrum_floats();                                        // per orientation
-// (spec_conv_shifted, optional: the convolution orientation for windows that start xshift pixels further left -- k_synth_gradk_fft<true>)
-hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s, float* spec_conv_shifted = nullptr, int xshift = 0);
+hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s);
 // modes 0 and 1 of ics_launch_conv; `planar` = bit mask of the frames of `a` that are origins of planar mirrors (ICS_FFT_PL_*)
 #define ICS_FFT_PL_IN 1
 #define ICS_FFT_PL_OUT 2
@@ -98,12 +97,6 @@ size_t ics_conv2_fft_fspec_floats(const IcsGeom& g);
 bool ics_conv2_fft_supported(const IcsGeom& g);
 hipError_t ics_launch_fft_image_spectrum(const float* f, const IcsGeom& g, float* fspec, hipStream_t s);
 hipError_t ics_launch_conv2_fft(const IcsConvArgs& c, const float* spec_conv, const float* spec_corr, const float* fspec, hipStream_t s);
-// ... and with the update pass (A5 - A10) in front of it, in the same launch: the window is formed from (u, ut, raw back-projection, image) and the
-// updated u stored to c.u_out on the way (bit-identical to ics_launch_update_planar; the residual and the gradient agree with the two-launch form to
-// rounding -- the windows start on whole quads, ics_synth_gradk_fft_xshift)
-int ics_synth_gradk_fft_xshift(const IcsGeom& g);
-bool ics_upd_synth_gradk_fft_supported(const IcsGeom& g);
-hipError_t ics_launch_upd_synth_gradk_fft(const IcsConvArgs& c, const float* spec_shifted, int wy0, int wy1, int wx0, int wx1, int store_all, float* partial, float* gradk, hipStream_t s);
 // A12 + A13 on the same tiles (fp32): u, e = origins of planar mirrors; partial = ics_gradk_fft_blocks(cus) * K * K floats of scratch
 int ics_gradk_fft_blocks(int cus);
 hipError_t ics_launch_gradk_fft(const float* u, const float* e, const IcsGeom& g, float* partial, float* gradk, hipStream_t s);

@@ -518,154 +518,6 @@ int emulate_conv2(int M, int K, int N) {
   return ok ? 0 : 1;
 }
 
-// host restatement of k_update_planar's arithmetic (ics_planar.hip; -ffp-contract=off: every operation rounded separately) over the whole u-frame
-void host_update(const Host& h, const std::vector<float>& g, const float dt[3], float lambd, int blind, std::vector<float>& un) {
-  const IcsGeom& G = h.g;
-  un.assign(h.nf, 0.f);
-  for (int y = 0; y < G.uM; ++y)
-    for (int x = 0; x < G.uN; ++x)
-      for (int c = 0; c < 3; ++c) {
-        const size_t o = h.org + (size_t)y * G.pitch + 3 * x + c;
-        const float uv = h.u[o], gv = g[o];
-        const float gg = lambd * gv + (uv - h.ut[o]) * 0.5f;
-        float v = uv - dt[c] * gg;
-        if (y >= G.pad && y < G.pad + G.M && x >= G.pad && x < G.pad + G.N) {
-          const float fv = h.f[o];
-          const float d = (gv == 0.f && fv == 0.f) ? 1.0f : (gv - fv) / (gv + fv);
-          float D = d * d;
-          if (!blind) D = D / lambd;
-          v = (1.0f - D) * v + D * fv;
-        }
-        un[o] = v;
-      }
-}
-
-// k_synth_gradk_fft<true>: the update pass in front of the fused A11 + A13 unit.  The updated u against host_update BIT FOR BIT (every pixel of the
-// u-frame stored exactly once), the residual and the gradient against float64 sums over that updated u
-int emulate_upd(int M, int K, int N) {
-  Host h = make_host(M, N, K);
-  if (!ics_upd_synth_gradk_fft_supported(h.g)) return 0;
-  // a raw back-projection of the right size (dt g ~ 1e-3 u) with structure
-  std::vector<float> gr(h.nf, 0.f);
-  for (int y = 0; y < h.g.uM; ++y)
-    for (int x = 0; x < h.g.uN; ++x)
-      for (int c = 0; c < 3; ++c) { const size_t o = h.org + (size_t)y * h.g.pitch + 3 * x + c; gr[o] = 1e-4f * (h.u[o] - 0.45f) + 2e-5f * ((float)rand() / RAND_MAX - 0.5f); }
-  std::vector<float> pgr; to_planar(h, gr, pgr);
-  const int xs = ics_synth_gradk_fft_xshift(h.g);
-  // the shifted spectrum on the host: taps b -> b + xs
-  std::vector<v2f> spec((size_t)3 * 128 * 128);
-  {
-    const int KK = K;
-    std::vector<double> Gs((size_t)KK * 128 * 2);
-    for (int c = 0; c < 3; ++c) {
-      for (int a = 0; a < KK; ++a)
-        for (int kx = 0; kx < 128; ++kx) {
-          double re = 0, im = 0;
-          for (int b = 0; b < KK; ++b) {
-            const double w = h.psf[((size_t)(KK - 1 - a) * KK + (KK - 1 - b)) * 3 + c];
-            const double ph = -2.0 * M_PI * (((b + xs) * kx) & 127) / 128.0;
-            re += w * cos(ph); im += w * sin(ph);
-          }
-          Gs[((size_t)a * 128 + kx) * 2] = re; Gs[((size_t)a * 128 + kx) * 2 + 1] = im;
-        }
-      for (int ky = 0; ky < 128; ++ky)
-        for (int kx = 0; kx < 128; ++kx) {
-          double re = 0, im = 0;
-          for (int a = 0; a < KK; ++a) {
-            const double ph = -2.0 * M_PI * ((a * ky) & 127) / 128.0, wr = cos(ph), wi = sin(ph);
-            const double gr_ = Gs[((size_t)a * 128 + kx) * 2], gi = Gs[((size_t)a * 128 + kx) * 2 + 1];
-            re += gr_ * wr - gi * wi; im += gr_ * wi + gi * wr;
-          }
-          spec[icsfft::spec_index(c, ky, kx)] = (v2f){(float)(re / 16384.0), (float)(-im / 16384.0)};
-        }
-    }
-  }
-  const float dt[3] = {0.7f, 0.9f, 1.1f};
-  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES);
-  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
-  std::vector<float> pe(h.pnf, 0.f), puo(h.pnf, -7.f);
-  IcsConvArgs c = conv_args(h, 0, h.pu.data(), pe.data(), h.pf.data(), h.pu.data(), h.put.data(), nullptr);
-  c.gr = pgr.data() + h.porg; c.u_out = puo.data() + h.porg; c.lambd = 10000.f; c.blind = 1; c.want_dof = 1;
-  IcsFftArgs a;
-  ics_conv_fft_fill_args(0, c, (const float*)spec.data(), &a);
-  a.planar = 63; a.store_all = 1; a.xshift = xs;
-  icsfft::Mem mem = icsfft::make_mem(a, 3);
-  icsfft::upd_bufs(a, mem);
-  std::vector<float> gk((size_t)K * K * 3, 0.f);
-  const int npairs = (a.ntiles + 1) / 2;
-  icsfft::UpdKeys keys = {0xFFFFFFFFu, 0u, 0u};
-  for (int ch = 0; ch < 3; ++ch) {
-    std::vector<v2f> acc((size_t)1024 * 16, (v2f){0.f, 0.f}), zu((size_t)1024 * 16);
-    for (int p = 0; p < npairs; ++p) {
-      const icsfft::Unit u = icsfft::decode_unit(a, 3 * p + ch);
-      for (int t = 0; t < 1024; ++t) { v4f q[3][4]; icsfft::upd_window<0>(a, mem, u, dt[ch], t, lds.data(), keys, q); }
-      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
-      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
-      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
-      for (int t = 0; t < 1024; ++t) {
-        v2f sp[2][8], z[2][8];
-        icsfft::load_spectrum(mem, u.c, t, sp);
-        icsfft::stage_d_keep(sp, lds.data(), t, z);
-        for (int i = 0; i < 16; ++i) zu[(size_t)t * 16 + i] = z[i >> 3][i & 7];
-      }
-      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e_lean(snap.data(), lds.data(), twl.data(), t); }
-      for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
-      for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
-      for (int t = 0; t < 1024; ++t) {
-        v4f fimg[2][4];
-        icsfft::load_image(a, mem, u, t, fimg);
-        icsfft::QuadOut qo[2];
-        for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
-        const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
-        for (int i = 0; i < 4; ++i) icsfft::residual_quads(a, mem, qo, edge, true, lds.data(), t, i, fimg);
-      }
-      for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
-      for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
-      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
-      for (int t = 0; t < 1024; ++t) {
-        v2f z[2][8], ac[2][8];
-        for (int i = 0; i < 16; ++i) { z[i >> 3][i & 7] = zu[(size_t)t * 16 + i]; ac[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; }
-        icsfft::stage_d_acc(lds.data(), t, z, ac);
-        for (int i = 0; i < 16; ++i) acc[(size_t)t * 16 + i] = ac[i >> 3][i & 7];
-      }
-    }
-    for (int t = 0; t < 1024; ++t) { v2f z[2][8]; for (int i = 0; i < 16; ++i) z[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; icsfft::stage_d_inverse(z, lds.data(), t); }
-    { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
-    for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
-    for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
-    for (int aa = 0; aa < K; ++aa)
-      for (int bb = 0; bb < K; ++bb) gk[((size_t)aa * K + bb) * 3 + ch] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb) + xs].x / 16384.f;
-  }
-  // 1. the updated u, bit for bit, every pixel of the u-frame written
-  std::vector<float> un_ref, un(h.nf, 0.f);
-  host_update(h, gr, dt, 10000.f, 1, un_ref);
-  from_planar(h, puo, un);
-  size_t nbad = 0;
-  for (int y = 0; y < h.g.uM; ++y)
-    for (int x = 0; x < h.g.uN; ++x)
-      for (int cc = 0; cc < 3; ++cc) { const size_t o = h.org + (size_t)y * h.g.pitch + 3 * x + cc; nbad += memcmp(&un[o], &un_ref[o], 4) != 0; }
-  // the frame's slack / apron beyond the u-frame must hold what it held or zeros (never a computed value): -7 marks "not written"
-  size_t nslack = 0;
-  { const IcsGeom& g = h.g; const int pp = ics_ppitch(g); const size_t pl = ics_plane_floats(g);
-    for (int cc = 0; cc < 3; ++cc) for (int y = 0; y < g.rows; ++y) for (int x = 0; x < pp; ++x) {
-      const int Y = y - g.ay, X = x - g.ax;
-      if (Y >= 0 && Y < g.uM && X >= 0 && X < g.uN) continue;
-      const float v = puo[cc * pl + (size_t)y * pp + x];
-      nslack += !(v == -7.f || v == 0.f);
-    } }
-  // 2. residual and gradient from the updated u (float64)
-  Host h2 = h; h2.u = un_ref; to_planar(h2, h2.u, h2.pu);
-  std::vector<float> e(h.nf, 0.f);
-  from_planar(h, pe, e);
-  double wa;
-  const double rel = check(h2, 0, e, 1, &wa);
-  const double relg = check_gradk(h2, e, gk, 3);
-  const bool ok = nbad == 0 && nslack == 0 && rel < 5e-6 && relg < 1e-5;
-  printf("emulation %d x %d, K = %d, update + fused A11 + A13 (windows %d px further left): %zu updated pixels differ from the update pass, %zu stray values outside the u-frame, residual %.3e, PSF gradient %.3e  %s\n",
-         M, N, K, xs, nbad, nslack, rel, relg, ok ? "OK" : "FAIL");
-  return ok ? 0 : 1;
-}
-
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 int gpu(int M, int K, int N, int reps) {
@@ -879,67 +731,6 @@ int gpu(int M, int K, int N, int reps) {
     CK(hipEventElapsedTime(&m2, e0, e1));
     printf("  image spectra (once per image): %.4f ms, %.1f MB\n", m2 / 5, nfs * 4 / 1e6);
   }
-  if (ics_upd_synth_gradk_fft_supported(h.g)) {   // the update pass inside the fused unit (k_synth_gradk_fft<true>)
-    const int xs = ics_synth_gradk_fft_xshift(h.g);
-    float *dspec2, *dgr, *duo, *de3, *dpart, *dgk, *dscal; uint32_t* ddof;
-    CK(hipMalloc(&dspec2, sf * 4)); CK(hipMalloc(&dgr, fb)); CK(hipMalloc(&duo, fb)); CK(hipMalloc(&de3, fb));
-    CK(hipMalloc(&dpart, (size_t)768 * K * K * 4)); CK(hipMalloc(&dgk, (size_t)3 * K * K * 4)); CK(hipMalloc(&dscal, 256)); CK(hipMalloc(&ddof, 64));
-    CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0, dspec2, xs));
-    std::vector<float> gr(h.nf, 0.f), pgr;
-    for (int y = 0; y < h.g.uM; ++y)
-      for (int x = 0; x < h.g.uN; ++x)
-        for (int c = 0; c < 3; ++c) { const size_t o = h.org + (size_t)y * h.g.pitch + 3 * x + c; gr[o] = 1e-4f * (h.u[o] - 0.45f) + 2e-5f * ((float)rand() / RAND_MAX - 0.5f); }
-    to_planar(h, gr, pgr);
-    CK(hipMemcpy(dgr, pgr.data(), fb, hipMemcpyHostToDevice));
-    CK(hipMemcpy(df, h.pf.data(), fb, hipMemcpyHostToDevice));
-    CK(hipMemset(duo, 0, fb)); CK(hipMemset(de3, 0, fb));
-    // maxima keys such that dt = step * maxu / (maxg + 1e-15) is a plain number per channel
-    uint32_t red[16] = {0};
-    for (int c = 0; c < 3; ++c) { red[ICS_RED_MAXG + c] = ics_f2key(1.0f + 0.25f * c); red[ICS_RED_MAXU + c] = ics_f2key(0.9f); }
-    CK(hipMemcpy(dred, red, 64, hipMemcpyHostToDevice));
-    const uint32_t dof0[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
-    CK(hipMemcpy(ddof, dof0, 16, hipMemcpyHostToDevice));
-    IcsConvArgs a = conv_args(h, 0, du, de3, df, du, dut, dred);
-    a.gr = dgr + h.porg; a.u_out = duo + h.porg; a.scal = dscal; a.dofkeys = ddof; a.step = 1.0f; a.lambd = 10000.f; a.blind = 1; a.want_dof = 1;
-    CK(ics_launch_upd_synth_gradk_fft(a, dspec2, 0, 0, 0, 0, 1, dpart, dgk, 0));
-    CK(hipDeviceSynchronize());
-    float dt[3];
-    for (int c = 0; c < 3; ++c) dt[c] = (1.0f * 0.9f) / ((1.0f + 0.25f * c) + 1e-15f);
-    std::vector<float> un_ref, un(h.nf, 0.f), puo(h.pnf), pe3(h.pnf), gk((size_t)3 * K * K);
-    host_update(h, gr, dt, 10000.f, 1, un_ref);
-    CK(hipMemcpy(puo.data(), duo, fb, hipMemcpyDeviceToHost)); CK(hipMemcpy(pe3.data(), de3, fb, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(gk.data(), dgk, gk.size() * 4, hipMemcpyDeviceToHost));
-    from_planar(h, puo, un);
-    size_t nbad = 0;
-    for (int y = 0; y < h.g.uM; ++y)
-      for (int x = 0; x < h.g.uN; ++x)
-        for (int cc = 0; cc < 3; ++cc) { const size_t o = h.org + (size_t)y * h.g.pitch + 3 * x + cc; nbad += memcmp(&un[o], &un_ref[o], 4) != 0; }
-    // the same unit WITHOUT the update on the host-updated frame: the residual and the gradient must agree to rounding
-    std::vector<float> pun; { Host h2 = h; h2.u = un_ref; to_planar(h2, h2.u, pun); }
-    float* dun; CK(hipMalloc(&dun, fb)); CK(hipMemcpy(dun, pun.data(), fb, hipMemcpyHostToDevice));
-    float *de4, *dgk4; CK(hipMalloc(&de4, fb)); CK(hipMemset(de4, 0, fb)); CK(hipMalloc(&dgk4, (size_t)3 * K * K * 4));
-    CK(ics_launch_synth_gradk_fft(dun + h.porg, df + h.porg, de4 + h.porg, dspec0, h.g, 0, 0, 0, 0, 1, dpart, dgk4, 0));
-    CK(hipDeviceSynchronize());
-    std::vector<float> pe4(h.pnf), gk4((size_t)3 * K * K);
-    CK(hipMemcpy(pe4.data(), de4, fb, hipMemcpyDeviceToHost)); CK(hipMemcpy(gk4.data(), dgk4, gk4.size() * 4, hipMemcpyDeviceToHost));
-    double em = 0, ed = 0, gm = 0, gd = 0;
-    for (size_t i = 0; i < h.pnf; ++i) { em = fmax(em, fabs(pe4[i])); ed = fmax(ed, fabs((double)pe4[i] - (double)pe3[i])); }
-    for (size_t i = 0; i < gk.size(); ++i) { gm = fmax(gm, fabs(gk4[i])); gd = fmax(gd, fabs((double)gk4[i] - (double)gk[i])); }
-    uint32_t dof[4]; CK(hipMemcpy(dof, ddof, 16, hipMemcpyDeviceToHost));
-    const bool ok = nbad == 0 && ed < 2e-6 && gd / gm < 2e-6;
-    printf("update + fused A11 + A13 in one launch (windows %d px further left): %zu updated pixels differ from the host's update pass; against the unit without the update on that frame: residual max |d| %.3e (max |e| %.3e), gradient %.3e of its maximum; DoF keys %.6g .. %.6g nan %u  %s\n",
-           xs, nbad, ed, em, gd / gm, ics_key2f(dof[0]), ics_key2f(dof[1]), dof[2], ok ? "OK" : "FAIL");
-    if (!ok) rc = 1;
-    const int wy0 = h.g.pad + M / 2 - 100, wx0 = h.g.pad + N / 2 - 100;
-    for (int i = 0; i < 3; ++i) CK(ics_launch_upd_synth_gradk_fft(a, dspec2, wy0, wy0 + 200, wx0, wx0 + 200, 0, dpart, dgk, 0));
-    CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) CK(ics_launch_upd_synth_gradk_fft(a, dspec2, wy0, wy0 + 200, wx0, wx0 + 200, 0, dpart, dgk, 0));
-    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-    float mu; CK(hipEventElapsedTime(&mu, e0, e1));
-    IcsFftArgs fa0; ics_conv_fft_fill_args(0, a, dspec2, &fa0);
-    const int npairs = (fa0.ntiles + 1) / 2;
-    printf("  update + fused A11 + A13 (window tiles store e'): %.4f ms per launch, %d rounds, %.2f us per unit\n", mu / reps, (npairs + 84) / 85, 1e3 * mu / reps / ((npairs + 84) / 85));
-  }
   CK(hipEventRecord(e0, 0));
   for (int i = 0; i < 20; ++i) CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0));
   CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -953,7 +744,7 @@ int gpu(int M, int K, int N, int reps) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
-    return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N) | (128 - 2 * K + 2 >= 16 ? emulate_conv2(M, K, N) : 0) | emulate_upd(M, K, N);
+    return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N) | (128 - 2 * K + 2 >= 16 ? emulate_conv2(M, K, N) : 0);
   }
   const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
   return gpu(M, K, N, reps);

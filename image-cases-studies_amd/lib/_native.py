@@ -17,13 +17,13 @@ LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "l
 ICS_ABI_VERSION = 4
 ICS_KERNEL_COUNT = 12
 KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth",
-                "synth_gradk", "synth_backproject", "update_synth_gradk", "_11")
+                "synth_gradk", "synth_backproject", "_10", "_11")
 
 # error codes (include/ics_hip.h)
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
 
 # stages / buffers
-STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK, STAGE_BAND_REDUCE, STAGE_BAND_MASK_E, STAGE_SYNTH_BACKPROJECT, STAGE_UPDATE_SYNTH_GRADK = range(1, 15)
+STAGE_SYNTH_RESIDUAL, STAGE_BACKPROJECT, STAGE_UPDATE, STAGE_PSF_GRADIENT, STAGE_PSF_UPDATE, STAGE_MAJORIZE, STAGE_STATS, STAGE_UPDATE_SYNTH, STAGE_TVTERM, STAGE_SYNTH_GRADK, STAGE_BAND_REDUCE, STAGE_BAND_MASK_E, STAGE_SYNTH_BACKPROJECT = range(1, 14)
 FLAG_NO_FUSED_GRADK = 1   # ics_rl_params.flags (include/ics_hip.h ICS_FLAG_*)
 FLAG_STAGE_ASYNC = 2      # ics_rl_stage returns once the stage is queued
 BUF_U, BUF_UT, BUF_GRADU, BUF_IMAGE, BUF_ERROR, BUF_PSF, BUF_GRADK, BUF_SCALARS, BUF_TV, BUF_RED = range(10)

@@ -273,8 +273,6 @@ unsigned long long ics_rl_frame_bytes(int M, int N, int MK);
                                       of ICS_STAGE_PSF_GRADIENT sums the owned rows only (the caller adds the bands)       */
 #define ICS_STAGE_SYNTH_BACKPROJECT 13 /* params.conv = ICS_CONV_FFT only: A1 + A2 + A3 (+A7) as ONE unit per tile pair (k_conv_fft<2>): gradu and the
                                           step-size maxima straight from u and the image; the residual frame is not written   */
-#define ICS_STAGE_UPDATE_SYNTH_GRADK 14 /* params.conv = ICS_CONV_FFT only: ICS_STAGE_UPDATE and ICS_STAGE_SYNTH_GRADK in ONE launch (k_synth_gradk_fft<true>): the
-                                           updated u (bit-identical to ICS_STAGE_UPDATE), its residual over the whole frame, gradk                     */
 int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 
 /* Reads one device frame back in the reference's shape. */
@@ -311,8 +309,7 @@ int ics_rl_copy_rows(ics_rl *dst, int dst_which, int dst_row0, ics_rl *src, int 
 #define ICS_K_UPDATE_SYNTH 7 /* fused A5-A10 + A1/A2 (or A11) kernel */
 #define ICS_K_SYNTH_GRADK 8  /* fused A11 + A13 kernel (+ reduction)  */
 #define ICS_K_SYNTH_BACKPROJECT 9 /* A1 + A2 + A3 (+A7) in one unit per tile pair (transform tiles, small PSFs) */
-#define ICS_K_UPDATE_SYNTH_GRADK 10 /* A5 - A10 + A11 + A12 + A13 in one launch (transform tiles, blind) */
-#define ICS_KERNEL_COUNT 12  /* (11 reserved) */
+#define ICS_KERNEL_COUNT 12  /* (10..11 reserved) */
 
 /* ---- small standalone operators ---------------------------------------------------------- */
 /* lib/deconvolution.pyx:73-75 -- in place on a host MK*MK*3 float32 array, computed on device. */

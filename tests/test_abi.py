@@ -74,7 +74,7 @@ def test_python_constants_equal_the_header():
     pairs = {"ICS_ABI_VERSION": nv.ICS_ABI_VERSION, "ICS_ENOMEM": nv.ICS_ENOMEM, "ICS_ENOSUP": nv.ICS_ENOSUP, "ICS_ENODEV": nv.ICS_ENODEV,
              "ICS_CONV_AUTO": nv.CONV_AUTO, "ICS_CONV_VECTOR": nv.CONV_VECTOR, "ICS_CONV_MATRIX": nv.CONV_MATRIX, "ICS_CONV_FFT": nv.CONV_FFT,
              "ICS_FLAG_NO_FUSED_GRADK": nv.FLAG_NO_FUSED_GRADK, "ICS_FLAG_STAGE_ASYNC": nv.FLAG_STAGE_ASYNC, "ICS_FRAME_LIMIT_BYTES": nv.FRAME_LIMIT_BYTES,
-             "ICS_STAGE_SYNTH_RESIDUAL": nv.STAGE_SYNTH_RESIDUAL, "ICS_STAGE_BAND_MASK_E": nv.STAGE_BAND_MASK_E, "ICS_STAGE_SYNTH_GRADK": nv.STAGE_SYNTH_GRADK, "ICS_STAGE_SYNTH_BACKPROJECT": nv.STAGE_SYNTH_BACKPROJECT, "ICS_STAGE_UPDATE_SYNTH_GRADK": nv.STAGE_UPDATE_SYNTH_GRADK}
+             "ICS_STAGE_SYNTH_RESIDUAL": nv.STAGE_SYNTH_RESIDUAL, "ICS_STAGE_BAND_MASK_E": nv.STAGE_BAND_MASK_E, "ICS_STAGE_SYNTH_GRADK": nv.STAGE_SYNTH_GRADK, "ICS_STAGE_SYNTH_BACKPROJECT": nv.STAGE_SYNTH_BACKPROJECT}
     for name, value in pairs.items():
         assert name in defs, name
         assert defs[name] == value, (name, defs[name], value)

@@ -324,76 +324,6 @@ def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, bli
     dc._drop_jobs()
 
 
-@pytest.mark.parametrize("blind", [True, False])
-@pytest.mark.parametrize("M,N,MK", [(300, 330, 15), (150, 260, 9), (200, 170, 31), (176, 108, 17), (128, 70, 63), (64, 129, 65), (333, 410, 23), (700, 520, 15)])
-def test_update_inside_the_fused_unit(M, N, MK, blind):
-    """ICS_STAGE_UPDATE_SYNTH_GRADK (k_synth_gradk_fft<true>): A5 - A10 (pyx:499-552) inside the unit that needs the updated u -- the window
-    is formed from (u, majoriser, raw back-projection, image) and the updated frame stored on the way.  The updated u and the DoF extrema
-    BIT FOR BIT those of ICS_STAGE_UPDATE (the update is pointwise: the same operations on the same operands), the residual and the PSF
-    gradient of that updated u against float64 sums at the gates of the kernels it replaces."""
-    from lib import _native as nv
-    out = {}
-    rng = np.random.default_rng(11)
-    case = None
-    for fused in (False, True):
-        job, case, psf = make_job(M, N, MK, seed=MK + N, blind=True)
-        u = (case["u0"] + 0.02 * rng.standard_normal(case["u0"].shape)).astype(np.float32) if not fused else out["u_in"]
-        ut = case["u0"]
-        g = ((u - 0.45) * np.float32(1e-4) + np.float32(2e-5) * rng.standard_normal(u.shape)).astype(np.float32) if not fused else out["g_in"]
-        out.setdefault("u_in", u); out.setdefault("g_in", g)
-        job.write(nv.BUF_U, u); job.write(nv.BUF_UT, ut); job.write(nv.BUF_GRADU, g)
-        p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=blind, conv=FFT)
-        pb = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=blind, conv=0, band_rows=(0, u.shape[0]))
-        job.stage(nv.STAGE_BAND_REDUCE, pb)                      # the maxima the update reads
-        if fused:
-            job.write(nv.BUF_ERROR, np.full_like(case["image"], 7.0))
-            job.stage(nv.STAGE_UPDATE_SYNTH_GRADK, p)
-        else:
-            job.stage(nv.STAGE_UPDATE, p)
-            job.stage(nv.STAGE_SYNTH_GRADK, p)
-        out[fused] = (job.read(nv.BUF_U), job.read(nv.BUF_ERROR), job.read(nv.BUF_GRADK), job.red_keys(), job.scalars())
-        job.close()
-    un, e, gk = out[True][:3]
-    assert np.array_equal(un, out[False][0], equal_nan=True)                     # A5 - A10: bit-identical
-    assert np.array_equal(out[True][3][12:15], out[False][3][12:15])             # DoF min / max / NaN keys
-    full = conv_valid64(un, psf)
-    err_e = np.max(np.abs(e - (full - case["image"]))) / np.max(np.abs(full))
-    err_g = rel_err(gk, gradk64(un.astype(np.float64), e.astype(np.float64)))
-    print("%dx%d K=%d blind=%s: residual %.2e gradient %.2e; against the two-launch form: residual %.2e gradient %.2e"
-          % (M, N, MK, blind, err_e, err_g, np.max(np.abs(e - out[False][1])) / np.max(np.abs(full)), rel_err(gk, out[False][2])))
-    assert err_e < CONV_TOL and err_g < 1e-5
-    sc_t, sc_f = out[True][4], out[False][4]
-    assert all(sc_t[k] == sc_f[k] for k in sc_t if k.startswith(("dt", "maxu", "maxg")))      # the step sizes it recorded
-
-
-@pytest.mark.parametrize("MK", [15, 31])
-def test_whole_blind_run_with_the_update_inside_the_fused_unit(MK, debug_switch):
-    """ics_rl_run on the tiles with the update pass inside the fused A11 + A13 unit (fft_upd, default) against the same run with the update
-    as a launch of its own: the same sums evaluated from windows one pixel apart -- u, PSF within 1e-5 after three outer iterations, the
-    stop-test scalars within 2e-3, the DoF lines of the log equal."""
-    from lib import deconvolution as dc
-    import contextlib, io
-    M, N = 700, 820
-    case = orc.synth_case_large(M, N, MK, seed=MK, blind=True)
-    res = {}
-    for sw in (1, 0):
-        debug_switch("fft_upd", sw)
-        dc._drop_jobs()
-        u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
-        buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 3, 1e-3, 10000.0, blind=True, conv=FFT)
-        st = dc.richardson_lucy_MM.last
-        assert st.iterations_done == 3 and not st.has_nan
-        res[sw] = (u, psf, np.array(st.trace_M_r[:3]), np.array(st.trace_Hu[:3]), np.array(st.trace_varu[:3]), np.array(st.trace_dof_min[:3]), np.array(st.trace_dof_max[:3]))
-    eu, ep = rel_err(res[1][0], res[0][0]), rel_err(res[1][1], res[0][1])
-    print("K=%d: update inside the unit vs a launch of its own: u %.2e psf %.2e" % (MK, eu, ep))
-    assert eu < 1e-5 and ep < 1e-5
-    for k in (2, 3, 4, 5, 6):
-        np.testing.assert_allclose(res[1][k], res[0][k], rtol=2e-3)
-    dc._drop_jobs()
-
-
 @pytest.mark.parametrize("blind", [False, True])
 def test_nan_in_the_image_on_the_tiles_is_reported_not_raised(blind):
     """pyx:671-672: NaN is printed, never raised.  The reference's own frame-wide FFT convolution turns one NaN pixel into an all-NaN
