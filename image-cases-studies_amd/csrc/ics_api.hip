@@ -900,7 +900,11 @@ static bool pam_on_tiles(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (env == 3) return true;
   // bench.py --tv-mode 2, ICS_CONV_PATH=matrix -> fft (measured with the convolutions and the gradient on the tiles only), ms per inner iteration: 1448^2 / 31 blind 0.357 -> 0.297; 2048^2 / 21 blind 0.470 -> 0.396,
   // non-blind 0.271 -> 0.259; 4096^2 / 19 blind 1.563 -> 1.132; 1100^2 / 45 blind 0.432 -> 0.310
-  return env == 0 && j->g.K >= 19 && (long)j->g.uM * j->g.uN >= (p->blind ? 1000000L : 1500000L);
+  // round 6: the shipped loop's thresholds -- the same kernels but for the epilogue's operands -- except below 6 Mpx at 15 x 15 and less, where the
+  // TV term's own pass on the planes tips it back (bench.py --tv-mode 2, ms per inner iteration, matrix cores -> tiles: 4096^2 / 15 blind 0.873 -> 0.780,
+  // tv_mode 3 0.869 -> 0.794; 2048^2 / 15 non-blind 0.176 -> 0.190, blind 0.261 -> 0.293)
+  const long px = (long)j->g.uM * j->g.uN;
+  return env == 0 && fft_preferred(j->g, p->blind != 0) && (j->g.K >= 17 || px >= 6000000L);
 }
 static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (p->tv_mode != ICS_TV_SHIPPED) return pam_on_tiles(j, p, in_run);   // PAM kinds: TV term, back-projection epilogue and update on the mirrors too
@@ -1028,7 +1032,7 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
 #define ICS_CONV2_MAX_K 25
 #endif
 static bool use_conv2(const ics_rl* j, const ics_rl_params* p) {
-  if (!j->fft_on || p->tv_mode != ICS_TV_SHIPPED || p->fuse) return false;
+  if (!j->fft_on || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse) return false;      // (shipped loop and the PAM kinds, whose epilogue takes u and T)
   const int sw = ics_debug().fft_conv2.load(std::memory_order_relaxed);
   if (sw == 0 || !ics_conv2_fft_supported(j->g)) return false;
   return sw == 2 || j->g.K <= ICS_CONV2_MAX_K;
@@ -1046,6 +1050,10 @@ static int do_conv2(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
   a.in = porg(j, j->u); a.out = porg(j, j->gr); a.f = porg(j, j->f); a.u = porg(j, j->u); a.ut = porg(j, ut_of(j));
   a.red = red_of(j) + slot * ICS_RED_STRIDE;
   a.step = p->step_factor; a.blind = p->blind;
+  if (p->tv_mode >= ICS_TV_PAM_ISO) {   // PAM kinds: the epilogue takes u and T, stores G = T + lambd gradu
+    a.tv = j->tvf ? porg(j, j->tvf) : nullptr; a.tv_kind = p->tv_mode;
+    if (!a.tv) return fail(ICS_ESTATE, "FFT pipeline: the TV frame has no planar mirror");
+  }
   if (!a.in || !a.out || !a.f || !a.ut) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
   RC(pr.begin(ICS_K_SYNTH_BACKPROJECT));
   HIPCHK(ics_launch_conv2_fft(a, j->spec_conv, j->spec_corr, j->fspec, j->ctx->stream));
@@ -1500,6 +1508,7 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       // between dependent kernels cost ~4 % of a 4096^2 blind iteration, a sample of them does not.
       Prof& pr = (p->profile > 0 && inner_done % p->profile == 0) ? pr_on : pr_off;
       if (conv2) {
+        if (tv) RC(do_tvterm(j, p, itt, pr));                 // (PAM kinds: T of u, read by the back-projection's epilogue)
         RC(do_conv2(j, p, itt, pr));                          // A1 + A2 + A3 (+A7) in one unit per tile pair; the residual frame is not written ...
         if (!p->blind && last) RC(do_conv_fft_window(j, p, pr));   // ... so the statistics' window of it is (blind: A11 rewrites it, do_synth_gradk_fft)
       } else {

@@ -1415,9 +1415,11 @@ hipError_t ics_launch_conv_fft_args(int mode, const IcsFftArgs& a, hipStream_t s
   auto k1 = icsfft::k_conv_fft<1, false>;
   auto k1t = icsfft::k_conv_fft<1, true>;
   auto k2 = icsfft::k_conv_fft<2, false>;
-  if (mode == 2 && (pam || !a.spec1 || !a.fspec)) return hipErrorInvalidValue;   // (mode 2 serves the shipped loop)
-  auto kern = mode == 2 ? k2 : (mode == 0 ? k0 : (pam ? k1t : k1));
-  const int slot = mode == 2 ? 3 : (pam ? 2 : mode);
+  auto k2t = icsfft::k_conv_fft<2, true>;
+  const bool pam2 = mode == 2 && a.c.tv && a.c.tv_kind >= 2;      // (the PAM kinds' epilogue on mode 2's units: operands u and T, G = T + lambd gradu stored)
+  if (mode == 2 && (!a.spec1 || !a.fspec)) return hipErrorInvalidValue;
+  auto kern = mode == 2 ? (pam2 ? k2t : k2) : (mode == 0 ? k0 : (pam ? k1t : k1));
+  const int slot = mode == 2 ? (pam2 ? 4 : 3) : (pam ? 2 : mode);
   if (hipError_t e = ics_configure_lds(configured[slot], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
   return hipGetLastError();

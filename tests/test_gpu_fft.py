@@ -296,11 +296,11 @@ def test_synthesis_and_back_projection_in_one_unit(M, N, MK):
     job.close()
 
 
-@pytest.mark.parametrize("blind", [False, True])
-@pytest.mark.parametrize("MK", [9, 15])
-def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, blind, debug_switch):
+@pytest.mark.parametrize("MK,blind,tv_mode", [(9, False, 0), (9, True, 0), (15, False, 0), (15, True, 0), (15, True, 2), (9, False, 3), (21, True, 3)])
+def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, blind, tv_mode, debug_switch):
     """ics_rl_run on the tiles with A1 + A3 as one unit (fft_conv2, default for small PSFs) against the same run with the two kernels:
-    two correct evaluations of the same sums -- u, PSF within 1e-5 after three outer iterations, the stop-test scalars (whose residual
+    two correct evaluations of the same sums (the PAM kinds, tv_mode 2 / 3, included: their epilogue rides on the same units) -- u, PSF within 1e-5
+    after three outer iterations, the stop-test scalars (whose residual
     window comes from a window-sized launch of mode 0, non-blind, or from the fused A11 + A13 unit, blind) within 2e-3."""
     from lib import deconvolution as dc
     import contextlib, io
@@ -312,12 +312,12 @@ def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, bli
         dc._drop_jobs()
         u, psf, image = case["u0"].copy(), case["psf0"].copy(), case["image"].copy()
         with contextlib.redirect_stdout(io.StringIO()):
-            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 3, 1e-3, 10000.0, blind=blind, conv=FFT)
+            dc.richardson_lucy_MM(image, u, psf, *orc.default_window(M, N, MK), 1e9, M, N, 3, MK, 3, 1e-3, 10000.0, blind=blind, conv=FFT, tv_mode=tv_mode)
         st = dc.richardson_lucy_MM.last
         assert st.iterations_done == 3 and not st.has_nan
         res[sw] = (u, psf, np.array(st.trace_M_r[:3]), np.array(st.trace_Hu[:3]), np.array(st.trace_varu[:3]))
     eu, ep = rel_err(res[1][0], res[0][0]), rel_err(res[1][1], res[0][1])
-    print("K=%d blind=%s: one unit vs two kernels u %.2e psf %.2e" % (MK, blind, eu, ep))
+    print("K=%d blind=%s tv_mode=%d: one unit vs two kernels u %.2e psf %.2e" % (MK, blind, tv_mode, eu, ep))
     assert eu < 1e-5 and ep < 1e-5
     for k in (2, 3, 4):
         np.testing.assert_allclose(res[1][k], res[0][k], rtol=2e-3)
