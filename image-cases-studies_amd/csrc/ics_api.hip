@@ -197,6 +197,7 @@ struct ics_rl {
   float *spec_conv, *spec_corr;
   float* fspec;         // mode 2 of the tile convolutions (A1 + A3 in one unit): the image windows' spectra, valid while fspec_valid
   bool fspec_valid;
+  bool conv2_off;       // the spectra did not fit the device memory once: this job runs A1 and A3 as two kernels from then on
   bool fft_on;
   bool plf_valid;                       // the mirror of the image frame still mirrors it (every writer of j->f calls image_changed)
 };
@@ -1034,7 +1035,7 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
 static bool use_conv2(const ics_rl* j, const ics_rl_params* p) {
   if (!j->fft_on || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse) return false;      // (shipped loop and the PAM kinds, whose epilogue takes u and T)
   const int sw = ics_debug().fft_conv2.load(std::memory_order_relaxed);
-  if (sw == 0 || !ics_conv2_fft_supported(j->g)) return false;
+  if (sw == 0 || j->conv2_off || !ics_conv2_fft_supported(j->g)) return false;
   return sw == 2 || j->g.K <= ICS_CONV2_MAX_K;
 }
 static int do_conv2(ics_rl* j, const ics_rl_params* p, int slot, Prof& pr) {
@@ -1463,6 +1464,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     RC(to_planar(j, j->u, s));
     if (!j->plf_valid) { RC(to_planar(j, j->f, s)); j->plf_valid = true; }
     fft_scope.back = true;
+    // mode 2's image spectra are 1.6 frames more (128 KB per unit): when they do not fit, the run takes A1 and A3 as two kernels instead
+    if (use_conv2(j, p) && !j->fspec && dalloc(j->ctx, &j->fspec, ics_conv2_fft_fspec_floats(j->g), false) != ICS_OK) { j->fspec = nullptr; j->conv2_off = true; (void)hipGetLastError(); }
   }
   {  // everything but the caller's in-fields is overwritten
     ics_rl_stats in = *st;
