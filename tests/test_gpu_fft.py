@@ -324,6 +324,28 @@ def test_whole_run_with_one_unit_per_tile_pair_equals_the_two_kernel_run(MK, bli
     dc._drop_jobs()
 
 
+def test_few_persistent_workgroups_walk_many_units_of_one_unit_mode(debug_switch):
+    """mode 2 with a grid far smaller than its unit count and no multiple of eight (test hook max_wgs): interior and outer-ring units in turn
+    on the same workgroup, the next unit's window prefetched across both kinds"""
+    from lib import _native as nv
+    debug_switch("max_wgs", 5)
+    M, N, MK = 520, 610, 15
+    job, case, psf = make_job(M, N, MK, seed=9)
+    rng = np.random.default_rng(5)
+    u = (case["u0"] + 0.01 * rng.standard_normal(case["u0"].shape)).astype(np.float32)
+    job.write(nv.BUF_U, u); job.write(nv.BUF_UT, case["u0"])
+    p = job.params(1, 5, 1, 5, 1e9, 1, 1e-3, 10000.0, blind=True, conv=FFT)
+    job.stage(nv.STAGE_SYNTH_BACKPROJECT, p)
+    g5, red5 = job.read(nv.BUF_GRADU), job.red_keys()[:6].copy()
+    debug_switch("max_wgs", 0)
+    job.write(nv.BUF_GRADU, np.zeros_like(u))
+    job.stage(nv.STAGE_SYNTH_BACKPROJECT, p)
+    assert np.array_equal(job.read(nv.BUF_GRADU), g5) and np.array_equal(job.red_keys()[:6], red5)      # the walk does not change a bit
+    g_ref = corr_full64(conv_valid64(u, psf) - case["image"].astype(np.float64), psf)
+    assert np.max(np.abs(g5 - g_ref)) < CONV_TOL * np.max(np.abs(conv_valid64(u, psf)))
+    job.close()
+
+
 @pytest.mark.parametrize("blind", [False, True])
 def test_nan_in_the_image_on_the_tiles_is_reported_not_raised(blind):
     """pyx:671-672: NaN is printed, never raised.  The reference's own frame-wide FFT convolution turns one NaN pixel into an all-NaN
