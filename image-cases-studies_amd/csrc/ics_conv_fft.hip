@@ -2,6 +2,9 @@
 //
 //   mode 0 (A1+A2 / A11, lib/deconvolution.pyx:477-488, 555-565):  error = convolve(u, psf, "valid") - image
 //   mode 1 (A3, pyx:490-491):  gradu = convolve(error, rot180(psf), "full")  (+ the reductions of A7, pyx:523-524)
+//   mode 2 (A1+A2+A3 in one unit, round 6):  gradu straight from u and the image -- interior tiles never leave the frequency domain,
+//                                             G = S1 (16384 S0 T - F) with F = the image windows' spectra (k_fft_image_spectrum); see tile_is_border
+//   k_synth_gradk_fft (A11+A12+A13 in one unit, round 6), k_gradk_fft (A12+A13), k_fft_spectrum (the weight spectra): further down
 //
 // The reference computes both with scipy's complex64 FFT over the whole frame (pyx:478,491 -> scipy.signal.fftconvolve); here the frame is
 // cut into tiles of V = 128 - K + 1 output pixels a side, each the valid part of a 128 x 128 circular correlation (overlap-save), fp32
@@ -274,8 +277,8 @@ struct IcsFftArgs {
                             // is 16-byte aligned (measured on MI355X: a buffer_store_dwordx4 at 12 mod 16 bytes lost its first dword on
                             // some lanes); the pixels in front of ox0 are stored as zeros, like those behind ox1
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
-  int wpad;                 // a tile's window starts wpad pixels up and left of its first output pixel: pad (one convolution), 2 pad (k_conv2_fft: two in a row)
-  float* fspec;             // k_conv2_fft: DFT of the image windows of every unit, [unit][8][1024] quads in load_spectrum's order (k_fft_image_spectrum)
+  int wpad;                 // a tile's window starts wpad pixels up and left of its first output pixel: pad (one convolution), 2 pad (mode 2, k_conv_fft<2>: two in a row)
+  float* fspec;             // mode 2: DFT of the image windows of every unit, [unit][8][1024] quads in load_spectrum's order (k_fft_image_spectrum)
   int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
   int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
@@ -485,7 +488,7 @@ ICS_FFT_HD void store_spectrum(gbuf b, int blk, int tid, const v2f (&z)[2][8]) {
     st_f32x4(b, 4 * tid, (blk + l) * ICS_FFT_THREADS * 4, (v4f){z0.x, z0.y, z1.x, z1.y});
   }
 }
-// Stage D of the fused A1 + A3 unit (k_conv2_fft), interior tiles: with T = the window's spectrum (after the radix-8 pass),
+// Stage D of the fused A1 + A3 unit (mode 2, k_conv_fft<2>), interior tiles: with T = the window's spectrum (after the radix-8 pass),
 //     G = S1 . (16384 S0 T - F),     F = the UNNORMALISED transform of the image window (k_fft_image_spectrum),
 // i.e. the spectrum of corr(conv(u) - image): both weight spectra carry the 1 / 128^2 of an inverse transform, the first one's is undone
 // (a power of two: exact).  One forward and one inverse transform where k_conv_fft<0> + k_conv_fft<1> run two of each.
