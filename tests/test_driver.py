@@ -101,6 +101,8 @@ def test_device_resident_driver_equals_the_host_driver(pyramid, preview, blur, c
     log_h = capsys.readouterr().out
     out_d, psf_d = dv.deblur_module(pic, "d", ".", 5, device_resident=True, **kw)
     log_d = capsys.readouterr().out
+    # the resident call leaves its wall time per phase behind (what bench.py's deblur_module_end_to_end reports)
+    assert set(dv.deblur_module.last_phase_seconds) == {"blind", "non-blind"} and all(v > 0 for v in dv.deblur_module.last_phase_seconds.values())
     assert out_d.shape == out_h.shape == ((61 - 1, 61 - 1, 3) if preview else (118, 141, 3))
     assert np.abs(psf_d - psf_h).max() < 1e-5
     assert np.abs(out_d - out_h).max() / 65535 < 2e-5, np.abs(out_d - out_h).max()
