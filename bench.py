@@ -533,6 +533,8 @@ def main():
             oc["configs[3] blind 6144^2 31x31 PAM collaborative TV (tv_mode 3, build-defined)"] = timed_run(ctx, 6144, 31, True, 3, conv, 25, 5)
             # beyond BASELINE.json: the largest PSF of the reference's own examples (deconvolve.py:409, blur width 45)
             oc["example blind 4096^2 45x45 (shipped loop; reference deconvolve.py:409)"] = timed_run(ctx, 4096, 45, True, 0, conv, 10, 5)
+            # ... and a PSF beyond 65 x 65: the tiles serve sizes to 97 since round 6 (the matrix cores' tap blocks above)
+            oc["blind 4096^2 95x95 (shipped loop; the reference has no PSF size limit, pyx:378-390)"] = timed_run(ctx, 4096, 95, True, 0, conv, 10, 5)
             out["other_configs"] = oc
             out["deblur_module_end_to_end"] = {"4096^2 blur 15, reference defaults (iterations=20)": deblur_end_to_end(4096, 15, 20),
                                                "2048^2 blur 15, reference defaults (iterations=20)": deblur_end_to_end(2048, 15, 20)}

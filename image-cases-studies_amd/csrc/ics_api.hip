@@ -866,6 +866,13 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
 // fp32 throughout, with the update pass and the matrix-core PSF gradient on the mirrors as well.  Shipped loop only (tv_mode 0, fuse 0),
 // PSF sizes 3 ... 65.  Explicit: conv = ICS_CONV_FFT (also through the stage API); under ICS_CONV_AUTO inside ics_rl_run where it measured
 // ahead of the matrix-core kernels (fft_preferred); ICS_CONV_PATH=fft|matrix|vector overrides AUTO.
+// (PSF sizes 67 ... 97, opened to the tiles late in round 6 -- the stage functions never depended on the size, only the valid part of a tile
+//  shrinks: 62 pixels a side at 67, 32 at 97 -- against the matrix cores' tap blocks, profiles/r06_ab_fft_bigk.txt, non-blind / blind:
+//  1024^2 67: 0.659 -> 0.160 / 1.270 -> 0.332;  2048^2 67: 1.894 -> 0.333 / 3.621 -> 0.609;  97: 2.455 -> 0.793 / 5.182 -> 1.494;
+//  4096^2 67: 6.774 -> 1.059 / 12.78 -> 1.746;  85: 7.822 -> 1.676 / 14.43 -> 2.895;  97: 9.011 -> 2.848 / 18.46 -> 4.989)
+#ifndef ICS_FFT_AUTO_MAX_K
+#define ICS_FFT_AUTO_MAX_K 97
+#endif
 static bool fft_preferred(const IcsGeom& g, bool blind) {
   // measured on MI355X (NOTES_r05.md): per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
   // the Toeplitz matrix-core kernels pay K^2.  scripts/ab_fft.py at the end of round 5, ms per inner iteration, matrix cores -> tiles
@@ -881,6 +888,8 @@ static bool fft_preferred(const IcsGeom& g, bool blind) {
   // 17: 0.170 -> 0.151 / 0.315 -> 0.248;  2900^2 9: 0.286 -> 0.265 / 0.403 -> 0.363;  15: 0.332 -> 0.296 / 0.457 -> 0.400;  4096^2 5: level / 0.683 -> 0.643;  9: 0.532 -> 0.479 /
   // 0.732 -> 0.662;  15: 0.627 -> 0.526 / 0.851 -> 0.716;  6144^2 9: 1.140 -> 0.999 / 1.622 -> 1.365;  15: 1.256 -> 1.122 / 1.821 -> 1.502.
   const long px = (long)g.uM * g.uN;
+  if (g.K > ICS_FFT_AUTO_MAX_K) return false;
+  if (g.K >= 51) return px >= 500000L;
   if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
   if (g.K == 17) return px >= (blind ? 2000000L : 4000000L);
   if (g.K == 15) return px >= (blind ? 6000000L : 4000000L);
@@ -1332,7 +1341,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_FFT) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
   if (p->conv == ICS_CONV_FFT && (!ics_conv_fft_supported(j->g.K) || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse))
-    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 65, the shipped loop and the PAM kinds (tv_mode 0, 2, 3; fuse 0)");
+    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 97, the shipped loop and the PAM kinds (tv_mode 0, 2, 3; fuse 0)");
   if (p->conv == ICS_CONV_FFT && !fft_mirror_fits(j->g))
     return fail(ICS_ENOSUP, "ICS_CONV_FFT: the channel-planar mirror of a %d x %d frame with a %d x %d PSF is %zu bytes, beyond the 2^31 - 1 the tile kernels address "
                 "(ICS_CONV_AUTO runs such a frame on the matrix cores)", j->g.M, j->g.N, j->g.K, j->g.K, ics_planar_floats(j->g) * sizeof(float));

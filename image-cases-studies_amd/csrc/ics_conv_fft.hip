@@ -43,6 +43,9 @@
 #include "ics_tw128.h"
 
 #define ICS_FFT_P 128
+#ifndef ICS_FFT_MAX_K
+#define ICS_FFT_MAX_K 97        /* largest PSF size the tiles take (explicit ICS_CONV_FFT; ICS_CONV_AUTO picks them where they measured ahead: ics_api.hip fft_preferred) */
+#endif
 #define ICS_FFT_PITCH 136
 #define ICS_FFT_TWS 17         /* the twiddle table behind the tile: T[j][k1] = w^(j k1), j < 8, k1 < 16, rows of 17 entries (34 dwords: the eight j of a
                                   wave's lanes fall into different banks), so that a lane's fifteen reads are ONE address + immediate offsets */
@@ -1349,11 +1352,12 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
 }  // namespace icsfft
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------------------------
-bool ics_conv_fft_supported(int K) { return K >= 3 && K <= 65 && (K & 1); }
+// (the stage functions are exact for any K <= 125; what bounds the range is the valid part of a tile, 128 - K + 1 pixels a side: 32 at 97)
+bool ics_conv_fft_supported(int K) { return K >= 3 && K <= ICS_FFT_MAX_K && (K & 1); }
 size_t ics_conv_fft_spectrum_floats() { return (size_t)3 * ICS_FFT_P * ICS_FFT_P * 2; }   // per orientation
 
 hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s) {
-  const size_t lds = (256 + (size_t)K * 32 * 2) * sizeof(double);   // 35 KB at K = 65
+  const size_t lds = (256 + (size_t)K * 32 * 2) * sizeof(double);   // 35 KB at K = 65, 52 KB at 97
   hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(96), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr));
   return hipGetLastError();
 }

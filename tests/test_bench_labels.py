@@ -28,7 +28,7 @@ def test_labels_follow_the_library_routing(MK, blind):
         assert lab["matrix"] == bool(r.conv_fp16_split)
         assert lab["traffic_key"] == ("kernels_fft" if r.conv_family == 5 else ("kernels_matrix" if r.conv_fp16_split else "kernels_vector"))
         assert lab["conv"] == nv.RLRoute.CONV_FAMILIES[r.conv_family] and lab["gradk"] == nv.RLRoute.GRADK_FAMILIES[r.gradk_family]
-        if conv == nv.CONV_AUTO and 19 <= MK <= 65:      # round 5: fp32 transform tiles for wide PSFs on frames >= 1.5 Mpx, the PSF gradient included
+        if conv == nv.CONV_AUTO and 19 <= MK <= 97:      # round 5: fp32 transform tiles for wide PSFs on frames >= 1.5 Mpx, the PSF gradient included
             assert r.conv_fp16_split == 0 and r.conv_family == 5 and "FFT tiles" in lab["dtype_note"] and lab["dtype"] == "f32"
             assert r.gradk_family == (7 if blind else 0) and r.gradk_fp16_split == 0      # round 6: A11 + A13 fused on the tiles
             small = _route(512, MK, blind, conv)         # ... and the matrix cores below that
@@ -57,7 +57,9 @@ def test_route_switches():
     assert _route(2048, 15, True).conv_family == 1 and _route(2048, 15, False).conv_family == 5 and _route(1448, 15, False).conv_family == 1
     assert _route(6144, 13, True).conv_family == 5 and _route(2900, 9, True).conv_family == 5 and _route(2048, 9, False).conv_family == 1 and _route(2048, 13, True).conv_family == 1
     assert _route(4096, 5, True).conv_family == 5 and _route(2900, 5, True).conv_family == 1
-    assert _route(4096, 67, True).conv_family == 2
+    # 67 ... 97 (late round 6): the tiles from 0.5 Mpx (4-7 times the matrix cores' tap blocks); above 97 the tap blocks
+    assert _route(4096, 67, True).conv_family == 5 and _route(1024, 97, False).conv_family == 5 and _route(512, 67, True).conv_family == 2
+    assert _route(4096, 99, True).conv_family == 2 and _route(4096, 127, False).conv_family == 2
     # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
     assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 7
     assert _route(4096, 31, True, tv_mode=1).conv_family == 1 and _route(2048, 15, False, tv_mode=2).conv_family == 1
