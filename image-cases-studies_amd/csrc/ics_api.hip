@@ -482,7 +482,11 @@ static int pack_weights(ics_rl* j, int do_step, float step, int correlation, hip
   a.correlation = correlation; a.do_step = do_step;
   HIPCHK(ics_launch_psf(a, s));
   if (j->blk_conv) HIPCHK(ics_launch_pack_blocks(j->psf, j->g.K, j->blk_kb, j->blk_n, j->blk_conv, j->blk_corr, ics_conv_mfma_table_floats(j->blk_kb), s));
-  if (j->fft_on) HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s));   // conj(DFT2(W)) / 128^2 of both orientations
+  if (j->fft_on) {   // conj(DFT2(W)) / 128^2 of both orientations (PSF sizes above 97: of every tap block)
+    int nb = 0, kb = 0;
+    if (ics_conv_fft_blk_supported(j->g.K)) ics_conv_fft_blk_shape(j->g.K, &nb, &kb);
+    HIPCHK(ics_launch_fft_spectrum(j->psf, j->g.K, j->spec_conv, j->spec_corr, s, nb, kb));
+  }
   return ICS_OK;
 }
 
@@ -498,8 +502,10 @@ static int ensure_planar(ics_rl* j) {
     j->twins[j->ntwins].hwc = h; j->twins[j->ntwins].pl = pl; ++j->ntwins;
     if (h == j->f) j->plf_valid = false;
   }
-  if (!j->spec_conv) RC(dalloc(j->ctx, &j->spec_conv, ics_conv_fft_spectrum_floats()));
-  if (!j->spec_corr) RC(dalloc(j->ctx, &j->spec_corr, ics_conv_fft_spectrum_floats()));
+  int nb = 1, kb = 0;
+  if (ics_conv_fft_blk_supported(j->g.K)) ics_conv_fft_blk_shape(j->g.K, &nb, &kb);      // (one spectrum per tap block and orientation)
+  if (!j->spec_conv) RC(dalloc(j->ctx, &j->spec_conv, (size_t)nb * nb * ics_conv_fft_spectrum_floats()));
+  if (!j->spec_corr) RC(dalloc(j->ctx, &j->spec_corr, (size_t)nb * nb * ics_conv_fft_spectrum_floats()));
   return ICS_OK;
 }
 // whole-buffer copies HWC -> mirror / mirror -> HWC (run and stage boundaries), and the stop-test window mirror -> HWC
@@ -871,7 +877,10 @@ static bool use_matrix_conv(const ics_rl* j, const ics_rl_params* p) {
 //  1024^2 67: 0.659 -> 0.160 / 1.270 -> 0.332;  2048^2 67: 1.894 -> 0.333 / 3.621 -> 0.609;  97: 2.455 -> 0.793 / 5.182 -> 1.494;
 //  4096^2 67: 6.774 -> 1.059 / 12.78 -> 1.746;  85: 7.822 -> 1.676 / 14.43 -> 2.895;  97: 9.011 -> 2.848 / 18.46 -> 4.989)
 #ifndef ICS_FFT_AUTO_MAX_K
-#define ICS_FFT_AUTO_MAX_K 97
+#define ICS_FFT_AUTO_MAX_K 85
+#endif
+#ifndef ICS_FFT_BLK_MIN_PX
+#define ICS_FFT_BLK_MIN_PX 500000L
 #endif
 static bool fft_preferred(const IcsGeom& g, bool blind) {
   // measured on MI355X (NOTES_r05.md): per-pass time of the transform tiles is set by the tile count (128 - K + 1 valid pixels a side),
@@ -888,7 +897,7 @@ static bool fft_preferred(const IcsGeom& g, bool blind) {
   // 17: 0.170 -> 0.151 / 0.315 -> 0.248;  2900^2 9: 0.286 -> 0.265 / 0.403 -> 0.363;  15: 0.332 -> 0.296 / 0.457 -> 0.400;  4096^2 5: level / 0.683 -> 0.643;  9: 0.532 -> 0.479 /
   // 0.732 -> 0.662;  15: 0.627 -> 0.526 / 0.851 -> 0.716;  6144^2 9: 1.140 -> 0.999 / 1.622 -> 1.365;  15: 1.256 -> 1.122 / 1.821 -> 1.502.
   const long px = (long)g.uM * g.uN;
-  if (g.K > ICS_FFT_AUTO_MAX_K) return false;
+  if (g.K > ICS_FFT_AUTO_MAX_K) return ics_conv_fft_blk_supported(g.K) && px >= ICS_FFT_BLK_MIN_PX;      // tap blocks on the tiles
   if (g.K >= 51) return px >= 500000L;
   if (g.K >= 19) return px >= (blind ? 1000000L : 1500000L);
   if (g.K == 17) return px >= (blind ? 2000000L : 4000000L);
@@ -918,7 +927,7 @@ static bool pam_on_tiles(const ics_rl* j, const ics_rl_params* p, bool in_run) {
 }
 static bool use_fft_pipeline(const ics_rl* j, const ics_rl_params* p, bool in_run) {
   if (p->tv_mode != ICS_TV_SHIPPED) return pam_on_tiles(j, p, in_run);   // PAM kinds: TV term, back-projection epilogue and update on the mirrors too
-  if (!ics_conv_fft_supported(j->g.K) || p->fuse || !fft_mirror_fits(j->g)) return false;
+  if (!(ics_conv_fft_supported(j->g.K) || ics_conv_fft_blk_supported(j->g.K)) || p->fuse || !fft_mirror_fits(j->g)) return false;      // (87 ... 255: tap blocks on the tiles)
   if (p->conv == ICS_CONV_FFT) return true;
   if (p->conv != ICS_CONV_AUTO || !in_run) return false;
   const int env = ics_debug().conv_path.load(std::memory_order_relaxed);
@@ -1025,6 +1034,11 @@ static int do_conv_fft(ics_rl* j, int mode, const ics_rl_params* p, int slot, Pr
   }
   if (!a.in || !a.out || !a.f || !a.u || !a.ut) return fail(ICS_ESTATE, "FFT pipeline: a frame has no planar mirror");
   RC(pr.begin(mode == 0 ? ICS_K_SYNTH : ICS_K_BACKPROJECT));
+  if (ics_conv_fft_blk_supported(j->g.K)) {   // 87 ... 255: tap blocks, their products summed in the frequency domain (k_conv_fft_blk)
+    int nb, kb;
+    ics_conv_fft_blk_shape(j->g.K, &nb, &kb);
+    HIPCHK(ics_launch_conv_fft_blk(mode, a, mode == 1 ? j->spec_corr : j->spec_conv, nb, kb, j->ctx->stream));
+  } else
   HIPCHK(ics_launch_conv_fft(mode, a, mode == 1 ? j->spec_corr : j->spec_conv, ICS_FFT_PL_ALL, j->ctx->stream));
   RC(pr.end());
   return ICS_OK;
@@ -1217,6 +1231,12 @@ static bool use_fft_gradk(const ics_rl* j) { return j->fft_on && ics_debug().fft
 static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
   if (use_fft_gradk(j)) {
     RC(pr.begin(ICS_K_PSF_GRADIENT));
+    if (ics_conv_fft_blk_supported(j->g.K)) {   // one launch per block of lags
+      int nb, kb;
+      ics_conv_fft_blk_shape(j->g.K, &nb, &kb);
+      if ((size_t)ics_gradk_fft_blocks(j->ctx->cus) * kb * kb > j->partial_floats) return fail(ICS_ESTATE, "PSF gradient scratch too small for the lag blocks");
+      HIPCHK(ics_launch_gradk_fft_blk(porg(j, j->u), porg(j, j->e), j->g, nb, kb, j->partial, j->gradk, j->ctx->stream));
+    } else
     HIPCHK(ics_launch_gradk_fft(porg(j, j->u), porg(j, j->e), j->g, j->partial, j->gradk, j->ctx->stream));
     RC(pr.end());
     return ICS_OK;
@@ -1236,7 +1256,7 @@ static int do_gradk(ics_rl* j, const ics_rl_params* p, Prof& pr) {
 
 // A11 + A13 as one three-transform unit on the tiles (k_synth_gradk_fft): wherever the pipeline takes its gradient on the tiles
 static bool use_fused_fft(const ics_rl* j, const ics_rl_params* p) {
-  return use_fft_gradk(j) && !p->fuse && !(p->flags & ICS_FLAG_NO_FUSED_GRADK) && ics_debug().fft_fused.load(std::memory_order_relaxed) != 0;
+  return use_fft_gradk(j) && ics_conv_fft_supported(j->g.K) && !p->fuse && !(p->flags & ICS_FLAG_NO_FUSED_GRADK) && ics_debug().fft_fused.load(std::memory_order_relaxed) != 0;
 }
 static int do_synth_gradk_fft(ics_rl* j, const ics_rl_params* p, int store_all, Prof& pr) {
   const float *u = porg(j, j->u), *f = porg(j, j->f);
@@ -1340,8 +1360,8 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
     return fail(ICS_ENOSUP, "tv_mode %d not implemented (0 shipped, 1 active MM-TV, 2 PAM isotropic, 3 PAM collaborative)", p->tv_mode);
   if (p->tv_mode != ICS_TV_SHIPPED && p->fuse) return fail(ICS_ENOSUP, "fuse = 1 is only available with ICS_TV_SHIPPED");
   if (p->conv < ICS_CONV_AUTO || p->conv > ICS_CONV_FFT) return fail(ICS_EINVAL, "conv = %d is not an ICS_CONV_* value", p->conv);
-  if (p->conv == ICS_CONV_FFT && (!ics_conv_fft_supported(j->g.K) || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse))
-    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 97, the shipped loop and the PAM kinds (tv_mode 0, 2, 3; fuse 0)");
+  if (p->conv == ICS_CONV_FFT && (!(ics_conv_fft_supported(j->g.K) || (ics_conv_fft_blk_supported(j->g.K) && p->tv_mode == ICS_TV_SHIPPED)) || p->tv_mode == ICS_TV_MM_ACTIVE || p->fuse))
+    return fail(ICS_ENOSUP, "ICS_CONV_FFT: the transform-tile pipeline is built for PSF sizes 3 ... 85 (the shipped loop and the PAM kinds: tv_mode 0, 2, 3; fuse 0) and, as tap blocks, 87 ... 255 (the shipped loop)");
   if (p->conv == ICS_CONV_FFT && !fft_mirror_fits(j->g))
     return fail(ICS_ENOSUP, "ICS_CONV_FFT: the channel-planar mirror of a %d x %d frame with a %d x %d PSF is %zu bytes, beyond the 2^31 - 1 the tile kernels address "
                 "(ICS_CONV_AUTO runs such a frame on the matrix cores)", j->g.M, j->g.N, j->g.K, j->g.K, ics_planar_floats(j->g) * sizeof(float));
@@ -1792,6 +1812,7 @@ extern "C" int ics_rl_stage(ics_rl* j, int stage, const ics_rl_params* p) {
       HIPCHK(ics_launch_band_mask_e(org(j, j->e), j->g, p->band_row0, p->band_row1, s));
       break;
     case ICS_STAGE_SYNTH_GRADK:
+      if (j->fft_on && !ics_conv_fft_supported(j->g.K)) return fail(ICS_ENOSUP, "ICS_STAGE_SYNTH_GRADK on the tiles: the fused unit is built for PSF sizes that fit one tile (<= 85); above, A11 and A13 run as tap blocks");
       if (j->fft_on) {   // conv = ICS_CONV_FFT: the fused unit of the transform tiles, every tile stores its residual
         RC(pack_weights(j, 0, 0.f, 0, s));
         RC(do_synth_gradk_fft(j, p, 1, pr));

@@ -44,7 +44,8 @@
 
 #define ICS_FFT_P 128
 #ifndef ICS_FFT_MAX_K
-#define ICS_FFT_MAX_K 97        /* largest PSF size the tiles take (explicit ICS_CONV_FFT; ICS_CONV_AUTO picks them where they measured ahead: ics_api.hip fft_preferred) */
+#define ICS_FFT_MAX_K 85        /* largest PSF size ONE tile takes (44 valid pixels a side); above it the PSF is cut into tap blocks (k_conv_fft_blk), which measured
+                                   ahead from about there: 4096^2 non-blind 85 one tile 1.68 ms, 97 one tile 2.85, 99 as 2 x 2 blocks 1.59 */
 #endif
 #define ICS_FFT_PITCH 136
 #define ICS_FFT_TWS 17         /* the twiddle table behind the tile: T[j][k1] = w^(j k1), j < 8, k1 < 16, rows of 17 entries (34 dwords: the eight j of a
@@ -282,6 +283,9 @@ struct IcsFftArgs {
   int planar;               // bit mask of the frames that are channel-planar mirrors (ics_common.h): ICS_FFT_PL_*
   int wpad;                 // a tile's window starts wpad pixels up and left of its first output pixel: pad (one convolution), 2 pad (mode 2, k_conv_fft<2>: two in a row)
   float* fspec;             // mode 2: DFT of the image windows of every unit, [unit][8][1024] quads in load_spectrum's order (k_fft_image_spectrum)
+  int blk_n, blk_k;         // tap blocks (PSF sizes above ICS_FFT_MAX_K, k_conv_fft_blk / k_gradk_fft with a lag block): blk_n x blk_n blocks of blk_k x blk_k taps;
+                            // the tiles' valid part follows the BLOCK size, 128 - blk_k + 1 pixels a side.  0 = the whole PSF in one tile
+  int lag_y, lag_x;         // k_gradk_fft with tap blocks: the block of lags [lag_y, lag_y + blk_k) x [lag_x, lag_x + blk_k) this launch evaluates
   int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
   int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
@@ -359,12 +363,13 @@ static inline v2f lds_ld(const v2f* p) { return *p; }
 // instruction costs the texture addresser ~16 cycles whether it moves 4 or 16 bytes per lane: as single floats the 64 loads per thread of
 // a unit took 20 k of its 37 k shader clocks).  Rows and pixels beyond the frame's value range read as 0: rows as dropped accesses, pixels
 // through the apron's zeros (a quad that starts inside [.., uN + pad) ends inside the apron, ax >= pad + 3; quads beyond it are dropped).
-ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&pw)[2][4], int t0 = 0, int t1 = 2) {
+// (dy, dx: the window starts that much further down / right -- the tap blocks of wide PSFs)
+ICS_FFT_HD void load_window(const IcsFftArgs& a, const Mem& mem, const Unit& u, int tid, v4f (&pw)[2][4], int t0 = 0, int t1 = 2, int dy = 0, int dx = 0) {
   const int r0 = tid >> 5, xq = tid & 31;
   const int pad = a.wpad, pitch = mem.lin.pitch, ylast = a.c.g.uM + pad - 1, xlast = a.c.g.uN + pad - 1;
 #pragma unroll
   for (int t = t0; t < t1; ++t) {
-    const int X = u.ox[t] - pad + 4 * xq, Y0 = u.oy[t] - pad + r0;       // both >= -pad by construction
+    const int X = u.ox[t] - pad + dx + 4 * xq, Y0 = u.oy[t] - pad + dy + r0;       // both >= -pad by construction
     const int vo = (u.has[t] && X <= xlast) ? mem.lin.org + Y0 * pitch + X + mem.lin.cmul * u.c : ICS_FFT_NONE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pw[t][i] = ld_f32x4<4>(mem.in, (Y0 + 32 * i <= ylast) ? vo : ICS_FFT_NONE, 32 * i * pitch);
@@ -588,6 +593,22 @@ ICS_FFT_HD void stage_d_acc(const v2f* lds, int tid, const v2f (&zu)[2][8], v2f 
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) acc[s][k2] += cmulc(zu[s][k2], v[k2]);
   }
+}
+
+// Tap blocks (k_conv_fft_blk): the window's spectrum times the block's weight spectrum, added to the unit's sum -- the products of all
+// blocks meet in the frequency domain and share one inverse transform (stage_d_inverse)
+ICS_FFT_HD void stage_d_mac_half(const v2f* lds, int tid, int s, const v2f (&sp)[8], v2f (&acc)[8]) {
+  const int w = ICS_FFT_UNIFORM(tid >> 6), lane = tid & 63, row = 8 * w + (lane >> 3), q = lane & 7;
+  v2f v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = lds_ld(lds + row * ICS_FFT_PITCH + 8 * q + ((j + q) & 7) + 64 * s);
+  fft8<1>(v);
+#pragma unroll
+  for (int k2 = 0; k2 < 8; ++k2) acc[k2] += cmul(v[k2], sp[k2]);
+}
+ICS_FFT_HD void stage_d_mac(const v2f* lds, int tid, const v2f (&sp)[2][8], v2f (&acc)[2][8]) {
+  stage_d_mac_half(lds, tid, 0, sp[0], acc[0]);
+  stage_d_mac_half(lds, tid, 1, sp[1], acc[1]);
 }
 
 // E with its twiddles requested four at a time (the fused unit holds 64 registers of spectra beside this stage: as stage_c<4>)
@@ -1109,7 +1130,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
     store_window(pe, lds, opaque(tid));
     lds_barrier();
     stage_a(lds, opaque(tid));
-    load_window(a, mem, u, opaque(tid), pw);      // (behind stage A: registers)
+    load_window(a, mem, u, opaque(tid), pw, 0, 2, a.lag_y, a.lag_x);      // (behind stage A: registers; tap blocks: the window of this launch's lag block)
     lds_barrier();
     stage_b<1>(lds, opaque(tid));
     lds_barrier();
@@ -1143,9 +1164,128 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_gradk_fft(IcsFftArgs a, flo
   stage_g(lds, opaque(tid));
   lds_barrier();
   const int K = a.c.g.K;
+  if (a.blk_k) {   // tap blocks: the blk_k x blk_k lags of this launch's block, in lag order (k_gradk_fft_reduce_blk places them)
+    const int Kb = a.blk_k;
+    for (int i = tid; i < Kb * Kb; i += ICS_FFT_THREADS) {
+      const int ly = i / Kb, lx = i - ly * Kb;
+      partial[(size_t)blockIdx.x * Kb * Kb + i] = lds[ly * ICS_FFT_PITCH + lx].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
+    }
+    return;
+  }
   for (int i = tid; i < K * K; i += ICS_FFT_THREADS) {
     const int aa = i / K, bb = i - aa * K;
     partial[(size_t)blockIdx.x * K * K + i] = lds[(K - 1 - aa) * ICS_FFT_PITCH + (K - 1 - bb)].x * (1.0f / (ICS_FFT_P * ICS_FFT_P));
+  }
+}
+
+// ---- PSF sizes above ICS_FFT_MAX_K: tap blocks on the tiles -----------------------------------------------------------------------------------
+// A tile keeps 128 - K + 1 of its 128 pixels a side: 32 at 97, nothing at 129.  A convolution is linear in its taps, so the K x K PSF is cut
+// into blk_n x blk_n blocks of blk_k x blk_k taps (blk_k <= 65) and block (qa, qb) is the blk_k x blk_k kernel on the window that starts
+// (qa blk_k, qb blk_k) further down / right:
+//     out = sum_q IDFT( S_q . DFT(window_q) ) = IDFT( sum_q S_q . DFT(window_q) )
+// -- blk_n^2 forward transforms whose products meet in the frequency domain (sixteen complex values per thread), ONE inverse transform and
+// one epilogue per unit, with tiles of 128 - blk_k + 1 valid pixels a side.  The epilogues are those of modes 0 and 1 (shipped loop).
+template <int MODE>
+__global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft_blk(IcsFftArgs a) {
+  extern __shared__ __attribute__((aligned(16))) v2f lds[];
+  v2f* const twl = lds + ICS_FFT_P * ICS_FFT_PITCH;
+  const int tid = threadIdx.x;
+  const int G = gridDim.x;
+  if (tid < ICS_FFT_TW_ENTRIES) twl[tid] = tw128((tid / ICS_FFT_TWS) * (tid % ICS_FFT_TWS));
+  const Mem mem = make_mem(a, MODE);
+  const int q = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  uint32_t accg[3] = {0u, 0u, 0u}, accu[3] = {0u, 0u, 0u};
+  const int nblk = a.blk_n * a.blk_n;
+  // (the blocks' windows are NOT requested a block ahead: the running sum, the block's spectrum and a window in flight through the runtime
+  //  loop over the blocks spill 40 registers; every block waits out its window's round trip -- measured 5-10 x ahead of the matrix cores' tap
+  //  blocks as it is)
+  for (int n = q; n < a.nunits; n += G) {
+    const Unit u = decode_unit(a, n);
+    v2f acc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[s][k] = (v2f){0.f, 0.f};
+    for (int b = 0; b < nblk; ++b) {
+      const int qa = b / a.blk_n, qb = b - qa * a.blk_n;
+      {
+        v4f pw[2][4];
+        load_window(a, mem, u, opaque(tid), pw, 0, 2, qa * a.blk_k, qb * a.blk_k);
+        lds_barrier();                            // (the previous block's stage D / the previous unit's epilogue has read the tile)
+        store_window(pw, lds, opaque(tid));
+      }
+      lds_barrier();
+      stage_a(lds, opaque(tid));
+      lds_barrier();
+      stage_b<1>(lds, opaque(tid));
+      lds_barrier();
+      v2f sp[2][8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) load_spectrum_half<1>(mem.spec, 8 * (3 * b + u.c), opaque(tid), h, sp[h]);
+      stage_c<4>(lds, lds, twl, opaque(tid));
+      wave_sync();
+      stage_d_mac(lds, opaque(tid), sp, acc);
+    }
+    lds_barrier();
+    stage_d_inverse(acc, lds, opaque(tid));
+    wave_sync();
+    stage_e(lds, lds, twl, opaque(tid));
+    lds_barrier();
+    stage_b<-1>(lds, opaque(tid));
+    lds_barrier();
+    stage_g(lds, opaque(tid));
+    QuadOut qo[2];
+    const int te = opaque(tid);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) qo[t].vo = quad_lane(a, u, mem.lout, te, t, qo[t].rows, qo[t].X);
+    const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+    if (MODE == 0) {
+      v4f fimg[2][4];
+      load_image(a, mem, u, opaque(tid), fimg);
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v4f r[2];
+        read_quads(lds, te, i, r);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[t][e] = ICS_FSUB(r[t][e], fimg[t][i][e]);        // pyx:488
+          store_quad_at(a, mem, qo[t], edge, i, r[t]);
+        }
+      }
+    } else {
+      Ops ops;
+      load_ops<false>(a, mem, u, opaque(tid), 0, ops);
+      load_ops<false>(a, mem, u, opaque(tid), 1, ops);
+      lds_barrier();
+      Maxima mx; maxima_init(mx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v4f r[2];
+        read_quads(lds, te, i, r);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          maxima_quad<false>(a, u, te, t, i, r[t], ops, mx, qo[t], edge);
+          store_quad_at(a, mem, qo[t], edge, i, r[t]);
+        }
+      }
+      uint32_t kg, ku;
+      maxima_keys(mx, kg, ku);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        if (u.c == c) { accg[c] = accg[c] > kg ? accg[c] : kg; accu[c] = accu[c] > ku ? accu[c] : ku; }
+    }
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t kg = ics_wave_max_u32(accg[c]), ku = ics_wave_max_u32(accu[c]);
+      if ((tid & 63) == 0) {
+        if (kg > a.c.red[ICS_RED_MAXG + c]) atomicMax(a.c.red + ICS_RED_MAXG + c, kg);
+        if (ku > a.c.red[ICS_RED_MAXU + c]) atomicMax(a.c.red + ICS_RED_MAXU + c, ku);
+      }
+    }
   }
 }
 
@@ -1291,6 +1431,20 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_synth_gradk_fft(IcsFftArgs 
   }
 }
 
+// tap blocks: lag (lag_y + ly, lag_x + lx) is tap (K - 1 - lag_y - ly, K - 1 - lag_x - lx) of the gradient; one wave per value as below
+__global__ __launch_bounds__(256) void k_gradk_fft_reduce_blk(const float* __restrict__ partial, int nblocks, int K, int Kb, int lag_y, int lag_x, float* __restrict__ gradk) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= 3 * Kb * Kb) return;
+  const int c = i % 3, l = i / 3, ly = l / Kb, lx = l - ly * Kb;
+  const int aa = K - 1 - lag_y - ly, bb = K - 1 - lag_x - lx;
+  if (aa < 0 || bb < 0) return;
+  double s = 0.0;
+  for (int b = c + 3 * lane; b < nblocks; b += 192) s += (double)partial[(size_t)b * Kb * Kb + l];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) gradk[(aa * K + bb) * 3 + c] = (float)s;
+}
+
 // gradk[a][b][c] = sum of the blocks of the workgroups that kept channel c (block % 3 == c), in double.  One wave per value: lane l adds
 // blocks c + 3 l, c + 3 (l + 64), ... and the 64 lane sums meet in a fixed butterfly (the same bits run after run).  (One thread per value
 // with its 85 serial loads took 27 us, 7 % of the gradient kernel it follows.)
@@ -1309,7 +1463,9 @@ __global__ __launch_bounds__(256) void k_gradk_fft_reduce(const float* __restric
 // W_0 = rot180(psf) (mode 0), W_1 = psf (mode 1).  Double accumulation (a PSF value enters with its float32 value, the twiddles from a
 // double table built on the device); one workgroup per (orientation, channel, 32 columns kx): G[a][kx] = sum_b W[a][b] w^(b kx) in LDS,
 // then S[ky][kx] = conj(sum_a G[a][kx] w^(a ky)).
-__global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ psf, int K, v2f* __restrict__ spec0, v2f* __restrict__ spec1) {
+// (tap blocks: blockIdx.y = block q = qa * nb + qb of Kb x Kb taps starting at W_o[qa Kb][qb Kb], taps beyond K are zero; its spectra go to
+//  spec + q * 3 * 128 * 128.  nb = 1, Kb = K: the whole PSF.)
+__global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ psf, int K, v2f* __restrict__ spec0, v2f* __restrict__ spec1, int nb, int Kb) {
   extern __shared__ __attribute__((aligned(16))) double sm[];   // [128][2] twiddles, then [K][32][2] G
   double* twd = sm;
   double* Gs = sm + 256;
@@ -1318,17 +1474,21 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
   // products) and then its 32 x 32 values of S (K each).  (24 workgroups with all 128 rows each took 30 us at 31 x 31, 65 us at 63 x 63 --
   // per inner iteration of a blind run.)
   const int o = blockIdx.x / 48, c = (blockIdx.x / 16) % 3, kx0 = ((blockIdx.x >> 2) & 3) * 32, ky0 = (blockIdx.x & 3) * 32;
+  const int qa = (int)blockIdx.y / nb, qb = (int)blockIdx.y - qa * nb, a0 = qa * Kb, b0 = qb * Kb;
+  spec0 += (size_t)blockIdx.y * 3 * ICS_FFT_P * ICS_FFT_P; spec1 += (size_t)blockIdx.y * 3 * ICS_FFT_P * ICS_FFT_P;
   if (tid < 128) {
     double sn, cs;
     sincospi((double)tid / 64.0, &sn, &cs);
     twd[2 * tid] = cs; twd[2 * tid + 1] = -sn;
   }
   __syncthreads();
-  for (int i = tid; i < K * 32; i += 256) {
+  for (int i = tid; i < Kb * 32; i += 256) {
     const int aa = i >> 5, kx = kx0 + (i & 31);
     double re = 0.0, im = 0.0;
-    for (int b = 0; b < K; ++b) {
-      const double wv = o == 0 ? (double)psf[((K - 1 - aa) * K + (K - 1 - b)) * 3 + c] : (double)psf[(aa * K + b) * 3 + c];
+    for (int b = 0; b < Kb; ++b) {
+      const int ta = a0 + aa, tb = b0 + b;           // the tap of W_o this is
+      double wv = 0.0;
+      if (ta < K && tb < K) wv = o == 0 ? (double)psf[((K - 1 - ta) * K + (K - 1 - tb)) * 3 + c] : (double)psf[(ta * K + tb) * 3 + c];
       const int t = (b * kx) & 127;
       re += wv * twd[2 * t]; im += wv * twd[2 * t + 1];
     }
@@ -1338,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
   for (int i = tid; i < 32 * 32; i += 256) {
     const int ky = ky0 + (i >> 5), kxl = i & 31;
     double re = 0.0, im = 0.0;
-    for (int aa = 0; aa < K; ++aa) {
+    for (int aa = 0; aa < Kb; ++aa) {
       const double gr = Gs[2 * (aa * 32 + kxl)], gi = Gs[2 * (aa * 32 + kxl) + 1];
       const int t = (aa * ky) & 127;
       const double wr = twd[2 * t], wi = twd[2 * t + 1];
@@ -1352,25 +1512,34 @@ __global__ __launch_bounds__(256) void k_fft_spectrum(const float* __restrict__ 
 }  // namespace icsfft
 
 // ---- launchers -----------------------------------------------------------------------------------------------------------------------------
-// (the stage functions are exact for any K <= 125; what bounds the range is the valid part of a tile, 128 - K + 1 pixels a side: 32 at 97)
+// (the stage functions are exact for any K <= 125; what bounds the range is the valid part of a tile, 128 - K + 1 pixels a side: 44 at 85)
 bool ics_conv_fft_supported(int K) { return K >= 3 && K <= ICS_FFT_MAX_K && (K & 1); }
-size_t ics_conv_fft_spectrum_floats() { return (size_t)3 * ICS_FFT_P * ICS_FFT_P * 2; }   // per orientation
+size_t ics_conv_fft_spectrum_floats() { return (size_t)3 * ICS_FFT_P * ICS_FFT_P * 2; }   // per orientation (and per tap block)
+// tap blocks for PSF sizes above ICS_FFT_MAX_K: the fewest blocks per axis whose size stays at 65 or below (2 to 129, 3 to 193, 4 to 255)
+bool ics_conv_fft_blk_supported(int K) { return K > ICS_FFT_MAX_K && K <= 255 && (K & 1); }
+void ics_conv_fft_blk_shape(int K, int* blk_n, int* blk_k) {
+  int n = (K + 64) / 65;
+  int k = (K + n - 1) / n;
+  *blk_n = n; *blk_k = k;
+}
 
-hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s) {
-  const size_t lds = (256 + (size_t)K * 32 * 2) * sizeof(double);   // 35 KB at K = 65, 52 KB at 97
-  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(96), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr));
+hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s, int blk_n, int blk_k) {
+  const int nb = blk_n > 0 ? blk_n : 1, Kb = blk_n > 0 ? blk_k : K;
+  const size_t lds = (256 + (size_t)Kb * 32 * 2) * sizeof(double);   // 35 KB at 65, 52 KB at 97
+  hipLaunchKernelGGL(icsfft::k_fft_spectrum, dim3(96, nb * nb), dim3(256), lds, s, psf, K, reinterpret_cast<v2f*>(spec_conv), reinterpret_cast<v2f*>(spec_corr), nb, Kb);
   return hipGetLastError();
 }
 
-void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, IcsFftArgs* a) {
+void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, IcsFftArgs* a, int blk_n = 0, int blk_k = 0) {
   a->c = c;
   a->trace = nullptr;
   a->planar = 0;
   a->wy0 = a->wy1 = a->wx0 = a->wx1 = 0; a->store_all = 0;
-  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr;
+  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr; a->lag_y = a->lag_x = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
-  a->Vy = ICS_FFT_P - g.K + 1;           // valid rows per tile: all of them
+  a->blk_n = blk_n; a->blk_k = blk_k;
+  a->Vy = ICS_FFT_P - (blk_k ? blk_k : g.K) + 1;   // valid rows per tile: all of them (tap blocks: of the block's size)
   a->V = a->Vy & ~3;                     // valid pixels per tile row, whole quads (16-byte stores never straddle two tiles)
   if (mode == 2) { a->Vy = ICS_FFT_P - 2 * g.K + 2; a->V = a->Vy & ~3; a->wpad = 2 * g.pad; }   // A1 + A3 in one unit: the valid part of two convolutions in a row
   if (mode == 0) { a->oy0 = g.pad; a->ox0 = g.pad; a->oy1 = g.pad + g.M; a->ox1 = g.pad + g.N; }
@@ -1515,5 +1684,48 @@ hipError_t ics_launch_conv2_fft(const IcsConvArgs& c, const float* spec_conv, co
   a.planar = ICS_FFT_PL_ALL;
   a.spec1 = reinterpret_cast<const v2f*>(spec_corr); a.fspec = const_cast<float*>(fspec);
   return ics_launch_conv_fft_args(2, a, s);
+}
+// ---- tap blocks (PSF sizes above ICS_FFT_MAX_K) ------------------------------------------------------------------------------------------------
+// spec = this orientation's block spectra, blk_n^2 x [3][128][128] (ics_launch_fft_spectrum with blk_n, blk_k)
+hipError_t ics_launch_conv_fft_blk(int mode, const IcsConvArgs& c, const float* spec, int blk_n, int blk_k, hipStream_t s) {
+  if ((mode != 0 && mode != 1) || blk_n < 2 || blk_k < 3 || blk_k > 65 || (c.tv && c.tv_kind)) return hipErrorInvalidValue;   // (shipped loop)
+  IcsFftArgs a;
+  ics_conv_fft_fill_args(mode, c, spec, &a, blk_n, blk_k);
+  a.planar = ICS_FFT_PL_ALL;
+  static std::atomic<bool> configured[2][ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  int grid = ics_device_cus(dev);
+  if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
+  if (grid > a.nunits) grid = a.nunits;
+  auto k0 = icsfft::k_conv_fft_blk<0>;
+  auto k1 = icsfft::k_conv_fft_blk<1>;
+  auto kern = mode == 0 ? k0 : k1;
+  if (hipError_t e = ics_configure_lds(configured[mode], dev, kern, ICS_FFT_LDS_BYTES); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a);
+  return hipGetLastError();
+}
+// A12 + A13 with tap blocks: one launch of k_gradk_fft per block of lags (the residual's transform is repeated per block: the running sums of
+// several blocks do not fit the registers); partial: ics_gradk_fft_blocks() * blk_k^2 floats
+hipError_t ics_launch_gradk_fft_blk(const float* u, const float* e, const IcsGeom& g, int blk_n, int blk_k, float* partial, float* gradk, hipStream_t s) {
+  IcsConvArgs c;
+  memset(&c, 0, sizeof c);
+  c.g = g; c.in = u; c.f = e; c.out = const_cast<float*>(e); c.u = u; c.ut = u;
+  static std::atomic<bool> configured[ICS_MAX_DEVICES];
+  const int dev = ics_current_device();
+  auto kern = icsfft::k_gradk_fft<0>;
+  if (hipError_t err = ics_configure_lds(configured, dev, kern, ICS_FFT_LDS_BYTES); err != hipSuccess) return err;
+  for (int qy = 0; qy < blk_n; ++qy)
+    for (int qx = 0; qx < blk_n; ++qx) {
+      IcsFftArgs a;
+      ics_conv_fft_fill_args(0, c, nullptr, &a, blk_n, blk_k);
+      a.planar = ICS_FFT_PL_ALL;
+      a.lag_y = qy * blk_k; a.lag_x = qx * blk_k;
+      int grid = ics_gradk_fft_blocks(ics_device_cus(dev));
+      const int npairs = (a.ntiles + 1) / 2;
+      if (grid > 3 * npairs) grid = 3 * npairs;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(ICS_FFT_THREADS), ICS_FFT_LDS_BYTES, s, a, partial);
+      hipLaunchKernelGGL(icsfft::k_gradk_fft_reduce_blk, dim3((3 * blk_k * blk_k + 3) / 4), dim3(256), 0, s, partial, grid, g.K, blk_k, a.lag_y, a.lag_x, gradk);
+    }
+  return hipGetLastError();
 }
 #endif

@@ -79,7 +79,14 @@ hipError_t ics_launch_planar_convert(bool to_planar, const float* src, float* ds
 hipError_t ics_launch_update_planar(const IcsUpdateArgs& a, hipStream_t s);   // frame pointers = origins of planar mirrors
 bool ics_conv_fft_supported(int K);
 size_t ics_conv_fft_spectrum_floats();                                        // per orientation
-hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s);
+// (blk_n > 0: the spectra of blk_n x blk_n tap blocks of blk_k x blk_k taps, block q at spec + q * ics_conv_fft_spectrum_floats())
+hipError_t ics_launch_fft_spectrum(const float* psf, int K, float* spec_conv, float* spec_corr, hipStream_t s, int blk_n = 0, int blk_k = 0);
+// PSF sizes above the single-tile range (99 ... 255): the convolutions and the PSF gradient as tap blocks on the tiles -- the blocks' products
+// are summed in the frequency domain, one inverse transform per unit (k_conv_fft_blk); modes 0 and 1 of the shipped loop
+bool ics_conv_fft_blk_supported(int K);
+void ics_conv_fft_blk_shape(int K, int* blk_n, int* blk_k);
+hipError_t ics_launch_conv_fft_blk(int mode, const IcsConvArgs& c, const float* spec, int blk_n, int blk_k, hipStream_t s);
+hipError_t ics_launch_gradk_fft_blk(const float* u, const float* e, const IcsGeom& g, int blk_n, int blk_k, float* partial, float* gradk, hipStream_t s);
 // modes 0 and 1 of ics_launch_conv; `planar` = bit mask of the frames of `a` that are origins of planar mirrors (ICS_FFT_PL_*)
 #define ICS_FFT_PL_IN 1
 #define ICS_FFT_PL_OUT 2

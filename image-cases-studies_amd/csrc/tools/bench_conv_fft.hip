@@ -518,6 +518,145 @@ int emulate_conv2(int M, int K, int N) {
   return ok ? 0 : 1;
 }
 
+// spectra of the tap blocks on the host: block q = qa * nb + qb of Kb x Kb taps of orientation o, taps beyond K zero (as k_fft_spectrum with blocks)
+void host_spectrum_blk(const Host& h, int o, int nb, int Kb, std::vector<v2f>& spec) {
+  const int K = h.g.K;
+  spec.assign((size_t)nb * nb * 3 * 128 * 128, (v2f){0.f, 0.f});
+  std::vector<double> G((size_t)Kb * 128 * 2);
+  for (int q = 0; q < nb * nb; ++q) {
+    const int a0 = (q / nb) * Kb, b0 = (q % nb) * Kb;
+    for (int c = 0; c < 3; ++c) {
+      for (int a = 0; a < Kb; ++a)
+        for (int kx = 0; kx < 128; ++kx) {
+          double re = 0, im = 0;
+          for (int b = 0; b < Kb; ++b) {
+            const int ta = a0 + a, tb = b0 + b;
+            const double w = (ta < K && tb < K) ? (o == 0 ? h.psf[((size_t)(K - 1 - ta) * K + (K - 1 - tb)) * 3 + c] : h.psf[((size_t)ta * K + tb) * 3 + c]) : 0.0;
+            const double ph = -2.0 * M_PI * ((b * kx) & 127) / 128.0;
+            re += w * cos(ph); im += w * sin(ph);
+          }
+          G[((size_t)a * 128 + kx) * 2] = re; G[((size_t)a * 128 + kx) * 2 + 1] = im;
+        }
+      for (int ky = 0; ky < 128; ++ky)
+        for (int kx = 0; kx < 128; ++kx) {
+          double re = 0, im = 0;
+          for (int a = 0; a < Kb; ++a) {
+            const double ph = -2.0 * M_PI * ((a * ky) & 127) / 128.0, wr = cos(ph), wi = sin(ph);
+            const double gr = G[((size_t)a * 128 + kx) * 2], gi = G[((size_t)a * 128 + kx) * 2 + 1];
+            re += gr * wr - gi * wi; im += gr * wi + gi * wr;
+          }
+          spec[(size_t)q * 3 * 128 * 128 + icsfft::spec_index(c, ky, kx)] = (v2f){(float)(re / 16384.0), (float)(-im / 16384.0)};
+        }
+    }
+  }
+}
+
+// PSF sizes above the single-tile range: k_conv_fft_blk and the lag blocks of k_gradk_fft, stage by stage
+int emulate_blk(int M, int K, int N) {
+  Host h = make_host(M, N, K);
+  int nb, Kb;
+  ics_conv_fft_blk_shape(K, &nb, &Kb);
+  std::vector<v2f> lds((size_t)ICS_FFT_P * ICS_FFT_PITCH + 128), twl(ICS_FFT_TW_ENTRIES);
+  for (int t = 0; t < ICS_FFT_TW_ENTRIES; ++t) twl[t] = icsfft::tw128((t / ICS_FFT_TWS) * (t % ICS_FFT_TWS));
+  int rc = 0;
+  for (int mode = 0; mode < 2; ++mode) {
+    std::vector<v2f> spec;
+    host_spectrum_blk(h, mode, nb, Kb, spec);
+    std::vector<float> out(h.nf, 0.f), pout(h.pnf, 0.f);
+    uint32_t red[16] = {0};
+    IcsFftArgs a;
+    ics_conv_fft_fill_args(mode, conv_args(h, mode, mode == 0 ? h.pu.data() : h.pe.data(), pout.data(), h.pf.data(), h.pu.data(), h.put.data(), red), (const float*)spec.data(), &a, nb, Kb);
+    a.planar = 63;
+    const icsfft::Mem mem = icsfft::make_mem(a);
+    for (int n = 0; n < a.nunits; ++n) {
+      const icsfft::Unit u = icsfft::decode_unit(a, n);
+      std::vector<v2f> acc((size_t)1024 * 16, (v2f){0.f, 0.f});
+      for (int b = 0; b < nb * nb; ++b) {
+        for (int t = 0; t < 1024; ++t) { v4f pw[2][4]; icsfft::load_window(a, mem, u, t, pw, 0, 2, (b / nb) * Kb, (b % nb) * Kb); icsfft::store_window(pw, lds.data(), t); }
+        for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+        for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+        { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c<4>(snap.data(), lds.data(), twl.data(), t); }
+        for (int t = 0; t < 1024; ++t) {
+          v2f sp[2][8], ac[2][8];
+          for (int hf = 0; hf < 2; ++hf) icsfft::load_spectrum_half<1>(mem.spec, 8 * (3 * b + u.c), t, hf, sp[hf]);
+          for (int i = 0; i < 16; ++i) ac[i >> 3][i & 7] = acc[(size_t)t * 16 + i];
+          icsfft::stage_d_mac(lds.data(), t, sp, ac);
+          for (int i = 0; i < 16; ++i) acc[(size_t)t * 16 + i] = ac[i >> 3][i & 7];
+        }
+      }
+      for (int t = 0; t < 1024; ++t) { v2f z[2][8]; for (int i = 0; i < 16; ++i) z[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; icsfft::stage_d_inverse(z, lds.data(), t); }
+      { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+      for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+      for (int t = 0; t < 1024; ++t) {
+        icsfft::Maxima mx; icsfft::maxima_init(mx);
+        v4f fimg[2][4];
+        icsfft::Ops o;
+        if (mode == 0) icsfft::load_image(a, mem, u, t, fimg);
+        else { icsfft::load_ops<false>(a, mem, u, t, 0, o); icsfft::load_ops<false>(a, mem, u, t, 1, o); }
+        icsfft::QuadOut qo[2];
+        for (int tt = 0; tt < 2; ++tt) qo[tt].vo = icsfft::quad_lane(a, u, mem.lout, t, tt, qo[tt].rows, qo[tt].X);
+        const bool edge = u.ox[0] < a.ox0 || u.ox[0] + a.V > a.ox1 || u.ox[1] < a.ox0 || u.ox[1] + a.V > a.ox1;
+        for (int i = 0; i < 4; ++i) {
+          v4f r[2];
+          icsfft::read_quads(lds.data(), t, i, r);
+          if (mode == 0) { r[0] -= fimg[0][i]; r[1] -= fimg[1][i]; }
+          else { icsfft::maxima_quad<false>(a, u, t, 0, i, r[0], o, mx, qo[0], edge); icsfft::maxima_quad<false>(a, u, t, 1, i, r[1], o, mx, qo[1], edge); }
+          icsfft::store_quad_at(a, mem, qo[0], edge, i, r[0]); icsfft::store_quad_at(a, mem, qo[1], edge, i, r[1]);
+        }
+      }
+    }
+    from_planar(h, pout, out);
+    double wa;
+    const double rel = check(h, mode, out, 1, &wa);
+    printf("emulation %d x %d, K = %d as %d x %d tap blocks of %d, mode %d (%d units of %d x %d valid): max |d| = %.3e, relative to max |conv| = %.3e  %s\n", M, N, K, nb, nb, Kb, mode, a.nunits, a.Vy, a.V, wa, rel,
+           rel < 5e-6 ? "OK" : "FAIL");
+    if (!(rel < 5e-6)) rc = 1;
+  }
+  {   // the gradient's lag blocks
+    for (size_t i = 0; i < h.nf; ++i) h.e[i] = h.e[i] + 0.01f * (h.u[i] - 0.5f) * (h.f[i] != 0.f);
+    to_planar(h, h.e, h.pe);
+    IcsConvArgs c = conv_args(h, 0, h.pu.data(), h.pe.data(), h.pe.data(), h.pu.data(), h.pu.data(), nullptr);
+    std::vector<float> gk((size_t)K * K * 3, 0.f);
+    for (int qy = 0; qy < nb; ++qy)
+      for (int qx = 0; qx < nb; ++qx) {
+        IcsFftArgs a;
+        ics_conv_fft_fill_args(0, c, nullptr, &a, nb, Kb);
+        a.planar = 63; a.lag_y = qy * Kb; a.lag_x = qx * Kb;
+        const icsfft::Mem mem = icsfft::make_mem(a);
+        const int npairs = (a.ntiles + 1) / 2;
+        for (int ch = 0; ch < 3; ++ch) {
+          std::vector<v2f> acc((size_t)1024 * 16, (v2f){0.f, 0.f});
+          for (int p = 0; p < npairs; ++p) {
+            const icsfft::Unit u = icsfft::decode_unit(a, 3 * p + ch);
+            std::vector<v2f> ze((size_t)1024 * 16), zu((size_t)1024 * 16);
+            for (int pass = 0; pass < 2; ++pass) {
+              for (int t = 0; t < 1024; ++t) { v4f q[2][4]; if (pass == 0) icsfft::load_image(a, mem, u, t, q); else icsfft::load_window(a, mem, u, t, q, 0, 2, a.lag_y, a.lag_x); icsfft::store_window(q, lds.data(), t); }
+              for (int t = 0; t < 1024; ++t) icsfft::stage_a(lds.data(), t);
+              for (int t = 0; t < 1024; ++t) icsfft::stage_b<1>(lds.data(), t);
+              { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_c(snap.data(), lds.data(), twl.data(), t); }
+              for (int t = 0; t < 1024; ++t) { v2f z[2][8]; icsfft::stage_d_forward(lds.data(), t, z); for (int i = 0; i < 16; ++i) (pass ? zu : ze)[(size_t)t * 16 + i] = z[i >> 3][i & 7]; }
+            }
+            for (size_t i = 0; i < acc.size(); ++i) acc[i] += icsfft::cmulc(zu[i], ze[i]);
+          }
+          for (int t = 0; t < 1024; ++t) { v2f z[2][8]; for (int i = 0; i < 16; ++i) z[i >> 3][i & 7] = acc[(size_t)t * 16 + i]; icsfft::stage_d_inverse(z, lds.data(), t); }
+          { const std::vector<v2f> snap = lds; for (int t = 0; t < 1024; ++t) icsfft::stage_e(snap.data(), lds.data(), twl.data(), t); }
+          for (int t = 0; t < 1024; ++t) icsfft::stage_b<-1>(lds.data(), t);
+          for (int t = 0; t < 1024; ++t) icsfft::stage_g(lds.data(), t);
+          for (int ly = 0; ly < Kb; ++ly)
+            for (int lx = 0; lx < Kb; ++lx) {
+              const int aa = K - 1 - a.lag_y - ly, bb = K - 1 - a.lag_x - lx;
+              if (aa >= 0 && bb >= 0) gk[((size_t)aa * K + bb) * 3 + ch] = lds[ly * ICS_FFT_PITCH + lx].x / 16384.f;
+            }
+        }
+      }
+    const double rel = check_gradk(h, h.e, gk, 5);
+    printf("emulation %d x %d, K = %d, PSF gradient as %d x %d lag blocks: relative to max |gradk| = %.3e  %s\n", M, N, K, nb, nb, rel, rel < 1e-5 ? "OK" : "FAIL");
+    if (!(rel < 1e-5)) rc = 1;
+  }
+  return rc;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
 int gpu(int M, int K, int N, int reps) {
@@ -739,13 +878,77 @@ int gpu(int M, int K, int N, int reps) {
   return rc;
 }
 
+// GPU: the tap-block kernels (PSF sizes above the single-tile range) against float64 sums on a small frame, then timed on the given one
+int gpu_blk(int M, int K, int N, int reps) {
+  Host h = make_host(M, N, K);
+  int nb, Kb;
+  ics_conv_fft_blk_shape(K, &nb, &Kb);
+  float *du, *de, *df, *dut, *dout, *dpsf, *dspec0, *dspec1; uint32_t* dred;
+  const size_t fb = h.pnf * 4;
+  for (float** p : {&du, &de, &df, &dut, &dout}) CK(hipMalloc(p, fb));
+  CK(hipMalloc(&dpsf, h.psf.size() * 4)); CK(hipMalloc(&dred, 1024)); CK(hipMemset(dred, 0, 1024));
+  const size_t sf = (size_t)nb * nb * ics_conv_fft_spectrum_floats();
+  CK(hipMalloc(&dspec0, sf * 4)); CK(hipMalloc(&dspec1, sf * 4));
+  for (size_t i = 0; i < h.nf; ++i) h.e[i] = h.e[i] + 0.01f * (h.u[i] - 0.5f) * (h.f[i] != 0.f);
+  to_planar(h, h.e, h.pe);
+  CK(hipMemcpy(du, h.pu.data(), fb, hipMemcpyHostToDevice)); CK(hipMemcpy(de, h.pe.data(), fb, hipMemcpyHostToDevice));
+  CK(hipMemcpy(df, h.pf.data(), fb, hipMemcpyHostToDevice)); CK(hipMemcpy(dut, h.put.data(), fb, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dpsf, h.psf.data(), h.psf.size() * 4, hipMemcpyHostToDevice));
+  CK(ics_launch_fft_spectrum(dpsf, K, dspec0, dspec1, 0, nb, Kb));
+  CK(hipDeviceSynchronize());
+  int rc = 0;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const bool small = (long)M * N <= 300L * 300L;
+  for (int mode = 0; mode < 2; ++mode) {
+    CK(hipMemset(dout, 0, fb));
+    IcsConvArgs a = conv_args(h, mode, mode == 0 ? du : de, dout, df, du, dut, dred);
+    CK(ics_launch_conv_fft_blk(mode, a, mode == 0 ? dspec0 : dspec1, nb, Kb, 0));
+    CK(hipDeviceSynchronize());
+    if (small) {
+      std::vector<float> out(h.nf, 0.f), po(h.pnf);
+      CK(hipMemcpy(po.data(), dout, fb, hipMemcpyDeviceToHost)); from_planar(h, po, out);
+      double wa;
+      const double rel = check(h, mode, out, 1, &wa);
+      printf("GPU %d x %d, K = %d as %d x %d tap blocks of %d, mode %d: max |d| = %.3e, relative to max |conv| = %.3e  %s\n", M, N, K, nb, nb, Kb, mode, wa, rel, rel < 5e-6 ? "OK" : "FAIL");
+      if (!(rel < 5e-6)) rc = 1;
+    }
+    for (int i = 0; i < 2; ++i) CK(ics_launch_conv_fft_blk(mode, a, mode == 0 ? dspec0 : dspec1, nb, Kb, 0));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_conv_fft_blk(mode, a, mode == 0 ? dspec0 : dspec1, nb, Kb, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  mode %d: %.4f ms per launch\n", mode, ms / reps);
+  }
+  {
+    float *dpart, *dgk;
+    CK(hipMalloc(&dpart, (size_t)768 * Kb * Kb * 4)); CK(hipMalloc(&dgk, (size_t)3 * K * K * 4)); CK(hipMemset(dgk, 0, (size_t)3 * K * K * 4));
+    CK(ics_launch_gradk_fft_blk(du + h.porg, de + h.porg, h.g, nb, Kb, dpart, dgk, 0));
+    CK(hipDeviceSynchronize());
+    if (small) {
+      std::vector<float> gk((size_t)3 * K * K);
+      CK(hipMemcpy(gk.data(), dgk, gk.size() * 4, hipMemcpyDeviceToHost));
+      const double rel = check_gradk(h, h.e, gk, 5);
+      printf("GPU %d x %d, K = %d, PSF gradient as %d x %d lag blocks: relative to max |gradk| = %.3e  %s\n", M, N, K, nb, nb, rel, rel < 1e-5 ? "OK" : "FAIL");
+      if (!(rel < 1e-5)) rc = 1;
+    }
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) CK(ics_launch_gradk_fft_blk(du + h.porg, de + h.porg, h.g, nb, Kb, dpart, dgk, 0));
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  PSF gradient, %d launches: %.4f ms\n", nb * nb, ms / reps);
+  }
+  return rc;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "emulate")) {
     const int M = argc > 2 ? atoi(argv[2]) : 150, K = argc > 3 ? atoi(argv[3]) : 31, N = argc > 4 ? atoi(argv[4]) : 170;
+    if (ics_conv_fft_blk_supported(K)) return emulate_blk(M, K, N);
     return emulate(M, K, N) | emulate_gradk(M, K, N) | emulate_fused(M, K, N) | (128 - 2 * K + 2 >= 16 ? emulate_conv2(M, K, N) : 0);
   }
   const int M = argc > 1 ? atoi(argv[1]) : 6144, K = argc > 2 ? atoi(argv[2]) : 31, N = argc > 3 ? atoi(argv[3]) : M, reps = argc > 4 ? atoi(argv[4]) : 20;
+  if (ics_conv_fft_blk_supported(K)) return gpu_blk(M, K, N, reps);
   return gpu(M, K, N, reps);
 }

@@ -102,10 +102,10 @@ def _get_job(M, N, MK):
 def _job_bytes(key):
     """device bytes a job of this shape can come to hold: 6 frames at creation, the ping-pong residual frame and the image's
     accumulator-order copies of the overlapped / matrix-core runs (3 more), the channel-planar mirrors of the FFT-tile pipeline
-    (7, and the TV frame's for the PAM kinds; PSF sizes up to 97, any of them on a large frame since round 6) with the image
+    (7, and the TV frame's for the PAM kinds; any PSF size on a large frame since round 6) with the image
     windows' spectra of its mode 2 (1.7 frames, PSF sizes up to 25), the scratch frames of the tap-block path above 49"""
     M, N, MK = key[:3]
-    frames = 9 + (8 if MK <= 97 else 0) + (2 if MK <= 25 else 0) + (2 if MK >= 51 else 0)
+    frames = 9 + 8 + (2 if MK <= 25 else 0) + (2 if MK >= 51 else 0)
     return frames * (M + 2 * MK + 128) * (N + 2 * MK + 128) * 12
 
 

@@ -139,7 +139,7 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 49, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
-#define ICS_CONV_FFT 3    /* transform tiles (ics_conv_fft.hip, round 5; MK <= 97 since round 6): A1 / A3 / A11 as 128 x 128 overlap-save
+#define ICS_CONV_FFT 3    /* transform tiles (ics_conv_fft.hip, round 5; since round 6 every MK: one tile to 85, tap blocks to 255): A1 / A3 / A11 as 128 x 128 overlap-save
                              FFTs held in LDS, fp32 throughout -- the reference's own method (scipy's complex64 FFT over the frame,
                              lib/deconvolution.pyx:478,491), tile by tile; against float64 direct sums 2 - 5e-7 of the largest
                              convolution value.  The frames live as channel-planar mirrors for the duration of a run; the PSF gradient

@@ -57,9 +57,10 @@ def test_route_switches():
     assert _route(2048, 15, True).conv_family == 1 and _route(2048, 15, False).conv_family == 5 and _route(1448, 15, False).conv_family == 1
     assert _route(6144, 13, True).conv_family == 5 and _route(2900, 9, True).conv_family == 5 and _route(2048, 9, False).conv_family == 1 and _route(2048, 13, True).conv_family == 1
     assert _route(4096, 5, True).conv_family == 5 and _route(2900, 5, True).conv_family == 1
-    # 67 ... 97 (late round 6): the tiles from 0.5 Mpx (4-7 times the matrix cores' tap blocks); above 97 the tap blocks
+    # 67 ... 97 (late round 6): the tiles from 0.5 Mpx (4-7 times the matrix cores' tap blocks); 99 ... 255: tap blocks on the tiles, same threshold
     assert _route(4096, 67, True).conv_family == 5 and _route(1024, 97, False).conv_family == 5 and _route(512, 67, True).conv_family == 2
-    assert _route(4096, 99, True).conv_family == 2 and _route(4096, 127, False).conv_family == 2
+    assert _route(4096, 99, True).conv_family == 5 and _route(4096, 127, False).conv_family == 5 and _route(2048, 255, True).gradk_family == 6
+    assert _route(300, 129, True).conv_family == 2
     # the PAM kinds follow with their convolutions and PSF gradient (the TV term and the update stay on the HWC frames); active MM-TV does not
     assert _route(4096, 31, True, tv_mode=3).conv_family == 5 and _route(4096, 31, True, tv_mode=3).gradk_family == 7
     assert _route(4096, 31, True, tv_mode=1).conv_family == 1 and _route(2048, 15, False, tv_mode=2).conv_family == 1
@@ -80,7 +81,7 @@ def test_route_switches():
     with pytest.raises(nv.NativeError) as ei:
         nv.describe(18784, 9256, 33, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, True, conv=nv.CONV_FFT))
     assert ei.value.code == nv.ICS_ENOSUP and "mirror" in str(ei.value)
-    big = _route(512, 129, True)                   # 129 ... 255: tap blocks on the matrix cores and nothing else
+    big = _route(512, 129, True)                   # 129 ... 255 on frames below 0.5 Mpx: tap blocks on the matrix cores and nothing else
     assert (big.conv_family, big.conv_fp16_split, big.gradk_family) == (2, 1, 3)
     with pytest.raises(nv.NativeError) as ei:
         _route(512, 129, True, conv=nv.CONV_VECTOR)

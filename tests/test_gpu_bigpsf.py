@@ -27,11 +27,13 @@ def make_job(M, N, MK, seed=0, blind=False):
     return job, case, psf
 
 
-@pytest.mark.parametrize("conv", [0, 1])
+@pytest.mark.parametrize("conv", [0, 1, 3])
 @pytest.mark.parametrize("MK,M,N", [(65, 150, 131), (67, 40, 300), (99, 97, 70), (127, 140, 150), (127, 31, 33)])
 def test_big_psf_stages_against_float64_direct_sums(MK, M, N, conv):
-    """conv = 0 (ICS_CONV_AUTO): tap blocks on the matrix cores -- convolutions as blocks of <= 33 x 33 taps (do_conv_blocks), the
-    gradient as blocks of <= 31 x 31 (do_gradk_split); conv = 1 (ICS_CONV_VECTOR): the run-time-sized fp32 kernels of ics_big.hip."""
+    """conv = 0 (ICS_CONV_AUTO; these frames are below the tiles' thresholds): tap blocks on the matrix cores -- convolutions as blocks of
+    <= 33 x 33 taps (do_conv_blocks), the gradient as blocks of <= 31 x 31 (do_gradk_split); conv = 1 (ICS_CONV_VECTOR): the run-time-sized
+    fp32 kernels of ics_big.hip; conv = 3 (ICS_CONV_FFT, round 6): the transform tiles -- one tile to 97, tap blocks whose products meet in
+    the frequency domain above (k_conv_fft_blk, lag blocks of k_gradk_fft)."""
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=MK + M)
     rng = np.random.default_rng(7)
@@ -86,7 +88,7 @@ def _fft64(a, b, mode):
     return np.stack([fftconvolve(a[..., c].astype(np.float64), b[..., c].astype(np.float64), mode=mode) for c in range(3)], axis=-1)
 
 
-@pytest.mark.parametrize("conv", [0, 2])
+@pytest.mark.parametrize("conv", [0, 2, 3])
 @pytest.mark.parametrize("MK,M,N", [(129, 140, 150), (133, 64, 200), (191, 33, 300), (255, 90, 70), (255, 300, 280)])
 def test_psf_129_to_255_stages_against_float64(MK, M, N, conv):
     """PSF sizes above 127 (csrc/ics_api.hip psf_blocks_only): convolutions as up to 8 x 8 blocks of <= 33 x 33 taps, the gradient as up

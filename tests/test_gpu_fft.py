@@ -34,7 +34,7 @@ def make_job(M, N, MK, seed=0, blind=False):
 @pytest.mark.parametrize("M,N,MK", [(40, 50, 3), (70, 131, 9), (90, 100, 15), (114, 114, 15), (115, 229, 15), (150, 260, 17), (99, 197, 31),
                                     (200, 120, 31), (84, 169, 45), (130, 70, 63), (64, 129, 65), (300, 310, 23),
                                     (300, 100, 5), (260, 99, 9), (176, 108, 17), (400, 60, 31),      # (these four: ONE tile column, several tile rows)
-                                    (150, 170, 67), (200, 130, 85), (120, 140, 97)])                 # (round 6: 67 ... 97, tiles of 62 ... 32 valid pixels a side)
+                                    (150, 170, 67), (200, 130, 85), (120, 140, 97), (100, 120, 129)])   # (round 6: 67 ... 85 in one tile of 62 ... 44 valid pixels a side, above as tap blocks)
 def test_fft_convolutions_against_float64(M, N, MK):
     from lib import _native as nv
     job, case, psf = make_job(M, N, MK, seed=MK + M)
@@ -204,7 +204,7 @@ def test_fft_psf_gradient_against_float64(M, N, MK):
 
 
 @pytest.mark.parametrize("M,N,MK", [(90, 100, 15), (114, 114, 15), (115, 229, 15), (150, 260, 17), (200, 120, 31), (300, 310, 23), (230, 333, 45), (190, 170, 63),
-                                    (64, 129, 65), (300, 100, 5), (176, 108, 17), (40, 50, 3), (700, 900, 15), (150, 170, 67), (200, 130, 85), (120, 140, 97)])
+                                    (64, 129, 65), (300, 100, 5), (176, 108, 17), (40, 50, 3), (700, 900, 15), (150, 170, 67), (200, 130, 85)])
 def test_fused_residual_and_gradient_unit(M, N, MK):
     """A11 + A12 + A13 (pyx:555-571) as ONE unit per tile pair on the tiles (k_synth_gradk_fft: transform of the window, product, inverse,
     residual in the tile buffer, its transform, product with the kept window spectrum -- three transforms instead of four).
@@ -348,18 +348,19 @@ def test_few_persistent_workgroups_walk_many_units_of_one_unit_mode(debug_switch
     job.close()
 
 
-@pytest.mark.parametrize("MK,blind", [(71, True), (71, False), (97, True)])
+@pytest.mark.parametrize("MK,blind", [(71, True), (71, False), (85, True), (97, True), (111, True), (141, False), (255, True)])
 def test_whole_run_of_a_wide_psf_on_the_tiles_against_the_oracle(MK, blind):
-    """PSF sizes 67 ... 97 (late round 6): ICS_CONV_AUTO takes the tiles from 0.5 Mpx -- the stage functions never depended on the size, a
-    tile's valid part is 128 - K + 1 pixels a side -- where the matrix cores ran tap blocks.  A whole call against the pinned oracle
+    """PSF sizes 67 ... 85 (late round 6): ICS_CONV_AUTO takes the tiles from 0.5 Mpx -- the stage functions never depended on the size, a
+    tile's valid part is 128 - K + 1 pixels a side -- where the matrix cores ran tap blocks; 87 ... 255: tap blocks ON the tiles (2 x 2 to
+    4 x 4 blocks of at most 65 x 65 taps, their products summed in the frequency domain).  A whole call against the pinned oracle
     (scipy's complex64 FFT, the reference's own method), gate 1e-4 of the reference's maximum, same printed lines."""
     from lib import deconvolution as dc, _native as nv
     import contextlib, io
     M, N = 760, 800
     case = orc.synth_case_large(M, N, MK, seed=MK, blind=blind)
     r = nv.describe(M, N, MK, nv.RLJob.params(1, 200, 1, 200, 1e9, 1, 1e-3, 1e4, blind))
-    assert r.conv_family == 5 and r.gradk_family == (7 if blind else 0)
-    win = orc.default_window(M, N, MK)
+    assert r.conv_family == 5 and r.gradk_family == (0 if not blind else (7 if MK <= 85 else 6))
+    win = (40, 441, 60, 461)      # (the 255-px default window of the drivers is narrower than the widest PSFs here)
     u_r, psf_r = case["u0"].copy(), case["psf0"].copy()
     buf_r = io.StringIO()
     with contextlib.redirect_stdout(buf_r), np.errstate(all="ignore"):
