@@ -133,9 +133,11 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      (lib/banded.py BandRank: one per outer iteration, where the stop decision is taken); code that removes the
                                      exchange's host waits must replace them by events between the two streams.  Ignored by ics_rl_run.  */
 
-#define ICS_CONV_AUTO 0   /* matrix-core kernels at every size (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33;
-                             PSF gradient: MK <= 31 directly, above as tap blocks of <= 31 x 31); env
-                             ICS_CONV_PATH=vector|matrix overrides the choice of AUTO                     */
+#define ICS_CONV_AUTO 0   /* the library's choice (ics_rl_describe tells): inside ics_rl_run the fp32 transform tiles on large frames -- from 0.5 ... 12 Mpx
+                             depending on the PSF size, every size 3 ... 255 (csrc/ics_api.hip fft_preferred) -- and the fp16x2-split
+                             matrix-core kernels below (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33; PSF gradient: MK <= 31
+                             directly, above as tap blocks of <= 31 x 31); single stages (ics_rl_stage) always the latter; env
+                             ICS_CONV_PATH=vector|matrix|fft overrides the choice of AUTO                     */
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
 #define ICS_CONV_MATRIX 2 /* fp16 MFMA kernels (ics_conv_mfma.hip MK <= 49, ics_gradk_mfma.hip MK <= 31): operands split
                              into two fp16 terms (22 significand bits), three MFMAs per product, fp32 accumulate */
@@ -144,8 +146,10 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                              lib/deconvolution.pyx:478,491), tile by tile; against float64 direct sums 2 - 5e-7 of the largest
                              convolution value.  The frames live as channel-planar mirrors for the duration of a run; the PSF gradient
                              runs on the same tiles (two forward transforms per tile pair, products added up in the frequency domain; env
-                             ICS_FFT_GRADK=0: on the matrix cores).  What ICS_CONV_AUTO picks inside ics_rl_run from MK = 19 on for frames
-                             >= 1.5 Mpx (blind: 1 Mpx) and for MK = 17 from 8 Mpx; env ICS_CONV_PATH=fft forces it wherever it is built.
+                             ICS_FFT_GRADK=0: on the matrix cores).  Round 6: A11 + A13 as one three-transform unit per tile pair
+                             (ICS_FFT_FUSED=0: two kernels) and, up to 25 x 25, A1 + A3 as one unit whose interior tiles never leave the
+                             frequency domain (ICS_FFT_CONV2=0: two kernels).  What ICS_CONV_AUTO picks inside ics_rl_run on large frames
+                             (above); env ICS_CONV_PATH=fft forces it wherever it is built.
                              The PAM kinds (tv_mode 2, 3) run on it as well (TV term, back-projection epilogue G = T + lambd * gradu and
                              update on the planar mirrors); tv_mode 1 is refused.  Where image and u are exactly 0 the
                              transforms return rounding noise instead of exact zeros, like the reference's (see "DoF ratio" below) */

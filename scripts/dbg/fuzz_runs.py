@@ -11,7 +11,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 big = len(sys.argv) > 3 and sys.argv[3] == "big"      # PSF sizes 129 ... 255 (tap blocks only)
 only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]      # re-run these problems of the sequence only ...
 f64 = os.environ.get("FUZZ_F64") == "1"                                          # ... and place both results against float64 convolutions
-conv = int(os.environ.get("FUZZ_CONV", "0"))                                      # ics_rl_params.conv of the device runs (3: transform tiles, PSF sizes <= 65)
+conv = int(os.environ.get("FUZZ_CONV", "0"))                                      # ics_rl_params.conv of the device runs (3: transform tiles; FUZZ_WIDE=1: PSF sizes 67 ... 255 there)
 smax = int(os.environ.get("FUZZ_MAX", "200"))                                     # largest frame side
 worst = 0.0
 nfail = nrefnan = 0
@@ -21,6 +21,8 @@ for it in range(n):
         MK = int(rng.choice([129, 131, 133, 145, 165, 167, 199, 231, 253, 255]))
     if conv == 3:
         MK = int(rng.choice([3, 5, 9, 15, 17, 19, 21, 23, 27, 31, 33, 37, 45, 49, 51, 57, 63, 65]))
+        if os.environ.get("FUZZ_WIDE") == "1":      # round 6: one tile to 85, tap blocks on the tiles to 255
+            MK = int(rng.choice([67, 71, 79, 85, 87, 89, 97, 101, 127, 129, 161, 193, 201, 255]))
     M, N = int(rng.integers(max(8, MK // 3), smax)), int(rng.integers(max(8, MK // 3), smax))
     blind = bool(rng.integers(0, 2))
     case = orc.synth_case(M, N, MK, seed=int(rng.integers(0, 1 << 30)), blind=blind)
