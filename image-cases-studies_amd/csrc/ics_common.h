@@ -114,6 +114,7 @@ struct IcsDebug {
   std::atomic<int> fft_gradk;         // ICS_FFT_GRADK         0 = the FFT-tile pipeline takes its PSF gradient on the matrix cores (k_gradk_mfma on the mirrors) instead of on the tiles
   std::atomic<int> fft_fused;         // ICS_FFT_FUSED         0 = the FFT-tile pipeline runs A11 and A13 as two kernels (k_conv_fft<0> + k_gradk_fft) instead of the fused three-transform unit
   std::atomic<int> fft_conv2;         // ICS_FFT_CONV2         0 = the FFT-tile pipeline runs A1 and A3 as two kernels; 1 (default) = as one unit per tile pair (k_conv_fft<2>) for the PSF sizes it pays for; 2 = wherever it is built
+  std::atomic<int> fft_rot;           // ICS_FFT_ROT           0 = mode 2 of the tiles walks its units from the first tile row (the last, partial round is then the bottom row's four-transform units)
   std::atomic<int> graph;             // ICS_GRAPH             0 (default) never, 1 always, -1 frames <= 1.2 Mpx: one hipGraph launch per outer iteration (measured: no gain, NOTES_r04.md 4d)
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
   IcsDebug() {
@@ -133,6 +134,7 @@ struct IcsDebug {
     fft_gradk = env_int("ICS_FFT_GRADK", 1);
     fft_fused = env_int("ICS_FFT_FUSED", 1);
     fft_conv2 = env_int("ICS_FFT_CONV2", 1);
+    fft_rot = env_int("ICS_FFT_ROT", 1);
     graph = env_int("ICS_GRAPH", 0);
     overlap = env_int("ICS_OVERLAP", 1);
     pool_limit_mb = env_int("ICS_POOL_LIMIT_MB", -1);

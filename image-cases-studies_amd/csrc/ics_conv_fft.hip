@@ -41,6 +41,8 @@
 #include "ics_common.h"
 #include "ics_kernels.h"
 #include "ics_tw128.h"
+#include <algorithm>
+#include <vector>
 
 #define ICS_FFT_P 128
 #ifndef ICS_FFT_MAX_K
@@ -286,6 +288,8 @@ struct IcsFftArgs {
   int blk_n, blk_k;         // tap blocks (PSF sizes above ICS_FFT_MAX_K, k_conv_fft_blk / k_gradk_fft with a lag block): blk_n x blk_n blocks of blk_k x blk_k taps;
                             // the tiles' valid part follows the BLOCK size, 128 - blk_k + 1 pixels a side.  0 = the whole PSF in one tile
   int lag_y, lag_x;         // k_gradk_fft with tap blocks: the block of lags [lag_y, lag_y + blk_k) x [lag_x, lag_x + blk_k) this launch evaluates
+  int rot;                  // the walk starts `rot` units into the unit list and wraps around (mode 2: so that the last, partial round of units is
+                            // not the bottom tile row, whose units are the outer ring's four-transform ones).  Order only: results do not change
   int wy0, wy1, wx0, wx1;   // k_synth_gradk_fft: the stop-test window in u-frame coordinates -- the residual is stored to its frame for the tiles
   int store_all;            // that touch it (pyx:600-601, 627 read nothing else of it), or for every tile (single stage)
   long long* trace;         // harness builds with -DICS_FFT_TRACE: [workgroup][unit round][wave][10] shader-clock stamps, else unused
@@ -313,6 +317,12 @@ ICS_FFT_HD Unit decode_unit(const IcsFftArgs& a, int n) {
   return u;
 }
 
+// walk position k -> unit (positions beyond the list stay beyond it: their accesses are dropped)
+ICS_FFT_HD int walk_unit(const IcsFftArgs& a, int k) {
+  if (k >= a.nunits) return k;
+  const int n = k + a.rot;
+  return n < a.nunits ? n : n - a.nunits;
+}
 ICS_FFT_HD Lay make_lay(const IcsGeom& g, bool) {
   Lay l;
   l.pitch = ics_ppitch(g); l.org = g.ay * l.pitch + g.ax; l.cmul = g.rows * l.pitch;
@@ -919,12 +929,13 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
   v4f pw[2][4];
   ICS_FFT_PROBE_STAGGER();
   if (q < a.nunits) {
-    load_window(a, mem, decode_unit(a, q), opaque(tid), pw);
+    load_window(a, mem, decode_unit(a, walk_unit(a, q)), opaque(tid), pw);
     store_window(pw, lds, opaque(tid));
     lds_barrier();
     stage_a(lds, opaque(tid));
   }
-  for (int n = q; n < a.nunits; n += G) {
+  for (int k = q; k < a.nunits; k += G) {
+    const int n = walk_unit(a, k);
     const Unit u = decode_unit(a, n);
     ICS_FFT_STAMP(0);
     lds_barrier();
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     wave_sync();
     }
     ICS_FFT_STAMP(4);
-    load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
+    load_window(a, mem, decode_unit(a, walk_unit(a, k + G)), opaque(tid), pw, 0, MODE == 0 ? 2 : 1);   // next unit (beyond the last one: dropped accesses); mode 1 holds 64 operand registers through stage G and requests the second tile behind it
     stage_e(lds, lds, twl, opaque(tid));
     v4f fimg[2][4];
     Ops ops;
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
     // window goes out between the passes (registers: 128 per thread with 1024 of them).
     if (MODE >= 1) {
       load_ops<TV>(a, mem, u, opaque(tid), 1, ops, ICS_FFT_M1_EARLY, 4);
-      if (ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
+      if (ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, walk_unit(a, k + G)), opaque(tid), pw, 1, 2);
     }
     Maxima mx; maxima_init(mx);
     v4f res[4][2];
@@ -1060,7 +1071,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
         else { maxima_quad<TV>(a, u, te, 0, i, res[i][0], ops, mx, qo[0], false); store_quad_at(a, mem, qo[0], false, i, res[i][0]); }
         asm volatile("" ::: "memory");
       }
-      if (!ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, n + G), opaque(tid), pw, 1, 2);
+      if (!ICS_FFT_M1_WIN) load_window(a, mem, decode_unit(a, walk_unit(a, k + G)), opaque(tid), pw, 1, 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (edge) { maxima_quad<TV>(a, u, te, 1, i, res[i][1], ops, mx, qo[1], true); store_quad_at(a, mem, qo[1], true, i, res[i][1]); }
@@ -1068,7 +1079,7 @@ __global__ __launch_bounds__(ICS_FFT_THREADS) void k_conv_fft(IcsFftArgs a) {
       }
     }
     ICS_FFT_STAMP(8);
-    if (n + G < a.nunits) {
+    if (k + G < a.nunits) {
       store_window(pw, lds, opaque(tid));      // (the slots this thread just read)
       lds_barrier();
       stage_a(lds, opaque(tid));
@@ -1535,7 +1546,7 @@ void ics_conv_fft_fill_args(int mode, const IcsConvArgs& c, const float* spec, I
   a->trace = nullptr;
   a->planar = 0;
   a->wy0 = a->wy1 = a->wx0 = a->wx1 = 0; a->store_all = 0;
-  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr; a->lag_y = a->lag_x = 0;
+  a->wpad = c.g.pad; a->fspec = nullptr; a->spec1 = nullptr; a->lag_y = a->lag_x = 0; a->rot = 0;
   a->spec = reinterpret_cast<const v2f*>(spec);
   const IcsGeom& g = c.g;
   a->blk_n = blk_n; a->blk_k = blk_k;
@@ -1683,6 +1694,38 @@ hipError_t ics_launch_conv2_fft(const IcsConvArgs& c, const float* spec_conv, co
   ics_conv_fft_fill_args(2, c, spec_conv, &a);
   a.planar = ICS_FFT_PL_ALL;
   a.spec1 = reinterpret_cast<const v2f*>(spec_corr); a.fspec = const_cast<float*>(fspec);
+  // Where the static walk starts: the units of the outer ring take four transforms instead of two (about 1.6 of a unit's time), and a walk from
+  // the first tile row ends on the last one -- the final, partial round of units is then made of the heaviest units (4096^2 / 15: 86 units of
+  // the bottom row on 86 workgroups while 170 idle: 0.293 -> 0.281 ms with the walk started half way).  Of eight starting points the one with
+  // the lightest most-loaded workgroup is taken (workgroup of walk position k = k mod grid); the choice depends on the geometry and the grid
+  // only and is kept for the next launch.  Order only: results do not change.
+  if (ics_debug().fft_rot.load(std::memory_order_relaxed)) {
+    static std::atomic<long long> cache_key{-1};
+    static std::atomic<int> cache_rot{0};
+    const int dev = ics_current_device();
+    int grid = ics_device_cus(dev);
+    if (const int mw = ics_debug().max_wgs.load(std::memory_order_relaxed); mw > 0 && grid > mw) grid = mw;
+    if (grid > a.nunits) grid = a.nunits;
+    const long long key = ((long long)c.g.M << 40) ^ ((long long)c.g.N << 16) ^ ((long long)c.g.K << 8) ^ (long long)grid;
+    if (cache_key.load(std::memory_order_acquire) == key) a.rot = cache_rot.load(std::memory_order_relaxed);
+    else {
+      std::vector<unsigned char> ring((size_t)a.nunits);
+      for (int n = 0; n < a.nunits; ++n) ring[n] = icsfft::unit_is_border(a, icsfft::decode_unit(a, n)) ? 1 : 0;
+      std::vector<int> load((size_t)grid);
+      int best = 0; long best_cost = -1;
+      static const int order[8] = {4, 0, 2, 6, 1, 3, 5, 7};      // (ties: the walk started half way first -- the form that was measured)
+      for (int ci = 0; ci < 8; ++ci) {
+        const int cand = order[ci];
+        a.rot = (int)((long long)a.nunits * cand / 8);
+        std::fill(load.begin(), load.end(), 0);
+        for (int k = 0; k < a.nunits; ++k) load[k % grid] += ring[icsfft::walk_unit(a, k)] ? 16 : 10;      // (tenths of a two-transform unit)
+        const long cost = *std::max_element(load.begin(), load.end());
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = a.rot; }
+      }
+      a.rot = best;
+      cache_rot.store(best, std::memory_order_relaxed); cache_key.store(key, std::memory_order_release);
+    }
+  }
   return ics_launch_conv_fft_args(2, a, s);
 }
 // ---- tap blocks (PSF sizes above ICS_FFT_MAX_K) ------------------------------------------------------------------------------------------------
