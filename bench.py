@@ -59,6 +59,10 @@ def labels(route, fuse=False):
     elif split_gradk:
         dtype = "f32 (fp32-product convolutions; fp16x2-split MFMA PSF gradient, fp32 accumulate)"
         note = "fp32 products in the two PSF convolutions (packed-fp32 vector kernels); the PSF gradient on the matrix cores with fp16x2-split operands"
+    elif route.conv_family == 6 and not fuse:
+        dtype = "f32"
+        note = ("fp32 throughout: one cooperative launch per outer iteration, a (tile, channel) of the frame per compute unit with its operands resident "
+                "in LDS, fp32 FMA convolutions in a fixed order (ics_small.hip)")
     else:
         dtype = "f32"
         note = "fp32 throughout (packed-fp32 vector convolutions%s)" % (", fp32-MFMA PSF gradient" if route.gradk_family else "")
@@ -524,6 +528,10 @@ def main():
                                           "fp32 transform tiles (ics_conv_fft.hip), forced with --conv fft": timed_run(ctx, M, MK, blind, 0, 3, 50, 10)}
             oc = {}
             oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
+            # the reference's blind workload (deconvolve.py:277-286: a 255 x 255 window at every pyramid level): one cooperative launch per outer iteration
+            # since round 6 (ics_small.hip), and the multi-launch path it replaced (matrix cores, forced with conv = 2)
+            oc["blind 255^2 15x15 (the blind window of deblur_module; cooperative small-frame kernel)"] = timed_run(ctx, 255, 15, True, 0, conv, 400, 50)
+            oc["blind 255^2 15x15 on the multi-launch path (conv = matrix)"] = timed_run(ctx, 255, 15, True, 0, 2, 400, 50)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)
             oc["configs[1] non-blind 2048^2 15x15 + active MM-TV (tv_mode 1, build-defined)"] = timed_run(ctx, 2048, 15, False, 1, conv, 50, 5)
             oc["configs[1] non-blind 2048^2 15x15 + PAM isotropic TV (tv_mode 2, build-defined)"] = timed_run(ctx, 2048, 15, False, 2, conv, 50, 5)

@@ -200,6 +200,13 @@ struct ics_rl {
   bool conv2_off;       // the spectra did not fit the device memory once: this job runs A1 and A3 as two kernels from then on
   bool fft_on;
   bool plf_valid;                       // the mirror of the image frame still mirrors it (every writer of j->f calls image_changed)
+  // small frames (ics_small.hip): the inner iterations of an outer one as a cooperative launch
+  float* small_part;                    // the tiles' shares of the PSF gradient (3 x tiles x K^2)
+  unsigned long long* small_bar;        // the grid barrier's counters, zeroed at the start of a run
+  unsigned long long* small_keys;       // the tiles' step-size maxima (8 x workgroups)
+  unsigned long long small_gen;         // barriers passed since then
+  bool small_off;                       // the cooperative launch was refused once: this job stays on the multi-launch path
+  bool small_bak;                       // the next cooperative launch first copies psf / psf_caller to psf_bak (overlapped statistics, blind)
 };
 
 static inline float* org(ics_rl* j, float* base) { return base + j->origin; }
@@ -228,7 +235,7 @@ extern "C" int ics_debug_set(const char* name, int value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_rot", &d.fft_rot}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_rot", &d.fft_rot}, {"small_iter", &d.small_iter}, {"small_trace", &d.small_trace}, {"fail_small_launch", &d.fail_small_launch}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { t.v->store(value, std::memory_order_relaxed); g_debug_epoch.fetch_add(1, std::memory_order_relaxed); return 0; }
   return -1;
@@ -239,7 +246,7 @@ extern "C" int ics_debug_get(const char* name, int* value) {
   struct { const char* n; std::atomic<int>* v; } tab[] = {
       {"max_wgs", &d.max_wgs}, {"dynamic_tiles", &d.dynamic_tiles}, {"conv_rs", &d.conv_rs}, {"conv_nh", &d.conv_nh}, {"conv_path", &d.conv_path},
       {"fused_gradk", &d.fused_gradk}, {"update_wg_per_cu", &d.update_wg_per_cu}, {"update_kernel", &d.update_kernel}, {"fused_rs", &d.fused_rs},
-      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_rot", &d.fft_rot}};
+      {"planar_image", &d.planar_image}, {"pam_exact", &d.pam_exact}, {"fail_window_alloc", &d.fail_window_alloc}, {"graph", &d.graph}, {"pool_limit_mb", &d.pool_limit_mb}, {"overlap", &d.overlap}, {"fft_gradk", &d.fft_gradk}, {"fft_fused", &d.fft_fused}, {"fft_conv2", &d.fft_conv2}, {"fft_rot", &d.fft_rot}, {"small_iter", &d.small_iter}, {"small_trace", &d.small_trace}, {"fail_small_launch", &d.fail_small_launch}};
   for (auto& t : tab)
     if (strcmp(t.n, name) == 0) { *value = t.v->load(std::memory_order_relaxed); return 0; }
   return -1;
@@ -368,7 +375,7 @@ extern "C" void ics_rl_destroy(ics_rl* j) {
   hipSetDevice(j->ctx->device);
   hipStreamSynchronize(j->ctx->stream);
   void* ptrs[] = {j->facc[0], j->facc[1], j->tvf, j->u, j->u2, j->ut, j->gr, j->f, j->e, j->psf, j->gradk, j->wconv, j->wcorr, j->bt_conv, j->bt_corr, j->psf_caller, j->partial, j->psf_work, j->blk_conv, j->blk_corr, j->blk_scr, j->blk_negf, j->blk_red,
-                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64, j->e2, j->psf_bak};
+                  j->red, j->dofkeys, j->sched, j->scal, j->dacc, j->ukey, j->flags, j->z, j->tw, j->weights, j->gradk64, j->e2, j->psf_bak, j->small_part, j->small_bar, j->small_keys};
   if (j->ctx->stream2) hipStreamSynchronize(j->ctx->stream2);   // (the statistics' stream uses the job's buffers as well: drain it before they are recycled)
   for (void* p : ptrs) if (p) j->ctx->pool.release(p);   // (recycled by the context: ordered on its stream, no hipFree synchronisation)
   for (int i = 0; i < j->ntwins; ++i) if (j->twins[i].pl) j->ctx->pool.release(j->twins[i].pl);
@@ -1376,6 +1383,72 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
   return ICS_OK;
 }
 
+// Small frames (ics_small.hip): every (tile, channel) of the u-frame on a compute unit of its own, the operands of the five inner iterations
+// resident in LDS, ONE cooperative launch per outer iteration instead of 25 - 30.  What ICS_CONV_AUTO picks for the shipped loop when the
+// frame is small enough (3 x tiles of 32 or 64 <= compute units, operands <= 160 KB of LDS: up to ~290^2 at 31 x 31, ~570^2 at 15 x 15);
+// an explicit ICS_CONV_* request, ICS_CONV_PATH or the debug switch `small_iter` = 0 keep the multi-launch families.
+static bool use_small_iter(const ics_rl* j, const ics_rl_params* p, IcsSmallPlan* plan = nullptr) {
+  if (p->conv != ICS_CONV_AUTO || p->tv_mode != ICS_TV_SHIPPED || p->fuse || j->fft_on || j->small_off) return false;
+  if (ics_debug().conv_path.load(std::memory_order_relaxed) != 0 || !ics_debug().small_iter.load(std::memory_order_relaxed)) return false;
+  // non-blind (two convolutions and two barriers per inner iteration): measured level with the multi-launch path at 255^2 for PSF sizes up to 15 (0.029 ms
+  // either way), ahead of it from 17 x 17 (255^2 / 23: 0.057 -> 0.041) and on frames up to ~160^2 at every size (128^2 / 7: 0.022 -> 0.018)
+  if (!p->blind && j->g.K < 17 && (long)j->g.uM * j->g.uN > 26000L) return false;
+  IcsSmallPlan pl;
+  if (!ics_small_plan(j->g, j->ctx ? j->ctx->cus : 256, &pl, ics_debug().small_iter.load(std::memory_order_relaxed) == 2)) return false;
+  if (plan) *plan = pl;
+  return true;
+}
+
+static int ensure_small(ics_rl* j, const IcsSmallPlan& pl) {
+  if (!j->small_part) RC(dalloc(j->ctx, &j->small_part, (size_t)pl.nwg * j->g.K * j->g.K));
+  if (!j->small_bar) RC(dalloc(j->ctx, &j->small_bar, (size_t)ICS_SMALL_BAR_WORDS));
+  if (!j->small_keys) RC(dalloc(j->ctx, &j->small_keys, (size_t)8 * pl.nwg));
+  return ICS_OK;
+}
+
+// pyx:462-589 for one outer iteration: ut = u (the untouched input frame is the majoriser), INNER inner iterations, u2 receives u
+static int do_small_iter(ics_rl* j, const ics_rl_params* p, const IcsSmallPlan& pl, int inner, Prof& pr) {
+  IcsSmallArgs a;
+  memset(&a, 0, sizeof a);
+  a.u_in = org(j, j->u); a.u_out = org(j, j->u2); a.f = org(j, j->f); a.e = org(j, j->e);
+  a.red = red_of(j); a.dofkeys = dof_of(j); a.scal = j->scal;
+  a.psf = j->psf; a.psf_caller = j->psf_caller; a.frozen = j->flags;
+  a.psf_bak = j->small_bak ? j->psf_bak : nullptr;
+  a.part = j->small_part; a.keys = j->small_keys; a.gradk = j->gradk; a.bar = j->small_bar; a.bar_gen = j->small_gen;
+  a.step = p->step_factor; a.lambd = p->lambd; a.blind = p->blind; a.correlation = p->correlation; a.inner = inner;
+  a.plan = pl; a.g = j->g;
+  const bool trace = ics_debug().small_trace.load(std::memory_order_relaxed) != 0;
+  unsigned long long* tr = nullptr;
+  if (trace && dalloc(j->ctx, &tr, (size_t)pl.nwg * 64) == ICS_OK) a.trace = tr;
+  RC(pr.begin(ICS_K_SMALL_ITER));
+  const hipError_t he = ics_debug().fail_small_launch.exchange(0) ? hipErrorCooperativeLaunchTooLarge : ics_launch_small_iter(a, j->ctx->stream);
+  RC(pr.end());
+  if (he != hipSuccess) return fail(ICS_EHIP, "cooperative launch of the small-frame iteration: %s", hipGetErrorString(he));   // (nothing was queued)
+  if (tr) {   // phase timeline: per stamp the first and the last workgroup to reach it, in us from the first stamp of the launch (100 MHz clock)
+    std::vector<unsigned long long> h((size_t)pl.nwg * 64);
+    HIPCHK(hipStreamSynchronize(j->ctx->stream));
+    HIPCHK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (int w = 0; w < pl.nwg; ++w) if (h[(size_t)w * 64] && h[(size_t)w * 64] < t0) t0 = h[(size_t)w * 64];
+    fprintf(stderr, "small_trace: %d workgroups, stamp: first / last workgroup (us)\n", pl.nwg);
+    fprintf(stderr, "  workgroup 0: %llu shader clocks in %.2f us = %.0f MHz\n", h[62], (double)h[63] / 100.0, h[63] ? (double)h[62] / ((double)h[63] / 100.0) : 0.0);
+    for (int k = 0; k < 62; ++k) {
+      unsigned long long lo = ~0ull, hi = 0;
+      for (int w = 0; w < pl.nwg; ++w) { const unsigned long long v = h[(size_t)w * 64 + k]; if (!v) continue; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+      if (!hi) break;
+      fprintf(stderr, "  %2d  %7.2f  %7.2f\n", k, (double)(lo - t0) / 100.0, (double)(hi - t0) / 100.0);
+    }
+    j->ctx->pool.release(tr);
+  }
+  j->small_gen += (unsigned long long)ics_small_barriers(p->blind, inner);
+  j->small_bak = false;
+  // as after the first update of an outer iteration (do_update): the untouched old u is the majoriser, the spare holds u
+  float* old_ut = j->ut;
+  j->ut = j->u; j->u = j->u2; j->u2 = old_ut;
+  j->ut_is_u = false;
+  return ICS_OK;
+}
+
 // One submission per outer iteration (round 4).  deblur_module runs its blind phase on a 255-px window at every pyramid level
 // (deconvolve.py:138-141,277-286): 15 ... 35 launches of 5 ... 15 us each per outer iteration, where the host's launch calls and
 // the gaps between dependent dispatches weigh as much as the kernels.  The launches of an outer iteration (pyx:462-638: five inner
@@ -1383,7 +1456,7 @@ static int check_params(ics_rl* j, const ics_rl_params* p) {
 // with hipGraphLaunch.  Not with profiling (events between the kernels), not with the opt-in fused update + convolution (its own
 // ping-pong), not with an empty window (host-side NaN upload).  Default: frames up to 1.2 Mpx; debug switch `graph` = 0 / 1 forces.
 static bool use_graph(const ics_rl* j, const ics_rl_params* p) {
-  if (p->profile || p->fuse || j->win_empty || use_fft_pipeline(j, p, true)) return false;
+  if (p->profile || p->fuse || j->win_empty || use_fft_pipeline(j, p, true) || use_small_iter(j, p)) return false;
   const int g = ics_debug().graph.load(std::memory_order_relaxed);
   if (g >= 0) return g != 0;
   return (long)j->g.uM * j->g.uN <= 1200000L;
@@ -1418,7 +1491,7 @@ static int use_overlap(const ics_rl* j, const ics_rl_params* p) {
   if (sw != 1) return 0;
   // (round 6: on the transform tiles -- one persistent 1024-thread workgroup per CU -- the statistics' small kernels fit beside the iteration's at
   //  every size: 4096^2 / 15, drained -> second stream: blind 0.6713 -> 0.6591 ms, non-blind 0.4734 -> 0.4629; look-ahead on the job's own stream 0.669 / 0.470)
-  if (j->fft_on) return 1;
+  if (j->fft_on || use_small_iter(j, p)) return 1;   // (the cooperative iteration kernel of small frames leaves room beside it as well: blind 255^2 / 15 0.060 -> 0.052 ms)
   if (p->blind ? (px >= 600000L && px <= 2500000L) : px <= 4500000L) return 1;
   return ICS_LOOKAHEAD_DEFAULT ? 2 : 0;
 }
@@ -1434,9 +1507,11 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
   struct Flag { ics_rl* j; bool was; ~Flag() { j->fft_on = was; } } flag{j, j->fft_on};   // (the gradient's predicates read it)
   j->fft_on = fft;
   const bool blocks = !fft && use_block_conv(j, p, 0), matrix = !fft && !blocks && use_matrix_conv(j, p);
-  r->conv_family = fft ? 5 : (blocks ? 2 : (matrix ? 1 : (use_big_conv(j, p, 0) ? 4 : 3)));
-  r->conv_fp16_split = blocks || matrix;
-  if (p->blind) {
+  const bool small = !fft && use_small_iter(j, p);
+  r->conv_family = small ? 6 : (fft ? 5 : (blocks ? 2 : (matrix ? 1 : (use_big_conv(j, p, 0) ? 4 : 3))));
+  r->conv_fp16_split = !small && (blocks || matrix);
+  if (p->blind && small) r->gradk_family = 8;
+  else if (p->blind) {
     const bool fused = !p->fuse && use_fused_gradk(j, p);
     if (fused) r->gradk_family = 1;
     else if (use_fused_fft(j, p)) r->gradk_family = 7;
@@ -1446,7 +1521,7 @@ static int describe_impl(ics_rl* j, const ics_rl_params* p, ics_rl_route* r) {
     else r->gradk_family = use_matrix_gradk(j, p) ? 2 : 4;
     r->gradk_fp16_split = r->gradk_family <= 3;
   }
-  r->image_in_accumulator_order = (matrix && use_image_acc(p) && ics_conv_mfma_rs(j->g.K, j->g, j->ctx ? j->ctx->cus : 256) != 0) || (r->gradk_family == 1 && use_image_acc(p));   // (no HIP call on this path: ics_describe has no context and assumes an MI355X's 256 CUs)
+  r->image_in_accumulator_order = small ? 0 : (matrix && use_image_acc(p) && ics_conv_mfma_rs(j->g.K, j->g, j->ctx ? j->ctx->cus : 256) != 0) || (r->gradk_family == 1 && use_image_acc(p));   // (no HIP call on this path: ics_describe has no context and assumes an MI355X's 256 CUs)
   r->graph = use_graph(j, p) ? 1 : 0;
   return ICS_OK;
 }
@@ -1499,6 +1574,10 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     // mode 2's image spectra are 1.6 frames more (128 KB per unit): when they do not fit, the run takes A1 and A3 as two kernels instead
     if (use_conv2(j, p) && !j->fspec && dalloc(j->ctx, &j->fspec, ics_conv2_fft_fspec_floats(j->g), false) != ICS_OK) { j->fspec = nullptr; j->conv2_off = true; (void)hipGetLastError(); }
   }
+  IcsSmallPlan small_plan;
+  bool small = use_small_iter(j, p, &small_plan);
+  if (small && ensure_small(j, small_plan) != ICS_OK) { small = false; (void)hipGetLastError(); }   // (AUTO's choice: the multi-launch path needs nothing more)
+  if (small) { HIPCHK(hipMemsetAsync(j->small_bar, 0, (size_t)ICS_SMALL_BAR_WORDS * sizeof(unsigned long long), s)); j->small_gen = 0; j->small_bak = false; }
   {  // everything but the caller's in-fields is overwritten
     ics_rl_stats in = *st;
     memset(st, 0, sizeof *st);
@@ -1531,6 +1610,17 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
     j->ev_chain = -1;
     if (p->fuse) RC(do_majorize(j, pr));                      // pyx:462 (explicit copy only for the fused path)
     else j->ut_is_u = true;                                   // pyx:462 without a copy (see ut_of)
+    if (small) {   // one cooperative launch for the INNER inner iterations (ics_small.hip)
+      if (do_small_iter(j, p, small_plan, INNER, p->profile > 0 ? pr_on : pr_off) == ICS_OK) { inner_done += INNER; return ICS_OK; }
+      small = false; j->small_off = true; (void)hipGetLastError();   // refused by the runtime: this job runs the multi-launch path from here on
+      RC(pack_weights(j, 0, 0.f, 0, s));   // (the weight tables of the multi-launch kernels follow the PSF the cooperative launches have stepped so far)
+      if (j->small_bak) {   // (the copy of the PSF the refused launch was to take)
+        const size_t npsf = (size_t)3 * j->g.K * j->g.K;
+        HIPCHK(hipMemcpyAsync(j->psf_bak, j->psf, npsf * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(j->psf_bak + npsf, j->psf_caller, npsf * 4, hipMemcpyDeviceToDevice, s));
+        j->small_bak = false;
+      }
+    }
     const bool fuse = p->fuse != 0;
     const bool fused_gk = p->blind && !fuse && use_fused_gradk(j, p);
     const bool fused_fft = p->blind && !fuse && use_fused_fft(j, p);
@@ -1668,7 +1758,8 @@ extern "C" int ics_rl_run(ics_rl* j, const ics_rl_params* p, ics_rl_stats* st) {
       j->par = enq & 1;
       if (enq > 0) {
         { float* t = j->e; j->e = j->e2; j->e2 = t; }         // the statistics of the previous iteration read the other frame
-        if (p->blind) {
+        if (p->blind && small) j->small_bak = true;           // (the cooperative kernel takes the copy itself: two launches and a queue switch less per outer iteration)
+        else if (p->blind) {
           HIPCHK(hipMemcpyAsync(j->psf_bak, j->psf, npsf * 4, hipMemcpyDeviceToDevice, s));
           HIPCHK(hipMemcpyAsync(j->psf_bak + npsf, j->psf_caller, npsf * 4, hipMemcpyDeviceToDevice, s));
         }

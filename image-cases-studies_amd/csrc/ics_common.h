@@ -115,6 +115,9 @@ struct IcsDebug {
   std::atomic<int> fft_fused;         // ICS_FFT_FUSED         0 = the FFT-tile pipeline runs A11 and A13 as two kernels (k_conv_fft<0> + k_gradk_fft) instead of the fused three-transform unit
   std::atomic<int> fft_conv2;         // ICS_FFT_CONV2         0 = the FFT-tile pipeline runs A1 and A3 as two kernels; 1 (default) = as one unit per tile pair (k_conv_fft<2>) for the PSF sizes it pays for; 2 = wherever it is built
   std::atomic<int> fft_rot;           // ICS_FFT_ROT           0 = mode 2 of the tiles walks its units from the first tile row (the last, partial round is then the bottom row's four-transform units)
+  std::atomic<int> small_iter;        // ICS_SMALL_ITER        0 = small frames run the multi-launch families instead of the cooperative iteration kernel (ics_small.hip)
+  std::atomic<int> fail_small_launch; // (test hook)           1 = the next cooperative launch of the small-frame kernel is refused once (the job falls back to the multi-launch path)
+  std::atomic<int> small_trace;       // ICS_SMALL_TRACE       1 = every cooperative launch is followed by a drain and a phase timeline on stderr
   std::atomic<int> graph;             // ICS_GRAPH             0 (default) never, 1 always, -1 frames <= 1.2 Mpx: one hipGraph launch per outer iteration (measured: no gain, NOTES_r04.md 4d)
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return (e && e[0]) ? atoi(e) : dflt; }
   IcsDebug() {
@@ -135,6 +138,9 @@ struct IcsDebug {
     fft_fused = env_int("ICS_FFT_FUSED", 1);
     fft_conv2 = env_int("ICS_FFT_CONV2", 1);
     fft_rot = env_int("ICS_FFT_ROT", 1);
+    small_iter = env_int("ICS_SMALL_ITER", 1);
+    small_trace = env_int("ICS_SMALL_TRACE", 0);
+    fail_small_launch = 0;
     graph = env_int("ICS_GRAPH", 0);
     overlap = env_int("ICS_OVERLAP", 1);
     pool_limit_mb = env_int("ICS_POOL_LIMIT_MB", -1);

@@ -161,6 +161,50 @@ hipError_t ics_launch_pack_blocks(const float* psf, int K, int Kb, int nblk, voi
 hipError_t ics_launch_frame_add(float* out, const float* add, int pitch, int y0, int y1, int f0, int f1, hipStream_t s);
 hipError_t ics_launch_frame_neg(float* out, const float* in, size_t count, hipStream_t s);   // out = -in over a whole frame buffer
 
+// ---- the inner iterations of an outer iteration as one cooperative launch, small frames (ics_small.hip) ------------------------------
+// threads of a workgroup and outputs per thread and kernel row.  (1024 threads with 8 outputs -- all that fits 128 registers -- measured slower at
+// every PSF size it was tried for, 3 ... 15: 255^2 / 15 blind 0.051 -> 0.063 ms per inner iteration; more LDS reads and partial sums per product)
+constexpr int ics_small_threads(int K) { return 512; }
+constexpr int ics_small_cw(int K) { return 16; }
+#define ICS_SMALL_MAX_K 31
+#define ICS_SMALL_LDS_BYTES 163840
+#define ICS_SMALL_BAR_GROUPS 16
+#define ICS_SMALL_BAR_WORDS (16 * ICS_SMALL_BAR_GROUPS)   /* 64-bit counters, one per 128 bytes: [16 g] = arrivals of the workgroups w with w % 16 == g */
+struct IcsSmallPlan {
+  int T, tiles_x, tiles_y, nwg;       // tile edge (32 / 64), tiles of the u-frame, workgroups = 3 x tiles
+  int HU, pU, H1, pE, pT;             // LDS regions: U (T + 4 pad)^2 at pitch pU, E and F (T + 2 pad)^2 at pE, UT and G T^2 at pT (odd pitches)
+  int chunks1, Cp1, AG1, AGn1;        // A1 on the tile +- pad: 16-column chunks, pitch of the partial sums, kernel rows per group, groups
+  int chunksT, CpT, AGT, AGnT;        // A3 / A11 on the tile
+  int YG, rpy;                        // A13: row groups of rpy rows
+  int off_U, off_E, off_F, off_UT, off_G, off_P, off_W, off_PSF, lds_floats;
+  uint32_t m_HU, m_H1, m_T, m_per1, m_perT, m_perG, m_YG;   // 2^32 / d + 1 of the divisors of the index arithmetic (ics_small.hip, udiv)
+};
+struct IcsSmallArgs {
+  const float* u_in;        // u at the start of the outer iteration = its majoriser ut (pyx:462); read only
+  float* u_out;             // receives u after every inner iteration
+  const float* f;           // image
+  float* e;                 // residual: the tile interiors of the last inner iteration (the stop test's operand)
+  uint32_t* red;            // inner x ICS_RED_STRIDE keys: the maxima of every inner iteration are left here
+  unsigned long long* keys; // inner x workgroups: every tile's max |gradu| (high word) and max u as order-preserving keys
+  uint32_t* dofkeys;
+  float* scal;
+  float* psf; float* psf_caller; int* frozen;   // as IcsPsfArgs
+  float* psf_bak;           // not NULL: psf and psf_caller as they are when the launch starts are copied here first (2 x 3 K^2)
+  float* part;              // 3 x tiles x K^2: the tiles' shares of the PSF gradient
+  float* gradk;             // [K][K][3]
+  unsigned long long* bar;  // ICS_SMALL_BAR_WORDS counters, zeroed with the job's state
+  unsigned long long bar_gen;   // barriers passed since then
+  unsigned long long* trace;    // debug switch small_trace: 64 wall-clock stamps per workgroup, else NULL
+  float step, lambd;
+  int blind, correlation, inner;
+  IcsSmallPlan plan;
+  IcsGeom g;
+};
+// (64-pixel tiles -- frames up to ~570^2 -- are built but measured behind the multi-launch path: allow64 = debug switch small_iter = 2)
+bool ics_small_plan(const IcsGeom& g, int cus, IcsSmallPlan* out, bool allow64 = false);
+static inline int ics_small_barriers(int blind, int inner) { return blind ? 4 * inner : 2 * inner - 1; }
+hipError_t ics_launch_small_iter(const IcsSmallArgs& a, hipStream_t s);
+
 // ---- A18/A19 (pyx:593-638): window statistics and residual-whiteness metric -------------------
 struct IcsStatsArgs {
   const float* e;      // residual frame origin

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ICS_HIP_LIB", os.path.join(os.path.dirname(_HERE), "l
 ICS_ABI_VERSION = 4
 ICS_KERNEL_COUNT = 12
 KERNEL_NAMES = ("synth_residual", "backproject", "update", "psf_gradient", "psf_update", "majorize", "stats", "update_synth",
-                "synth_gradk", "synth_backproject", "_10", "_11")
+                "synth_gradk", "synth_backproject", "small_iteration", "_11")
 
 # error codes (include/ics_hip.h)
 ICS_OK, ICS_EINVAL, ICS_ENODEV, ICS_EHIP, ICS_ENOMEM, ICS_ESTATE, ICS_ENOSUP = 0, -1, -2, -3, -4, -5, -6
@@ -72,8 +72,8 @@ class RLRoute(C.Structure):
     """struct ics_rl_route (ics_rl_describe): which kernel families a run with these parameters launches."""
     _fields_ = [("struct_size", C.c_uint32), ("conv_family", C.c_int), ("conv_fp16_split", C.c_int), ("gradk_family", C.c_int),
                 ("gradk_fp16_split", C.c_int), ("image_in_accumulator_order", C.c_int), ("graph", C.c_int)]
-    CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big", 5: "fft-tiles"}
-    GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big", 6: "fft-tiles", 7: "fused-fft-tiles"}
+    CONV_FAMILIES = {1: "matrix", 2: "matrix-blocks", 3: "vector", 4: "vector-big", 5: "fft-tiles", 6: "lds-resident"}
+    GRADK_FAMILIES = {0: "none", 1: "fused-matrix", 2: "matrix", 3: "matrix-blocks", 4: "fp32-mfma", 5: "fp32-big", 6: "fft-tiles", 7: "fused-fft-tiles", 8: "lds-resident"}
 
 
 def describe(M, N, MK, params):

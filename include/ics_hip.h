@@ -313,7 +313,8 @@ int ics_rl_copy_rows(ics_rl *dst, int dst_which, int dst_row0, ics_rl *src, int 
 #define ICS_K_UPDATE_SYNTH 7 /* fused A5-A10 + A1/A2 (or A11) kernel */
 #define ICS_K_SYNTH_GRADK 8  /* fused A11 + A13 kernel (+ reduction)  */
 #define ICS_K_SYNTH_BACKPROJECT 9 /* A1 + A2 + A3 (+A7) in one unit per tile pair (transform tiles, small PSFs) */
-#define ICS_KERNEL_COUNT 12  /* (10..11 reserved) */
+#define ICS_K_SMALL_ITER 10   /* small frames: the inner iterations of an outer one as ONE cooperative launch (ics_small.hip) */
+#define ICS_KERNEL_COUNT 12  /* (11 reserved) */
 
 /* ---- small standalone operators ---------------------------------------------------------- */
 /* lib/deconvolution.pyx:73-75 -- in place on a host MK*MK*3 float32 array, computed on device. */

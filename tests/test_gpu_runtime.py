@@ -93,6 +93,7 @@ def test_graph_replay_is_bit_identical_to_eager_launches(blind, tv_mode, MK, deb
     case = orc.synth_case(M, N, MK, seed=7, blind=blind)
     win = orc.default_window(M, N, MK)
     out = {}
+    debug_switch("small_iter", 0)      # (graphs belong to the multi-launch families: the cooperative small-frame kernel is one launch per outer iteration already)
     for graph in (0, 1):
         debug_switch("graph", graph)
         job = nv.RLJob(M, N, MK)
