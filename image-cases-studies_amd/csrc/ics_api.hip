@@ -1423,7 +1423,10 @@ static int do_small_iter(ics_rl* j, const ics_rl_params* p, const IcsSmallPlan& 
   RC(pr.begin(ICS_K_SMALL_ITER));
   const hipError_t he = ics_debug().fail_small_launch.exchange(0) ? hipErrorCooperativeLaunchTooLarge : ics_launch_small_iter(a, j->ctx->stream);
   RC(pr.end());
-  if (he != hipSuccess) return fail(ICS_EHIP, "cooperative launch of the small-frame iteration: %s", hipGetErrorString(he));   // (nothing was queued)
+  if (he != hipSuccess) {   // (nothing was queued: the bracket does not count as a launch)
+    if (pr.on && !j->ev_pairs.empty()) j->ev_pairs.pop_back();
+    return fail(ICS_EHIP, "cooperative launch of the small-frame iteration: %s", hipGetErrorString(he));
+  }
   if (tr) {   // phase timeline: per stamp the first and the last workgroup to reach it, in us from the first stamp of the launch (100 MHz clock)
     std::vector<unsigned long long> h((size_t)pl.nwg * 64);
     HIPCHK(hipStreamSynchronize(j->ctx->stream));

@@ -236,7 +236,9 @@ int ics_rl_run(ics_rl *job, const ics_rl_params *params, ics_rl_stats *stats);
  * flags, the ICS_CONV_PATH override): the library's own routing predicates, so that a benchmark labels its precision and traffic
  * figures from what actually runs.  Families:  convolutions A1/A3 -- 1 fp16-split matrix cores (whole PSF), 2 the same as tap blocks
  * (PSF > 49), 3 packed-fp32 kernels compiled per size, 4 run-time-sized fp32 kernels (ics_big.hip), 5 fp32 transform tiles on planar
- * mirrors (ics_conv_fft.hip);  PSF gradient A13 -- 1 fused with
+ * mirrors (ics_conv_fft.hip), 6 the cooperative small-frame iteration kernel (ics_small.hip: the five inner iterations of an outer one in
+ * ONE launch, a tile of a channel per compute unit, fp32 FMAs; frames up to ~290 px a side, PSF <= 31, shipped loop, ICS_CONV_AUTO only;
+ * the PSF gradient is then family 8, inside the same launch);  PSF gradient A13 -- 1 fused with
  * A11 (k_synth_gradk, MK <= 15), 2 fp16-split matrix cores (k_gradk_mfma), 3 the same as tap blocks (MK >= 33), 4 fp32 MFMA
  * (k_gradk), 5 run-time-sized fp32 (k_gradk_big), 6 fp32 transform tiles (k_gradk_fft, ics_conv_fft.hip),
  * 7 fused with A11 on the fp32 transform tiles (k_synth_gradk_fft: three transforms per tile pair); 0 = not run (non-blind).  products_fp16_split = 1 when the products of that
