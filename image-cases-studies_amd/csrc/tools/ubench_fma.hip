@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256) void k(float* out, const float* __restrict__ w
       } else if (MODE == 3) {  // pk, broadcast high half
 #pragma unroll
         for (int i = 0; i < 8; ++i) { const float s = p[(i + 1) & 7].y; p[i] = __builtin_elementwise_fma(wp, (f2){s, s}, p[i]); }
+      } else if (MODE == 4) {  // the form ics_small.hip's convolutions compile to: the WEIGHT is a per-lane register (from LDS), broadcast to both halves; two inputs in a VGPR pair
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float wl = a[(i + r) & 15]; p[i] = __builtin_elementwise_fma((f2){wl, wl}, p[(i + 1) & 7], p[i]); }
       }
     }
   }
@@ -64,6 +67,7 @@ int main() {
     run<1>("v_pk_fma_f32 (sgpr pair weight)", d, w, wv);
     run<2>("v_pk_fma_f32 (sgpr pair, bcast lo input)", d, w, wv);
     run<3>("v_pk_fma_f32 (sgpr pair, bcast hi input)", d, w, wv);
+    run<4>("v_pk_fma_f32 (VGPR weight bcast, VGPR pair in)", d, w, wv);
   }
   return 0;
 }
