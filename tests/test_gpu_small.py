@@ -112,6 +112,19 @@ def test_abort_drops_the_iteration_that_ran_ahead():
         assert np.array_equal(ref[k], got[k]), k
 
 
+def test_two_runs_are_bit_identical():
+    """every sum in the kernel has a fixed order (partial sums meet in group order, the tiles' gradient shares in tile order, maxima are order-free):
+    results do not depend on which workgroup reaches a barrier first"""
+    M, N, MK = 230, 255, 13
+    case = orc.synth_case(M, N, MK, seed=9, blind=True)
+    win = orc.default_window(M, N, MK)
+    a = _run(case, M, N, MK, win, 6, True)
+    b = _run(case, M, N, MK, win, 6, True)
+    assert a["route"].conv_family == 6
+    for k in ("u", "psf", "psf_caller", "M_r", "Hu", "varu", "dof_min", "dof_max"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
 def test_profile_counts_one_launch_per_outer_iteration():
     M = N = 255; MK = 15
     case = orc.synth_case(M, N, MK, seed=1, blind=True)
