@@ -23,6 +23,8 @@ for it in range(n):
         MK = int(rng.choice([3, 5, 9, 15, 17, 19, 21, 23, 27, 31, 33, 37, 45, 49, 51, 57, 63, 65]))
         if os.environ.get("FUZZ_WIDE") == "1":      # round 6: one tile to 85, tap blocks on the tiles to 255
             MK = int(rng.choice([67, 71, 79, 85, 87, 89, 97, 101, 127, 129, 161, 193, 201, 255]))
+    if os.environ.get("FUZZ_SMALL") == "1":        # round 6: the cooperative small-frame kernel (ics_small.hip): PSF sizes 3 ... 31, frames to 288 px a side
+        MK = int(rng.choice(np.arange(3, 33, 2)))
     M, N = int(rng.integers(max(8, MK // 3), smax)), int(rng.integers(max(8, MK // 3), smax))
     blind = bool(rng.integers(0, 2))
     case = orc.synth_case(M, N, MK, seed=int(rng.integers(0, 1 << 30)), blind=blind)
