@@ -241,6 +241,7 @@ def timed_run(ctx, M, MK, blind, tv_mode, conv, steps, warm, seed=0):
     job.upload(image, u0, psf_uniform if blind else psf_true)
     pad = MK // 2
     win = (pad + 1, 255 - pad - 1, pad + 1, 255 - pad - 1)
+    route = job.describe(job.params(*win, 1e9, 1, 1e-3, 10000.0, blind, 0, 3, stop_test=2, tv_mode=tv_mode, conv=conv))
     job.run(job.params(*win, 1e9, max(1, warm // 5), 1e-3, 10000.0, blind, 0, 3, stop_test=2, tv_mode=tv_mode, conv=conv))
     ctx.synchronize()
     t0 = time.perf_counter()
@@ -254,7 +255,7 @@ def timed_run(ctx, M, MK, blind, tv_mode, conv, steps, warm, seed=0):
     job.close()
     mode = "blind" if blind else "nonblind"
     gb = ITER_BYTES_PER_PX[mode] * M * M / (el / steps) / 1e9
-    return {"ms_per_step": round(el * 1e3 / steps, 4), "MPixels_per_s_per_iter": round(M * M * steps / el / 1e6, 1),
+    return {"ms_per_step": round(el * 1e3 / steps, 4), "conv": _native.RLRoute.CONV_FAMILIES[route.conv_family], "MPixels_per_s_per_iter": round(M * M * steps / el / 1e6, 1),
             "algorithmic_bytes_per_px": ITER_BYTES_PER_PX[mode], "frac_of_8TBps": round(gb / HBM_PEAK_GBPS, 4), "kernels_ms": kern, "steps": steps}
 
 
@@ -530,7 +531,7 @@ def main():
             oc["configs[0] non-blind 512^2 9x9 (the reference's CPU plumbing case; launch-bound on a GPU)"] = timed_run(ctx, 512, 9, False, 0, conv, 400, 50)   # (a 34-us step: 100 steps were 3 ms, a third of the call's fixed cost in the figure)
             # the reference's blind workload (deconvolve.py:277-286: a 255 x 255 window at every pyramid level): one cooperative launch per outer iteration
             # since round 6 (ics_small.hip), and the multi-launch path it replaced (matrix cores, forced with conv = 2)
-            oc["blind 255^2 15x15 (the blind window of deblur_module; cooperative small-frame kernel)"] = timed_run(ctx, 255, 15, True, 0, conv, 400, 50)
+            oc["blind 255^2 15x15 (the blind window of deblur_module; ICS_CONV_AUTO: the cooperative small-frame kernel, `conv`: lds-resident -- not under rocprofv3, see README)"] = timed_run(ctx, 255, 15, True, 0, conv, 400, 50)
             oc["blind 255^2 15x15 on the multi-launch path (conv = matrix)"] = timed_run(ctx, 255, 15, True, 0, 2, 400, 50)
             oc["configs[1] non-blind 2048^2 15x15 (shipped loop)"] = timed_run(ctx, 2048, 15, False, 0, conv, 100, 10)
             oc["configs[1] non-blind 2048^2 15x15 + active MM-TV (tv_mode 1, build-defined)"] = timed_run(ctx, 2048, 15, False, 1, conv, 50, 5)

@@ -115,7 +115,7 @@ struct IcsDebug {
   std::atomic<int> fft_fused;         // ICS_FFT_FUSED         0 = the FFT-tile pipeline runs A11 and A13 as two kernels (k_conv_fft<0> + k_gradk_fft) instead of the fused three-transform unit
   std::atomic<int> fft_conv2;         // ICS_FFT_CONV2         0 = the FFT-tile pipeline runs A1 and A3 as two kernels; 1 (default) = as one unit per tile pair (k_conv_fft<2>) for the PSF sizes it pays for; 2 = wherever it is built
   std::atomic<int> fft_rot;           // ICS_FFT_ROT           0 = mode 2 of the tiles walks its units from the first tile row (the last, partial round is then the bottom row's four-transform units)
-  std::atomic<int> small_iter;        // ICS_SMALL_ITER        0 = small frames run the multi-launch families instead of the cooperative iteration kernel (ics_small.hip)
+  std::atomic<int> small_iter;        // ICS_SMALL_ITER        0 = small frames run the multi-launch families instead of the cooperative iteration kernel (ics_small.hip); 2 = 64-pixel tiles too; default 1, 0 under rocprofv3
   std::atomic<int> fail_small_launch; // (test hook)           1 = the next cooperative launch of the small-frame kernel is refused once (the job falls back to the multi-launch path)
   std::atomic<int> small_trace;       // ICS_SMALL_TRACE       1 = every cooperative launch is followed by a drain and a phase timeline on stderr
   std::atomic<int> graph;             // ICS_GRAPH             0 (default) never, 1 always, -1 frames <= 1.2 Mpx: one hipGraph launch per outer iteration (measured: no gain, NOTES_r04.md 4d)
@@ -138,7 +138,13 @@ struct IcsDebug {
     fft_fused = env_int("ICS_FFT_FUSED", 1);
     fft_conv2 = env_int("ICS_FFT_CONV2", 1);
     fft_rot = env_int("ICS_FFT_ROT", 1);
-    small_iter = env_int("ICS_SMALL_ITER", 1);
+    // (a process that has made a cooperative launch under rocprofv3 -- ROCm 7.2, rocprofiler-sdk tool library preloaded -- crashes in its exit handlers AFTER the
+    //  profiler has written its output: exit code 139 for an otherwise complete run.  Under an attached profiler the small frames therefore stay on the
+    //  multi-launch families unless ICS_SMALL_ITER=1 asks for the cooperative kernel explicitly)
+    const char* tool = getenv("ROCP_TOOL_LIBRARIES");
+    const char* pre = getenv("LD_PRELOAD");
+    const bool profiler = (tool && tool[0]) || (pre && strstr(pre, "rocprofiler"));
+    small_iter = env_int("ICS_SMALL_ITER", profiler ? 0 : 1);
     small_trace = env_int("ICS_SMALL_TRACE", 0);
     fail_small_launch = 0;
     graph = env_int("ICS_GRAPH", 0);
