@@ -3,13 +3,13 @@
 // deconvolve.py:277-286 runs on a 255 x 255 window at every pyramid level).
 //
 // At 255 x 255 / 15 x 15 the multi-launch path spends 54 us in six kernel bodies and 12 us between them per inner iteration, and the bodies
-// are start-up latency: each re-stages its operands from L2.  Here a workgroup = one T x T tile of one channel (T = 32 or 64; <= 85 tiles x 3
-// channels <= 256 compute units), 512 threads, and its operands live in LDS for the whole launch:
+// are start-up latency: each re-stages its operands from L2.  Here a workgroup = one T x T tile of one channel (T = 32; 64 is built but not
+// routed, ics_small_plan; <= 85 tiles x 3 channels <= 256 compute units), 512 threads, and its operands live in LDS for the whole launch:
 //     U   u over the tile +- 2 pad    (refilled from global memory after every update: the halo belongs to the neighbours)
 //     F   the image over the tile +- pad, UT the majoriser over the tile (both constant for the launch)
 //     E   the residual over the tile +- pad: A1 + A2 are evaluated on the halo too (2x the products at 32 / 15) -- cheaper than a fifth barrier
 // and an inner iteration is (pyx line numbers as in ics_conv.hip / ics_kernels.hip)
-//     A1+A2  E = conv(U, rot180 psf) - F on tile +- pad          A3  G = conv(E, psf) on the tile; max |lambd G + (u - ut)/2|, max u -> atomics
+//     A1+A2  E = conv(U, rot180 psf) - F on tile +- pad          A3  G = conv(E, psf) on the tile; max |lambd G + (u - ut)/2|, max u -> the tile's slot
 //     -- grid barrier --  A5...A10 on the tile, u -> global      -- grid barrier --  U refilled
 //     blind: A11 e' on the tile, A13 the tile's share of the PSF gradient -> global   -- grid barrier --   the shares summed, three taps per
 //     workgroup, in tile order   -- grid barrier --   A14...A17 by every workgroup for itself (the PSF step is 3 K^2 values)
@@ -18,8 +18,8 @@
 //
 // Across workgroups only four things travel, all through agent-scope relaxed atomics (coherent accesses; a __threadfence() either side of a
 // barrier costs 20 us on this part -- L2 write-back and invalidate -- against 1.2 us for the accesses, tools/ubench_grid_barrier.hip): the
-// updated u, the step-size maxima, the gradient shares and the summed gradient.  The barrier is a two-level counter (16 groups, then one),
-// monotone over the run.
+// updated u, the tiles' step-size maxima, the gradient shares and the summed gradient.  The barrier is sixteen counters (workgroup w arrives on
+// counter w % 16), all watched by one wave-wide load per workgroup, monotone over the run (grid_barrier below).
 #include "ics_common.h"
 #include "ics_kernels.h"
 
