@@ -285,8 +285,8 @@ int ics_rl_stage(ics_rl *job, int stage, const ics_rl_params *params);
 #define ICS_BUF_U 0      /* uM x uN x 3  */
 #define ICS_BUF_UT 1     /* uM x uN x 3  */
 #define ICS_BUF_GRADU 2  /* uM x uN x 3 : raw back-projection (A3), before A6.  After ics_rl_run: the last inner iteration's on the multi-launch families;
-                            not written by the fused tile unit (conv family 5 with A1 + A3 as one unit) nor by the cooperative small-frame kernel
-                            (family 6), whose back-projection never leaves the chip -- single stages (ics_rl_stage) always write it */
+                            on the transform tiles (family 5) it lives in the frame's planar mirror and the buffer read here is not refreshed; the
+                            cooperative small-frame kernel (family 6) never stores it (it stays in LDS) -- single stages (ics_rl_stage) always write it */
 #define ICS_BUF_IMAGE 3  /* M x N x 3    */
 #define ICS_BUF_ERROR 4  /* M x N x 3    */
 #define ICS_BUF_PSF 5    /* MK x MK x 3  */
