@@ -134,8 +134,9 @@ size_t ics_rl_params_size(void); /* sizeof(ics_rl_params) as the library was bui
                                      exchange's host waits must replace them by events between the two streams.  Ignored by ics_rl_run.  */
 
 #define ICS_CONV_AUTO 0   /* the library's choice (ics_rl_describe tells): inside ics_rl_run the fp32 transform tiles on large frames -- from 0.5 ... 12 Mpx
-                             depending on the PSF size, every size 3 ... 255 (csrc/ics_api.hip fft_preferred) -- and the fp16x2-split
-                             matrix-core kernels below (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33; PSF gradient: MK <= 31
+                             depending on the PSF size, every size 3 ... 255 (csrc/ics_api.hip fft_preferred) --, the cooperative fp32
+                             iteration kernel on small ones -- up to ~290 px a side, MK <= 31, shipped loop (ics_small.hip) -- and the fp16x2-split
+                             matrix-core kernels between (convolutions: MK <= 49 directly, above as tap blocks of <= 33 x 33; PSF gradient: MK <= 31
                              directly, above as tap blocks of <= 31 x 31); single stages (ics_rl_stage) always the latter; env
                              ICS_CONV_PATH=vector|matrix|fft overrides the choice of AUTO                     */
 #define ICS_CONV_VECTOR 1 /* packed-fp32 VALU convolutions (ics_conv.hip; ics_big.hip above 63) + fp32 PSF gradient: fp32 products */
