@@ -37,14 +37,15 @@ __device__ __forceinline__ uint32_t ld_coh(const uint32_t* p) { return __hip_ato
 // i / d for i < 2^32 / d with m = 2^32 / d + 1 (ics_small_plan): one v_mul_hi_u32 instead of the ~35 instructions of an integer division
 __device__ __forceinline__ int udiv(int i, uint32_t m) { return (int)__umulhi((uint32_t)i, m); }
 
-// sum of the partial sums p[0], p[stride], ... (n <= 8 of them) in that order, all of them requested before the first add
+// sum of the partial sums p[0], p[stride], ... (n <= MAXG of them) in that order, all of them requested before the first add
+template <int MAXG>
 __device__ __forceinline__ float sum_partials(const float* __restrict__ p, int stride, int n) {
-  float v[8];
+  float v[MAXG];
 #pragma unroll
-  for (int g = 0; g < 8; ++g) v[g] = p[(g < n ? g : 0) * stride];
+  for (int g = 0; g < MAXG; ++g) v[g] = p[(g < n ? g : 0) * stride];
   float s = v[0];
 #pragma unroll
-  for (int g = 1; g < 8; ++g) s = g < n ? __fadd_rn(s, v[g]) : s;
+  for (int g = 1; g < MAXG; ++g) s = g < n ? __fadd_rn(s, v[g]) : s;
   return s;
 }
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NT) void k_small_iter(IcsSmallArgs A) {
     __syncthreads();
     for (int i = tid; i < H1 * H1; i += NT) {
       const int y = udiv(i, P.m_H1), x = i - y * H1, fy = ty0 - pad + y, fx = tx0 - pad + x;
-      const float s = sum_partials(sP + y * P.Cp1 + x, H1 * P.Cp1, P.AGn1);
+      const float s = sum_partials<4>(sP + y * P.Cp1 + x, H1 * P.Cp1, P.AGn1);
       const bool in = fy >= pad && fy < pad + G.M && fx >= pad && fx < pad + G.N;
       const float e = in ? __fsub_rn(s, sF[y * pE + x]) : 0.f;
       sE[y * pE + x] = e;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(NT) void k_small_iter(IcsSmallArgs A) {
     uint32_t kg = 0u, ku = 0u;
     for (int i = tid; i < T * T; i += NT) {
       const int y = udiv(i, P.m_T), x = i - y * T, fy = ty0 + y, fx = tx0 + x;
-      const float s = sum_partials(sP + y * P.CpT + x, T * P.CpT, P.AGnT);
+      const float s = sum_partials<8>(sP + y * P.CpT + x, T * P.CpT, P.AGnT);
       sG[y * pT + x] = s;
       if (fy < G.uM && fx < G.uN) {
         const float uv = sU[(y + 2 * pad) * pU + x + 2 * pad];
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(NT) void k_small_iter(IcsSmallArgs A) {
     __syncthreads();
     for (int i = tid; i < T * T; i += NT) {
       const int y = udiv(i, P.m_T), x = i - y * T, fy = ty0 + y, fx = tx0 + x;
-      const float s = sum_partials(sP + y * P.CpT + x, T * P.CpT, P.AGnT);
+      const float s = sum_partials<8>(sP + y * P.CpT + x, T * P.CpT, P.AGnT);
       const bool in = fy >= pad && fy < pad + G.M && fx >= pad && fx < pad + G.N;
       const float e = in ? __fsub_rn(s, sF[(y + pad) * pE + x + pad]) : 0.f;
       sE[(y + pad) * pE + x + pad] = e;
@@ -367,18 +368,16 @@ __global__ __launch_bounds__(NT) void k_small_iter(IcsSmallArgs A) {
       float gv[NG];
 #pragma unroll
       for (int r = 0; r < NG; ++r) { const int i = tid + r * NT; gv[r] = ld_coh(A.gradk + (i < n3 ? i : n3 - 1)); }
-      if (tid < 8) skeys[tid] = 0u;
-      __syncthreads();
-      uint32_t kp = 0u, kq = 0u;
+      uint32_t kp = 0u, kq = 0u;     // (their slots, skeys[5] and [6], were cleared with the others before A3's epilogue of this inner iteration)
 #pragma unroll
       for (int r = 0; r < NG; ++r) {
         const int i = tid + r * NT;
         if (i < n3) { const uint32_t k1 = key_of(sPSF[i]), k2 = key_of(__builtin_fabsf(gv[r])); kp = kp > k1 ? kp : k1; kq = kq > k2 ? kq : k2; }
       }
       kp = ics_wave_max_u32(kp); kq = ics_wave_max_u32(kq);
-      if ((tid & 63) == 0) { atomicMax(&skeys[0], kp); atomicMax(&skeys[1], kq); }
+      if ((tid & 63) == 0) { atomicMax(&skeys[5], kp); atomicMax(&skeys[6], kq); }
       __syncthreads();
-      const float maxp = ics_key2f(skeys[0]), maxq = ics_key2f(skeys[1]);
+      const float maxp = ics_key2f(skeys[5]), maxq = ics_key2f(skeys[6]);
       const float dtpsf = __fdiv_rn(__fmul_rn(__fdiv_rn(A.step, (float)K), maxp), __fadd_rn(maxq, 1e-15f));
       const bool writer = wg == 0;
       if (writer && tid == 0) A.scal[ICS_SC_DTPSF] = dtpsf;
@@ -416,17 +415,14 @@ __global__ __launch_bounds__(NT) void k_small_iter(IcsSmallArgs A) {
       }
       __syncthreads();
       const bool detach = A.correlation != 0;
-      for (int i = tid; i < n3; i += NT) {
-        sPSF[i] = __fdiv_rn(sPSF[i], ssum[i % 3]);
-        if (writer) { A.psf[i] = sPSF[i]; if (!frozen && !detach) A.psf_caller[i] = sPSF[i]; }
+      for (int i = tid; i < n3; i += NT) {   // A16, and this channel's values straight into the two weight tables (their pad column stays zero)
+        const int px = i / 3, ch = i - 3 * px;
+        const float v = __fdiv_rn(sPSF[i], ssum[ch]);
+        sPSF[i] = v;
+        if (ch == c) { const int a = px / K, b = px - a * K; sW2[a * KP + b] = v; sW1[(K - 1 - a) * KP + (K - 1 - b)] = v; }
+        if (writer) { A.psf[i] = v; if (!frozen && !detach) A.psf_caller[i] = v; }
       }
       if (detach) { frozen = 1; if (writer && tid == 0) *A.frozen = 1; }
-      __syncthreads();
-    }
-    for (int i = tid; i < K * KP; i += NT) {
-      const int a = i / KP, b = i - a * KP;
-      sW1[i] = b < K ? sPSF[((K - 1 - a) * K + (K - 1 - b)) * 3 + c] : 0.f;
-      sW2[i] = b < K ? sPSF[(a * K + b) * 3 + c] : 0.f;
     }
     __syncthreads();
     ICS_SMALL_STAMP();   // PSF step
@@ -466,14 +462,14 @@ bool ics_small_plan(const IcsGeom& g, int cus, IcsSmallPlan* out, bool allow64) 
     p.Cp1 = odd(p.chunks1 * CW); p.CpT = odd(T);
     const int needU = p.chunks1 * CW + K - 1;
     p.pU = odd(p.HU > needU ? p.HU : needU); p.pE = odd(p.H1); p.pT = odd(T);
-    auto groups = [&](int R, int chunks, int* AG, int* AGn) {
+    auto groups = [&](int R, int chunks, int cap, int* AG, int* AGn) {
       int n = NT / (R * chunks);
       n = n < 1 ? 1 : (n > K ? K : n);
-      n = n > 8 ? 8 : n;                       // (sum_partials)
+      n = n > cap ? cap : n;                   // (sum_partials<cap>)
       *AG = (K + n - 1) / n; *AGn = (K + *AG - 1) / *AG;
     };
-    groups(p.H1, p.chunks1, &p.AG1, &p.AGn1);
-    groups(T, p.chunksT, &p.AGT, &p.AGnT);
+    groups(p.H1, p.chunks1, 4, &p.AG1, &p.AGn1);
+    groups(T, p.chunksT, 8, &p.AGT, &p.AGnT);
     int yg = NT / (K * p.chunksT);
     yg = yg < 1 ? 1 : (yg > T ? T : yg);
     p.rpy = (T + yg - 1) / yg; p.YG = (T + p.rpy - 1) / p.rpy;
